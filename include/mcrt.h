@@ -1,0 +1,236 @@
+/*
+ * mcrt.h — C ABI of libmcrt_hip.so, the MI355X (gfx950) path-tracing / BVH-traversal /
+ * photon-kNN engine that drops in behind linusmossberg/monte-carlo-ray-tracer's
+ * Camera::sampleImage() (reference: source/camera/camera.cpp:101-145).
+ *
+ * The reference has no FFI; its seam is the C++ call Camera::sampleImage(), whose contract is
+ * "on return camera.image(x,y) holds the filtered mean radiance of every pixel"
+ * (camera/camera.cpp:138-144, camera/image.cpp:53-56). The entry points below are what a
+ * maintainer binds in its place (binding stub: INTEGRATION.md). Everything is plain pointers and
+ * sizes; no C++ types, no torch types, no exceptions cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative mcrt_status; mcrt_last_error() gives text
+ *     (the reference's convention is exceptions caught in main, source/main.cpp:24-32,48-56);
+ *   - all *_desc arrays are host memory owned by the caller and are copied during the call;
+ *   - all floating point is FP64 unless the field says otherwise (the reference computes in
+ *     glm::dvec3 everywhere; only stored photons are FP32, integrator/photon-mapper/photon.hpp:36-37);
+ *   - the library never falls back to a CPU path: without a gfx950 device mcrt_create fails.
+ */
+#ifndef MCRT_H
+#define MCRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRT_ABI_VERSION 1u
+
+typedef enum mcrt_status {
+    MCRT_OK = 0,
+    MCRT_ERR_INVALID = -1,      /* bad argument / inconsistent descriptor            */
+    MCRT_ERR_NO_DEVICE = -2,    /* no gfx950 device / HIP runtime error at create    */
+    MCRT_ERR_HIP = -3,          /* HIP runtime error (text in mcrt_last_error)       */
+    MCRT_ERR_NO_SCENE = -4,     /* render called before mcrt_upload_scene            */
+    MCRT_ERR_NO_PHOTONS = -5,   /* photon-mapping render without mcrt_upload_photons */
+    MCRT_ERR_IO = -6,           /* scene-image file could not be read / parsed       */
+    MCRT_ERR_UNSUPPORTED = -7   /* e.g. quadric surfaces, non-box film filter        */
+} mcrt_status;
+
+/* ------------------------------------------------------------------------------------------
+ * Scene. Replaces the data reached through Integrator::scene (integrator/integrator.hpp:26):
+ * Scene::{surfaces, emissives, cumulative_emissives_importance, bvh, ior} (scene/scene.hpp:27-40),
+ * BVH::{linear_tree, ordered_surfaces} (bvh/bvh.hpp:105-108) and the per-surface / per-material
+ * fields the hot path reads.
+ * ---------------------------------------------------------------------------------------- */
+
+enum { MCRT_SURF_TRIANGLE = 0, MCRT_SURF_SPHERE = 1 };
+
+/* Material flag bits = the bools of class Material (material/material.hpp:41-44) as they stand
+ * AFTER scene construction (scene/scene.cpp:83-89 copies materials without recomputing them). */
+enum {
+    MCRT_MAT_ROUGH = 1u << 0,
+    MCRT_MAT_ROUGH_SPECULAR = 1u << 1,
+    MCRT_MAT_OPAQUE = 1u << 2,
+    MCRT_MAT_EMISSIVE = 1u << 3,
+    MCRT_MAT_DIRAC_DELTA = 1u << 4,
+    MCRT_MAT_PERFECT_MIRROR = 1u << 5,
+    MCRT_MAT_COMPLEX_IOR = 1u << 6
+};
+
+/* One record per Material object (material/material.hpp:9-55). emittance is the value left by
+ * Scene::generateEmissives (scene/scene.cpp:202), i.e. radiosity, not flux. */
+typedef struct mcrt_material {
+    double reflectance[3];
+    double specular_reflectance[3];
+    double transmittance[3];
+    double emittance[3];
+    double roughness, specular_roughness, ior, transparency;
+    double A, B;           /* Oren-Nayar terms, material.cpp:106-108       */
+    double a[2];           /* GGX alpha, material.cpp:110                  */
+    double ior_real[3];    /* ComplexIOR::real      (material/fresnel.hpp:6-11) */
+    double ior_imag[3];    /* ComplexIOR::imaginary                         */
+    uint32_t flags;        /* MCRT_MAT_*                                    */
+    uint32_t reserved;
+} mcrt_material;
+
+typedef struct mcrt_scene_desc {
+    uint32_t abi_version;              /* MCRT_ABI_VERSION */
+
+    /* BVH::linear_tree in the reference's depth-first order (bvh/bvh.hpp:68-74).
+     * num_nodes == 0 selects the brute-force loop of Scene::intersect (scene/scene.cpp:161-173). */
+    uint32_t num_nodes;
+    const double*   node_bounds;        /* [num_nodes][6]  BB.min xyz, BB.max xyz      */
+    const uint32_t* node_start_surface; /* [num_nodes]                                  */
+    const uint32_t* node_num_surfaces;  /* [num_nodes]  >0 ⇒ leaf (uint8 in reference) */
+    const uint32_t* node_next_sibling;  /* [num_nodes]  0 ⇒ none                       */
+
+    /* Surfaces in BVH::ordered_surfaces order (Scene::surfaces order when num_nodes == 0). */
+    uint32_t num_surfaces;
+    const uint8_t*  surf_kind;          /* MCRT_SURF_*                                          */
+    const uint8_t*  surf_interpolate;   /* 1 ⇔ Triangle::N != nullptr (surface/triangle.cpp:56) */
+    const uint32_t* surf_material;      /* index into materials                                 */
+    const double*   surf_area;          /* Base::area_                                          */
+    const double*   surf_v;             /* [n][9] triangle: v0,v1,v2 · sphere: origin,radius,0… */
+    const double*   surf_e;             /* [n][9] triangle: E1,E2,normal_ · sphere: unused      */
+    const double*   surf_vn;            /* [n][9] vertex normals N[0..2], or NULL if none       */
+
+    uint32_t num_materials;
+    const mcrt_material* materials;
+
+    /* Scene::emissives / cumulative_emissives_importance in the order the reference produced. */
+    uint32_t num_lights;
+    const uint32_t* light_surface;      /* index into the surface arrays above */
+    const double*   light_cdf;
+
+    double scene_ior;                   /* Scene::ior (scene/scene.cpp:22)   */
+    double bb_min[3], bb_max[3];        /* Scene::BB()                        */
+} mcrt_scene_desc;
+
+/* ------------------------------------------------------------------------------------------
+ * Photon maps. Replaces PhotonMapper::{caustic_map, global_map} =
+ * LinearOctree<Photon>::{linear_tree, ordered_data} (octree/linear-octree.hpp:19-29).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mcrt_photon_map_desc {
+    uint32_t num_octants;
+    const double*   octant_bounds;          /* [n][6] tight BB min,max (linear-octree.cpp:220,241) */
+    const uint64_t* octant_start_data;
+    const uint64_t* octant_contained_data;
+    const uint32_t* octant_next_sibling;    /* 0xFFFFFFFF ⇒ none (linear-octree.hpp:36) */
+    const uint8_t*  octant_leaf;
+    uint64_t num_photons;
+    const float*    photons;                /* [n][8] flux rgb, position xyz, phi, theta (photon.hpp:36-37) */
+} mcrt_photon_map_desc;
+
+/* ------------------------------------------------------------------------------------------
+ * Camera. The public fields of class Camera read by samplePixel (camera/camera.hpp:39-51,
+ * camera/camera.cpp:66-99) plus the work split.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mcrt_camera_desc {
+    double eye[3], forward[3], left[3], up[3];
+    double focal_length, sensor_width, aperture_radius, focus_distance;
+    uint32_t thin_lens;
+    uint32_t width, height;
+    uint32_t sqrtspp;
+    /* Image-space sharding (multi-GPU): rows are dealt to shards in groups of shard_rows rows,
+     * group g belongs to shard g % shard_count. shard_count <= 1 renders every row. Per-pixel
+     * seeding stays hashCombine(global_seed, hash(y*width+x)) (camera.cpp:73, sampler.hpp:32-35)
+     * so the image is independent of the split. */
+    uint32_t shard_index, shard_count, shard_rows;
+    uint32_t reserved;
+} mcrt_camera_desc;
+
+enum { MCRT_INTEGRATOR_PATH_TRACER = 0, MCRT_INTEGRATOR_PHOTON_MAPPER = 1 };
+
+typedef struct mcrt_stats {
+    uint64_t paths;         /* pixel samples traced = Integrator::sampleRay calls             */
+    uint64_t rays;          /* closest-hit queries  = Scene::intersect calls (bounce + shadow) */
+    uint64_t node_tests;    /* BoundingBox::intersect calls performed by the GPU traversal     */
+    uint64_t prim_tests;    /* primitive intersect calls performed by the GPU traversal        */
+    uint64_t knn_searches;  /* LinearOctree::knnSearch calls                                   */
+    double   kernel_ms;     /* HIP-event time of the integrator kernel(s) on their stream      */
+    double   total_ms;      /* wall time of the call incl. copies                              */
+    uint32_t kernel_launches;
+    uint32_t reserved;
+} mcrt_stats;
+
+typedef struct mcrt_ctx mcrt_ctx; /* opaque; owns all device memory and one HIP stream */
+
+/* Lifecycle. device_id = HIP ordinal of the gfx950 device this context drives (one context per
+ * device / per process rank). */
+int  mcrt_create(mcrt_ctx** out, int device_id);
+void mcrt_destroy(mcrt_ctx* ctx);
+const char* mcrt_last_error(const mcrt_ctx* ctx); /* ctx may be NULL: last create error */
+
+int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene);
+int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map,
+                        const mcrt_photon_map_desc* caustic_map,
+                        uint32_t k_nearest_photons, int direct_visualization);
+
+/* Replaces the thread fan-out of Camera::sampleImage (camera.cpp:120-144): renders every owned
+ * pixel with spp = sqrtspp^2 samples and writes image(x,y) as FP64 RGB, row-major, width*height*3
+ * doubles, into caller-allocated HOST memory (rows not owned by this shard are left untouched).
+ * global_seed replaces Sampler::global_seed (sampling/sampler.hpp:58). */
+int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator,
+                double* out_rgb, mcrt_stats* stats /* may be NULL */);
+
+/* Same, but the image stays in DEVICE memory owned by the caller (e.g. the buffer RCCL gathers
+ * from) and the launch is asynchronous on `stream` (a hipStream_t; NULL = the context's stream).
+ * d_out_rgb holds owned rows only, packed in ascending row order: mcrt_shard_rows() rows of
+ * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. */
+int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed,
+                       int integrator, double* d_out_rgb, void* stream);
+int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);
+
+/* Number of rows owned by (shard_index, shard_count, shard_rows) of `cam`, and their indices. */
+uint32_t mcrt_shard_rows(const mcrt_camera_desc* cam, uint32_t* rows /* may be NULL */);
+
+/* ---- operator-level entry points (each mirrors one reference function; used by parity tests
+ * and by hosts that only want the traversal / kNN engine) -------------------------------- */
+
+/* Scene::intersect (scene/scene.cpp:151-176) for n rays given as start[3], direction[3] (FP64,
+ * host). Outputs: t (DBL_MAX when no hit, ray/intersection.hpp:14), surface index (0xFFFFFFFF when
+ * no hit), uv[2] (meaningful when the surface interpolates normals). */
+int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double* direction,
+                   double* out_t, uint32_t* out_surface, double* out_uv);
+
+/* Sampler (sampling/sampler.hpp:13-90): for each (pixel[i], index[i]) runs initiate(pixel),
+ * setIndex(index), then `shuffles` times shuffle(); writes get<0,7>() after the last step
+ * (shuffles == 0 gives the un-shuffled camera dimensions). out[n][7]. */
+int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_t* index,
+                 uint32_t shuffles, uint32_t global_seed, double* out);
+
+/* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map
+ * (which = 0 global, 1 caustic) for n query points p[n][3]. Outputs per query: count found
+ * (≤ k), photon indices and squared distances sorted by ascending distance (ties by index),
+ * each [n][k]; unused slots get 0xFFFFFFFF / +inf. */
+int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k,
+             uint32_t* out_count, uint32_t* out_index, double* out_distance2);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene-image files (*.mcrt): a flat dump of the three descriptors above, written by the
+ * flattener that runs inside the reference host and read by stand-alone hosts.
+ * Host-only helpers; they never touch the GPU.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mcrt_image mcrt_image; /* opaque; owns the host arrays the descs point into */
+
+int  mcrt_image_load(const char* path, mcrt_image** out);
+void mcrt_image_free(mcrt_image* img);
+const mcrt_scene_desc*      mcrt_image_scene(const mcrt_image* img);
+const mcrt_camera_desc*     mcrt_image_camera(const mcrt_image* img);
+const mcrt_photon_map_desc* mcrt_image_photons(const mcrt_image* img, int which /*0 global,1 caustic*/);
+/* key = "k_nearest_photons" | "direct_visualization" | "global_seed" | "photon_mapping"; 0 if absent */
+uint64_t mcrt_image_param(const mcrt_image* img, const char* key);
+int mcrt_image_save(const char* path, const mcrt_scene_desc* scene, const mcrt_camera_desc* cam,
+                    const mcrt_photon_map_desc* global_map, const mcrt_photon_map_desc* caustic_map,
+                    const char* const* param_keys, const uint64_t* param_values, uint32_t num_params);
+
+uint32_t mcrt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCRT_H */

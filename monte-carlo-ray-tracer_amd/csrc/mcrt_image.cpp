@@ -1,0 +1,260 @@
+// Scene-image (*.mcrt) reader/writer: a flat, chunked dump of mcrt_scene_desc / mcrt_camera_desc /
+// mcrt_photon_map_desc (include/mcrt.h). Host-only; compiled into libmcrt_hip.so and linked by the
+// flattener that runs inside the reference host (oracle/ref_main.cpp).
+//
+// Layout: "MCRTIMG1" | u32 abi | u32 num_chunks | { char name[24]; u64 nbytes; data; pad to 8 }*
+#include "../../include/mcrt.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Chunk {
+    std::vector<unsigned char> bytes;
+};
+
+const char kMagic[8] = {'M', 'C', 'R', 'T', 'I', 'M', 'G', '1'};
+
+struct ParamKV {
+    char key[24];
+    uint64_t value;
+};
+
+}  // namespace
+
+struct mcrt_image {
+    std::map<std::string, Chunk> chunks;
+    mcrt_scene_desc scene;
+    mcrt_camera_desc camera;
+    mcrt_photon_map_desc maps[2];
+    bool has_map[2];
+    std::map<std::string, uint64_t> params;
+};
+
+namespace {
+
+template <class T>
+const T* chunkPtr(const mcrt_image* img, const char* name, size_t* count = nullptr) {
+    auto it = img->chunks.find(name);
+    if (it == img->chunks.end() || it->second.bytes.empty()) {
+        if (count) *count = 0;
+        return nullptr;
+    }
+    if (count) *count = it->second.bytes.size() / sizeof(T);
+    return reinterpret_cast<const T*>(it->second.bytes.data());
+}
+
+bool loadMap(mcrt_image* img, const char* prefix, mcrt_photon_map_desc* m) {
+    std::string p(prefix);
+    size_t n_oct = 0, n_ph = 0;
+    memset(m, 0, sizeof(*m));
+    m->octant_bounds = chunkPtr<double>(img, (p + "oct_bounds").c_str(), &n_oct);
+    if (!m->octant_bounds) return false;
+    m->num_octants = (uint32_t)(n_oct / 6);
+    m->octant_start_data = chunkPtr<uint64_t>(img, (p + "oct_start").c_str());
+    m->octant_contained_data = chunkPtr<uint64_t>(img, (p + "oct_contained").c_str());
+    m->octant_next_sibling = chunkPtr<uint32_t>(img, (p + "oct_next").c_str());
+    m->octant_leaf = chunkPtr<uint8_t>(img, (p + "oct_leaf").c_str());
+    m->photons = chunkPtr<float>(img, (p + "photons").c_str(), &n_ph);
+    m->num_photons = n_ph / 8;
+    return m->octant_start_data && m->octant_contained_data && m->octant_next_sibling &&
+           m->octant_leaf && m->photons;
+}
+
+struct Writer {
+    FILE* f;
+    uint32_t count = 0;
+    bool ok = true;
+    void put(const char* name, const void* data, size_t nbytes) {
+        if (!data || nbytes == 0) return;
+        char nm[24];
+        memset(nm, 0, sizeof(nm));
+        strncpy(nm, name, sizeof(nm) - 1);
+        uint64_t nb = nbytes;
+        ok = ok && fwrite(nm, 1, sizeof(nm), f) == sizeof(nm);
+        ok = ok && fwrite(&nb, sizeof(nb), 1, f) == 1;
+        ok = ok && fwrite(data, 1, nbytes, f) == nbytes;
+        static const char zeros[8] = {0};
+        size_t pad = (8 - nbytes % 8) % 8;
+        if (pad) ok = ok && fwrite(zeros, 1, pad, f) == pad;
+        count++;
+    }
+};
+
+void writeMap(Writer& w, const char* prefix, const mcrt_photon_map_desc* m) {
+    if (!m || m->num_octants == 0) return;
+    std::string p(prefix);
+    size_t n = m->num_octants;
+    w.put((p + "oct_bounds").c_str(), m->octant_bounds, n * 6 * sizeof(double));
+    w.put((p + "oct_start").c_str(), m->octant_start_data, n * sizeof(uint64_t));
+    w.put((p + "oct_contained").c_str(), m->octant_contained_data, n * sizeof(uint64_t));
+    w.put((p + "oct_next").c_str(), m->octant_next_sibling, n * sizeof(uint32_t));
+    w.put((p + "oct_leaf").c_str(), m->octant_leaf, n * sizeof(uint8_t));
+    w.put((p + "photons").c_str(), m->photons, (size_t)m->num_photons * 8 * sizeof(float));
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mcrt_abi_version(void) { return MCRT_ABI_VERSION; }
+
+int mcrt_image_load(const char* path, mcrt_image** out) {
+    if (!path || !out) return MCRT_ERR_INVALID;
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MCRT_ERR_IO;
+    char magic[8];
+    uint32_t abi = 0, num_chunks = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0;
+    ok = ok && fread(&abi, 4, 1, f) == 1 && fread(&num_chunks, 4, 1, f) == 1;
+    if (!ok || abi != MCRT_ABI_VERSION) {
+        fclose(f);
+        return MCRT_ERR_IO;
+    }
+    mcrt_image* img = new mcrt_image();
+    for (uint32_t c = 0; c < num_chunks && ok; c++) {
+        char nm[25];
+        uint64_t nb = 0;
+        memset(nm, 0, sizeof(nm));
+        ok = fread(nm, 1, 24, f) == 24 && fread(&nb, 8, 1, f) == 1;
+        if (!ok) break;
+        Chunk& ch = img->chunks[nm];
+        ch.bytes.resize(nb);
+        ok = nb == 0 || fread(ch.bytes.data(), 1, nb, f) == nb;
+        size_t pad = (8 - nb % 8) % 8;
+        if (ok && pad) ok = fseek(f, (long)pad, SEEK_CUR) == 0;
+    }
+    fclose(f);
+    if (!ok) {
+        delete img;
+        return MCRT_ERR_IO;
+    }
+
+    mcrt_scene_desc& s = img->scene;
+    memset(&s, 0, sizeof(s));
+    s.abi_version = MCRT_ABI_VERSION;
+    size_t n = 0;
+    s.node_bounds = chunkPtr<double>(img, "node_bounds", &n);
+    s.num_nodes = (uint32_t)(n / 6);
+    s.node_start_surface = chunkPtr<uint32_t>(img, "node_start");
+    s.node_num_surfaces = chunkPtr<uint32_t>(img, "node_count");
+    s.node_next_sibling = chunkPtr<uint32_t>(img, "node_next");
+    s.surf_kind = chunkPtr<uint8_t>(img, "surf_kind", &n);
+    s.num_surfaces = (uint32_t)n;
+    s.surf_interpolate = chunkPtr<uint8_t>(img, "surf_interp");
+    s.surf_material = chunkPtr<uint32_t>(img, "surf_material");
+    s.surf_area = chunkPtr<double>(img, "surf_area");
+    s.surf_v = chunkPtr<double>(img, "surf_v");
+    s.surf_e = chunkPtr<double>(img, "surf_e");
+    s.surf_vn = chunkPtr<double>(img, "surf_vn");
+    s.materials = chunkPtr<mcrt_material>(img, "materials", &n);
+    s.num_materials = (uint32_t)n;
+    s.light_surface = chunkPtr<uint32_t>(img, "light_surface", &n);
+    s.num_lights = (uint32_t)n;
+    s.light_cdf = chunkPtr<double>(img, "light_cdf");
+    const double* sc = chunkPtr<double>(img, "scene_scalars", &n);
+    if (sc && n >= 7) {
+        s.scene_ior = sc[0];
+        for (int i = 0; i < 3; i++) {
+            s.bb_min[i] = sc[1 + i];
+            s.bb_max[i] = sc[4 + i];
+        }
+    }
+    const mcrt_camera_desc* cam = chunkPtr<mcrt_camera_desc>(img, "camera", &n);
+    if (cam && n >= 1) img->camera = *cam;
+    else memset(&img->camera, 0, sizeof(img->camera));
+    img->has_map[0] = loadMap(img, "g_", &img->maps[0]);
+    img->has_map[1] = loadMap(img, "c_", &img->maps[1]);
+    const ParamKV* kv = chunkPtr<ParamKV>(img, "params", &n);
+    for (size_t i = 0; kv && i < n; i++) {
+        char key[25];
+        memset(key, 0, sizeof(key));
+        memcpy(key, kv[i].key, 24);
+        img->params[key] = kv[i].value;
+    }
+    bool scene_ok = s.num_surfaces > 0 && s.surf_kind && s.surf_interpolate && s.surf_material &&
+                    s.surf_area && s.surf_v && s.surf_e && s.materials &&
+                    (s.num_nodes == 0 ||
+                     (s.node_start_surface && s.node_num_surfaces && s.node_next_sibling)) &&
+                    (s.num_lights == 0 || s.light_cdf);
+    if (!scene_ok) {
+        delete img;
+        return MCRT_ERR_IO;
+    }
+    *out = img;
+    return MCRT_OK;
+}
+
+void mcrt_image_free(mcrt_image* img) { delete img; }
+
+const mcrt_scene_desc* mcrt_image_scene(const mcrt_image* img) { return img ? &img->scene : nullptr; }
+
+const mcrt_camera_desc* mcrt_image_camera(const mcrt_image* img) {
+    return img ? &img->camera : nullptr;
+}
+
+const mcrt_photon_map_desc* mcrt_image_photons(const mcrt_image* img, int which) {
+    if (!img || which < 0 || which > 1 || !img->has_map[which]) return nullptr;
+    return &img->maps[which];
+}
+
+uint64_t mcrt_image_param(const mcrt_image* img, const char* key) {
+    if (!img || !key) return 0;
+    auto it = img->params.find(key);
+    return it == img->params.end() ? 0 : it->second;
+}
+
+int mcrt_image_save(const char* path, const mcrt_scene_desc* s, const mcrt_camera_desc* cam,
+                    const mcrt_photon_map_desc* global_map, const mcrt_photon_map_desc* caustic_map,
+                    const char* const* param_keys, const uint64_t* param_values,
+                    uint32_t num_params) {
+    if (!path || !s) return MCRT_ERR_INVALID;
+    FILE* f = fopen(path, "wb");
+    if (!f) return MCRT_ERR_IO;
+    uint32_t abi = MCRT_ABI_VERSION, zero = 0;
+    fwrite(kMagic, 1, 8, f);
+    fwrite(&abi, 4, 1, f);
+    fwrite(&zero, 4, 1, f);  // chunk count patched below
+    Writer w{f};
+    size_t nn = s->num_nodes, ns = s->num_surfaces;
+    w.put("node_bounds", s->node_bounds, nn * 6 * sizeof(double));
+    w.put("node_start", s->node_start_surface, nn * sizeof(uint32_t));
+    w.put("node_count", s->node_num_surfaces, nn * sizeof(uint32_t));
+    w.put("node_next", s->node_next_sibling, nn * sizeof(uint32_t));
+    w.put("surf_kind", s->surf_kind, ns);
+    w.put("surf_interp", s->surf_interpolate, ns);
+    w.put("surf_material", s->surf_material, ns * sizeof(uint32_t));
+    w.put("surf_area", s->surf_area, ns * sizeof(double));
+    w.put("surf_v", s->surf_v, ns * 9 * sizeof(double));
+    w.put("surf_e", s->surf_e, ns * 9 * sizeof(double));
+    w.put("surf_vn", s->surf_vn, ns * 9 * sizeof(double));
+    w.put("materials", s->materials, (size_t)s->num_materials * sizeof(mcrt_material));
+    w.put("light_surface", s->light_surface, (size_t)s->num_lights * sizeof(uint32_t));
+    w.put("light_cdf", s->light_cdf, (size_t)s->num_lights * sizeof(double));
+    double sc[7] = {s->scene_ior, s->bb_min[0], s->bb_min[1], s->bb_min[2],
+                    s->bb_max[0], s->bb_max[1], s->bb_max[2]};
+    w.put("scene_scalars", sc, sizeof(sc));
+    if (cam) w.put("camera", cam, sizeof(*cam));
+    writeMap(w, "g_", global_map);
+    writeMap(w, "c_", caustic_map);
+    if (num_params && param_keys && param_values) {
+        std::vector<ParamKV> kv(num_params);
+        for (uint32_t i = 0; i < num_params; i++) {
+            memset(&kv[i], 0, sizeof(ParamKV));
+            strncpy(kv[i].key, param_keys[i], 23);
+            kv[i].value = param_values[i];
+        }
+        w.put("params", kv.data(), kv.size() * sizeof(ParamKV));
+    }
+    bool ok = w.ok && fseek(f, 12, SEEK_SET) == 0 && fwrite(&w.count, 4, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MCRT_OK : MCRT_ERR_IO;
+}
+
+}  // extern "C"

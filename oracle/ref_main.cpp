@@ -1,0 +1,584 @@
+// oracle/ref_main.cpp — TEST INFRASTRUCTURE ONLY (never linked into or called by the product path).
+//
+// Host program that links the UNMODIFIED reference translation units (compiled in place from
+// /root/reference/source by oracle/Makefile, with oracle/ref_seed_pin.hpp force-included) and
+//   1. "flatten": walks the reference's Scene / BVH / LinearOctree / Camera objects and writes the
+//      scene image (*.mcrt) that include/mcrt.h's descriptors describe — this is exactly the
+//      flattener a maintainer adds to the reference host;
+//   2. "render":  runs the reference's own Camera::samplePixel (camera/camera.cpp:66-99) over a row
+//      range with the reference's 32x32 bucket work split and dumps camera.film.scan(x,y) as FP64
+//      (the value Camera::sampleImage stores into camera.image, camera.cpp:138-144), timing only
+//      the worker section (the reference's own timer is quantised to 1 s, camera.cpp:131,224);
+//   3. "kat":     calls individual reference functions on seeded random inputs and dumps
+//      known-answer vectors (the reference has no tests of its own).
+//
+// Private members are reached with -fno-access-control (this TU only; layout is unaffected).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <thread>
+#include <unordered_map>
+
+#include <glm/glm.hpp>
+#include <glm/gtx/norm.hpp>
+#include <nlohmann/json.hpp>
+
+#include "bvh/bvh.hpp"
+#include "camera/camera.hpp"
+#include "common/coordinate-system.hpp"
+#include "common/option.hpp"
+#include "integrator/integrator.hpp"
+#include "integrator/path-tracer/path-tracer.hpp"
+#include "integrator/photon-mapper/photon-mapper.hpp"
+#include "material/fresnel.hpp"
+#include "material/ggx.hpp"
+#include "material/material.hpp"
+#include "octree/linear-octree.cpp"  // template bodies (the reference includes them the same way)
+#include "octree/octree.cpp"
+#include "ray/interaction.hpp"
+#include "sampling/sampler.hpp"
+#include "sampling/sampling.hpp"
+#include "scene/scene.hpp"
+#include "surface/surface.hpp"
+
+#include "../include/mcrt.h"
+
+namespace {
+
+struct Args {
+    std::string mode, scene, out, out_samples;
+    int camera = 0;
+    bool photon = false;
+    long width = -1, height = -1, sqrtspp = -1, threads = -1;
+    long row0 = 0, row1 = -1;
+    double emissions = -1, caustic_factor = -1;
+    long knn_k = -1;
+    std::string bvh;
+    long bins = -1;
+    long n = 100000;
+    std::vector<std::pair<std::string, double>> rough;  // material specular_roughness overrides
+};
+
+[[noreturn]] void usage() {
+    std::fprintf(stderr,
+        "usage: mcrt_ref <flatten|render|kat> --scene file.json [--camera N] [--photon]\n"
+        "   [--width W --height H --sqrtspp S] [--bvh octree|binary_sah|quaternary_sah] [--bins B]\n"
+        "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K]\n"
+        "   [--specular-roughness material value]... [--n N] --out path [--out-samples path]\n");
+    std::exit(2);
+}
+
+Args parse(int argc, char** argv) {
+    Args a;
+    if (argc < 2) usage();
+    a.mode = argv[1];
+    for (int i = 2; i < argc; i++) {
+        std::string k = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) usage(); return argv[++i]; };
+        if (k == "--scene") a.scene = next();
+        else if (k == "--out") a.out = next();
+        else if (k == "--out-samples") a.out_samples = next();
+        else if (k == "--camera") a.camera = std::stoi(next());
+        else if (k == "--photon") a.photon = true;
+        else if (k == "--width") a.width = std::stol(next());
+        else if (k == "--height") a.height = std::stol(next());
+        else if (k == "--sqrtspp") a.sqrtspp = std::stol(next());
+        else if (k == "--threads") a.threads = std::stol(next());
+        else if (k == "--rows") { a.row0 = std::stol(next()); a.row1 = std::stol(next()); }
+        else if (k == "--emissions") a.emissions = std::stod(next());
+        else if (k == "--caustic-factor") a.caustic_factor = std::stod(next());
+        else if (k == "--k") a.knn_k = std::stol(next());
+        else if (k == "--bvh") a.bvh = next();
+        else if (k == "--bins") a.bins = std::stol(next());
+        else if (k == "--n") a.n = std::stol(next());
+        else if (k == "--specular-roughness") { std::string m = next(); a.rough.push_back({m, std::stod(next())}); }
+        else usage();
+    }
+    if (a.scene.empty() || a.out.empty()) usage();
+    return a;
+}
+
+nlohmann::json loadScene(const Args& a) {
+    std::ifstream f(a.scene);
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", a.scene.c_str()); std::exit(1); }
+    nlohmann::json j;
+    f >> j;
+    auto& cam = j.at("cameras").at(a.camera);
+    if (a.width > 0) cam["image"]["width"] = a.width;
+    if (a.height > 0) cam["image"]["height"] = a.height;
+    if (a.sqrtspp > 0) cam["sqrtspp"] = a.sqrtspp;
+    if (a.threads > 0) j["num_render_threads"] = a.threads;
+    if (!a.bvh.empty()) {
+        if (a.bvh == "none") j.erase("bvh");
+        else j["bvh"] = {{"type", a.bvh}};
+        if (a.bins > 0 && a.bvh != "none") j["bvh"]["bins_per_axis"] = a.bins;
+    }
+    if (a.emissions > 0) j["photon_map"]["emissions"] = a.emissions;
+    if (a.caustic_factor > 0) j["photon_map"]["caustic_factor"] = a.caustic_factor;
+    if (a.knn_k > 0) j["photon_map"]["k_nearest_photons"] = a.knn_k;
+    for (const auto& r : a.rough) j["materials"][r.first]["specular_roughness"] = r.second;
+    Scene::path = std::filesystem::absolute(std::filesystem::path(a.scene)).parent_path();
+    return j;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flatten
+// ---------------------------------------------------------------------------------------------
+struct Flat {
+    std::vector<double> node_bounds;
+    std::vector<uint32_t> node_start, node_count, node_next;
+    std::vector<uint8_t> kind, interp;
+    std::vector<uint32_t> surf_material;
+    std::vector<double> area, v, e, vn;
+    std::vector<mcrt_material> materials;
+    std::vector<uint32_t> light_surface;
+    std::vector<double> light_cdf;
+    std::unordered_map<const Surface::Base*, uint32_t> index;
+    mcrt_scene_desc desc;
+};
+
+void put3(std::vector<double>& dst, const glm::dvec3& x) { dst.push_back(x.x); dst.push_back(x.y); dst.push_back(x.z); }
+
+void flattenScene(const Scene& scene, Flat& F) {
+    const std::vector<std::shared_ptr<Surface::Base>>* ordered = &scene.surfaces;
+    if (scene.bvh) {
+        const BVH& bvh = *scene.bvh;
+        ordered = &bvh.ordered_surfaces;
+        for (const auto& n : bvh.linear_tree) {
+            put3(F.node_bounds, n.BB.min);
+            put3(F.node_bounds, n.BB.max);
+            F.node_start.push_back(n.start_surface);
+            F.node_count.push_back(n.num_surfaces);
+            F.node_next.push_back(n.next_sibling);
+        }
+    }
+    std::unordered_map<const Material*, uint32_t> mat_index;
+    bool any_vn = false;
+    for (const auto& sp : *ordered) {
+        const Surface::Base* s = sp.get();
+        F.index[s] = (uint32_t)F.kind.size();
+        const Material* m = s->material.get();
+        auto it = mat_index.find(m);
+        if (it == mat_index.end()) {
+            mcrt_material mm;
+            std::memset(&mm, 0, sizeof(mm));
+            for (int c = 0; c < 3; c++) {
+                mm.reflectance[c] = m->reflectance[c];
+                mm.specular_reflectance[c] = m->specular_reflectance[c];
+                mm.transmittance[c] = m->transmittance[c];
+                mm.emittance[c] = m->emittance[c];
+                if (m->complex_ior) {
+                    mm.ior_real[c] = m->complex_ior->real[c];
+                    mm.ior_imag[c] = m->complex_ior->imaginary[c];
+                }
+            }
+            mm.roughness = m->roughness;
+            mm.specular_roughness = m->specular_roughness;
+            mm.ior = m->ior;
+            mm.transparency = m->transparency;
+            mm.A = m->A;
+            mm.B = m->B;
+            mm.a[0] = m->a.x;
+            mm.a[1] = m->a.y;
+            mm.flags = (m->rough ? MCRT_MAT_ROUGH : 0) | (m->rough_specular ? MCRT_MAT_ROUGH_SPECULAR : 0) |
+                       (m->opaque ? MCRT_MAT_OPAQUE : 0) | (m->emissive ? MCRT_MAT_EMISSIVE : 0) |
+                       (m->dirac_delta ? MCRT_MAT_DIRAC_DELTA : 0) |
+                       (m->perfect_mirror ? MCRT_MAT_PERFECT_MIRROR : 0) |
+                       (m->complex_ior ? MCRT_MAT_COMPLEX_IOR : 0);
+            it = mat_index.emplace(m, (uint32_t)F.materials.size()).first;
+            F.materials.push_back(mm);
+        }
+        F.surf_material.push_back(it->second);
+        F.area.push_back(s->area_);
+        if (auto t = dynamic_cast<const Surface::Triangle*>(s)) {
+            F.kind.push_back(MCRT_SURF_TRIANGLE);
+            put3(F.v, t->v0); put3(F.v, t->v1); put3(F.v, t->v2);
+            put3(F.e, t->E1); put3(F.e, t->E2); put3(F.e, t->normal_);
+            if (t->N) {
+                any_vn = true;
+                F.interp.push_back(1);
+                put3(F.vn, (*t->N)[0]); put3(F.vn, (*t->N)[1]); put3(F.vn, (*t->N)[2]);
+            } else {
+                F.interp.push_back(0);
+                for (int i = 0; i < 9; i++) F.vn.push_back(0.0);
+            }
+        } else if (auto sph = dynamic_cast<const Surface::Sphere*>(s)) {
+            F.kind.push_back(MCRT_SURF_SPHERE);
+            F.interp.push_back(0);
+            put3(F.v, sph->origin);
+            F.v.push_back(sph->radius);
+            for (int i = 0; i < 5; i++) F.v.push_back(0.0);
+            for (int i = 0; i < 9; i++) { F.e.push_back(0.0); F.vn.push_back(0.0); }
+        } else {
+            std::fprintf(stderr, "flatten: unsupported surface type (quadric)\n");
+            std::exit(3);
+        }
+    }
+    for (size_t i = 0; i < scene.emissives.size(); i++) {
+        F.light_surface.push_back(F.index.at(scene.emissives[i].get()));
+        F.light_cdf.push_back(scene.cumulative_emissives_importance[i]);
+    }
+    mcrt_scene_desc& d = F.desc;
+    std::memset(&d, 0, sizeof(d));
+    d.abi_version = MCRT_ABI_VERSION;
+    d.num_nodes = (uint32_t)F.node_start.size();
+    d.node_bounds = F.node_bounds.data();
+    d.node_start_surface = F.node_start.data();
+    d.node_num_surfaces = F.node_count.data();
+    d.node_next_sibling = F.node_next.data();
+    d.num_surfaces = (uint32_t)F.kind.size();
+    d.surf_kind = F.kind.data();
+    d.surf_interpolate = F.interp.data();
+    d.surf_material = F.surf_material.data();
+    d.surf_area = F.area.data();
+    d.surf_v = F.v.data();
+    d.surf_e = F.e.data();
+    d.surf_vn = any_vn ? F.vn.data() : nullptr;
+    d.num_materials = (uint32_t)F.materials.size();
+    d.materials = F.materials.data();
+    d.num_lights = (uint32_t)F.light_surface.size();
+    d.light_surface = F.light_surface.data();
+    d.light_cdf = F.light_cdf.data();
+    d.scene_ior = scene.ior;
+    BoundingBox bb = scene.BB();
+    for (int c = 0; c < 3; c++) { d.bb_min[c] = bb.min[c]; d.bb_max[c] = bb.max[c]; }
+}
+
+struct FlatMap {
+    std::vector<double> bounds;
+    std::vector<uint64_t> start, contained;
+    std::vector<uint32_t> next;
+    std::vector<uint8_t> leaf;
+    std::vector<float> photons;
+    mcrt_photon_map_desc desc;
+};
+
+void flattenMap(const LinearOctree<Photon>& map, FlatMap& M) {
+    for (const auto& o : map.linear_tree) {
+        put3(M.bounds, o.BB.min);
+        put3(M.bounds, o.BB.max);
+        M.start.push_back(o.start_data);
+        M.contained.push_back(o.contained_data);
+        M.next.push_back(o.next_sibling);
+        M.leaf.push_back(o.leaf);
+    }
+    M.photons.resize(map.ordered_data.size() * 8);
+    for (size_t i = 0; i < map.ordered_data.size(); i++) {
+        const Photon& p = map.ordered_data[i];
+        float* o = &M.photons[i * 8];
+        o[0] = p.flux_.x; o[1] = p.flux_.y; o[2] = p.flux_.z;
+        o[3] = p.position_.x; o[4] = p.position_.y; o[5] = p.position_.z;
+        o[6] = p.phi; o[7] = p.theta;
+    }
+    std::memset(&M.desc, 0, sizeof(M.desc));
+    M.desc.num_octants = (uint32_t)M.start.size();
+    M.desc.octant_bounds = M.bounds.data();
+    M.desc.octant_start_data = M.start.data();
+    M.desc.octant_contained_data = M.contained.data();
+    M.desc.octant_next_sibling = M.next.data();
+    M.desc.octant_leaf = M.leaf.data();
+    M.desc.num_photons = map.ordered_data.size();
+    M.desc.photons = M.photons.data();
+}
+
+mcrt_camera_desc flattenCamera(const Camera& c) {
+    mcrt_camera_desc d;
+    std::memset(&d, 0, sizeof(d));
+    for (int i = 0; i < 3; i++) {
+        d.eye[i] = c.eye[i]; d.forward[i] = c.forward[i]; d.left[i] = c.left[i]; d.up[i] = c.up[i];
+    }
+    d.focal_length = c.focal_length;
+    d.sensor_width = c.sensor_width;
+    d.aperture_radius = c.aperture_radius;
+    d.focus_distance = c.focus_distance;
+    d.thin_lens = c.thin_lens ? 1 : 0;
+    d.width = (uint32_t)c.image.width;
+    d.height = (uint32_t)c.image.height;
+    d.sqrtspp = (uint32_t)c.sqrtspp;
+    d.shard_index = 0; d.shard_count = 1; d.shard_rows = 1;
+    return d;
+}
+
+void writeRaw(const std::string& path, const void* data, size_t nbytes) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f || std::fwrite(data, 1, nbytes, f) != nbytes) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(1); }
+    std::fclose(f);
+}
+
+int doFlatten(const Args& a, Camera& camera) {
+    Flat F;
+    flattenScene(camera.integrator->scene, F);
+    mcrt_camera_desc cd = flattenCamera(camera);
+    FlatMap G, C;
+    const mcrt_photon_map_desc *gp = nullptr, *cp = nullptr;
+    std::vector<const char*> keys = {"global_seed", "photon_mapping"};
+    std::vector<uint64_t> vals = {Sampler::global_seed, a.photon ? 1u : 0u};
+    if (auto pm = dynamic_cast<PhotonMapper*>(camera.integrator.get())) {
+        flattenMap(pm->global_map, G);
+        flattenMap(pm->caustic_map, C);
+        if (G.desc.num_octants) gp = &G.desc;
+        if (C.desc.num_octants) cp = &C.desc;
+        keys.push_back("k_nearest_photons"); vals.push_back(pm->k_nearest_photons);
+        keys.push_back("direct_visualization"); vals.push_back(pm->direct_visualization ? 1 : 0);
+    }
+    int rc = mcrt_image_save(a.out.c_str(), &F.desc, &cd, gp, cp, keys.data(), vals.data(), (uint32_t)keys.size());
+    std::printf("flatten: %u nodes, %u surfaces, %u materials, %u lights, photons g=%llu c=%llu -> %s (rc=%d)\n",
+                F.desc.num_nodes, F.desc.num_surfaces, F.desc.num_materials, F.desc.num_lights,
+                (unsigned long long)G.desc.num_photons, (unsigned long long)C.desc.num_photons, a.out.c_str(), rc);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// render (reference Camera::samplePixel over a row range)
+// ---------------------------------------------------------------------------------------------
+int doRender(const Args& a, Camera& camera) {
+    const long W = (long)camera.image.width, H = (long)camera.image.height;
+    long y0 = a.row0, y1 = a.row1 < 0 ? H : std::min(a.row1, H);
+    const long B = 32;  // Camera::bucket_size (camera/camera.hpp:68)
+    struct Bucket { long x0, x1, y0, y1; };
+    std::vector<Bucket> buckets;
+    for (long x = 0; x < W; x += B)
+        for (long y = y0; y < y1; y += B)
+            buckets.push_back({x, std::min(x + B, W), y, std::min(y + B, y1)});
+    std::atomic<size_t> next{0};
+    size_t nthreads = camera.integrator->num_threads;
+
+    std::vector<double> samples;
+    const size_t spp = camera.sqrtspp * camera.sqrtspp;
+    const bool per_sample = !a.out_samples.empty();
+    if (per_sample) samples.assign((size_t)W * (y1 - y0) * spp * 3, 0.0);
+
+    auto worker = [&]() {
+        size_t b;
+        while ((b = next.fetch_add(1)) < buckets.size()) {
+            const Bucket& k = buckets[b];
+            for (long y = k.y0; y < k.y1; y++)
+                for (long x = k.x0; x < k.x1; x++) {
+                    if (!per_sample) {
+                        camera.samplePixel((size_t)x, (size_t)y);
+                    } else {
+                        // Same statements as Camera::samplePixel (camera.cpp:66-99), but keeping each
+                        // sample's radiance; pinhole only (asserted below).
+                        double pixel_size = camera.sensor_width / camera.image.width;
+                        glm::dvec2 half_dim = glm::dvec2(camera.image.width, camera.image.height) * 0.5;
+                        Sampler::initiate(static_cast<uint32_t>(y * camera.image.width + x));
+                        for (size_t i = 0; i < spp; i++) {
+                            Sampler::setIndex((uint32_t)i);
+                            auto u = Sampler::get<Dim::PIXEL, 2>();
+                            glm::dvec2 px(x + u[0], y + u[1]);
+                            glm::dvec2 local = pixel_size * (half_dim - px);
+                            glm::dvec3 direction = glm::normalize(camera.forward * camera.focal_length + camera.left * local.x + camera.up * local.y);
+                            Ray ray(camera.eye, direction, camera.integrator->scene.ior);
+                            glm::dvec3 L = camera.integrator->sampleRay(ray);
+                            camera.film.deposit(px, L);
+                            double* o = &samples[(((size_t)(y - y0) * W + x) * spp + i) * 3];
+                            o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                        }
+                    }
+                }
+        }
+    };
+    if (per_sample && camera.thin_lens) { std::fprintf(stderr, "--out-samples supports pinhole cameras only\n"); return 3; }
+
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; t++) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+
+    std::vector<double> out((size_t)W * (y1 - y0) * 3);
+    for (long y = y0; y < y1; y++)
+        for (long x = 0; x < W; x++) {
+            glm::dvec3 c = camera.film.scan((size_t)x, (size_t)y);
+            double* o = &out[((size_t)(y - y0) * W + x) * 3];
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        }
+    writeRaw(a.out, out.data(), out.size() * sizeof(double));
+    if (per_sample) writeRaw(a.out_samples, samples.data(), samples.size() * sizeof(double));
+    double paths = (double)W * (y1 - y0) * spp;
+    std::printf("{\"mode\":\"render\",\"width\":%ld,\"rows\":[%ld,%ld],\"spp\":%zu,\"threads\":%zu,"
+                "\"paths\":%.0f,\"seconds\":%.6f,\"paths_per_s\":%.1f,\"seed\":%u}\n",
+                W, y0, y1, spp, nthreads, paths, sec, paths / sec, Sampler::global_seed);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kat: known-answer vectors from individual reference functions
+// ---------------------------------------------------------------------------------------------
+struct Rng {  // splitmix64; the tests regenerate the same inputs from the dumped arrays, not from this
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() { uint64_t z = (s += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+    double uni() { return (next() >> 11) * 0x1p-53; }
+    double range(double a, double b) { return a + (b - a) * uni(); }
+};
+
+glm::dvec3 randDir(Rng& r) {
+    double z = r.range(-1, 1), phi = r.range(0, 6.283185307179586);
+    double s = std::sqrt(1 - z * z);
+    return glm::dvec3(s * std::cos(phi), s * std::sin(phi), z);
+}
+
+int doKat(const Args& a, Camera& camera) {
+    std::string dir = a.out;
+    std::filesystem::create_directories(dir);
+    const Scene& scene = camera.integrator->scene;
+    Flat F;
+    flattenScene(scene, F);
+    const size_t N = (size_t)a.n;
+    Rng rng(0xC0FFEE);
+
+    {   // Sampler (sampling/sampler.hpp): (pixel, index, shuffles) -> get<0,7>()
+        const size_t n = 4096;
+        std::vector<uint32_t> in(n * 3);
+        std::vector<double> out(n * 7);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t pixel = i < 8 ? (uint32_t[]){0, 0, 0, 12345, 2073599, 1, 65535, 0xFFFFFFFFu}[i] : (uint32_t)(rng.next() % 8294400ull);
+            uint32_t index = i < 8 ? (uint32_t[]){0, 1, 255, 0, 1, 1023, 7, 0xFFFFFFFFu}[i] : (uint32_t)(rng.next() % 1024ull);
+            uint32_t shuffles = (uint32_t)(i % 5);
+            in[i * 3] = pixel; in[i * 3 + 1] = index; in[i * 3 + 2] = shuffles;
+            Sampler::initiate(pixel);
+            Sampler::setIndex(index);
+            for (uint32_t s = 0; s < shuffles; s++) Sampler::shuffle();
+            auto u = Sampler::get<0, 7>();
+            for (int d = 0; d < 7; d++) out[i * 7 + d] = u[d];
+        }
+        writeRaw(dir + "/sampler_in.u32", in.data(), in.size() * 4);
+        writeRaw(dir + "/sampler_out.f64", out.data(), out.size() * 8);
+    }
+    {   // Scene::intersect (scene/scene.cpp:151-176) on random rays
+        BoundingBox bb = scene.BB();
+        std::vector<double> rays(N * 6), t(N), uv(N * 2);
+        std::vector<uint32_t> surf(N);
+        for (size_t i = 0; i < N; i++) {
+            glm::dvec3 o(rng.range(bb.min.x, bb.max.x), rng.range(bb.min.y, bb.max.y), rng.range(bb.min.z, bb.max.z));
+            glm::dvec3 d = randDir(rng);
+            if (i % 7 == 0) { o = camera.eye; }
+            if (i % 97 == 0) { d = glm::dvec3(0); d[(i / 97) % 3] = (i & 1) ? 1.0 : -1.0; }  // axis-parallel: inf/NaN slabs
+            Ray ray(o, d, 1.0);
+            Intersection is = scene.intersect(ray);
+            for (int c = 0; c < 3; c++) { rays[i * 6 + c] = o[c]; rays[i * 6 + 3 + c] = d[c]; }
+            t[i] = is.t;
+            surf[i] = is ? F.index.at(is.surface.get()) : 0xFFFFFFFFu;
+            uv[i * 2] = is.interpolate ? is.uv.x : 0.0;
+            uv[i * 2 + 1] = is.interpolate ? is.uv.y : 0.0;
+        }
+        writeRaw(dir + "/isect_rays.f64", rays.data(), rays.size() * 8);
+        writeRaw(dir + "/isect_t.f64", t.data(), t.size() * 8);
+        writeRaw(dir + "/isect_surface.u32", surf.data(), surf.size() * 4);
+        writeRaw(dir + "/isect_uv.f64", uv.data(), uv.size() * 8);
+    }
+    {   // Fresnel / GGX / Material lobes on random local-frame directions.
+        // in: wi(3) wo(3) n1 n2 alpha u v | out: F_dielectric, conductor(3), GGX refl (f,pdf), GGX trans (f,pdf),
+        //     visibleMicrofacet(3), D(m), Lambda(wo), OrenNayar-diffuse (rgb, pdf)
+        const size_t n = std::min<size_t>(N, 20000);
+        std::vector<double> in(n * 11), out(n * 18);
+        Material rough_mat;
+        rough_mat.roughness = 0.7; rough_mat.reflectance = glm::dvec3(0.8, 0.6, 0.4);
+        rough_mat.computeProperties();
+        ComplexIOR cior(glm::dvec3(0.27, 0.68, 1.32), glm::dvec3(3.6, 2.6, 2.3));
+        writeRaw(dir + "/bsdf_consts.f64", (const double[]){0.7, 0.8, 0.6, 0.4, 0.27, 0.68, 1.32, 3.6, 2.6, 2.3}, 80);
+        for (size_t i = 0; i < n; i++) {
+            glm::dvec3 wo = randDir(rng); wo.z = std::abs(wo.z) + 1e-3; wo = glm::normalize(wo);
+            glm::dvec3 wi = randDir(rng);
+            double n1 = (i & 1) ? 1.0 : rng.range(1.0, 2.5), n2 = rng.range(1.0, 3.5);
+            double alpha = rng.range(0.01, 0.9), u = rng.uni(), v = rng.uni();
+            double* I = &in[i * 11];
+            I[0] = wi.x; I[1] = wi.y; I[2] = wi.z; I[3] = wo.x; I[4] = wo.y; I[5] = wo.z;
+            I[6] = n1; I[7] = n2; I[8] = alpha; I[9] = u; I[10] = v;
+            double* O = &out[i * 18];
+            glm::dvec2 al(alpha);
+            O[0] = Fresnel::dielectric(n1, n2, wo.z);
+            glm::dvec3 fc = Fresnel::conductor(n1, &cior, wo.z);
+            O[1] = fc.x; O[2] = fc.y; O[3] = fc.z;
+            glm::dvec3 wir = wi; wir.z = std::abs(wir.z) + 1e-3; wir = glm::normalize(wir);
+            double pdf;
+            O[4] = GGX::reflection(wir, wo, al, pdf); O[5] = pdf;
+            glm::dvec3 wit = -wir;
+            O[6] = GGX::transmission(wit, wo, n1, n2, al, pdf); O[7] = pdf;
+            glm::dvec3 m = GGX::visibleMicrofacet(u, v, wo, al);
+            O[8] = m.x; O[9] = m.y; O[10] = m.z;
+            O[11] = GGX::D(m, al);
+            O[12] = GGX::Lambda(wo, al);
+            glm::dvec3 d = rough_mat.diffuseReflection(wir, wo, pdf);
+            O[13] = d.x; O[14] = d.y; O[15] = d.z; O[16] = pdf;
+            O[17] = 0.0;
+        }
+        writeRaw(dir + "/bsdf_in.f64", in.data(), in.size() * 8);
+        writeRaw(dir + "/bsdf_out.f64", out.data(), out.size() * 8);
+    }
+    if (auto pm = dynamic_cast<PhotonMapper*>(camera.integrator.get())) {
+        // LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117)
+        const size_t n = std::min<size_t>(N, 20000);
+        const size_t k = pm->k_nearest_photons;
+        BoundingBox bb = scene.BB();
+        for (int which = 0; which < 2; which++) {
+            const LinearOctree<Photon>& map = which ? pm->caustic_map : pm->global_map;
+            if (map.linear_tree.empty()) continue;
+            std::vector<double> pts(n * 3), d2(n * k, std::numeric_limits<double>::infinity());
+            std::vector<uint32_t> cnt(n), idx(n * k, 0xFFFFFFFFu);
+            PriorityQueue<SearchResult<Photon>> res;
+            for (size_t i = 0; i < n; i++) {
+                glm::dvec3 p(rng.range(bb.min.x, bb.max.x), rng.range(bb.min.y, bb.max.y), rng.range(bb.min.z, bb.max.z));
+                if (i % 3 == 0) {  // near a stored photon (the realistic query)
+                    const Photon& ph = map.ordered_data[rng.next() % map.ordered_data.size()];
+                    p = ph.pos() + glm::dvec3(rng.range(-0.05, 0.05), rng.range(-0.05, 0.05), rng.range(-0.05, 0.05));
+                }
+                for (int c = 0; c < 3; c++) pts[i * 3 + c] = p[c];
+                map.knnSearch(p, k, res);
+                // identify photons by their position in ordered_data via exact distance + payload match
+                std::vector<std::pair<double, uint32_t>> found;
+                for (const auto& r : res) {
+                    // linear probe over candidates is too slow; recover index by pointer arithmetic on payload equality
+                    found.push_back({r.distance2, 0});
+                }
+                // brute-force exact k-NN gives the same set (ties measure zero); indices from brute force
+                std::vector<std::pair<double, uint32_t>> all;
+                double worst = 0;
+                for (const auto& f : found) worst = std::max(worst, f.first);
+                for (size_t q = 0; q < map.ordered_data.size(); q++) {
+                    double dd = glm::distance2(map.ordered_data[q].pos(), p);
+                    if (dd <= worst) all.push_back({dd, (uint32_t)q});
+                }
+                std::sort(all.begin(), all.end());
+                std::sort(found.begin(), found.end());
+                if (all.size() != found.size()) {
+                    std::fprintf(stderr, "kat knn: reference returned %zu, brute force within radius %zu (query %zu)\n", found.size(), all.size(), i);
+                }
+                cnt[i] = (uint32_t)found.size();
+                for (size_t q = 0; q < found.size() && q < k; q++) {
+                    d2[i * k + q] = found[q].first;
+                    idx[i * k + q] = q < all.size() ? all[q].second : 0xFFFFFFFFu;
+                }
+            }
+            std::string tag = which ? "c" : "g";
+            writeRaw(dir + "/knn_" + tag + "_points.f64", pts.data(), pts.size() * 8);
+            writeRaw(dir + "/knn_" + tag + "_count.u32", cnt.data(), cnt.size() * 4);
+            writeRaw(dir + "/knn_" + tag + "_index.u32", idx.data(), idx.size() * 4);
+            writeRaw(dir + "/knn_" + tag + "_d2.f64", d2.data(), d2.size() * 8);
+        }
+    }
+    std::printf("kat: wrote vectors to %s\n", dir.c_str());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Args a = parse(argc, argv);
+    try {
+        nlohmann::json j = loadScene(a);
+        Camera camera(j, Option(a.scene, "", a.camera, a.photon));
+        if (a.mode == "flatten") return doFlatten(a, camera);
+        if (a.mode == "render") return doRender(a, camera);
+        if (a.mode == "kat") return doKat(a, camera);
+        usage();
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "mcrt_ref: %s\n", ex.what());
+        return 1;
+    }
+}
