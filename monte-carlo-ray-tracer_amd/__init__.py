@@ -1,0 +1,303 @@
+"""Host-side Python binding of libmcrt_hip.so (the C ABI in include/mcrt.h).
+
+The reference (linusmossberg/monte-carlo-ray-tracer) is a C++ program whose render seam is
+``Camera::sampleImage()`` (source/camera/camera.cpp:101-145); the product is the HIP library behind
+the C ABI, and the C++ host driver lives in ``host/``. This module is the thin ctypes layer the
+tests and bench.py use to reach the same entry points; it contains no rendering logic and no CPU
+fallback: if the shared library (built in-tree by ``build.py`` / ``__graft_entry__.build()``) is
+missing, importing :func:`lib` raises.
+
+Import with ``importlib.import_module("monte-carlo-ray-tracer_amd")`` (the directory name is not a
+Python identifier).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmcrt_hip.so")
+ABI_VERSION = 1
+
+INTEGRATOR_PATH_TRACER = 0
+INTEGRATOR_PHOTON_MAPPER = 1
+SURF_TRIANGLE, SURF_SPHERE = 0, 1
+NO_SURFACE = 0xFFFFFFFF
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_fp = C.POINTER(C.c_float)
+
+
+class Material(C.Structure):
+    """mcrt_material — one record per reference Material (material/material.hpp:9-55)."""
+    _fields_ = [
+        ("reflectance", C.c_double * 3), ("specular_reflectance", C.c_double * 3),
+        ("transmittance", C.c_double * 3), ("emittance", C.c_double * 3),
+        ("roughness", C.c_double), ("specular_roughness", C.c_double), ("ior", C.c_double),
+        ("transparency", C.c_double), ("A", C.c_double), ("B", C.c_double), ("a", C.c_double * 2),
+        ("ior_real", C.c_double * 3), ("ior_imag", C.c_double * 3),
+        ("flags", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class SceneDesc(C.Structure):
+    """mcrt_scene_desc."""
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("num_nodes", C.c_uint32),
+        ("node_bounds", _dp), ("node_start_surface", _u32p), ("node_num_surfaces", _u32p),
+        ("node_next_sibling", _u32p),
+        ("num_surfaces", C.c_uint32),
+        ("surf_kind", _u8p), ("surf_interpolate", _u8p), ("surf_material", _u32p),
+        ("surf_area", _dp), ("surf_v", _dp), ("surf_e", _dp), ("surf_vn", _dp),
+        ("num_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+        ("num_lights", C.c_uint32), ("light_surface", _u32p), ("light_cdf", _dp),
+        ("scene_ior", C.c_double), ("bb_min", C.c_double * 3), ("bb_max", C.c_double * 3),
+    ]
+
+
+class PhotonMapDesc(C.Structure):
+    """mcrt_photon_map_desc."""
+    _fields_ = [
+        ("num_octants", C.c_uint32), ("octant_bounds", _dp), ("octant_start_data", _u64p),
+        ("octant_contained_data", _u64p), ("octant_next_sibling", _u32p), ("octant_leaf", _u8p),
+        ("num_photons", C.c_uint64), ("photons", _fp),
+    ]
+
+
+class CameraDesc(C.Structure):
+    """mcrt_camera_desc — the Camera fields read by samplePixel (camera/camera.cpp:66-99)."""
+    _fields_ = [
+        ("eye", C.c_double * 3), ("forward", C.c_double * 3), ("left", C.c_double * 3),
+        ("up", C.c_double * 3),
+        ("focal_length", C.c_double), ("sensor_width", C.c_double),
+        ("aperture_radius", C.c_double), ("focus_distance", C.c_double),
+        ("thin_lens", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+        ("sqrtspp", C.c_uint32),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("shard_rows", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+    def copy(self):
+        c = CameraDesc()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(CameraDesc))
+        return c
+
+
+class Stats(C.Structure):
+    """mcrt_stats."""
+    _fields_ = [
+        ("paths", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
+        ("prim_tests", C.c_uint64), ("knn_searches", C.c_uint64),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class McrtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmcrt_hip.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McrtError(
+            "%s is missing: build it with `python __graft_entry__.py build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.mcrt_abi_version.restype = C.c_uint32
+    L.mcrt_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.mcrt_destroy.argtypes = [vp]
+    L.mcrt_destroy.restype = None
+    L.mcrt_last_error.argtypes = [vp]
+    L.mcrt_last_error.restype = C.c_char_p
+    L.mcrt_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.mcrt_upload_photons.argtypes = [vp, C.POINTER(PhotonMapDesc), C.POINTER(PhotonMapDesc),
+                                      C.c_uint32, C.c_int]
+    L.mcrt_render.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, _dp, C.POINTER(Stats)]
+    L.mcrt_render_device.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, vp, vp]
+    L.mcrt_render_finish.argtypes = [vp, C.POINTER(Stats)]
+    L.mcrt_shard_rows.argtypes = [C.POINTER(CameraDesc), _u32p]
+    L.mcrt_shard_rows.restype = C.c_uint32
+    L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
+    L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
+    L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
+    L.mcrt_image_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.mcrt_image_free.argtypes = [vp]
+    L.mcrt_image_free.restype = None
+    L.mcrt_image_scene.argtypes = [vp]
+    L.mcrt_image_scene.restype = C.POINTER(SceneDesc)
+    L.mcrt_image_camera.argtypes = [vp]
+    L.mcrt_image_camera.restype = C.POINTER(CameraDesc)
+    L.mcrt_image_photons.argtypes = [vp, C.c_int]
+    L.mcrt_image_photons.restype = C.POINTER(PhotonMapDesc)
+    L.mcrt_image_param.argtypes = [vp, C.c_char_p]
+    L.mcrt_image_param.restype = C.c_uint64
+    if L.mcrt_abi_version() != ABI_VERSION:
+        raise McrtError("libmcrt_hip.so ABI %d != binding ABI %d" % (L.mcrt_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class SceneImage:
+    """A scene image (*.mcrt) loaded through mcrt_image_load: flattened Scene/BVH/Camera (+ photon
+    maps) as written by the flattener inside the reference host."""
+
+    def __init__(self, path):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        rc = self._lib.mcrt_image_load(os.fsencode(path), C.byref(self._h))
+        if rc != 0:
+            raise McrtError("mcrt_image_load(%s) failed: %d" % (path, rc))
+        self.path = path
+
+    @property
+    def scene(self):
+        return self._lib.mcrt_image_scene(self._h).contents
+
+    @property
+    def camera(self):
+        return self._lib.mcrt_image_camera(self._h).contents.copy()
+
+    def photons(self, which):
+        p = self._lib.mcrt_image_photons(self._h, which)
+        return p.contents if p else None
+
+    def param(self, key):
+        return int(self._lib.mcrt_image_param(self._h, key.encode()))
+
+    def close(self):
+        if self._h:
+            self._lib.mcrt_image_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """mcrt_ctx: one per GPU / process rank. Mirrors the reference's render seam:
+    ``Context.sample_image(camera)`` stands where ``Camera::sampleImage()`` stood."""
+
+    def __init__(self, device_id=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        rc = self._lib.mcrt_create(C.byref(self._h), int(device_id))
+        if rc != 0:
+            msg = self._lib.mcrt_last_error(None)
+            raise McrtError("mcrt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.mcrt_last_error(self._h)
+            raise McrtError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def upload_scene(self, scene_desc):
+        self._check(self._lib.mcrt_upload_scene(self._h, C.byref(scene_desc)), "mcrt_upload_scene")
+
+    def upload_photons(self, global_map, caustic_map, k_nearest, direct_visualization=False):
+        g = C.byref(global_map) if global_map is not None else None
+        c = C.byref(caustic_map) if caustic_map is not None else None
+        self._check(self._lib.mcrt_upload_photons(self._h, g, c, int(k_nearest),
+                                                  int(bool(direct_visualization))),
+                    "mcrt_upload_photons")
+
+    def upload_image(self, image):
+        """Upload everything a SceneImage holds (scene + photon maps if present)."""
+        self.upload_scene(image.scene)
+        g, c = image.photons(0), image.photons(1)
+        if g is not None or c is not None:
+            self.upload_photons(g, c, image.param("k_nearest_photons") or 50,
+                                bool(image.param("direct_visualization")))
+
+    def sample_image(self, cam, global_seed, integrator=INTEGRATOR_PATH_TRACER):
+        """mcrt_render -> (image[H,W,3] float64, stats dict)."""
+        out = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
+        st = Stats()
+        self._check(self._lib.mcrt_render(self._h, C.byref(cam), int(global_seed), int(integrator),
+                                          _ptr(out, C.c_double), C.byref(st)), "mcrt_render")
+        return out, st.as_dict()
+
+    def render_device(self, cam, global_seed, integrator, device_ptr, stream=None):
+        self._check(self._lib.mcrt_render_device(self._h, C.byref(cam), int(global_seed),
+                                                 int(integrator), C.c_void_p(int(device_ptr)),
+                                                 C.c_void_p(int(stream)) if stream else None),
+                    "mcrt_render_device")
+
+    def render_finish(self):
+        st = Stats()
+        self._check(self._lib.mcrt_render_finish(self._h, C.byref(st)), "mcrt_render_finish")
+        return st.as_dict()
+
+    def intersect(self, start, direction):
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        direction = np.ascontiguousarray(direction, dtype=np.float64)
+        n = start.shape[0]
+        t = np.empty(n, dtype=np.float64)
+        surf = np.empty(n, dtype=np.uint32)
+        uv = np.empty((n, 2), dtype=np.float64)
+        self._check(self._lib.mcrt_intersect(self._h, n, _ptr(start, C.c_double),
+                                             _ptr(direction, C.c_double), _ptr(t, C.c_double),
+                                             _ptr(surf, C.c_uint32), _ptr(uv, C.c_double)),
+                    "mcrt_intersect")
+        return t, surf, uv
+
+    def sampler(self, pixel, index, shuffles, global_seed):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        index = np.ascontiguousarray(index, dtype=np.uint32)
+        out = np.empty((pixel.shape[0], 7), dtype=np.float64)
+        self._check(self._lib.mcrt_sampler(self._h, pixel.shape[0], _ptr(pixel, C.c_uint32),
+                                           _ptr(index, C.c_uint32), int(shuffles), int(global_seed),
+                                           _ptr(out, C.c_double)), "mcrt_sampler")
+        return out
+
+    def knn(self, which, points, k):
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        n = points.shape[0]
+        cnt = np.empty(n, dtype=np.uint32)
+        idx = np.empty((n, k), dtype=np.uint32)
+        d2 = np.empty((n, k), dtype=np.float64)
+        self._check(self._lib.mcrt_knn(self._h, int(which), n, _ptr(points, C.c_double), int(k),
+                                       _ptr(cnt, C.c_uint32), _ptr(idx, C.c_uint32),
+                                       _ptr(d2, C.c_double)), "mcrt_knn")
+        return cnt, idx, d2
+
+    def close(self):
+        if self._h:
+            self._lib.mcrt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_rows(cam):
+    """Row indices owned by cam's (shard_index, shard_count, shard_rows)."""
+    L = lib()
+    n = L.mcrt_shard_rows(C.byref(cam), None)
+    rows = np.empty(n, dtype=np.uint32)
+    if n:
+        L.mcrt_shard_rows(C.byref(cam), _ptr(rows, C.c_uint32))
+    return rows

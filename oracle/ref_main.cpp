@@ -49,7 +49,7 @@
 namespace {
 
 struct Args {
-    std::string mode, scene, out, out_samples;
+    std::string mode, scene, out, out_samples, out_radiance, out_kat;
     int camera = 0;
     bool photon = false;
     long width = -1, height = -1, sqrtspp = -1, threads = -1;
@@ -64,10 +64,12 @@ struct Args {
 
 [[noreturn]] void usage() {
     std::fprintf(stderr,
-        "usage: mcrt_ref <flatten|render|kat> --scene file.json [--camera N] [--photon]\n"
+        "usage: mcrt_ref <flatten|render|kat>[,<mode>...] --scene file.json [--camera N] [--photon]\n"
         "   [--width W --height H --sqrtspp S] [--bvh octree|binary_sah|quaternary_sah] [--bins B]\n"
         "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K]\n"
-        "   [--specular-roughness material value]... [--n N] --out path [--out-samples path]\n");
+        "   [--specular-roughness material value]... [--n N]\n"
+        "   --out image.mcrt (flatten) --out-radiance file.f64 [--out-samples file.f64] (render) --out-kat dir (kat)\n"
+        "   several modes in one run share ONE Camera/Scene/photon map (photon order is thread-dependent)\n");
     std::exit(2);
 }
 
@@ -81,6 +83,8 @@ Args parse(int argc, char** argv) {
         if (k == "--scene") a.scene = next();
         else if (k == "--out") a.out = next();
         else if (k == "--out-samples") a.out_samples = next();
+        else if (k == "--out-radiance") a.out_radiance = next();
+        else if (k == "--out-kat") a.out_kat = next();
         else if (k == "--camera") a.camera = std::stoi(next());
         else if (k == "--photon") a.photon = true;
         else if (k == "--width") a.width = std::stol(next());
@@ -97,7 +101,10 @@ Args parse(int argc, char** argv) {
         else if (k == "--specular-roughness") { std::string m = next(); a.rough.push_back({m, std::stod(next())}); }
         else usage();
     }
-    if (a.scene.empty() || a.out.empty()) usage();
+    if (a.scene.empty()) usage();
+    // single-mode shorthand: --out names that mode's output
+    if (a.mode == "render" && a.out_radiance.empty()) a.out_radiance = a.out;
+    if (a.mode == "kat" && a.out_kat.empty()) a.out_kat = a.out;
     return a;
 }
 
@@ -254,6 +261,7 @@ struct FlatMap {
     std::vector<uint8_t> leaf;
     std::vector<float> photons;
     mcrt_photon_map_desc desc;
+    FlatMap() { std::memset(&desc, 0, sizeof(desc)); }
 };
 
 void flattenMap(const LinearOctree<Photon>& map, FlatMap& M) {
@@ -397,7 +405,7 @@ int doRender(const Args& a, Camera& camera) {
             double* o = &out[((size_t)(y - y0) * W + x) * 3];
             o[0] = c.x; o[1] = c.y; o[2] = c.z;
         }
-    writeRaw(a.out, out.data(), out.size() * sizeof(double));
+    writeRaw(a.out_radiance, out.data(), out.size() * sizeof(double));
     if (per_sample) writeRaw(a.out_samples, samples.data(), samples.size() * sizeof(double));
     double paths = (double)W * (y1 - y0) * spp;
     std::printf("{\"mode\":\"render\",\"width\":%ld,\"rows\":[%ld,%ld],\"spp\":%zu,\"threads\":%zu,"
@@ -424,7 +432,7 @@ glm::dvec3 randDir(Rng& r) {
 }
 
 int doKat(const Args& a, Camera& camera) {
-    std::string dir = a.out;
+    std::string dir = a.out_kat;
     std::filesystem::create_directories(dir);
     const Scene& scene = camera.integrator->scene;
     Flat F;
@@ -573,10 +581,13 @@ int main(int argc, char** argv) {
     try {
         nlohmann::json j = loadScene(a);
         Camera camera(j, Option(a.scene, "", a.camera, a.photon));
-        if (a.mode == "flatten") return doFlatten(a, camera);
-        if (a.mode == "render") return doRender(a, camera);
-        if (a.mode == "kat") return doKat(a, camera);
-        usage();
+        int rc = 0, did = 0;
+        auto has = [&](const char* m) { return ("," + a.mode + ",").find(std::string(",") + m + ",") != std::string::npos; };
+        if (has("flatten")) { if (a.out.empty()) usage(); rc |= doFlatten(a, camera); did++; }
+        if (has("kat")) { if (a.out_kat.empty()) usage(); rc |= doKat(a, camera); did++; }
+        if (has("render")) { if (a.out_radiance.empty()) usage(); rc |= doRender(a, camera); did++; }
+        if (!did) usage();
+        return rc;
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "mcrt_ref: %s\n", ex.what());
         return 1;
