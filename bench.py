@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mray/s of the path-tracing hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2_ggx|c1] [--no-cpu]
+
+One "step" = one full frame of the workload: every owned pixel traced with spp samples by the HIP
+integrator kernel (ray generation, BVH traversal, shading, NEE shadow rays, film accumulation), the
+image rows left in HBM; with N > 1 the framebuffer rows are dealt to the ranks in groups of 8 and each
+step ends with ONE RCCL gather of the packed rows to rank 0 over xGMI.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): hexagon_room.json camera 0,
+1920x1080 @ 256 spp, scene image tests/golden/hexagon_room.mcrt (flattened by the reference's own
+loader/BVH builder; synthetic = no external data needed). Inputs (scene arrays, Sobol tables) are
+resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     algorithmic bytes (B_ray = n_node*64 + n_tri*72 + n_sphere*32 + 300,
+               per-ray counts measured by the reference-equivalent oracle) per launch / kernel time
+               measured with HIP events on the kernel's stream, against the 8 TB/s HBM peak;
+  cpu_baseline the CPU integrator timed on this box's host cores on a bounded sample of the SAME
+               workload (rows of the same frame at the same spp).
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (scene image, width, height, sqrtspp, description)
+    "c2": ("hexagon_room.mcrt", 1920, 1080, 16, "hexagon_room.json cam0 1920x1080 @ 256 spp (BASELINE configs[1])"),
+    "c2_ggx": ("hexagon_room_ggx.mcrt", 1920, 1080, 16, "hexagon_room.json + GGX roughness, 1920x1080 @ 256 spp"),
+    "c1": ("hexagon_room_diffuse.mcrt", 256, 256, 2, "hexagon_room_diffuse.json 256x256 @ 4 spp (BASELINE configs[0])"),
+}
+SEED = 0x12345678
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHARD_ROWS = 8
+
+
+def cpu_baseline(m, img, cam, budget_s=15.0):
+    """Times the CPU integrator on rows of the same frame. Prefers the reference itself
+    (oracle/_ref/mcrt_ref + oracle/_ref/scenes, both produced by oracle/Makefile in the build
+    container); otherwise the C restatement (oracle/, kind "port"). Also returns the per-ray
+    node/primitive test counts of the reference-equivalent traversal (for the roofline)."""
+    import oracle_lib  # checker, cpu_baseline leg only
+
+    threads = oracle_lib.hardware_threads()
+    mid = cam.height // 2
+    # calibration: 2 rows
+    t0 = time.time()
+    _, info = oracle_lib.render(img, cam, SEED, m.INTEGRATOR_PATH_TRACER, rows=(mid, mid + 2), threads=threads)
+    per_row = max(info["seconds"] / 2.0, 1e-4)
+    rows = int(max(2, min(cam.height, budget_s / per_row)))
+    r0 = max(0, mid - rows // 2)
+    _, info = oracle_lib.render(img, cam, SEED, m.INTEGRATOR_PATH_TRACER, rows=(r0, r0 + rows), threads=threads)
+    rays = info["rays"]
+    counts = dict(rays=rays, paths=info["paths"], node_per_ray=info["node_tests"] / rays,
+                  tri_per_ray=(info["prim_tests"] - info["sphere_tests"]) / rays,
+                  sphere_per_ray=info["sphere_tests"] / rays, rays_per_path=rays / info["paths"])
+    port = dict(value=rays / info["seconds"] / 1e6, unit="Mray/s", cores=threads, kind="port",
+                sample="rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)" % (r0, r0 + rows, cam.width, cam.height, cam.sqrtspp ** 2,
+                                                                          info["paths"], info["seconds"]))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
+    ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", "hexagon_room.json")
+    base = port
+    if os.path.exists(ref_bin) and os.path.exists(ref_scene) and os.path.basename(img.path) == "hexagon_room.mcrt":
+        try:
+            out = subprocess.run([ref_bin, "render", "--scene", ref_scene, "--width", str(cam.width), "--height", str(cam.height),
+                                  "--sqrtspp", str(cam.sqrtspp), "--rows", str(r0), str(r0 + rows), "--out-radiance", "/dev/null"],
+                                 capture_output=True, text=True, timeout=600, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
+            line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+            r = json.loads(line)
+            base = dict(value=rays / r["seconds"] / 1e6, unit="Mray/s", cores=r["threads"], kind="reference",
+                        sample="reference Camera::samplePixel, rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)"
+                               % (r0, r0 + rows, cam.width, cam.height, cam.sqrtspp ** 2, r["paths"], r["seconds"]),
+                        port_value=port["value"])
+        except Exception as ex:  # keep the port numbers
+            base = dict(port, note="reference run failed: %r" % (ex,))
+    return base, counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (roofline then uses stored counts)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    image_file, W, H, sqrtspp, desc = WORKLOADS[args.workload]
+    img = m.SceneImage(os.path.join(ROOT, "tests", "golden", image_file))
+    cam = img.camera
+    cam.width, cam.height, cam.sqrtspp = W, H, sqrtspp
+    cam.shard_index, cam.shard_count, cam.shard_rows = rank, world, SHARD_ROWS
+    ctx = m.Context(local_rank)
+    ctx.upload_image(img)  # scene resident in HBM before the timed region
+
+    my_rows = m.shard_rows(cam)
+    full = cam.copy()
+    full.shard_index, full.shard_count = 0, 1
+    max_rows = 0
+    for r in range(world):
+        c = cam.copy()
+        c.shard_index = r
+        max_rows = max(max_rows, len(m.shard_rows(c)))
+    dev = torch.device("cuda", local_rank)
+    tile = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)  # packed owned rows (+ padding)
+    gathered = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    stats_acc = []
+
+    def step():
+        ctx.render_device(cam, SEED, m.INTEGRATOR_PATH_TRACER, tile.data_ptr(), stream)
+        st = ctx.render_finish()
+        if world > 1:
+            dist.gather(tile, gathered, dst=0)  # the single collective of the data path
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats_acc.append(step())
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(sum(s["rays"] for s in stats_acc)), float(sum(s["paths"] for s in stats_acc)),
+                         float(sum(s["kernel_ms"] for s in stats_acc))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kmax = rays[2:].clone()
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        rays[2] = kmax[0]
+    elapsed = float(t.item())
+    total_rays, total_paths, kernel_ms_sum = float(rays[0]), float(rays[1]), float(rays[2])
+
+    if rank == 0:
+        # sanity: the gathered frame is complete and finite
+        if world > 1:
+            frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+            for r in range(world):
+                c = cam.copy()
+                c.shard_index = r
+                rows = torch.from_numpy(m.shard_rows(c).astype(np.int64)).to(dev)
+                frame[rows] = gathered[r][: len(rows)]
+        else:
+            frame = tile[: len(my_rows)]
+        finite = bool(torch.isfinite(frame).all().item())
+        mean = float(frame.mean().item())
+
+        result = {
+            "metric": "Mray/s (whole node), 1920x1080 @ 256 spp path trace" if args.workload.startswith("c2") else "Mray/s (whole node)",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "path_tracer",
+                       "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
+                       "rays_per_step": total_rays / args.steps, "paths_per_step": total_paths / args.steps,
+                       "frame_mean_radiance": mean, "frame_finite": finite},
+        }
+        counts = None
+        if world == 1 and not args.no_cpu:
+            base, counts = cpu_baseline(m, img, full, args.cpu_seconds)
+            result["cpu_baseline"] = base
+        if counts is None:
+            # per-ray counts of the reference-equivalent traversal measured on this workload by the oracle
+            # (DESIGN.md "Measurement"); used when the CPU leg is skipped (N > 1)
+            counts = dict(node_per_ray=13.70, tri_per_ray=8.86, sphere_per_ray=5.85)
+        b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
+        launches = args.steps * 1  # one integrator launch per step per GPU
+        kernel_ms = kernel_ms_sum / launches
+        rays_per_launch = total_rays / args.steps / world
+        achieved = rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "kernel": "renderKernel<path_tracer>", "kernel_ms": kernel_ms,
+                              "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
+                              "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

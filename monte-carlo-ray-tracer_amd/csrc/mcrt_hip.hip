@@ -1,0 +1,957 @@
+// libmcrt_hip.so — gfx950 kernels and the C ABI of include/mcrt.h.
+//
+// Kernel structure (one launch per render):
+//   persistent workgroups; every LANE owns one pixel at a time and runs that pixel's spp samples in
+//   the reference's order (so the per-pixel FP64 sum is the reference's, film.cpp:99-113). The loop
+//   body is ONE BOUNCE (mcrt_integrator.hpp); a lane whose path ended is re-armed with the next
+//   sample in the same iteration, and a lane whose pixel is complete takes the next pixel from a
+//   global work counter through a wave-aggregated pop: __ballot of the lanes that need work, one
+//   atomicAdd of popcount by the first such lane, prefix-popcount as each lane's offset. The wave
+//   therefore stays compacted (all 64 lanes tracing) until the frame runs out of pixels.
+//   Pixels are enumerated in 8x8 tiles so that a wave's rays are coherent.
+//   LDS per workgroup: Sobol byte tables (24 KiB), per-lane traversal stack [depth][lane], and a
+//   staged copy of the scene: the whole scene when it is small (hexagon_room: 16 nodes, 44 prims),
+//   else the top of the BVH (breadth-first prefix of the node array).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcrt.h"
+#include "mcrt_integrator.hpp"
+#include "mcrt_layout.hpp"
+
+using namespace mcrt;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// kernel parameter blocks
+// ------------------------------------------------------------------------------------------------
+struct DeviceScene {
+    // global memory
+    uint32_t num_nodes, num_surfaces, num_materials, num_lights;
+    const double* node_bounds;
+    const NodeMeta* node_meta;
+    const double* prim;
+    const double* surf_v;
+    const double* surf_normal;
+    const double* surf_vn;  // may be null
+    const double* surf_area;
+    const uint32_t* surf_material;
+    const uint8_t* surf_kind;
+    const mcrt_material* materials;
+    const uint32_t* light_surface;
+    const double* light_cdf;
+    const uint32_t* sobol_tab;
+    double scene_ior;
+    // staging plan
+    uint32_t stage_all;    // 1: whole scene in LDS
+    uint32_t stage_nodes;  // number of leading nodes staged
+};
+
+struct DevicePhotonMap {
+    PhotonMapView view;
+};
+
+struct RenderParams {
+    mcrt_camera_desc cam;
+    uint32_t global_seed, spp;
+    uint32_t owned_rows;
+    uint32_t tiles_x, tiles_y;
+    uint64_t work_items;  // tiles_x * tiles_y * 64
+    double* out;          // [owned_rows][width][3]
+    unsigned long long* work_counter;
+    unsigned long long* stats;  // paths, rays, node_tests, prim_tests, knn_searches, overflow, knn_octants
+    StackEntry* spill;
+    uint32_t total_lanes;
+    // photon mapping
+    PhotonMapView global_map, caustic_map;
+    uint32_t k_nearest, direct_visualization;
+    double* knn_res_d2;
+    uint32_t* knn_res_idx;
+    double* knn_visit_d2;
+    uint32_t* knn_visit_oct;
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS carving
+// ------------------------------------------------------------------------------------------------
+struct LdsPlan {
+    uint32_t sobol, stack, node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material,
+        surf_kind, materials, light_surface, light_cdf, total;
+};
+
+__host__ __device__ inline uint32_t alignUp(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block) {
+    LdsPlan p;
+    uint32_t off = 0;
+    p.sobol = off; off += kSobolTableWords * 4;
+    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(StackEntry);
+    off = alignUp(off, 16);
+    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
+    p.node_bounds = off; off += nn * 48;
+    p.node_meta = off; off = alignUp(off + nn * 8, 16);
+    if (s.stage_all) {
+        const uint32_t ns = s.num_surfaces;
+        p.prim = off; off += ns * kPrimStride * 8;
+        p.surf_v = off; off += ns * 72;
+        p.surf_normal = off; off += ns * 24;
+        p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
+        p.surf_area = off; off += ns * 8;
+        p.surf_material = off; off = alignUp(off + ns * 4, 16);
+        p.surf_kind = off; off = alignUp(off + ns, 16);
+        p.materials = off; off = alignUp(off + s.num_materials * (uint32_t)sizeof(mcrt_material), 16);
+        p.light_cdf = off; off += s.num_lights * 8;
+        p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
+    } else {
+        p.prim = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
+            p.light_cdf = p.light_surface = off;
+    }
+    p.total = off;
+    return p;
+}
+
+template <class T>
+__device__ inline void stageCopy(T* dst, const T* src, uint32_t count) {
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+
+// Builds the per-lane views; stages the scene into LDS (ends with __syncthreads()).
+__device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneView& sv, ShadeView& sh,
+                                  const uint32_t*& tab, LaneStack& stk, StackEntry* spill, uint32_t total_lanes) {
+    const LdsPlan p = planLds(s, blockDim.x);
+    uint32_t* ltab = reinterpret_cast<uint32_t*>(lds + p.sobol);
+    stageCopy(ltab, s.sobol_tab, (uint32_t)kSobolTableWords);
+    tab = ltab;
+
+    stk.lds = reinterpret_cast<StackEntry*>(lds + p.stack) + threadIdx.x;
+    stk.lds_stride = blockDim.x;
+    stk.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    stk.spill_stride = total_lanes;
+
+    sv.num_nodes = s.num_nodes;
+    sv.num_surfaces = s.num_surfaces;
+    sv.node_bounds = s.node_bounds;
+    sv.node_meta = s.node_meta;
+    sv.prim = s.prim;
+    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
+    double* lnb = reinterpret_cast<double*>(lds + p.node_bounds);
+    NodeMeta* lnm = reinterpret_cast<NodeMeta*>(lds + p.node_meta);
+    stageCopy(lnb, s.node_bounds, nn * 6);
+    stageCopy(lnm, s.node_meta, nn);
+    sv.lds_nodes = nn;
+    sv.lds_node_bounds = lnb;
+    sv.lds_node_meta = lnm;
+    sv.lds_prims = 0;
+    sv.lds_prim = nullptr;
+
+    sh.surf_v = s.surf_v;
+    sh.surf_normal = s.surf_normal;
+    sh.surf_vn = s.surf_vn;
+    sh.surf_area = s.surf_area;
+    sh.surf_material = s.surf_material;
+    sh.surf_kind = s.surf_kind;
+    sh.materials = s.materials;
+    sh.num_lights = s.num_lights;
+    sh.light_surface = s.light_surface;
+    sh.light_cdf = s.light_cdf;
+    sh.scene_ior = s.scene_ior;
+
+    if (s.stage_all) {
+        const uint32_t ns = s.num_surfaces;
+        double* lp = reinterpret_cast<double*>(lds + p.prim);
+        stageCopy(lp, s.prim, ns * kPrimStride);
+        sv.lds_prims = ns;
+        sv.lds_prim = lp;
+        double* lv = reinterpret_cast<double*>(lds + p.surf_v);
+        stageCopy(lv, s.surf_v, ns * 9);
+        sh.surf_v = lv;
+        double* ln = reinterpret_cast<double*>(lds + p.surf_normal);
+        stageCopy(ln, s.surf_normal, ns * 3);
+        sh.surf_normal = ln;
+        if (s.surf_vn) {
+            double* lvn = reinterpret_cast<double*>(lds + p.surf_vn);
+            stageCopy(lvn, s.surf_vn, ns * 9);
+            sh.surf_vn = lvn;
+        }
+        double* la = reinterpret_cast<double*>(lds + p.surf_area);
+        stageCopy(la, s.surf_area, ns);
+        sh.surf_area = la;
+        uint32_t* lm = reinterpret_cast<uint32_t*>(lds + p.surf_material);
+        stageCopy(lm, s.surf_material, ns);
+        sh.surf_material = lm;
+        uint8_t* lk = reinterpret_cast<uint8_t*>(lds + p.surf_kind);
+        stageCopy(lk, s.surf_kind, ns);
+        sh.surf_kind = lk;
+        uint64_t* lmat = reinterpret_cast<uint64_t*>(lds + p.materials);
+        stageCopy(lmat, reinterpret_cast<const uint64_t*>(s.materials), s.num_materials * (uint32_t)(sizeof(mcrt_material) / 8));
+        sh.materials = reinterpret_cast<const mcrt_material*>(lmat);
+        double* lc = reinterpret_cast<double*>(lds + p.light_cdf);
+        stageCopy(lc, s.light_cdf, s.num_lights);
+        sh.light_cdf = lc;
+        uint32_t* ll = reinterpret_cast<uint32_t*>(lds + p.light_surface);
+        stageCopy(ll, s.light_surface, s.num_lights);
+        sh.light_surface = ll;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (wavefront = 64 lanes on gfx950)
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint32_t laneId() { return __lane_id(); }
+
+__device__ inline unsigned long long waveBroadcast64(unsigned long long v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Wave-aggregated pop from a global counter: lanes with need == true each receive a distinct index.
+__device__ inline unsigned long long wavePop(bool need, unsigned long long* counter) {
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return 0ull;
+    const int leader = __ffsll((long long)mask) - 1;
+    const uint32_t lane = laneId();
+    unsigned long long base = 0ull;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+    base = waveBroadcast64(base, leader);
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+__device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
+    unsigned long long x = v;
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t lo = __shfl_down((uint32_t)x, off, 64), hi = __shfl_down((uint32_t)(x >> 32), off, 64);
+        x += ((unsigned long long)hi << 32) | lo;
+    }
+    if (laneId() == 0 && x) atomicAdd(dst, x);
+}
+
+// shard-local row -> image row (include/mcrt.h: rows dealt in groups of shard_rows)
+__host__ __device__ inline uint32_t localToGlobalRow(const mcrt_camera_desc& cam, uint32_t ly) {
+    if (cam.shard_count <= 1) return ly;
+    const uint32_t g = cam.shard_rows ? cam.shard_rows : 1;
+    return ((ly / g) * cam.shard_count + cam.shard_index) * g + ly % g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the integrator kernel
+// ------------------------------------------------------------------------------------------------
+template <int kIntegrator, bool kCount>
+__global__ void __launch_bounds__(256) renderKernel(const DeviceScene scene, const RenderParams prm) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    SceneView sv;
+    ShadeView sh;
+    const uint32_t* tab;
+    LaneStack stk;
+    setupViews(scene, lds, sv, sh, tab, stk, prm.spill, prm.total_lanes);
+
+    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+    KnnScratch ks;
+    PhotonViews pv;
+    if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER) {
+        ks.res_d2 = prm.knn_res_d2 + gl;
+        ks.res_idx = prm.knn_res_idx + gl;
+        ks.visit_d2 = prm.knn_visit_d2 + gl;
+        ks.visit_oct = prm.knn_visit_oct + gl;
+        ks.stride = prm.total_lanes;
+        pv.global_map = prm.global_map;
+        pv.caustic_map = prm.caustic_map;
+        pv.k_nearest = prm.k_nearest;
+        pv.direct_visualization = prm.direct_visualization != 0;
+    }
+
+    PathState st;
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    uint32_t paths = 0, searches = 0, octant_visits = 0;
+    bool have_pixel = false, path_active = false, exhausted = false;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const uint32_t W = prm.cam.width;
+
+    for (;;) {
+        const bool need = !have_pixel && !exhausted;
+        if (__ballot(need)) {
+            const unsigned long long w = wavePop(need, prm.work_counter);
+            if (need) {
+                if (w >= prm.work_items) {
+                    exhausted = true;
+                } else {
+                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
+                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
+                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
+                    if (lx < W && ly < prm.owned_rows) {
+                        px = lx;
+                        py = localToGlobalRow(prm.cam, ly);
+                        have_pixel = true;
+                        sample = 0;
+                        acc0 = acc1 = acc2 = 0.0;
+                        st.smp.initiate(prm.global_seed, py * W + px);  // camera.cpp:73
+                    }
+                }
+            }
+        }
+        if (!__ballot(have_pixel)) {
+            if (!__ballot(!exhausted)) break;
+            continue;
+        }
+        if (have_pixel) {
+            if (!path_active) {
+                st.smp.setIndex(sample);  // camera.cpp:77
+                pathBegin(st, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                path_active = true;
+                paths++;
+            }
+            bool done;
+            if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
+                done = photonMapperBounce<kCount>(st, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
+            else
+                done = pathTracerBounce<kCount>(st, sv, sh, stk, cnt, tab);
+            if (done) {
+                // Film::deposit, default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105)
+                acc0 += st.radiance.x * 1.0;
+                acc1 += st.radiance.y * 1.0;
+                acc2 += st.radiance.z * 1.0;
+                path_active = false;
+                if (++sample == prm.spp) {
+                    // Film::Splat::get (film.cpp:107-113): max(sum / weight_sum, 0)
+                    const double wsum = (double)prm.spp;
+                    double* o = prm.out + ((size_t)ly * W + px) * 3;
+                    o[0] = gmax(acc0 / wsum, 0.0);
+                    o[1] = gmax(acc1 / wsum, 0.0);
+                    o[2] = gmax(acc2 / wsum, 0.0);
+                    have_pixel = false;
+                }
+            }
+        }
+    }
+
+    waveAccumulate(prm.stats + 0, paths);
+    waveAccumulate(prm.stats + 1, cnt.rays);
+    if (kCount) {
+        waveAccumulate(prm.stats + 2, cnt.node_tests);
+        waveAccumulate(prm.stats + 3, cnt.prim_tests);
+    }
+    waveAccumulate(prm.stats + 4, searches);
+    waveAccumulate(prm.stats + 5, cnt.overflow);
+    waveAccumulate(prm.stats + 6, octant_visits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) intersectKernel(const DeviceScene scene, uint64_t n, const double* start,
+                                                       const double* direction, double* out_t, uint32_t* out_surface,
+                                                       double* out_uv, StackEntry* spill, uint32_t total_lanes) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    SceneView sv;
+    ShadeView sh;
+    const uint32_t* tab;
+    LaneStack stk;
+    setupViews(scene, lds, sv, sh, tab, stk, spill, total_lanes);
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
+        Hit h = sceneIntersect<false>(sv, ray, stk, cnt);
+        out_t[i] = h.t;
+        out_surface[i] = h.surface;
+        out_uv[2 * i] = h.u;
+        out_uv[2 * i + 1] = h.v;
+    }
+}
+
+__global__ void samplerKernel(const uint32_t* tab, uint64_t n, const uint32_t* pixel, const uint32_t* index,
+                              uint32_t shuffles, uint32_t global_seed, double* out) {
+    __shared__ uint32_t ltab[kSobolTableWords];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kSobolTableWords; i += blockDim.x) ltab[i] = tab[i];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Sampler s;
+        s.initiate(global_seed, pixel[i]);
+        s.setIndex(index[i]);
+        for (uint32_t k = 0; k < shuffles; k++) s.shuffle();
+        for (int d = 0; d < 7; d++) out[i * 7 + d] = s.get(d, ltab);
+    }
+}
+
+__global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
+                          uint32_t* out_index, double* out_d2, double* res_d2, uint32_t* res_idx, double* visit_d2,
+                          uint32_t* visit_oct, uint32_t total_lanes) {
+    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+    KnnScratch ks;
+    ks.res_d2 = res_d2 + gl;
+    ks.res_idx = res_idx + gl;
+    ks.visit_d2 = visit_d2 + gl;
+    ks.visit_oct = visit_oct + gl;
+    ks.stride = total_lanes;
+    for (uint64_t i = gl; i < n; i += total_lanes) {
+        uint32_t visits = 0;
+        uint32_t c = knnSearch(map, ld3(p + 3 * i), k, ks, visits);
+        out_count[i] = c;
+        // heap-sort the result in place (ascending distance, ties by index) into the output row
+        for (uint32_t q = 0; q < k; q++) {
+            out_index[i * k + q] = 0xFFFFFFFFu;
+            out_d2[i * k + q] = INFINITY;
+        }
+        // selection by repeated extraction of the max-heap root
+        uint32_t size = c;
+        while (size > 0) {
+            KnnEntry top = ks.res(0);
+            out_index[i * k + (size - 1)] = top.index;
+            out_d2[i * k + (size - 1)] = top.distance2;
+            KnnEntry last = ks.res(size - 1);
+            size--;
+            if (size > 0) knnSiftDown(ks, size, last, 0);
+        }
+        // fix tie order (equal distance2: ascending index) with a local insertion pass
+        for (uint32_t a = 1; a < c; a++) {
+            uint32_t b = a;
+            while (b > 0 && out_d2[i * k + b - 1] == out_d2[i * k + b] && out_index[i * k + b - 1] > out_index[i * k + b]) {
+                uint32_t t = out_index[i * k + b - 1];
+                out_index[i * k + b - 1] = out_index[i * k + b];
+                out_index[i * k + b] = t;
+                b--;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct mcrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string error;
+    int num_cus = 0;
+    size_t max_lds = 0;
+
+    bool has_scene = false;
+    DeviceScene scene{};
+    DevBuf node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+        light_surface, light_cdf, sobol_tab;
+
+    bool has_photons = false;
+    PhotonMapView maps[2]{};
+    DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2];
+    uint32_t k_nearest = 50;
+    int direct_visualization = 0;
+
+    DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
+    uint32_t spill_lanes = 0, knn_lanes = 0, knn_k = 0;
+
+    // in-flight render
+    bool pending = false;
+    std::chrono::steady_clock::time_point t_begin;
+    uint32_t launches = 0;
+};
+
+namespace {
+
+int fail(mcrt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, MCRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+template <class T>
+int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
+    HIP_TRY(ctx, buf.alloc(count * sizeof(T)));
+    if (count) HIP_TRY(ctx, hipMemcpy(buf.p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return MCRT_OK;
+}
+
+constexpr uint32_t kBlock = 256;
+
+struct LaunchGeom {
+    uint32_t grid, lds_bytes, total_lanes;
+};
+
+template <class K>
+int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g) {
+    const LdsPlan p = planLds(s, kBlock);
+    g.lds_bytes = p.total;
+    if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)g.lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kBlock, g.lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    g.grid = (uint32_t)(per_cu * ctx->num_cus);
+    g.total_lanes = g.grid * kBlock;
+    return MCRT_OK;
+}
+
+int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
+    if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
+    if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(8 * sizeof(unsigned long long)));
+    if (ctx->spill_lanes < total_lanes) {
+        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
+        ctx->spill_lanes = total_lanes;
+    }
+    if (photon && (ctx->knn_lanes < total_lanes || ctx->knn_k < ctx->k_nearest)) {
+        const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1);
+        HIP_TRY(ctx, ctx->knn_res_d2.alloc((size_t)total_lanes * k * sizeof(double)));
+        HIP_TRY(ctx, ctx->knn_res_idx.alloc((size_t)total_lanes * k * sizeof(uint32_t)));
+        HIP_TRY(ctx, ctx->knn_visit_d2.alloc((size_t)total_lanes * kMaxVisit * sizeof(double)));
+        HIP_TRY(ctx, ctx->knn_visit_oct.alloc((size_t)total_lanes * kMaxVisit * sizeof(uint32_t)));
+        ctx->knn_lanes = total_lanes;
+        ctx->knn_k = k;
+    }
+    return MCRT_OK;
+}
+
+int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
+    if (!cam || cam->width == 0 || cam->height == 0 || cam->sqrtspp == 0)
+        return fail(ctx, MCRT_ERR_INVALID, "camera: width, height and sqrtspp must be non-zero");
+    if (cam->shard_count > 1 && cam->shard_index >= cam->shard_count)
+        return fail(ctx, MCRT_ERR_INVALID, "camera: shard_index >= shard_count");
+    if ((uint64_t)cam->width * cam->height > 0xFFFFFFFFull)
+        return fail(ctx, MCRT_ERR_INVALID, "camera: more than 2^32 pixels");
+    return MCRT_OK;
+}
+
+int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out,
+                 hipStream_t stream) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_render before mcrt_upload_scene");
+    if (int rc = validateCamera(ctx, cam)) return rc;
+    const bool photon = integrator == MCRT_INTEGRATOR_PHOTON_MAPPER;
+    if (integrator != MCRT_INTEGRATOR_PATH_TRACER && !photon) return fail(ctx, MCRT_ERR_INVALID, "unknown integrator");
+    if (photon && !ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "photon mapping render before mcrt_upload_photons");
+    if (ctx->pending) return fail(ctx, MCRT_ERR_INVALID, "a render is already in flight: call mcrt_render_finish");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    static const bool count_tests = getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0;
+    using KernelT = void (*)(const DeviceScene, const RenderParams);
+    KernelT kernel;
+    if (photon) kernel = count_tests ? renderKernel<MCRT_INTEGRATOR_PHOTON_MAPPER, true> : renderKernel<MCRT_INTEGRATOR_PHOTON_MAPPER, false>;
+    else kernel = count_tests ? renderKernel<MCRT_INTEGRATOR_PATH_TRACER, true> : renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false>;
+
+    LaunchGeom g;
+    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g)) return rc;
+    if (int rc = ensureScratch(ctx, g.total_lanes, photon)) return rc;
+
+    RenderParams prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.cam = *cam;
+    prm.global_seed = global_seed;
+    prm.spp = cam->sqrtspp * cam->sqrtspp;
+    prm.owned_rows = mcrt_shard_rows(cam, nullptr);
+    prm.tiles_x = (cam->width + 7) / 8;
+    prm.tiles_y = (prm.owned_rows + 7) / 8;
+    prm.work_items = (uint64_t)prm.tiles_x * prm.tiles_y * 64ull;
+    prm.out = d_out;
+    prm.work_counter = ctx->work_counter.as<unsigned long long>();
+    prm.stats = ctx->stats.as<unsigned long long>();
+    prm.spill = ctx->spill.as<StackEntry>();
+    prm.total_lanes = g.total_lanes;
+    if (photon) {
+        prm.global_map = ctx->maps[0];
+        prm.caustic_map = ctx->maps[1];
+        prm.k_nearest = ctx->k_nearest;
+        prm.direct_visualization = (uint32_t)ctx->direct_visualization;
+        prm.knn_res_d2 = ctx->knn_res_d2.as<double>();
+        prm.knn_res_idx = ctx->knn_res_idx.as<uint32_t>();
+        prm.knn_visit_d2 = ctx->knn_visit_d2.as<double>();
+        prm.knn_visit_oct = ctx->knn_visit_oct.as<uint32_t>();
+    }
+    if (prm.owned_rows == 0) {
+        ctx->pending = true;
+        ctx->launches = 0;
+        ctx->t_begin = std::chrono::steady_clock::now();
+        HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+        return MCRT_OK;
+    }
+    // never launch more lanes than there is work
+    const uint64_t needed_blocks = (prm.work_items + kBlock - 1) / kBlock;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, needed_blocks);
+
+    ctx->t_begin = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->pending = true;
+    ctx->launches = 1;
+    return MCRT_OK;
+}
+
+int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
+    PhotonMapView& v = ctx->maps[which];
+    memset(&v, 0, sizeof(v));
+    if (!m || m->num_octants == 0 || m->num_photons == 0) return MCRT_OK;
+    if (m->num_photons > 0xFFFFFFFEull) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon map larger than 2^32-2 photons per GPU");
+    if (!m->octant_bounds || !m->octant_start_data || !m->octant_contained_data || !m->octant_next_sibling || !m->octant_leaf || !m->photons)
+        return fail(ctx, MCRT_ERR_INVALID, "photon map descriptor has null arrays");
+    const size_t n = m->num_octants;
+    std::vector<uint32_t> start(n), contained(n);
+    for (size_t i = 0; i < n; i++) {
+        if (m->octant_start_data[i] + m->octant_contained_data[i] > m->num_photons)
+            return fail(ctx, MCRT_ERR_INVALID, "photon map octant range exceeds the photon array");
+        start[i] = (uint32_t)m->octant_start_data[i];
+        contained[i] = (uint32_t)m->octant_contained_data[i];
+    }
+    if (int rc = uploadArray(ctx, ctx->map_bounds[which], m->octant_bounds, n * 6)) return rc;
+    if (int rc = uploadArray(ctx, ctx->map_start[which], start.data(), n)) return rc;
+    if (int rc = uploadArray(ctx, ctx->map_contained[which], contained.data(), n)) return rc;
+    if (int rc = uploadArray(ctx, ctx->map_next[which], m->octant_next_sibling, n)) return rc;
+    if (int rc = uploadArray(ctx, ctx->map_leaf[which], m->octant_leaf, n)) return rc;
+    if (int rc = uploadArray(ctx, ctx->map_photons[which], m->photons, (size_t)m->num_photons * 8)) return rc;
+    v.num_octants = m->num_octants;
+    v.num_photons = m->num_photons;
+    v.octant_bounds = ctx->map_bounds[which].as<double>();
+    v.octant_start = ctx->map_start[which].as<uint32_t>();
+    v.octant_contained = ctx->map_contained[which].as<uint32_t>();
+    v.octant_next = ctx->map_next[which].as<uint32_t>();
+    v.octant_leaf = ctx->map_leaf[which].as<uint8_t>();
+    v.photons = ctx->map_photons[which].as<float>();
+    return MCRT_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int mcrt_create(mcrt_ctx** out, int device_id) {
+    if (!out) return MCRT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MCRT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(nullptr, MCRT_ERR_NO_DEVICE, "device_id out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return fail(nullptr, MCRT_ERR_NO_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0 && !getenv("MCRT_ALLOW_ANY_ARCH"))
+        return fail(nullptr, MCRT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if ((e = hipSetDevice(device_id)) != hipSuccess)
+        return fail(nullptr, MCRT_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    mcrt_ctx* ctx = new mcrt_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->max_lds = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 65536;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && v > 0)
+            ctx->max_lds = std::max(ctx->max_lds, (size_t)v);
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MCRT_ERR_HIP, "stream/event creation failed");
+    }
+    std::vector<uint32_t> tab(kSobolTableWords);
+    buildSobolByteTables(tab.data());
+    if (int rc = uploadArray(ctx, ctx->sobol_tab, tab.data(), tab.size())) {
+        g_create_error = ctx->error;
+        mcrt_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MCRT_OK;
+}
+
+void mcrt_destroy(mcrt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* mcrt_last_error(const mcrt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!s || s->abi_version != MCRT_ABI_VERSION) return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: wrong abi_version");
+    if (s->num_surfaces == 0 || !s->surf_kind || !s->surf_interpolate || !s->surf_material || !s->surf_area || !s->surf_v || !s->surf_e ||
+        !s->materials || s->num_materials == 0)
+        return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: missing surface/material arrays");
+    if (s->num_nodes && (!s->node_bounds || !s->node_start_surface || !s->node_num_surfaces || !s->node_next_sibling))
+        return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: missing node arrays");
+    if (s->num_lights && (!s->light_surface || !s->light_cdf)) return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: missing light arrays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->has_scene = false;
+
+    const size_t ns = s->num_surfaces;
+    HostLayout L;
+    std::string lerr;
+    if (int rc = buildLayout(s, L, lerr)) return fail(ctx, rc, lerr);
+    const bool any_vn = L.any_vn;
+    std::vector<double>& prim = L.prim;
+    std::vector<double>& normal = L.normal;
+    std::vector<double>& bounds = L.node_bounds;
+    std::vector<NodeMeta>& meta = L.node_meta;
+
+    if (int rc = uploadArray(ctx, ctx->node_bounds, bounds.data(), bounds.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_v, s->surf_v, ns * 9)) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_normal, normal.data(), normal.size())) return rc;
+    if (any_vn) {
+        if (int rc = uploadArray(ctx, ctx->surf_vn, s->surf_vn, ns * 9)) return rc;
+    } else {
+        ctx->surf_vn.release();
+    }
+    if (int rc = uploadArray(ctx, ctx->surf_area, s->surf_area, ns)) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_material, s->surf_material, ns)) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_kind, s->surf_kind, ns)) return rc;
+    if (int rc = uploadArray(ctx, ctx->materials, s->materials, (size_t)s->num_materials)) return rc;
+    if (int rc = uploadArray(ctx, ctx->light_surface, s->light_surface, (size_t)s->num_lights)) return rc;
+    if (int rc = uploadArray(ctx, ctx->light_cdf, s->light_cdf, (size_t)s->num_lights)) return rc;
+
+    DeviceScene& d = ctx->scene;
+    memset(&d, 0, sizeof(d));
+    d.num_nodes = s->num_nodes;
+    d.num_surfaces = s->num_surfaces;
+    d.num_materials = s->num_materials;
+    d.num_lights = s->num_lights;
+    d.node_bounds = ctx->node_bounds.as<double>();
+    d.node_meta = ctx->node_meta.as<NodeMeta>();
+    d.prim = ctx->prim.as<double>();
+    d.surf_v = ctx->surf_v.as<double>();
+    d.surf_normal = ctx->surf_normal.as<double>();
+    d.surf_vn = any_vn ? ctx->surf_vn.as<double>() : nullptr;
+    d.surf_area = ctx->surf_area.as<double>();
+    d.surf_material = ctx->surf_material.as<uint32_t>();
+    d.surf_kind = ctx->surf_kind.as<uint8_t>();
+    d.materials = ctx->materials.as<mcrt_material>();
+    d.light_surface = ctx->light_surface.as<uint32_t>();
+    d.light_cdf = ctx->light_cdf.as<double>();
+    d.sobol_tab = ctx->sobol_tab.as<uint32_t>();
+    d.scene_ior = s->scene_ior;
+
+    // Staging plan: whole scene when its LDS image is <= 48 KiB, else the top 512 nodes of the BVH.
+    d.stage_all = 1;
+    d.stage_nodes = 0;
+    const uint32_t fixed = planLds(DeviceScene{}, kBlock).total;
+    if (planLds(d, kBlock).total - fixed > 48u * 1024u) {
+        d.stage_all = 0;
+        d.stage_nodes = std::min<uint32_t>(d.num_nodes, 512u);
+    }
+    ctx->has_scene = true;
+    return MCRT_OK;
+}
+
+int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map, const mcrt_photon_map_desc* caustic_map,
+                        uint32_t k_nearest_photons, int direct_visualization) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (k_nearest_photons == 0) return fail(ctx, MCRT_ERR_INVALID, "k_nearest_photons must be > 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->has_photons = false;
+    if (int rc = uploadMap(ctx, 0, global_map)) return rc;
+    if (int rc = uploadMap(ctx, 1, caustic_map)) return rc;
+    ctx->k_nearest = k_nearest_photons;
+    ctx->direct_visualization = direct_visualization ? 1 : 0;
+    ctx->has_photons = true;
+    return MCRT_OK;
+}
+
+uint32_t mcrt_shard_rows(const mcrt_camera_desc* cam, uint32_t* rows) {
+    if (!cam) return 0;
+    if (cam->shard_count <= 1) {
+        if (rows)
+            for (uint32_t y = 0; y < cam->height; y++) rows[y] = y;
+        return cam->height;
+    }
+    const uint32_t g = cam->shard_rows ? cam->shard_rows : 1;
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < cam->height; y++)
+        if ((y / g) % cam->shard_count == cam->shard_index) {
+            if (rows) rows[n] = y;
+            n++;
+        }
+    return n;
+}
+
+int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out_rgb,
+                       void* stream) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!d_out_rgb) return fail(ctx, MCRT_ERR_INVALID, "d_out_rgb is NULL");
+    return launchRender(ctx, cam, global_seed, integrator, d_out_rgb, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!ctx->pending) return fail(ctx, MCRT_ERR_INVALID, "no render in flight");
+    ctx->pending = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    unsigned long long h[8];
+    HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->paths = h[0];
+        stats->rays = h[1];
+        stats->node_tests = h[2];
+        stats->prim_tests = h[3];
+        stats->knn_searches = h[4];
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
+        stats->kernel_launches = ctx->launches;
+    }
+    if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
+    return MCRT_OK;
+}
+
+int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* out_rgb,
+                mcrt_stats* stats) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!out_rgb) return fail(ctx, MCRT_ERR_INVALID, "out_rgb is NULL");
+    if (int rc = validateCamera(ctx, cam)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t rows = mcrt_shard_rows(cam, nullptr);
+    const size_t row_bytes = (size_t)cam->width * 3 * sizeof(double);
+    if (ctx->out_tmp.bytes < rows * row_bytes) HIP_TRY(ctx, ctx->out_tmp.alloc(std::max<size_t>(rows * row_bytes, 8)));
+    if (int rc = launchRender(ctx, cam, global_seed, integrator, ctx->out_tmp.as<double>(), ctx->stream)) return rc;
+    mcrt_stats st;
+    int rc = mcrt_render_finish(ctx, &st);
+    if (rc) return rc;
+    if (rows) {
+        std::vector<double> packed((size_t)rows * cam->width * 3);
+        HIP_TRY(ctx, hipMemcpy(packed.data(), ctx->out_tmp.p, packed.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> idx(rows);
+        mcrt_shard_rows(cam, idx.data());
+        for (uint32_t r = 0; r < rows; r++) memcpy(out_rgb + (size_t)idx[r] * cam->width * 3, &packed[(size_t)r * cam->width * 3], row_bytes);
+    }
+    st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
+    if (stats) *stats = st;
+    return MCRT_OK;
+}
+
+int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double* direction, double* out_t, uint32_t* out_surface,
+                   double* out_uv) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_intersect before mcrt_upload_scene");
+    if (n == 0) return MCRT_OK;
+    if (!start || !direction || !out_t || !out_surface) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LaunchGeom g;
+    if (int rc = launchGeometry(ctx, intersectKernel, ctx->scene, g)) return rc;
+    if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
+    DevBuf ds, dd, dt, dsf, duv;
+    if (int rc = uploadArray(ctx, ds, start, n * 3)) return rc;
+    if (int rc = uploadArray(ctx, dd, direction, n * 3)) return rc;
+    HIP_TRY(ctx, dt.alloc(n * 8));
+    HIP_TRY(ctx, dsf.alloc(n * 4));
+    HIP_TRY(ctx, duv.alloc(n * 16));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(intersectKernel, dim3(grid), dim3(kBlock), g.lds_bytes, ctx->stream, ctx->scene, n, ds.as<double>(),
+                       dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>(), ctx->spill.as<StackEntry>(),
+                       g.total_lanes);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out_t, dt.p, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_surface, dsf.p, n * 4, hipMemcpyDeviceToHost));
+    if (out_uv) HIP_TRY(ctx, hipMemcpy(out_uv, duv.p, n * 16, hipMemcpyDeviceToHost));
+    return MCRT_OK;
+}
+
+int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_t* index, uint32_t shuffles, uint32_t global_seed,
+                 double* out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (n == 0) return MCRT_OK;
+    if (!pixel || !index || !out) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dp, di, dout;
+    if (int rc = uploadArray(ctx, dp, pixel, n)) return rc;
+    if (int rc = uploadArray(ctx, di, index, n)) return rc;
+    HIP_TRY(ctx, dout.alloc(n * 7 * 8));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(samplerKernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->sobol_tab.as<uint32_t>(), n, dp.as<uint32_t>(),
+                       di.as<uint32_t>(), shuffles, global_seed, dout.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 7 * 8, hipMemcpyDeviceToHost));
+    return MCRT_OK;
+}
+
+int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, uint32_t* out_count, uint32_t* out_index,
+             double* out_distance2) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "mcrt_knn before mcrt_upload_photons");
+    if (which < 0 || which > 1 || k == 0) return fail(ctx, MCRT_ERR_INVALID, "bad map selector or k");
+    if (n == 0) return MCRT_OK;
+    if (!p || !out_count || !out_index || !out_distance2) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t block = 64;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + block - 1) / block);
+    const uint32_t lanes = grid * block;
+    DevBuf dp, dc, di, dd, r_d2, r_idx, v_d2, v_oct;
+    if (int rc = uploadArray(ctx, dp, p, n * 3)) return rc;
+    HIP_TRY(ctx, dc.alloc(n * 4));
+    HIP_TRY(ctx, di.alloc(n * k * 4));
+    HIP_TRY(ctx, dd.alloc(n * k * 8));
+    HIP_TRY(ctx, r_d2.alloc((size_t)lanes * k * 8));
+    HIP_TRY(ctx, r_idx.alloc((size_t)lanes * k * 4));
+    HIP_TRY(ctx, v_d2.alloc((size_t)lanes * kMaxVisit * 8));
+    HIP_TRY(ctx, v_oct.alloc((size_t)lanes * kMaxVisit * 4));
+    hipLaunchKernelGGL(knnKernel, dim3(grid), dim3(block), 0, ctx->stream, ctx->maps[which], n, dp.as<double>(), k, dc.as<uint32_t>(),
+                       di.as<uint32_t>(), dd.as<double>(), r_d2.as<double>(), r_idx.as<uint32_t>(), v_d2.as<double>(),
+                       v_oct.as<uint32_t>(), lanes);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));
+    return MCRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// Per-lane integrators (the §8 rows a1, a3, a22-a24) written as ONE-BOUNCE step functions so that the
+// persistent kernel can keep every lane of a wavefront busy: a lane whose path ends is re-armed with
+// the next sample / next pixel in the same loop iteration instead of idling until the slowest path
+// of the wave finishes (mcrt_kernels.hip).
+//   PathTracer::sampleRay     integrator/path-tracer/path-tracer.cpp:14-51
+//   PhotonMapper::sampleRay   integrator/photon-mapper/photon-mapper.cpp:279-341
+//   estimate{Global,Caustic}Radiance  photon-mapper.cpp:343-391
+//   LinearOctree::knnSearch   octree/linear-octree.cpp:25-117
+#pragma once
+
+#include "mcrt_shade.hpp"
+
+namespace mcrt {
+
+struct PathState {
+    Ray ray;
+    d3 radiance, throughput;
+    LightSample ls;
+    RefractionHistory rh;
+    Sampler smp;
+};
+
+// Start of sampleRay (path-tracer.cpp:16-19 / photon-mapper.cpp:281-284) for the ray samplePixel built.
+MCRT_HD void pathBegin(PathState& st, const Ray& camera_ray) {
+    st.ray = camera_ray;
+    st.radiance = splat(0.0);
+    st.throughput = splat(1.0);
+    st.rh.init(camera_ray);
+    st.ls.bsdf_pdf = 0.0;
+    st.ls.select_probability = 0.0;
+    st.ls.light = kNoSurface;
+}
+
+// One iteration of the while(true) in PathTracer::sampleRay. Returns true when the path has ended;
+// st.radiance then holds sampleRay's return value.
+template <bool kCount>
+MCRT_HD bool pathTracerBounce(PathState& st, const SceneView& sv, const ShadeView& sh, const LaneStack& stk,
+                              TraceCounters& cnt, const uint32_t* tab) {
+    st.smp.shuffle();                                                     // :23
+    Hit isect = sceneIntersect<kCount>(sv, st.ray, stk, cnt);             // :25
+    if (isect.surface == kNoSurface) {                                    // :27-30
+        st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
+        return true;
+    }
+    Interaction ia;
+    interactionInit(ia, sh, isect, st.ray, st.rh.externalIOR(st.ray), st.smp, tab);  // :32
+    st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;       // :34
+
+    DirectQuery dq;                                                       // :35 Integrator::sampleDirect
+    if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+        Hit shadow = sceneIntersect<kCount>(sv, dq.shadow_ray, stk, cnt);
+        st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
+    }
+
+    d3 bsdf_absIdotN;
+    if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;  // :37-40
+    st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);     // :42
+    if (absorb(st.ray, st.throughput, st.smp, tab)) return true;          // :44-47
+    st.rh.update(st.ray);                                                 // :49
+    return false;
+}
+
+// ------------------------------------------------------------------ photon map
+struct PhotonMapView {
+    uint32_t num_octants;
+    uint64_t num_photons;
+    const double* octant_bounds;       // [n][6]
+    const uint32_t* octant_start;      // [n] (u32 on the device: maps are < 4G photons per GPU)
+    const uint32_t* octant_contained;  // [n]
+    const uint32_t* octant_next;       // [n] 0xFFFFFFFF = none
+    const uint8_t* octant_leaf;        // [n]
+    const float* photons;              // [n][8] flux rgb, position xyz, phi, theta
+};
+
+struct KnnEntry {
+    double distance2;
+    uint32_t index;
+};
+struct OctantEntry {
+    double distance2;
+    uint32_t octant;
+};
+
+// Per-lane scratch for the search, in global memory, interleaved by lane ([slot][lane]) so that a
+// wave touching the same slot coalesces.
+struct KnnScratch {
+    double* res_d2;      // &res_d2[lane],   stride lanes, k slots
+    uint32_t* res_idx;   // &res_idx[lane]
+    double* visit_d2;    // &visit_d2[lane], stride lanes, kMaxVisit slots
+    uint32_t* visit_oct;
+    uint32_t stride;
+    MCRT_HD KnnEntry res(uint32_t i) const { return KnnEntry{res_d2[(size_t)i * stride], res_idx[(size_t)i * stride]}; }
+    MCRT_HD void setRes(uint32_t i, KnnEntry e) const { res_d2[(size_t)i * stride] = e.distance2; res_idx[(size_t)i * stride] = e.index; }
+    MCRT_HD OctantEntry visit(uint32_t i) const { return OctantEntry{visit_d2[(size_t)i * stride], visit_oct[(size_t)i * stride]}; }
+    MCRT_HD void setVisit(uint32_t i, OctantEntry e) const { visit_d2[(size_t)i * stride] = e.distance2; visit_oct[(size_t)i * stride] = e.octant; }
+};
+constexpr uint32_t kMaxVisit = 96;  // best-first frontier: <= 7 new entries per level of an octree
+
+MCRT_HD double boxDistance2(const double* b, d3 p) {  // BoundingBox::distance2, bounding-box.cpp:43-47
+    d3 a = ld3(b) - p, c = p - ld3(b + 3);
+    d3 d = d3{gmax(gmax(a.x, c.x), 0.0), gmax(gmax(a.y, c.y), 0.0), gmax(gmax(a.z, c.z), 0.0)};
+    return dot(d, d);
+}
+MCRT_HD double boxMaxDistance2(const double* b, d3 p) {  // BoundingBox::max_distance2, bounding-box.cpp:50-54
+    d3 a = ld3(b + 3) - p, c = p - ld3(b);
+    d3 d = d3{gmax(a.x, c.x), gmax(a.y, c.y), gmax(a.z, c.z)};
+    return dot(d, d);
+}
+
+// Max-heap on distance2 of the k best photons (the reference's PriorityQueue<SearchResult<Photon>>,
+// common/priority-queue.hpp:47-50,103-123). Returns the number of results; the heap root (slot 0)
+// holds the farthest of them once `count == k`.
+MCRT_HD void knnSiftDown(const KnnScratch& s, uint32_t size, KnnEntry value, uint32_t index) {
+    for (;;) {
+        uint32_t left = 2 * index + 1, right = left + 1, max_child;
+        if (right < size) max_child = left + (s.res(left).distance2 < s.res(right).distance2 ? 1u : 0u);
+        else if (left < size) max_child = left;
+        else break;
+        KnnEntry mc = s.res(max_child);
+        if (!(value.distance2 < mc.distance2)) break;
+        s.setRes(index, mc);
+        index = max_child;
+    }
+    s.setRes(index, value);
+}
+// Min-heap on distance2 of octants still to visit (linear-octree.cpp:37-44; priority-queue.hpp:19-45).
+MCRT_HD void visitPush(const KnnScratch& s, uint32_t& size, OctantEntry value) {
+    if (size >= kMaxVisit) return;  // cannot happen for octrees of depth <= 13; guarded anyway
+    uint32_t index = size++;
+    while (index > 0) {
+        uint32_t parent = (index - 1) / 2;
+        OctantEntry pe = s.visit(parent);
+        if (!(value.distance2 < pe.distance2)) break;
+        s.setVisit(index, pe);
+        index = parent;
+    }
+    s.setVisit(index, value);
+}
+MCRT_HD void visitPop(const KnnScratch& s, uint32_t& size) {
+    if (size > 1) {
+        OctantEntry value = s.visit(--size);
+        uint32_t index = 0;
+        for (;;) {
+            uint32_t left = 2 * index + 1, right = left + 1, c;
+            if (right < size) c = left + (s.visit(right).distance2 < s.visit(left).distance2 ? 1u : 0u);
+            else if (left < size) c = left;
+            else break;
+            OctantEntry ce = s.visit(c);
+            if (!(ce.distance2 < value.distance2)) break;
+            s.setVisit(index, ce);
+            index = c;
+        }
+        s.setVisit(index, value);
+    } else {
+        size--;
+    }
+}
+
+// LinearOctree<Photon>::knnSearch (linear-octree.cpp:25-117). The k-set returned equals the
+// reference's (same pruning rules, inclusive <= comparisons); only the order of equal-distance
+// octants in the frontier may differ, which does not change the set.
+MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnScratch& s, uint32_t& octant_visits) {
+    if (m.num_octants == 0) return 0;
+    if ((uint64_t)k > m.num_photons) k = (uint32_t)m.num_photons;
+    if (k == 0) return 0;
+    double max_distance2 = kDblMax;
+    uint32_t count = 0, nvisit = 0;
+    OctantEntry current{boxDistance2(m.octant_bounds, p), 0u};
+    for (;;) {
+        const uint32_t oc = current.octant;
+        octant_visits++;
+        const uint32_t contained = m.octant_contained[oc];
+        if (m.octant_leaf[oc] || contained <= k) {
+            const uint32_t start = m.octant_start[oc], end = start + contained;
+            for (uint32_t i = start; i < end; i++) {
+                const float* ph = m.photons + (size_t)i * 8;
+                d3 d = p - d3{(double)ph[3], (double)ph[4], (double)ph[5]};  // glm::distance2(data.pos(), p)
+                double distance2 = dot(d, d);
+                if (distance2 <= max_distance2) {
+                    if (count < k) {
+                        // The reference appends unordered and heapifies at the k-th element
+                        // (linear-octree.cpp:60-72); sifting up keeps a heap throughout.
+                        uint32_t index = count++;
+                        KnnEntry value{distance2, i};
+                        while (index > 0) {
+                            uint32_t parent = (index - 1) / 2;
+                            KnnEntry pe = s.res(parent);
+                            if (!(pe.distance2 < value.distance2)) break;
+                            s.setRes(index, pe);
+                            index = parent;
+                        }
+                        s.setRes(index, value);
+                        if (count == k) max_distance2 = gmin(max_distance2, s.res(0).distance2);
+                    } else {
+                        knnSiftDown(s, count, KnnEntry{distance2, i}, 0);  // pop_push
+                        double top = s.res(0).distance2;
+                        if (top < max_distance2) max_distance2 = top;
+                    }
+                }
+            }
+        } else {
+            uint32_t child = oc + 1;
+            while (child != 0xFFFFFFFFu) {
+                const double* cb = m.octant_bounds + (size_t)child * 6;
+                double distance2 = boxDistance2(cb, p);
+                if (distance2 <= max_distance2) {
+                    visitPush(s, nvisit, OctantEntry{distance2, child});
+                    if (m.octant_contained[child] >= k) {
+                        double md = boxMaxDistance2(cb, p);
+                        if (md < max_distance2) max_distance2 = md;
+                    }
+                }
+                child = m.octant_next[child];
+            }
+        }
+        if (nvisit == 0) break;
+        current = s.visit(0);
+        if (current.distance2 > max_distance2) break;
+        visitPop(s, nvisit);
+    }
+    return count;
+}
+
+MCRT_HD d3 photonDirection(const float* ph) {  // Photon::dir, photon.hpp:19-27 (float sin/cos overloads)
+    float phi = ph[6], theta = ph[7];
+    double sin_theta = (double)sinf(theta);
+    return d3{sin_theta * (double)cosf(phi), sin_theta * (double)sinf(phi), (double)cosf(theta)};
+}
+
+struct PhotonViews {
+    PhotonMapView global_map, caustic_map;
+    uint32_t k_nearest;
+    bool direct_visualization;
+};
+
+// estimateGlobalRadiance, photon-mapper.cpp:343-363
+MCRT_HD d3 estimateGlobalRadiance(const PhotonViews& pv, const Interaction& ia, const KnnScratch& s, uint32_t& searches,
+                                  uint32_t& octant_visits) {
+    searches++;
+    const PhotonMapView& m = pv.global_map;
+    uint32_t n = knnSearch(m, ia.position, pv.k_nearest, s, octant_visits);
+    if (n == 0) return splat(0.0);
+    d3 radiance = splat(0.0);
+    for (uint32_t i = 0; i < n; i++) {
+        const float* ph = m.photons + (size_t)s.res(i).index * 8;
+        d3 bsdf_absIdotN;
+        double bsdf_pdf;
+        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection(ph), bsdf_pdf))
+            radiance = radiance + d3{(double)ph[0], (double)ph[1], (double)ph[2]} * bsdf_absIdotN / bsdf_pdf;
+    }
+    return radiance / (s.res(0).distance2 * kPi);
+}
+
+// estimateCausticRadiance (cone filter), photon-mapper.cpp:368-391
+MCRT_HD d3 estimateCausticRadiance(const PhotonViews& pv, const Interaction& ia, const KnnScratch& s, uint32_t& searches,
+                                   uint32_t& octant_visits) {
+    searches++;
+    const PhotonMapView& m = pv.caustic_map;
+    uint32_t n = knnSearch(m, ia.position, pv.k_nearest, s, octant_visits);
+    if (n == 0) return splat(0.0);
+    double inv_max_squared_radius = 1.0 / s.res(0).distance2;
+    d3 radiance = splat(0.0);
+    for (uint32_t i = 0; i < n; i++) {
+        KnnEntry e = s.res(i);
+        const float* ph = m.photons + (size_t)e.index * 8;
+        d3 bsdf_absIdotN;
+        double bsdf_pdf;
+        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
+            double wp = gmax(0.0, 1.0 - sqrt(e.distance2 * inv_max_squared_radius));
+            radiance = radiance + (d3{(double)ph[0], (double)ph[1], (double)ph[2]} * bsdf_absIdotN * wp) / bsdf_pdf;
+        }
+    }
+    return 3.0 * radiance * inv_max_squared_radius * kInvPi;
+}
+
+// One iteration of the while(true) in PhotonMapper::sampleRay (photon-mapper.cpp:288-340).
+template <bool kCount>
+MCRT_HD bool photonMapperBounce(PathState& st, const SceneView& sv, const ShadeView& sh, const PhotonViews& pv,
+                                const LaneStack& stk, const KnnScratch& ks, TraceCounters& cnt, uint32_t& searches,
+                                uint32_t& octant_visits, const uint32_t* tab) {
+    st.smp.shuffle();
+    Hit isect = sceneIntersect<kCount>(sv, st.ray, stk, cnt);
+    if (isect.surface == kNoSurface) return true;  // no sky in photon mode, :292-295
+    Interaction ia;
+    interactionInit(ia, sh, isect, st.ray, st.rh.externalIOR(st.ray), st.smp, tab);
+    st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;
+    d3 bsdf_absIdotN;
+    if (ia.dirac_delta) {  // :301-312
+        if (!st.ray.dirac_delta && st.ray.depth != 0) return true;
+        if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;
+        st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);
+    } else {
+        st.radiance = st.radiance + estimateCausticRadiance(pv, ia, ks, searches, octant_visits) * st.throughput;  // :315
+        if (!pv.direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0)) {  // :317-326
+            DirectQuery dq;
+            if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+                Hit shadow = sceneIntersect<kCount>(sv, dq.shadow_ray, stk, cnt);
+                st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
+            }
+            if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;
+            st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);
+        } else {  // :327-331
+            st.radiance = st.radiance + estimateGlobalRadiance(pv, ia, ks, searches, octant_visits) * st.throughput;
+            return true;
+        }
+    }
+    if (absorb(st.ray, st.throughput, st.smp, tab)) return true;
+    st.rh.update(st.ray);
+    return false;
+}
+
+}  // namespace mcrt

@@ -224,7 +224,7 @@ static int sphIntersect(const mcrt_scene_desc* s, uint32_t i, const Ray* ray, Hi
 }
 
 static int surfIntersect(const SceneRef* S, uint32_t i, const Ray* ray, Hit* out) {
-    if (S->c) S->c->prim_tests++;
+    if (S->c) { S->c->prim_tests++; if (S->s->surf_kind[i] == MCRT_SURF_SPHERE) S->c->sphere_tests++; }
     return S->s->surf_kind[i] == MCRT_SURF_SPHERE ? sphIntersect(S->s, i, ray, out) : triIntersect(S->s, i, ray, out);
 }
 
@@ -1008,6 +1008,7 @@ static void* worker(void* arg) {
     job->total.paths += cnt.paths; job->total.rays += cnt.rays; job->total.node_tests += cnt.node_tests;
     job->total.prim_tests += cnt.prim_tests; job->total.knn_searches += cnt.knn_searches;
     job->total.knn_octants += cnt.knn_octants; job->total.knn_photons += cnt.knn_photons;
+    job->total.sphere_tests += cnt.sphere_tests;
     pthread_mutex_unlock(&job->lock);
     free(ts.to_visit.H); free(kh[0].H); free(kh[1].H); free(dq.H);
     return NULL;

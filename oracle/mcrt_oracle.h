@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef struct oracle_counters {
-    uint64_t paths, rays, node_tests, prim_tests, knn_searches, knn_octants, knn_photons;
+    uint64_t paths, rays, node_tests, prim_tests, knn_searches, knn_octants, knn_photons, sphere_tests;
 } oracle_counters;
 
 /* Sampler (sampling/sampler.hpp:13-90): initiate(pixel), setIndex(index), `shuffles` x shuffle(),

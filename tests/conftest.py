@@ -1,0 +1,98 @@
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(TESTS, ".."))
+GOLDEN = os.path.join(TESTS, "golden")
+for p in (ROOT, TESTS):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (the HIP path has no CPU fallback)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product binding. The shared library must already be built (python __graft_entry__.py build)."""
+    m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    if not os.path.exists(m.LIB_PATH):
+        importlib.import_module("monte-carlo-ray-tracer_amd.build").build_lib()
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    return json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """Host build of the product's per-lane device code (tests/emu/mcrt_emu.cpp) — test harness only."""
+    src = os.path.join(TESTS, "emu", "mcrt_emu.cpp")
+    out = os.path.join(TESTS, "emu", "_build", "libmcrt_emu.so")
+    csrc = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, src])
+    L = C.CDLL(out)
+    vp = C.c_void_p
+    L.emu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
+    L.emu_intersect.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, vp, vp, vp]
+    L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
+    return L
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name)
+
+
+def load_radiance(render):
+    r0, r1 = render["rows"]
+    return np.fromfile(golden_path(render["file"]), dtype=np.float64).reshape(r1 - r0, render["width"], 3)
+
+
+def camera_for(image, render):
+    cam = image.camera
+    cam.width, cam.height, cam.sqrtspp = render["width"], render["height"], render["sqrtspp"]
+    return cam
+
+
+def rel_error(a, ref):
+    """per-pixel, per-channel |a-ref| / max(|ref|, 1e-3)  (SURVEY.md §8(d) parity metric)."""
+    return np.abs(a - ref) / np.maximum(np.abs(ref), 1e-3)

@@ -1,0 +1,94 @@
+"""Checks the product's per-lane device code (monte-carlo-ray-tracer_amd/csrc/*.hpp — the functions the
+gfx950 kernels inline) compiled for the host (tests/emu) against the reference's golden dumps and
+the oracle. This runs in the GPU-less container; the GPU execution of the same code through the
+C ABI is checked in test_gpu_parity.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import camera_for, golden_path, load_radiance, rel_error
+
+
+def _emu_render(emu, pkg, img, cam, seed, integ, rows, stage):
+    r0, r1 = rows
+    out = np.zeros((r1 - r0, cam.width, 3))
+    cnt = (C.c_uint64 * 5)()
+    g, c = img.photons(0), img.photons(1)
+    rc = emu.emu_render(C.byref(img.scene), C.byref(g) if g is not None else None, C.byref(c) if c is not None else None,
+                        img.param("k_nearest_photons") or 50, int(img.param("direct_visualization")), C.byref(cam), seed,
+                        integ, r0, r1, stage, out.ctypes.data, cnt)
+    assert rc == 0
+    return out, dict(rays=cnt[0], node_tests=cnt[1], prim_tests=cnt[2], overflow=cnt[3], paths=cnt[4])
+
+
+@pytest.mark.parametrize("name,stage", [("hexagon_room_diffuse", 1), ("hexagon_room", 0), ("hexagon_room_ggx", 1),
+                                        ("coffee_maker_qsah", 1), ("coffee_maker_bsah", 0), ("ior_test", 1),
+                                        ("veach_mis", 1), ("metals", 0), ("oren_nayar_test", 1), ("ggx_test", 0)])
+def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, name, stage):
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    out, cnt = _emu_render(emu, pkg, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, r["rows"], stage)
+    ref = load_radiance(r)
+    # depth-first traversal instead of the reference's best-first heap: same closest hits -> same bits
+    assert np.array_equal(out, ref), "max rel err %.3e" % rel_error(out, ref).max()
+    assert cnt["overflow"] == 0
+    # same rays as the reference-equivalent oracle (one Scene::intersect call per bounce/shadow ray)
+    _, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
+    assert cnt["rays"] == info["rays"] and cnt["paths"] == info["paths"]
+
+
+def test_photon_mapper_device_code(pkg, emu, manifest):
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    out, _ = _emu_render(emu, pkg, img, camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER, r["rows"], 1)
+    ref = load_radiance(r)
+    # the k photons are summed in heap-array order, which differs from the reference's -> few ulp
+    assert rel_error(out, ref).max() < 1e-12
+
+
+def test_sampler_byte_tables_equal_reference(emu, manifest):
+    d = golden_path(manifest["cases"]["hexagon_room"]["kat"])
+    inp = np.fromfile(os.path.join(d, "sampler_in.u32"), dtype=np.uint32).reshape(-1, 3)
+    ref = np.fromfile(os.path.join(d, "sampler_out.f64")).reshape(-1, 7)
+    out = np.empty(7)
+    for (pixel, index, shuffles), want in zip(inp, ref):
+        emu.emu_sampler(manifest["seed"], int(pixel), int(index), int(shuffles), out.ctypes.data)
+        np.testing.assert_array_equal(out, want)
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "ior_test"])
+def test_traversal_device_code_kat(pkg, emu, manifest, name):
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    d = golden_path(case["kat"])
+    rays = np.fromfile(os.path.join(d, "isect_rays.f64")).reshape(-1, 6)
+    n = rays.shape[0]
+    start, direction = rays[:, :3].copy(), rays[:, 3:].copy()
+    for stage in (0, 1):
+        t, surf, uv = np.empty(n), np.empty(n, dtype=np.uint32), np.empty((n, 2))
+        rc = emu.emu_intersect(C.byref(img.scene), n, start.ctypes.data, direction.ctypes.data, stage, t.ctypes.data,
+                               surf.ctypes.data, uv.ctypes.data)
+        assert rc == 0
+        np.testing.assert_array_equal(surf, np.fromfile(os.path.join(d, "isect_surface.u32"), dtype=np.uint32))
+        np.testing.assert_array_equal(t, np.fromfile(os.path.join(d, "isect_t.f64")))
+        np.testing.assert_array_equal(uv, np.fromfile(os.path.join(d, "isect_uv.f64")).reshape(-1, 2))
+
+
+def test_knn_device_code_kat(pkg, emu, manifest):
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    k = img.param("k_nearest_photons")
+    d = golden_path(case["kat"])
+    for which, tag in ((0, "g"), (1, "c")):
+        pts = np.fromfile(os.path.join(d, "knn_%s_points.f64" % tag)).reshape(-1, 3)
+        n = pts.shape[0]
+        cnt, idx, d2 = np.empty(n, dtype=np.uint32), np.empty((n, k), dtype=np.uint32), np.empty((n, k))
+        emu.emu_knn(C.byref(img.photons(which)), n, pts.ctypes.data, k, cnt.ctypes.data, idx.ctypes.data, d2.ctypes.data)
+        np.testing.assert_array_equal(cnt, np.fromfile(os.path.join(d, "knn_%s_count.u32" % tag), dtype=np.uint32))
+        np.testing.assert_array_equal(d2, np.fromfile(os.path.join(d, "knn_%s_d2.f64" % tag)).reshape(-1, k))
+        np.testing.assert_array_equal(idx, np.fromfile(os.path.join(d, "knn_%s_index.u32" % tag), dtype=np.uint32).reshape(-1, k))
