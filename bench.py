@@ -114,22 +114,18 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
     image_file, W, H, sqrtspp, desc = WORKLOADS[args.workload]
     img = m.SceneImage(os.path.join(ROOT, "tests", "golden", image_file))
     cam = img.camera
     cam.width, cam.height, cam.sqrtspp = W, H, sqrtspp
-    cam.shard_index, cam.shard_count, cam.shard_rows = rank, world, SHARD_ROWS
+    full = cam.copy()
+    cam = tiling.shard_camera(full, rank, world, SHARD_ROWS)
     ctx = m.Context(local_rank)
     ctx.upload_image(img)  # scene resident in HBM before the timed region
 
     my_rows = m.shard_rows(cam)
-    full = cam.copy()
-    full.shard_index, full.shard_count = 0, 1
-    max_rows = 0
-    for r in range(world):
-        c = cam.copy()
-        c.shard_index = r
-        max_rows = max(max_rows, len(m.shard_rows(c)))
+    max_rows = tiling.max_rows(full, world, SHARD_ROWS)
     dev = torch.device("cuda", local_rank)
     tile = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)  # packed owned rows (+ padding)
     gathered = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
@@ -174,9 +170,7 @@ def main():
         if world > 1:
             frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
             for r in range(world):
-                c = cam.copy()
-                c.shard_index = r
-                rows = torch.from_numpy(m.shard_rows(c).astype(np.int64)).to(dev)
+                rows = torch.from_numpy(tiling.rows_of(full, r, world, SHARD_ROWS)).to(dev)
                 frame[rows] = gathered[r][: len(rows)]
         else:
             frame = tile[: len(my_rows)]
