@@ -81,8 +81,10 @@ struct RenderParams {
 // ------------------------------------------------------------------------------------------------
 // LDS carving
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
+
 struct LdsPlan {
-    uint32_t sobol, stack, node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material,
+    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material,
         surf_kind, materials, light_surface, light_cdf, total;
 };
 
@@ -93,6 +95,7 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block)
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
     p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(StackEntry);
+    p.iors = off; off += kMaxIors * block * 8u;
     off = alignUp(off, 16);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
     p.node_bounds = off; off += nn * 48;
@@ -118,86 +121,94 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block)
 }
 
 template <class T>
-__device__ inline void stageCopy(T* dst, const T* src, uint32_t count) {
+__device__ inline MCRT_LDS_AS T* ldsAt(unsigned char* base, uint32_t off) {
+    return (MCRT_LDS_AS T*)(base + off);
+}
+
+template <class T>
+__device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t count) {
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
 }
 
 // Builds the per-lane views; stages the scene into LDS (ends with __syncthreads()).
-__device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneView& sv, ShadeView& sh,
-                                  const uint32_t*& tab, LaneStack& stk, StackEntry* spill, uint32_t total_lanes) {
+// kAll: whole scene LDS-resident (the views carry address-space-3 pointers, so every scene access in
+// the hot loops is a ds_read); otherwise only the top of the BVH is staged.
+template <bool kAll>
+__device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
+                                  SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes) {
     const LdsPlan p = planLds(s, blockDim.x);
-    uint32_t* ltab = reinterpret_cast<uint32_t*>(lds + p.sobol);
+    rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
+    rh.stride = blockDim.x;
+    rh.size = 0;
+    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
     stageCopy(ltab, s.sobol_tab, (uint32_t)kSobolTableWords);
     tab = ltab;
 
-    stk.lds = reinterpret_cast<StackEntry*>(lds + p.stack) + threadIdx.x;
+    stk.lds = ldsAt<StackEntry>(lds, p.stack) + threadIdx.x;
     stk.lds_stride = blockDim.x;
     stk.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = total_lanes;
 
     sv.num_nodes = s.num_nodes;
     sv.num_surfaces = s.num_surfaces;
-    sv.node_bounds = s.node_bounds;
-    sv.node_meta = s.node_meta;
-    sv.prim = s.prim;
-    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
-    double* lnb = reinterpret_cast<double*>(lds + p.node_bounds);
-    NodeMeta* lnm = reinterpret_cast<NodeMeta*>(lds + p.node_meta);
+    const uint32_t nn = kAll ? s.num_nodes : s.stage_nodes;
+    MCRT_LDS_AS double* lnb = ldsAt<double>(lds, p.node_bounds);
+    MCRT_LDS_AS NodeMeta* lnm = ldsAt<NodeMeta>(lds, p.node_meta);
     stageCopy(lnb, s.node_bounds, nn * 6);
     stageCopy(lnm, s.node_meta, nn);
     sv.lds_nodes = nn;
     sv.lds_node_bounds = lnb;
     sv.lds_node_meta = lnm;
-    sv.lds_prims = 0;
-    sv.lds_prim = nullptr;
-
-    sh.surf_v = s.surf_v;
-    sh.surf_normal = s.surf_normal;
-    sh.surf_vn = s.surf_vn;
-    sh.surf_area = s.surf_area;
-    sh.surf_material = s.surf_material;
-    sh.surf_kind = s.surf_kind;
-    sh.materials = s.materials;
     sh.num_lights = s.num_lights;
-    sh.light_surface = s.light_surface;
-    sh.light_cdf = s.light_cdf;
     sh.scene_ior = s.scene_ior;
 
-    if (s.stage_all) {
+    if constexpr (kAll) {
         const uint32_t ns = s.num_surfaces;
-        double* lp = reinterpret_cast<double*>(lds + p.prim);
+        sv.node_bounds = lnb;
+        sv.node_meta = lnm;
+        MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
         stageCopy(lp, s.prim, ns * kPrimStride);
-        sv.lds_prims = ns;
-        sv.lds_prim = lp;
-        double* lv = reinterpret_cast<double*>(lds + p.surf_v);
+        sv.prim = lp;
+        MCRT_LDS_AS double* lv = ldsAt<double>(lds, p.surf_v);
         stageCopy(lv, s.surf_v, ns * 9);
         sh.surf_v = lv;
-        double* ln = reinterpret_cast<double*>(lds + p.surf_normal);
+        MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
         stageCopy(ln, s.surf_normal, ns * 3);
         sh.surf_normal = ln;
-        if (s.surf_vn) {
-            double* lvn = reinterpret_cast<double*>(lds + p.surf_vn);
-            stageCopy(lvn, s.surf_vn, ns * 9);
-            sh.surf_vn = lvn;
-        }
-        double* la = reinterpret_cast<double*>(lds + p.surf_area);
+        MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
+        if (s.surf_vn) stageCopy(lvn, s.surf_vn, ns * 9);
+        sh.surf_vn = lvn;
+        MCRT_LDS_AS double* la = ldsAt<double>(lds, p.surf_area);
         stageCopy(la, s.surf_area, ns);
         sh.surf_area = la;
-        uint32_t* lm = reinterpret_cast<uint32_t*>(lds + p.surf_material);
+        MCRT_LDS_AS uint32_t* lm = ldsAt<uint32_t>(lds, p.surf_material);
         stageCopy(lm, s.surf_material, ns);
         sh.surf_material = lm;
-        uint8_t* lk = reinterpret_cast<uint8_t*>(lds + p.surf_kind);
+        MCRT_LDS_AS uint8_t* lk = ldsAt<uint8_t>(lds, p.surf_kind);
         stageCopy(lk, s.surf_kind, ns);
         sh.surf_kind = lk;
-        uint64_t* lmat = reinterpret_cast<uint64_t*>(lds + p.materials);
+        MCRT_LDS_AS uint64_t* lmat = ldsAt<uint64_t>(lds, p.materials);
         stageCopy(lmat, reinterpret_cast<const uint64_t*>(s.materials), s.num_materials * (uint32_t)(sizeof(mcrt_material) / 8));
-        sh.materials = reinterpret_cast<const mcrt_material*>(lmat);
-        double* lc = reinterpret_cast<double*>(lds + p.light_cdf);
+        sh.materials = (MCRT_LDS_AS const mcrt_material*)lmat;
+        MCRT_LDS_AS double* lc = ldsAt<double>(lds, p.light_cdf);
         stageCopy(lc, s.light_cdf, s.num_lights);
         sh.light_cdf = lc;
-        uint32_t* ll = reinterpret_cast<uint32_t*>(lds + p.light_surface);
+        MCRT_LDS_AS uint32_t* ll = ldsAt<uint32_t>(lds, p.light_surface);
         stageCopy(ll, s.light_surface, s.num_lights);
         sh.light_surface = ll;
+    } else {
+        sv.node_bounds = s.node_bounds;
+        sv.node_meta = s.node_meta;
+        sv.prim = s.prim;
+        sh.surf_v = s.surf_v;
+        sh.surf_normal = s.surf_normal;
+        sh.surf_vn = s.surf_vn;
+        sh.surf_area = s.surf_area;
+        sh.surf_material = s.surf_material;
+        sh.surf_kind = s.surf_kind;
+        sh.materials = s.materials;
+        sh.light_surface = s.light_surface;
+        sh.light_cdf = s.light_cdf;
     }
     __syncthreads();
 }
@@ -246,14 +257,15 @@ __host__ __device__ inline uint32_t localToGlobalRow(const mcrt_camera_desc& cam
 // ------------------------------------------------------------------------------------------------
 // the integrator kernel
 // ------------------------------------------------------------------------------------------------
-template <int kIntegrator, bool kCount>
-__global__ void __launch_bounds__(256) renderKernel(const DeviceScene scene, const RenderParams prm) {
+template <int kIntegrator, bool kCount, bool kAll>
+__global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
     extern __shared__ __align__(16) unsigned char lds[];
-    SceneView sv;
-    ShadeView sh;
-    const uint32_t* tab;
+    SceneViewT<kAll> sv;
+    ShadeViewT<kAll> sh;
+    SobolTab tab;
     LaneStack stk;
-    setupViews(scene, lds, sv, sh, tab, stk, prm.spill, prm.total_lanes);
+    RefractionHistory rh;
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
 
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
     KnnScratch ks;
@@ -307,15 +319,15 @@ __global__ void __launch_bounds__(256) renderKernel(const DeviceScene scene, con
         if (have_pixel) {
             if (!path_active) {
                 st.smp.setIndex(sample);  // camera.cpp:77
-                pathBegin(st, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
                 path_active = true;
                 paths++;
             }
             bool done;
             if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
-                done = photonMapperBounce<kCount>(st, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
+                done = photonMapperBounce<kCount, kAll>(st, rh, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
             else
-                done = pathTracerBounce<kCount>(st, sv, sh, stk, cnt, tab);
+                done = pathTracerBounce<kCount, kAll>(st, rh, sv, sh, stk, cnt, tab);
             if (done) {
                 // Film::deposit, default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105)
                 acc0 += st.radiance.x * 1.0;
@@ -349,19 +361,21 @@ __global__ void __launch_bounds__(256) renderKernel(const DeviceScene scene, con
 // ------------------------------------------------------------------------------------------------
 // operator-level kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) intersectKernel(const DeviceScene scene, uint64_t n, const double* start,
+template <bool kAll>
+__global__ void __launch_bounds__(kBlock) intersectKernel(const DeviceScene scene, uint64_t n, const double* start,
                                                        const double* direction, double* out_t, uint32_t* out_surface,
                                                        double* out_uv, StackEntry* spill, uint32_t total_lanes) {
     extern __shared__ __align__(16) unsigned char lds[];
-    SceneView sv;
-    ShadeView sh;
-    const uint32_t* tab;
+    SceneViewT<kAll> sv;
+    ShadeViewT<kAll> sh;
+    SobolTab tab;
     LaneStack stk;
-    setupViews(scene, lds, sv, sh, tab, stk, spill, total_lanes);
+    RefractionHistory rh;
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, spill, total_lanes);
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
-        Hit h = sceneIntersect<false>(sv, ray, stk, cnt);
+        Hit h = sceneIntersect<kAll, false, false>(sv, ray, stk, cnt);
         out_t[i] = h.t;
         out_surface[i] = h.surface;
         out_uv[2 * i] = h.u;
@@ -379,7 +393,7 @@ __global__ void samplerKernel(const uint32_t* tab, uint64_t n, const uint32_t* p
         s.initiate(global_seed, pixel[i]);
         s.setIndex(index[i]);
         for (uint32_t k = 0; k < shuffles; k++) s.shuffle();
-        for (int d = 0; d < 7; d++) out[i * 7 + d] = s.get(d, ltab);
+        for (int d = 0; d < 7; d++) out[i * 7 + d] = s.get(d, (SobolTab)ltab);
     }
 }
 
@@ -503,7 +517,6 @@ int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
     return MCRT_OK;
 }
 
-constexpr uint32_t kBlock = 256;
 
 struct LaunchGeom {
     uint32_t grid, lds_bytes, total_lanes;
@@ -566,9 +579,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
 
     static const bool count_tests = getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0;
     using KernelT = void (*)(const DeviceScene, const RenderParams);
-    KernelT kernel;
-    if (photon) kernel = count_tests ? renderKernel<MCRT_INTEGRATOR_PHOTON_MAPPER, true> : renderKernel<MCRT_INTEGRATOR_PHOTON_MAPPER, false>;
-    else kernel = count_tests ? renderKernel<MCRT_INTEGRATOR_PATH_TRACER, true> : renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false>;
+    const bool all = ctx->scene.stage_all != 0;
+    constexpr int PT = MCRT_INTEGRATOR_PATH_TRACER, PM = MCRT_INTEGRATOR_PHOTON_MAPPER;
+    static const KernelT table[2][2][2] = {
+        {{renderKernel<PT, false, false>, renderKernel<PT, false, true>}, {renderKernel<PT, true, false>, renderKernel<PT, true, true>}},
+        {{renderKernel<PM, false, false>, renderKernel<PM, false, true>}, {renderKernel<PM, true, false>, renderKernel<PM, true, true>}}};
+    KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
 
     LaunchGeom g;
     if (int rc = launchGeometry(ctx, kernel, ctx->scene, g)) return rc;
@@ -884,7 +900,8 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     if (!start || !direction || !out_t || !out_surface) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     LaunchGeom g;
-    if (int rc = launchGeometry(ctx, intersectKernel, ctx->scene, g)) return rc;
+    auto ikernel = ctx->scene.stage_all ? intersectKernel<true> : intersectKernel<false>;
+    if (int rc = launchGeometry(ctx, ikernel, ctx->scene, g)) return rc;
     if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
     DevBuf ds, dd, dt, dsf, duv;
     if (int rc = uploadArray(ctx, ds, start, n * 3)) return rc;
@@ -893,7 +910,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     HIP_TRY(ctx, dsf.alloc(n * 4));
     HIP_TRY(ctx, duv.alloc(n * 16));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(intersectKernel, dim3(grid), dim3(kBlock), g.lds_bytes, ctx->stream, ctx->scene, n, ds.as<double>(),
+    hipLaunchKernelGGL(ikernel, dim3(grid), dim3(kBlock), g.lds_bytes, ctx->stream, ctx->scene, n, ds.as<double>(),
                        dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>(), ctx->spill.as<StackEntry>(),
                        g.total_lanes);
     HIP_TRY(ctx, hipGetLastError());

@@ -16,16 +16,15 @@ struct PathState {
     Ray ray;
     d3 radiance, throughput;
     LightSample ls;
-    RefractionHistory rh;
     Sampler smp;
 };
 
 // Start of sampleRay (path-tracer.cpp:16-19 / photon-mapper.cpp:281-284) for the ray samplePixel built.
-MCRT_HD void pathBegin(PathState& st, const Ray& camera_ray) {
+MCRT_HD void pathBegin(PathState& st, RefractionHistory& rh, const Ray& camera_ray) {
     st.ray = camera_ray;
     st.radiance = splat(0.0);
     st.throughput = splat(1.0);
-    st.rh.init(camera_ray);
+    rh.init(camera_ray);
     st.ls.bsdf_pdf = 0.0;
     st.ls.select_probability = 0.0;
     st.ls.light = kNoSurface;
@@ -33,22 +32,22 @@ MCRT_HD void pathBegin(PathState& st, const Ray& camera_ray) {
 
 // One iteration of the while(true) in PathTracer::sampleRay. Returns true when the path has ended;
 // st.radiance then holds sampleRay's return value.
-template <bool kCount>
-MCRT_HD bool pathTracerBounce(PathState& st, const SceneView& sv, const ShadeView& sh, const LaneStack& stk,
-                              TraceCounters& cnt, const uint32_t* tab) {
+template <bool kCount, bool kAll>
+MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh, const LaneStack& stk,
+                              TraceCounters& cnt, SobolTab tab) {
     st.smp.shuffle();                                                     // :23
-    Hit isect = sceneIntersect<kCount>(sv, st.ray, stk, cnt);             // :25
+    Hit isect = sceneIntersect<kAll, kCount, false>(sv, st.ray, stk, cnt);  // :25
     if (isect.surface == kNoSurface) {                                    // :27-30
         st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
         return true;
     }
-    Interaction ia;
-    interactionInit(ia, sh, isect, st.ray, st.rh.externalIOR(st.ray), st.smp, tab);  // :32
+    InteractionT<kAll> ia;
+    interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);  // :32
     st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;       // :34
 
     DirectQuery dq;                                                       // :35 Integrator::sampleDirect
     if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
-        Hit shadow = sceneIntersect<kCount>(sv, dq.shadow_ray, stk, cnt);
+        Hit shadow = sceneIntersect<kAll, kCount, true>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
         st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
     }
 
@@ -56,7 +55,7 @@ MCRT_HD bool pathTracerBounce(PathState& st, const SceneView& sv, const ShadeVie
     if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;  // :37-40
     st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);     // :42
     if (absorb(st.ray, st.throughput, st.smp, tab)) return true;          // :44-47
-    st.rh.update(st.ray);                                                 // :49
+    rh.update(st.ray);                                                 // :49
     return false;
 }
 
@@ -94,7 +93,7 @@ struct KnnScratch {
     MCRT_HD OctantEntry visit(uint32_t i) const { return OctantEntry{visit_d2[(size_t)i * stride], visit_oct[(size_t)i * stride]}; }
     MCRT_HD void setVisit(uint32_t i, OctantEntry e) const { visit_d2[(size_t)i * stride] = e.distance2; visit_oct[(size_t)i * stride] = e.octant; }
 };
-constexpr uint32_t kMaxVisit = 96;  // best-first frontier: <= 7 new entries per level of an octree
+constexpr uint32_t kMaxVisit = 160;  // best-first frontier: <= 7 new entries per level of an octree (22 levels)
 
 MCRT_HD double boxDistance2(const double* b, d3 p) {  // BoundingBox::distance2, bounding-box.cpp:43-47
     d3 a = ld3(b) - p, c = p - ld3(b + 3);
@@ -234,7 +233,8 @@ struct PhotonViews {
 };
 
 // estimateGlobalRadiance, photon-mapper.cpp:343-363
-MCRT_HD d3 estimateGlobalRadiance(const PhotonViews& pv, const Interaction& ia, const KnnScratch& s, uint32_t& searches,
+template <bool L>
+MCRT_HD d3 estimateGlobalRadiance(const PhotonViews& pv, const InteractionT<L>& ia, const KnnScratch& s, uint32_t& searches,
                                   uint32_t& octant_visits) {
     searches++;
     const PhotonMapView& m = pv.global_map;
@@ -252,7 +252,8 @@ MCRT_HD d3 estimateGlobalRadiance(const PhotonViews& pv, const Interaction& ia, 
 }
 
 // estimateCausticRadiance (cone filter), photon-mapper.cpp:368-391
-MCRT_HD d3 estimateCausticRadiance(const PhotonViews& pv, const Interaction& ia, const KnnScratch& s, uint32_t& searches,
+template <bool L>
+MCRT_HD d3 estimateCausticRadiance(const PhotonViews& pv, const InteractionT<L>& ia, const KnnScratch& s, uint32_t& searches,
                                    uint32_t& octant_visits) {
     searches++;
     const PhotonMapView& m = pv.caustic_map;
@@ -274,15 +275,15 @@ MCRT_HD d3 estimateCausticRadiance(const PhotonViews& pv, const Interaction& ia,
 }
 
 // One iteration of the while(true) in PhotonMapper::sampleRay (photon-mapper.cpp:288-340).
-template <bool kCount>
-MCRT_HD bool photonMapperBounce(PathState& st, const SceneView& sv, const ShadeView& sh, const PhotonViews& pv,
+template <bool kCount, bool kAll>
+MCRT_HD bool photonMapperBounce(PathState& st, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh, const PhotonViews& pv,
                                 const LaneStack& stk, const KnnScratch& ks, TraceCounters& cnt, uint32_t& searches,
-                                uint32_t& octant_visits, const uint32_t* tab) {
+                                uint32_t& octant_visits, SobolTab tab) {
     st.smp.shuffle();
-    Hit isect = sceneIntersect<kCount>(sv, st.ray, stk, cnt);
+    Hit isect = sceneIntersect<kAll, kCount, false>(sv, st.ray, stk, cnt);
     if (isect.surface == kNoSurface) return true;  // no sky in photon mode, :292-295
-    Interaction ia;
-    interactionInit(ia, sh, isect, st.ray, st.rh.externalIOR(st.ray), st.smp, tab);
+    InteractionT<kAll> ia;
+    interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);
     st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;
     d3 bsdf_absIdotN;
     if (ia.dirac_delta) {  // :301-312
@@ -294,7 +295,7 @@ MCRT_HD bool photonMapperBounce(PathState& st, const SceneView& sv, const ShadeV
         if (!pv.direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0)) {  // :317-326
             DirectQuery dq;
             if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
-                Hit shadow = sceneIntersect<kCount>(sv, dq.shadow_ray, stk, cnt);
+                Hit shadow = sceneIntersect<kAll, kCount, true>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
                 st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
             }
             if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;
@@ -305,7 +306,7 @@ MCRT_HD bool photonMapperBounce(PathState& st, const SceneView& sv, const ShadeV
         }
     }
     if (absorb(st.ray, st.throughput, st.smp, tab)) return true;
-    st.rh.update(st.ray);
+    rh.update(st.ray);
     return false;
 }
 

@@ -15,7 +15,27 @@
 #define MCRT_HD inline
 #endif
 
+// LDS (address space 3) pointers: telling the compiler that staged scene data lives in LDS turns the
+// generic flat_load (which occupies the vector-memory path and both wait counters) into ds_read with
+// 32-bit addressing. On the host build (tests/emu) the qualifier is empty.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MCRT_LDS_AS __attribute__((address_space(3)))
+#else
+#define MCRT_LDS_AS
+#endif
+
 namespace mcrt {
+
+template <class T, bool kLds>
+struct PtrSel {
+    using type = const T*;
+};
+template <class T>
+struct PtrSel<T, true> {
+    using type = MCRT_LDS_AS const T*;
+};
+template <class T, bool kLds>
+using cptr = typename PtrSel<T, kLds>::type;
 
 constexpr double kPi = 3.14159265358979323846;      // common/constants.hpp:5-8
 constexpr double kInvPi = 0.31830988618379067154;
@@ -50,12 +70,20 @@ MCRT_HD d3 cross(d3 x, d3 y) {
 MCRT_HD d3 normalize(d3 v) { return v * (1.0 / sqrt(dot(v, v))); }
 MCRT_HD double gmin(double x, double y) { return (y < x) ? y : x; }  // glm::min / std::min(x,y)
 MCRT_HD double gmax(double x, double y) { return (x < y) ? y : x; }  // glm::max / std::max(x,y)
+// IEEE minNum/maxNum (one v_min_f64 / v_max_f64). Equal to gmin/gmax whenever neither input is NaN
+// (up to the sign of a zero result, which no comparison can observe).
+MCRT_HD double fastMin(double x, double y) { return fmin(x, y); }
+MCRT_HD double fastMax(double x, double y) { return fmax(x, y); }
+MCRT_HD bool finite64(double x) { return fabs(x) <= kDblMax; }  // false for NaN and +-inf
 MCRT_HD double compMax(d3 v) { return gmax(gmax(v.x, v.y), v.z); }
 MCRT_HD double compMin(d3 v) { return gmin(gmin(v.x, v.y), v.z); }
 MCRT_HD d3 mix(d3 x, d3 y, double a) { return x * (1.0 - a) + y * a; }
 MCRT_HD double mix(double x, double y, double a) { return x * (1.0 - a) + y * a; }
 MCRT_HD d3 sqrt3(d3 a) { return d3{sqrt(a.x), sqrt(a.y), sqrt(a.z)}; }
-MCRT_HD d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+template <class P>
+MCRT_HD d3 ld3(P p) {
+    return d3{p[0], p[1], p[2]};
+}
 
 // glm::dmat3 by columns; only what CoordinateSystem needs (common/coordinate-system.cpp:7-35).
 struct m3 {

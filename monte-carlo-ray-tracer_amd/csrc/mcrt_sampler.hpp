@@ -12,6 +12,8 @@
 
 namespace mcrt {
 
+using SobolTab = MCRT_LDS_AS const uint32_t*;
+
 constexpr int kSobolDims = 6;                       // dims 1..6 (dim 0 is the index itself)
 constexpr int kSobolTableWords = kSobolDims * 4 * 256;  // 6144 u32 = 24 KiB
 
@@ -88,10 +90,10 @@ struct Sampler {
         shuffled_index = owenScramble(bit_reversed_index, seed);
     }
     // get<DIM>() (sampler.hpp:20-30). `tab` = byte tables (LDS on the GPU).
-    MCRT_HD double get(int dim, const uint32_t* tab) const {
+    MCRT_HD double get(int dim, MCRT_LDS_AS const uint32_t* tab) const {
         uint32_t x = shuffled_index;
         if (dim != 0) {
-            const uint32_t* t = tab + (dim - 1) * 1024;
+            MCRT_LDS_AS const uint32_t* t = tab + (dim - 1) * 1024;
             uint32_t i = shuffled_index;
             x = t[i & 255u] ^ t[256 + ((i >> 8) & 255u)] ^ t[512 + ((i >> 16) & 255u)] ^ t[768 + (i >> 24)];
         }

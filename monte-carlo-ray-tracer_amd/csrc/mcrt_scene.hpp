@@ -16,10 +16,18 @@
 //
 // Traversal: the reference pops nodes best-first from a binary heap. The closest hit does not depend
 // on visiting order (only exact-t ties between different surfaces do), so each lane runs a
-// near-child-first DEPTH-first walk with an 8-byte-per-entry stack {float entry_t rounded down, node}
-// kept in LDS ([depth][lane] so a wave's accesses are conflict-free), spilling to a per-lane global
-// slab past kLdsStackDepth. Entry distances are only used to cull (conservatively); every box and
+// depth-first "while-while" walk: an inner loop that only descends through inner nodes (all lanes of
+// the wave execute box tests together) and a leaf step (all lanes execute primitive tests together),
+// nearest hit child kept in registers, the others on an 8-byte-per-entry stack
+// {float entry_t rounded down, node} in LDS ([depth][lane], conflict-free), spilling to a per-lane
+// global slab past kLdsStackDepth. Entry distances only cull (conservatively); every box and
 // primitive test is the reference's FP64 arithmetic.
+//
+// Shadow rays (Integrator::sampleDirect, integrator.cpp:45-73) only need to know whether the closest
+// hit is the sampled light and, if so, its t. With d = |light point - start| the query is therefore
+// bounded to t < d(1+1e-9) (anything farther cannot be closer than the light) and ends at the first
+// hit of ANOTHER surface with t < d(1-1e-9) (the light cannot be the closest hit any more); the
+// estimate is unchanged.
 #pragma once
 
 #include "mcrt_math.hpp"
@@ -70,30 +78,31 @@ struct StackEntry {
     uint32_t node;
 };
 
-// Everything a lane needs to traverse. Pointers may address LDS (staged copies) or global memory.
-struct SceneView {
+// What a lane traverses. kAll: the whole BVH and all primitives are staged in LDS (small scenes);
+// otherwise the first `lds_nodes` nodes are in LDS and the rest, and all primitives, in global memory.
+template <bool kAll>
+struct SceneViewT {
     uint32_t num_nodes, num_surfaces;
-    const double* node_bounds;   // global, all nodes
-    const NodeMeta* node_meta;   // global, all nodes
-    const double* prim;          // global, all primitives
-    uint32_t lds_nodes;          // nodes [0, lds_nodes) are also in LDS
-    const double* lds_node_bounds;
-    const NodeMeta* lds_node_meta;
-    uint32_t lds_prims;          // primitives [0, lds_prims) are also in LDS
-    const double* lds_prim;
+    cptr<double, kAll> node_bounds;
+    cptr<NodeMeta, kAll> node_meta;
+    cptr<double, kAll> prim;
+    uint32_t lds_nodes;  // only meaningful when !kAll
+    MCRT_LDS_AS const double* lds_node_bounds;
+    MCRT_LDS_AS const NodeMeta* lds_node_meta;
 };
 
 struct LaneStack {
-    StackEntry* lds;       // &lds_stack[lane_in_block]; stride = block size
+    MCRT_LDS_AS StackEntry* lds;  // &lds_stack[lane_in_block]; stride = block size
     uint32_t lds_stride;
-    StackEntry* spill;     // &spill[global_lane]; stride = total lanes
+    StackEntry* spill;            // &spill[global_lane]; stride = total lanes
     uint32_t spill_stride;
     MCRT_HD void put(int sp, StackEntry e) const {
         if (sp < kLdsStackDepth) lds[(uint32_t)sp * lds_stride] = e;
         else spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride] = e;
     }
     MCRT_HD StackEntry get(int sp) const {
-        return sp < kLdsStackDepth ? lds[(uint32_t)sp * lds_stride] : spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
+        if (sp < kLdsStackDepth) return lds[(uint32_t)sp * lds_stride];
+        return spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
     }
 };
 
@@ -102,15 +111,53 @@ struct TraceCounters {
 };
 
 MCRT_HD float floatBelow(double t) {  // largest float <= t (conservative cull key)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2float_rd(t);
+#else
     float f = (float)t;
     if ((double)f > t) f = nextafterf(f, -INFINITY);
     return f;
+#endif
 }
 
-// BoundingBox::intersect (bounding-box.cpp:9-17)
-MCRT_HD bool boxIntersect(const double* b, const Ray& ray, double& t) {
-    d3 t0 = (ld3(b) - ray.start) * ray.inv_direction;
-    d3 t1 = (ld3(b + 3) - ray.start) * ray.inv_direction;
+struct Box {
+    double v[6];
+};
+
+template <bool kAll>
+MCRT_HD Box loadBox(const SceneViewT<kAll>& sv, uint32_t i) {
+    Box b;
+    if (kAll) {
+        cptr<double, kAll> p = sv.node_bounds + (size_t)i * 6;
+        for (int k = 0; k < 6; k++) b.v[k] = p[k];
+    } else if (i < sv.lds_nodes) {
+        MCRT_LDS_AS const double* p = sv.lds_node_bounds + i * 6u;
+        for (int k = 0; k < 6; k++) b.v[k] = p[k];
+    } else {
+        cptr<double, kAll> p = sv.node_bounds + (size_t)i * 6;
+        for (int k = 0; k < 6; k++) b.v[k] = p[k];
+    }
+    return b;
+}
+template <bool kAll>
+MCRT_HD NodeMeta loadMeta(const SceneViewT<kAll>& sv, uint32_t i) {
+    if (!kAll && i < sv.lds_nodes) return sv.lds_node_meta[i];
+    return sv.node_meta[i];
+}
+
+// BoundingBox::intersect (bounding-box.cpp:9-17). kFast uses v_min/v_max_f64; the caller selects it
+// only when no slab product can be NaN (all components of ray.inv_direction finite), where it gives
+// the same decision and the same t.
+template <bool kFast>
+MCRT_HD bool boxIntersect(const Box& b, const Ray& ray, double& t) {
+    d3 t0 = (d3{b.v[0], b.v[1], b.v[2]} - ray.start) * ray.inv_direction;
+    d3 t1 = (d3{b.v[3], b.v[4], b.v[5]} - ray.start) * ray.inv_direction;
+    if (kFast) {
+        double lo = fastMax(fastMax(fastMin(t0.x, t1.x), fastMin(t0.y, t1.y)), fastMin(t0.z, t1.z));
+        double hi = fastMin(fastMin(fastMax(t0.x, t1.x), fastMax(t0.y, t1.y)), fastMax(t0.z, t1.z));
+        t = fastMax(lo, 0.0);
+        return hi >= t;
+    }
     d3 lo = d3{gmin(t0.x, t1.x), gmin(t0.y, t1.y), gmin(t0.z, t1.z)};
     d3 hi = d3{gmax(t0.x, t1.x), gmax(t0.y, t1.y), gmax(t0.z, t1.z)};
     t = gmax(compMax(lo), 0.0);
@@ -118,7 +165,8 @@ MCRT_HD bool boxIntersect(const double* b, const Ray& ray, double& t) {
 }
 
 // Triangle::intersect (triangle.cpp:23-63) / Sphere::intersect (sphere.cpp:13-26) on one record.
-MCRT_HD bool primIntersect(const double* rec, const Ray& ray, Hit& out) {
+template <class P>
+MCRT_HD bool primIntersect(P rec, const Ray& ray, Hit& out) {
     const double tag = rec[9];
     if (tag == 1.0) {  // sphere
         d3 so = ray.start - ld3(rec);
@@ -144,12 +192,12 @@ MCRT_HD bool primIntersect(const double* rec, const Ray& ray, Hit& out) {
         return true;
     }
     d3 v0 = ld3(rec), E1 = ld3(rec + 3), E2 = ld3(rec + 6);
-    d3 P = cross(ray.direction, E2);
-    double determinant = dot(P, E1);
+    d3 P_ = cross(ray.direction, E2);
+    double determinant = dot(P_, E1);
     if (determinant < kEpsilon && determinant > -kEpsilon) return false;
     double inv_determinant = 1.0 / determinant;
     d3 T = ray.start - v0;
-    double u = dot(P, T) * inv_determinant;
+    double u = dot(P_, T) * inv_determinant;
     if (u > 1.0 || u < 0.0) return false;
     d3 Q = cross(T, E1);
     double v = dot(Q, ray.direction) * inv_determinant;
@@ -163,10 +211,17 @@ MCRT_HD bool primIntersect(const double* rec, const Ray& ray, Hit& out) {
     return true;
 }
 
-template <bool kCount>
-MCRT_HD Hit sceneIntersect(const SceneView& sv, const Ray& ray, const LaneStack& stk, TraceCounters& cnt) {
+struct ShadowQuery {
+    uint32_t light;  // surface the shadow ray was aimed at
+    double t_near;   // d (1 - 1e-9): a closer hit of another surface decides the query
+    double t_far;    // d (1 + 1e-9): nothing farther can matter
+};
+
+template <bool kAll, bool kCount, bool kShadow>
+MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const LaneStack& stk, TraceCounters& cnt,
+                           const ShadowQuery* sq = nullptr) {
     Hit best;
-    best.t = kDblMax;
+    best.t = kShadow ? sq->t_far : kDblMax;
     best.u = 0.0;
     best.v = 0.0;
     best.surface = kNoSurface;
@@ -175,78 +230,103 @@ MCRT_HD Hit sceneIntersect(const SceneView& sv, const Ray& ray, const LaneStack&
 
     if (sv.num_nodes == 0) {  // brute force, scene.cpp:161-173
         for (uint32_t i = 0; i < sv.num_surfaces; i++) {
-            const double* rec = i < sv.lds_prims ? sv.lds_prim + (size_t)i * kPrimStride : sv.prim + (size_t)i * kPrimStride;
             Hit h;
             if (kCount) cnt.prim_tests++;
-            if (primIntersect(rec, ray, h) && h.t < best.t) {
+            if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && h.t < best.t) {
                 best = h;
                 best.surface = i;
+                if (kShadow && i != sq->light && h.t < sq->t_near) return best;
             }
         }
         return best;
     }
 
+    // v_min/v_max box test is exact unless a slab product can be 0*inf = NaN
+    const bool fast = finite64(ray.inv_direction.x) && finite64(ray.inv_direction.y) && finite64(ray.inv_direction.z);
+
     double t;
     if (kCount) cnt.node_tests++;
-    const double* rb = sv.lds_nodes > 0 ? sv.lds_node_bounds : sv.node_bounds;
-    if (!boxIntersect(rb, ray, t)) return best;
+    {
+        Box rb = loadBox(sv, 0u);
+        if (!(fast ? boxIntersect<true>(rb, ray, t) : boxIntersect<false>(rb, ray, t))) return best;
+    }
 
     int sp = 0;
     uint32_t node = 0;
-    for (;;) {
-        NodeMeta m = node < sv.lds_nodes ? sv.lds_node_meta[node] : sv.node_meta[node];
-        if (!(m.b & kInnerFlag)) {
-            const uint32_t end = m.a + m.b;
-            for (uint32_t i = m.a; i < end; i++) {
-                const double* rec = i < sv.lds_prims ? sv.lds_prim + (size_t)i * kPrimStride : sv.prim + (size_t)i * kPrimStride;
-                Hit h;
-                if (kCount) cnt.prim_tests++;
-                if (primIntersect(rec, ray, h) && h.t < best.t) {
-                    best = h;
-                    best.surface = i;
-                }
-            }
-        } else {
+    bool have = true;
+    while (have) {
+        NodeMeta m = loadMeta(sv, node);
+        // ---- descend: only inner nodes in this loop, so the wave's lanes run box tests together
+        while (m.b & kInnerFlag) {
             const uint32_t first = m.a, count = m.b & ~kInnerFlag;
-            const int sp0 = sp;
-            float nearest = INFINITY;
-            int nearest_sp = -1;
+            double near_t = 0.0;
+            uint32_t near_node = kNoSurface;
             for (uint32_t c = first; c < first + count; c++) {
-                const double* cb = c < sv.lds_nodes ? sv.lds_node_bounds + (size_t)c * 6 : sv.node_bounds + (size_t)c * 6;
+                Box cb = loadBox(sv, c);
                 if (kCount) cnt.node_tests++;
-                if (boxIntersect(cb, ray, t) && t < best.t) {
-                    if (sp < kMaxStackDepth) {
-                        StackEntry e;
-                        e.t = floatBelow(t);
-                        e.node = c;
-                        if (e.t < nearest) {
-                            nearest = e.t;
-                            nearest_sp = sp;
+                const bool hit = fast ? boxIntersect<true>(cb, ray, t) : boxIntersect<false>(cb, ray, t);
+                if (hit && t < best.t) {
+                    // keep the nearest child in registers, push the others
+                    uint32_t push_node = c;
+                    double push_t = t;
+                    if (near_node == kNoSurface || t < near_t) {
+                        push_node = near_node;
+                        push_t = near_t;
+                        near_node = c;
+                        near_t = t;
+                    }
+                    if (push_node != kNoSurface) {
+                        if (sp < kMaxStackDepth) {
+                            StackEntry e;
+                            e.t = floatBelow(push_t);
+                            e.node = push_node;
+                            stk.put(sp++, e);
+                        } else {
+                            cnt.overflow = 1;
                         }
-                        stk.put(sp++, e);
-                    } else {
-                        cnt.overflow = 1;
                     }
                 }
             }
-            // visit the nearest of the children just pushed first: move it to the top of the stack
-            if (sp - sp0 > 1 && nearest_sp != sp - 1) {
-                StackEntry a = stk.get(nearest_sp), b = stk.get(sp - 1);
-                stk.put(nearest_sp, b);
-                stk.put(sp - 1, a);
+            if (near_node != kNoSurface) {
+                node = near_node;
+            } else {
+                have = false;
+                while (sp > 0) {
+                    StackEntry e = stk.get(--sp);
+                    if ((double)e.t < best.t) {
+                        node = e.node;
+                        have = true;
+                        break;
+                    }
+                }
+                if (!have) break;
+            }
+            m = loadMeta(sv, node);
+        }
+        if (!have) break;
+        // ---- leaf
+        {
+            const uint32_t end = m.a + m.b;
+            for (uint32_t i = m.a; i < end; i++) {
+                Hit h;
+                if (kCount) cnt.prim_tests++;
+                if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && h.t < best.t) {
+                    best = h;
+                    best.surface = i;
+                    if (kShadow && i != sq->light && h.t < sq->t_near) return best;
+                }
             }
         }
-        // pop, culling entries that can no longer beat the current closest hit
-        bool found = false;
+        // ---- pop, culling entries that can no longer beat the current closest hit
+        have = false;
         while (sp > 0) {
             StackEntry e = stk.get(--sp);
             if ((double)e.t < best.t) {
                 node = e.node;
-                found = true;
+                have = true;
                 break;
             }
         }
-        if (!found) break;
     }
     return best;
 }

@@ -11,17 +11,19 @@
 namespace mcrt {
 
 // Per-surface data needed after the closest hit is known, plus materials and lights.
-struct ShadeView {
-    const double* surf_v;           // [n][9] triangle v0,v1,v2 / sphere origin,radius
-    const double* surf_normal;      // [n][3] Triangle::normal_
-    const double* surf_vn;          // [n][9] vertex normals (may be null when no surface interpolates)
-    const double* surf_area;        // [n]
-    const uint32_t* surf_material;  // [n]
-    const uint8_t* surf_kind;       // [n]
-    const mcrt_material* materials;
+// L: the arrays are the workgroup's LDS copies (small scenes) instead of global memory.
+template <bool L>
+struct ShadeViewT {
+    cptr<double, L> surf_v;           // [n][9] triangle v0,v1,v2 / sphere origin,radius
+    cptr<double, L> surf_normal;      // [n][3] Triangle::normal_
+    cptr<double, L> surf_vn;          // [n][9] vertex normals (may be null when no surface interpolates)
+    cptr<double, L> surf_area;        // [n]
+    cptr<uint32_t, L> surf_material;  // [n]
+    cptr<uint8_t, L> surf_kind;       // [n]
+    cptr<mcrt_material, L> materials;
     uint32_t num_lights;
-    const uint32_t* light_surface;
-    const double* light_cdf;
+    cptr<uint32_t, L> light_surface;
+    cptr<double, L> light_cdf;
     double scene_ior;
 };
 
@@ -96,14 +98,17 @@ MCRT_HD d3 ggxVisibleMicrofacet(double u, double v, d3 wo, double ax, double ay)
 }
 
 // ------------------------------------------------------------------ Material (material/material.cpp)
-MCRT_HD d3 matLambertian(const mcrt_material& m) { return ld3(m.reflectance) * kInvPi; }  // :76-79
-MCRT_HD d3 matOrenNayar(const mcrt_material& m, d3 wi, d3 wo) {                           // :82-95
+template <class M>
+MCRT_HD d3 matLambertian(const M& m) { return ld3(m.reflectance) * kInvPi; }  // :76-79
+template <class M>
+MCRT_HD d3 matOrenNayar(const M& m, d3 wi, d3 wo) {                           // :82-95
     double cos_delta_phi =
         gmin(gmax((wi.x * wo.x + wi.y * wo.y) / sqrt((sq(wi.x) + sq(wi.y)) * (sq(wo.x) + sq(wo.y))), 0.0), 1.0);
     double D = sqrt((1.0 - sq(wi.z)) * (1.0 - sq(wo.z))) / gmax(wi.z, wo.z);
     return matLambertian(m) * (m.A + m.B * cos_delta_phi * D);
 }
-MCRT_HD d3 matDiffuseReflection(const mcrt_material& m, d3 wi, d3 wo, double& pdf) {  // :17-27
+template <class M>
+MCRT_HD d3 matDiffuseReflection(const M& m, d3 wi, d3 wo, double& pdf) {  // :17-27
     if (wi.z < 0.0) {
         pdf = 0.0;
         return splat(0.0);
@@ -111,7 +116,8 @@ MCRT_HD d3 matDiffuseReflection(const mcrt_material& m, d3 wi, d3 wo, double& pd
     pdf = wi.z * kInvPi;
     return (m.flags & MCRT_MAT_ROUGH) ? matOrenNayar(m, wi, wo) : matLambertian(m);
 }
-MCRT_HD d3 matSpecularReflection(const mcrt_material& m, d3 wi, d3 wo, double& pdf) {  // :29-45
+template <class M>
+MCRT_HD d3 matSpecularReflection(const M& m, d3 wi, d3 wo, double& pdf) {  // :29-45
     if (wi.z < 0.0) {
         pdf = 0.0;
         return splat(0.0);
@@ -120,7 +126,8 @@ MCRT_HD d3 matSpecularReflection(const mcrt_material& m, d3 wi, d3 wo, double& p
     pdf = 1.0;
     return ld3(m.specular_reflectance) / fabs(wi.z);
 }
-MCRT_HD d3 matSpecularTransmission(const mcrt_material& m, d3 wi, d3 wo, double n1, double n2, double& pdf,
+template <class M>
+MCRT_HD d3 matSpecularTransmission(const M& m, d3 wi, d3 wo, double n1, double n2, double& pdf,
                                    bool inside, bool flux) {  // :47-69
     if (wi.z > 0.0) {
         pdf = 0.0;
@@ -139,19 +146,22 @@ MCRT_HD d3 matSpecularTransmission(const mcrt_material& m, d3 wi, d3 wo, double 
 }
 
 // ------------------------------------------------------------------ surfaces
-MCRT_HD d3 surfNormal(const ShadeView& sh, uint32_t i, d3 pos) {  // triangle.cpp:99-102, sphere.cpp:46-49
+template <bool L>
+MCRT_HD d3 surfNormal(const ShadeViewT<L>& sh, uint32_t i, d3 pos) {  // triangle.cpp:99-102, sphere.cpp:46-49
     if (sh.surf_kind[i] == MCRT_SURF_SPHERE) {
-        const double* p = sh.surf_v + (size_t)i * 9;
+        cptr<double, L> p = sh.surf_v + (size_t)i * 9;
         return (pos - ld3(p)) / p[3];
     }
     return ld3(sh.surf_normal + (size_t)i * 3);
 }
-MCRT_HD d3 surfInterpolatedNormal(const ShadeView& sh, uint32_t i, double u, double v) {  // triangle.cpp:109-113
-    const double* n = sh.surf_vn + (size_t)i * 9;
+template <bool L>
+MCRT_HD d3 surfInterpolatedNormal(const ShadeViewT<L>& sh, uint32_t i, double u, double v) {  // triangle.cpp:109-113
+    cptr<double, L> n = sh.surf_vn + (size_t)i * 9;
     return normalize((1.0 - u - v) * ld3(n) + u * ld3(n + 3) + v * ld3(n + 6));
 }
-MCRT_HD d3 surfSample(const ShadeView& sh, uint32_t i, double u, double v) {  // triangle.cpp:93-97, sphere.cpp:37-44
-    const double* p = sh.surf_v + (size_t)i * 9;
+template <bool L>
+MCRT_HD d3 surfSample(const ShadeViewT<L>& sh, uint32_t i, double u, double v) {  // triangle.cpp:93-97, sphere.cpp:37-44
+    cptr<double, L> p = sh.surf_v + (size_t)i * 9;
     if (sh.surf_kind[i] == MCRT_SURF_SPHERE) {
         double z = 1.0 - 2.0 * u;
         double r = sqrt(1.0 - sq(z));
@@ -163,11 +173,14 @@ MCRT_HD d3 surfSample(const ShadeView& sh, uint32_t i, double u, double v) {  //
 }
 
 // ------------------------------------------------------------------ RefractionHistory (ray/ray.cpp:74-98)
-// The reference keeps a std::vector<double> of medium IORs. Here it is a fixed stack of kMaxIors
-// entries (documented cap; deeper nesting than 16 dielectrics keeps the top entry).
-constexpr int kMaxIors = 16;
+// The reference keeps a std::vector<double> of medium IORs (reserve(8)). Here it is a per-lane stack of
+// kMaxIors doubles in LDS ([entry][lane]); it is a separate object, not a member of the path state,
+// so that the dynamically indexed array does not force the whole path state out of registers.
+// Documented cap: nesting deeper than kMaxIors dielectrics keeps the top entry.
+constexpr int kMaxIors = 8;
 struct RefractionHistory {
-    double iors[kMaxIors];
+    MCRT_LDS_AS double* iors;  // &lds_iors[lane]; stride = block size
+    uint32_t stride;
     int size;
     MCRT_HD void init(const Ray& ray) {
         iors[0] = ray.medium_ior;
@@ -176,7 +189,7 @@ struct RefractionHistory {
     MCRT_HD void update(const Ray& ray) {
         if (ray.refraction_level > 0) {
             if (ray.refraction_level == size) {
-                if (size < kMaxIors) iors[size++] = ray.medium_ior;
+                if (size < kMaxIors) iors[(uint32_t)(size++) * stride] = ray.medium_ior;
             } else if (ray.refraction_level < size - 1) {
                 size--;
             }
@@ -186,17 +199,18 @@ struct RefractionHistory {
         int i = ray.refraction_level - 1;
         i = i < 0 ? 0 : i;
         i = i > size - 1 ? size - 1 : i;
-        return iors[i];
+        return iors[(uint32_t)i * stride];
     }
 };
 
 // ------------------------------------------------------------------ Interaction (ray/interaction.cpp)
 enum : int { kReflect = 0, kRefract = 1, kDiffuse = 2 };
 
-struct Interaction {
+template <bool L>
+struct InteractionT {
     int type;
     double t, n1, n2, T, R;
-    const mcrt_material* material;
+    cptr<mcrt_material, L> material;
     uint32_t surface;
     d3 position, normal, out;
     m3 shading_cs;
@@ -209,8 +223,9 @@ struct Interaction {
     bool ray_dirac_delta;
 };
 
-MCRT_HD void interactionInit(Interaction& ia, const ShadeView& sh, const Hit& isect, const Ray& ray, double external_ior,
-                             const Sampler& smp, const uint32_t* tab) {  // interaction.cpp:12-54
+template <bool L>
+MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const Hit& isect, const Ray& ray, double external_ior,
+                             const Sampler& smp, SobolTab tab) {  // interaction.cpp:12-54
     ia.t = isect.t;
     ia.out = -ray.direction;
     ia.n1 = ray.medium_ior;
@@ -260,8 +275,9 @@ MCRT_HD void interactionInit(Interaction& ia, const ShadeView& sh, const Hit& is
 }
 
 // Interaction::BSDF (local frame), interaction.cpp:84-153
-MCRT_HD d3 interactionBSDFLocal(const Interaction& ia, d3 wo, d3 wi, double& pdf, bool flux, bool wi_dirac_delta) {
-    const mcrt_material& m = *ia.material;
+template <bool L>
+MCRT_HD d3 interactionBSDFLocal(const InteractionT<L>& ia, d3 wo, d3 wi, double& pdf, bool flux, bool wi_dirac_delta) {
+    const auto& m = *ia.material;
     const uint32_t f = m.flags;
     const double n1 = ia.n1, n2 = ia.n2;
     double cos_theta = wo.z;
@@ -306,7 +322,8 @@ MCRT_HD d3 interactionBSDFLocal(const Interaction& ia, d3 wo, d3 wi, double& pdf
 }
 
 // Interaction::BSDF (world wi), interaction.cpp:74-82
-MCRT_HD bool interactionBSDF(const Interaction& ia, d3& bsdf_absIdotN, d3 world_wi, double& pdf) {
+template <bool L>
+MCRT_HD bool interactionBSDF(const InteractionT<L>& ia, d3& bsdf_absIdotN, d3 world_wi, double& pdf) {
     d3 wi = csTo(ia.shading_cs, world_wi);
     d3 wo = csTo(ia.shading_cs, ia.out);
     bsdf_absIdotN = interactionBSDFLocal(ia, wo, wi, pdf, false, false) * fabs(wi.z);
@@ -319,7 +336,8 @@ MCRT_HD d3 cosWeightedHemi(double u, double v) {  // sampling/sampling.hpp:35-44
     return d3{r * cos(azimuth), r * sin(azimuth), sqrt(1 - u)};
 }
 
-MCRT_HD d3 interactionSpecularNormal(const Interaction& ia, const Sampler& smp, const uint32_t* tab) {  // interaction.cpp:185-193
+template <bool L>
+MCRT_HD d3 interactionSpecularNormal(const InteractionT<L>& ia, const Sampler& smp, SobolTab tab) {  // interaction.cpp:185-193
     if (ia.material->flags & MCRT_MAT_ROUGH_SPECULAR) {
         double u0 = smp.get(kDimBsdf, tab), u1 = smp.get(kDimBsdf + 1, tab);
         return csFrom(ia.shading_cs, ggxVisibleMicrofacet(u0, u1, csTo(ia.shading_cs, ia.out), ia.material->a[0], ia.material->a[1]));
@@ -328,7 +346,8 @@ MCRT_HD d3 interactionSpecularNormal(const Interaction& ia, const Sampler& smp, 
 }
 
 // Ray::Ray(const Interaction&), ray/ray.cpp:16-67
-MCRT_HD Ray rayFromInteraction(const Interaction& ia, const Sampler& smp, const uint32_t* tab) {
+template <bool L>
+MCRT_HD Ray rayFromInteraction(const InteractionT<L>& ia, const Sampler& smp, SobolTab tab) {
     Ray r;
     r.depth = (uint16_t)(ia.ray_depth + 1);
     r.diffuse_depth = ia.ray_diffuse_depth;
@@ -371,8 +390,9 @@ MCRT_HD Ray rayFromInteraction(const Interaction& ia, const Sampler& smp, const 
 }
 
 // Interaction::sampleBSDF, interaction.cpp:56-72
-MCRT_HD bool interactionSampleBSDF(const Interaction& ia, d3& bsdf_absIdotN, double& pdf, Ray& new_ray, bool flux,
-                                   const Sampler& smp, const uint32_t* tab) {
+template <bool L>
+MCRT_HD bool interactionSampleBSDF(const InteractionT<L>& ia, d3& bsdf_absIdotN, double& pdf, Ray& new_ray, bool flux,
+                                   const Sampler& smp, SobolTab tab) {
     new_ray = rayFromInteraction(ia, smp, tab);
     d3 wi = csTo(ia.shading_cs, new_ray.direction);
     if ((new_ray.refraction && wi.z >= 0.0) || (!new_ray.refraction && wi.z <= 0.0)) return false;
@@ -393,7 +413,8 @@ MCRT_HD double powerHeuristic(double a_pdf, double b_pdf) {  // common/util.hpp:
 }
 
 // Scene::selectLight (scene.cpp:225-236) with Sampling::weightedIdx (sampling.hpp:13-27)
-MCRT_HD uint32_t selectLight(const ShadeView& sh, double u, double& select_probability) {
+template <bool L>
+MCRT_HD uint32_t selectLight(const ShadeViewT<L>& sh, double u, double& select_probability) {
     uint32_t left = 0, right = sh.num_lights - 1;
     while (left < right) {
         uint32_t middle = (left + right) / 2;
@@ -411,9 +432,11 @@ MCRT_HD uint32_t selectLight(const ShadeView& sh, double u, double& select_proba
 struct DirectQuery {
     Ray shadow_ray;
     double cos_light_theta;
+    ShadowQuery sq;  // bounds for the shadow traversal (mcrt_scene.hpp)
 };
-MCRT_HD bool sampleDirectSetup(const ShadeView& sh, const Interaction& ia, LightSample& ls, DirectQuery& q,
-                               const Sampler& smp, const uint32_t* tab) {
+template <bool L>
+MCRT_HD bool sampleDirectSetup(const ShadeViewT<L>& sh, const InteractionT<L>& ia, LightSample& ls, DirectQuery& q,
+                               const Sampler& smp, SobolTab tab) {
     if (sh.num_lights == 0 || (ia.material->flags & MCRT_MAT_DIRAC_DELTA)) {
         ls.light = kNoSurface;
         return false;
@@ -421,18 +444,26 @@ MCRT_HD bool sampleDirectSetup(const ShadeView& sh, const Interaction& ia, Light
     double u0 = smp.get(kDimLight, tab), u1 = smp.get(kDimLight + 1, tab), u2 = smp.get(kDimLight + 2, tab);
     ls.light = selectLight(sh, u2, ls.select_probability);
     d3 light_pos = surfSample(sh, ls.light, u0, u1);
-    q.shadow_ray = makeRayTo(ia.position + ia.normal * kEpsilon, light_pos);
+    d3 shadow_start = ia.position + ia.normal * kEpsilon;
+    q.shadow_ray = makeRayTo(shadow_start, light_pos);
     q.cos_light_theta = dot(-q.shadow_ray.direction, surfNormal(sh, ls.light, light_pos));
     if (q.cos_light_theta <= 0.0) return false;
     double cos_theta = dot(q.shadow_ray.direction, ia.normal);
     if (cos_theta <= 0.0) {
         if ((ia.material->flags & MCRT_MAT_OPAQUE) || cos_theta == 0.0) return false;
-        q.shadow_ray = makeRayTo(ia.position - ia.normal * kEpsilon, light_pos);  // try transmission
+        shadow_start = ia.position - ia.normal * kEpsilon;
+        q.shadow_ray = makeRayTo(shadow_start, light_pos);  // try transmission
     }
+    const d3 to_light = light_pos - shadow_start;
+    const double dist = sqrt(dot(to_light, to_light));
+    q.sq.light = ls.light;
+    q.sq.t_near = dist * (1.0 - 1e-9);
+    q.sq.t_far = dist * (1.0 + 1e-9);
     return true;
 }
 // Second half (integrator.cpp:68-86), given the shadow ray's closest hit.
-MCRT_HD d3 sampleDirectFinish(const ShadeView& sh, const Interaction& ia, const LightSample& ls, const DirectQuery& q,
+template <bool L>
+MCRT_HD d3 sampleDirectFinish(const ShadeViewT<L>& sh, const InteractionT<L>& ia, const LightSample& ls, const DirectQuery& q,
                               const Hit& shadow_hit) {
     if (shadow_hit.surface == kNoSurface || shadow_hit.surface != ls.light) return splat(0.0);
     double light_pdf = sq(shadow_hit.t) / (sh.surf_area[ls.light] * q.cos_light_theta);
@@ -440,12 +471,13 @@ MCRT_HD d3 sampleDirectFinish(const ShadeView& sh, const Interaction& ia, const 
     d3 bsdf_absIdotN;
     if (!interactionBSDF(ia, bsdf_absIdotN, q.shadow_ray.direction, bsdf_pdf)) return splat(0.0);
     double mis_weight = powerHeuristic(light_pdf, bsdf_pdf);
-    const mcrt_material& lm = sh.materials[sh.surf_material[ls.light]];
+    const auto& lm = sh.materials[sh.surf_material[ls.light]];
     return mis_weight * bsdf_absIdotN * ld3(lm.emittance) / (light_pdf * ls.select_probability);
 }
 
 // Integrator::sampleEmissive, integrator.cpp:93-110
-MCRT_HD d3 sampleEmissive(const ShadeView& sh, const Interaction& ia, const LightSample& ls) {
+template <bool L>
+MCRT_HD d3 sampleEmissive(const ShadeViewT<L>& sh, const InteractionT<L>& ia, const LightSample& ls) {
     if ((ia.material->flags & MCRT_MAT_EMISSIVE) && !ia.inside) {
         if (ia.ray_depth == 0 || ia.ray_dirac_delta) return ld3(ia.material->emittance);
         if (ls.light == ia.surface) {
@@ -459,7 +491,7 @@ MCRT_HD d3 sampleEmissive(const ShadeView& sh, const Interaction& ia, const Ligh
 }
 
 // Integrator::absorb, integrator.cpp:112-129 (min_ray_depth 3, min_priority_ray_depth 16: integrator.hpp:28-29)
-MCRT_HD bool absorb(const Ray& ray, d3& throughput, const Sampler& smp, const uint32_t* tab) {
+MCRT_HD bool absorb(const Ray& ray, d3& throughput, const Sampler& smp, SobolTab tab) {
     double survive = compMax(throughput) * ray.refraction_scale;
     if (survive == 0.0) return true;
     if (ray.diffuse_depth > 3 || ray.depth > 16) {
@@ -478,7 +510,7 @@ MCRT_HD d3 skyColor(const Ray& ray) {
 
 // Camera::samplePixel ray generation, camera/camera.cpp:79-95 (sampler already at setIndex(i)).
 MCRT_HD Ray cameraRay(const mcrt_camera_desc& cam, double scene_ior, uint32_t x, uint32_t y, const Sampler& smp,
-                      const uint32_t* tab) {
+                      SobolTab tab) {
     double pixel_size = cam.sensor_width / (double)cam.width;
     double half_x = (double)cam.width * 0.5, half_y = (double)cam.height * 0.5;
     double px = (double)x + smp.get(kDimPixel, tab), py = (double)y + smp.get(kDimPixel + 1, tab);

@@ -20,11 +20,16 @@ namespace {
 
 struct Emu {
     HostLayout L;
-    SceneView sv;
-    ShadeView sh;
+    SceneViewT<true> sv_all;    // "whole scene staged" flavour of the views
+    SceneViewT<false> sv_top;   // "top of the BVH staged" flavour
+    ShadeViewT<true> sh_all;
+    ShadeViewT<false> sh_top;
+    bool stage_all;
     std::vector<uint32_t> tab;
     std::vector<StackEntry> stack_lds, stack_spill;
     LaneStack stk;
+    std::vector<double> iors;
+    RefractionHistory rh;
     std::vector<uint32_t> map_start[2], map_contained[2];
     PhotonViews pv;
     std::vector<double> res_d2, visit_d2;
@@ -43,30 +48,39 @@ int setup(Emu& E, const mcrt_scene_desc* s, bool stage_lds) {
     E.stk.lds_stride = 1;
     E.stk.spill = E.stack_spill.data();
     E.stk.spill_stride = 1;
-    SceneView& sv = E.sv;
-    sv.num_nodes = s->num_nodes;
-    sv.num_surfaces = s->num_surfaces;
-    sv.node_bounds = E.L.node_bounds.data();
-    sv.node_meta = E.L.node_meta.data();
-    sv.prim = E.L.prim.data();
-    // exercise both the "staged" and the "global" side of the index tests
-    sv.lds_nodes = stage_lds ? s->num_nodes / 2 : 0;
-    sv.lds_node_bounds = E.L.node_bounds.data();
-    sv.lds_node_meta = E.L.node_meta.data();
-    sv.lds_prims = stage_lds ? s->num_surfaces / 2 : 0;
-    sv.lds_prim = E.L.prim.data();
-    ShadeView& sh = E.sh;
-    sh.surf_v = s->surf_v;
-    sh.surf_normal = E.L.normal.data();
-    sh.surf_vn = s->surf_vn;
-    sh.surf_area = s->surf_area;
-    sh.surf_material = s->surf_material;
-    sh.surf_kind = s->surf_kind;
-    sh.materials = s->materials;
-    sh.num_lights = s->num_lights;
-    sh.light_surface = s->light_surface;
-    sh.light_cdf = s->light_cdf;
-    sh.scene_ior = s->scene_ior;
+    E.iors.assign(kMaxIors, 0.0);
+    E.rh.iors = E.iors.data();
+    E.rh.stride = 1;
+    E.rh.size = 0;
+    E.stage_all = stage_lds;
+    auto fillScene = [&](auto& sv) {
+        sv.num_nodes = s->num_nodes;
+        sv.num_surfaces = s->num_surfaces;
+        sv.node_bounds = E.L.node_bounds.data();
+        sv.node_meta = E.L.node_meta.data();
+        sv.prim = E.L.prim.data();
+        // the "top" flavour exercises both sides of the node-index test
+        sv.lds_nodes = s->num_nodes / 2;
+        sv.lds_node_bounds = E.L.node_bounds.data();
+        sv.lds_node_meta = E.L.node_meta.data();
+    };
+    auto fillShade = [&](auto& sh) {
+        sh.surf_v = s->surf_v;
+        sh.surf_normal = E.L.normal.data();
+        sh.surf_vn = s->surf_vn;
+        sh.surf_area = s->surf_area;
+        sh.surf_material = s->surf_material;
+        sh.surf_kind = s->surf_kind;
+        sh.materials = s->materials;
+        sh.num_lights = s->num_lights;
+        sh.light_surface = s->light_surface;
+        sh.light_cdf = s->light_cdf;
+        sh.scene_ior = s->scene_ior;
+    };
+    fillScene(E.sv_all);
+    fillScene(E.sv_top);
+    fillShade(E.sh_all);
+    fillShade(E.sh_top);
     return 0;
 }
 
@@ -126,12 +140,16 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
             double acc[3] = {0, 0, 0};
             for (uint32_t i = 0; i < spp; i++) {
                 st.smp.setIndex(i);
-                pathBegin(st, cameraRay(*cam, E.sh.scene_ior, x, y, st.smp, E.tab.data()));
+                pathBegin(st, E.rh, cameraRay(*cam, E.sh_all.scene_ior, x, y, st.smp, E.tab.data()));
                 totals[4]++;
                 for (;;) {
-                    bool done = integrator == MCRT_INTEGRATOR_PHOTON_MAPPER
-                                    ? photonMapperBounce<true>(st, E.sv, E.sh, E.pv, E.stk, E.ks, cnt, searches, octant_visits, E.tab.data())
-                                    : pathTracerBounce<true>(st, E.sv, E.sh, E.stk, cnt, E.tab.data());
+                    bool done;
+                    if (integrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
+                        done = E.stage_all ? photonMapperBounce<true, true>(st, E.rh, E.sv_all, E.sh_all, E.pv, E.stk, E.ks, cnt, searches, octant_visits, E.tab.data())
+                                           : photonMapperBounce<true, false>(st, E.rh, E.sv_top, E.sh_top, E.pv, E.stk, E.ks, cnt, searches, octant_visits, E.tab.data());
+                    else
+                        done = E.stage_all ? pathTracerBounce<true, true>(st, E.rh, E.sv_all, E.sh_all, E.stk, cnt, E.tab.data())
+                                           : pathTracerBounce<true, false>(st, E.rh, E.sv_top, E.sh_top, E.stk, cnt, E.tab.data());
                     if (done) break;
                 }
                 acc[0] += st.radiance.x * 1.0;
@@ -154,7 +172,8 @@ int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start,
     TraceCounters cnt = {0, 0, 0, 0};
     for (uint64_t i = 0; i < n; i++) {
         Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
-        Hit h = sceneIntersect<true>(E.sv, ray, E.stk, cnt);
+        Hit h = E.stage_all ? sceneIntersect<true, true, false>(E.sv_all, ray, E.stk, cnt)
+                            : sceneIntersect<false, true, false>(E.sv_top, ray, E.stk, cnt);
         out_t[i] = h.t;
         out_surface[i] = h.surface;
         out_uv[2 * i] = h.u;
