@@ -38,6 +38,9 @@ struct DeviceScene {
     const double* node_bounds;
     const NodeMeta* node_meta;
     const double* prim;
+    const double* flat_prim;      // kind-sorted copy (flat mode)
+    const uint32_t* flat_index;
+    uint32_t flat_tris;
     const double* surf_v;
     const double* surf_normal;
     const double* surf_vn;  // may be null
@@ -52,6 +55,7 @@ struct DeviceScene {
     // staging plan
     uint32_t stage_all;    // 1: whole scene in LDS
     uint32_t stage_nodes;  // number of leading nodes staged
+    uint32_t flat;         // 1: tiny scene, test every primitive in a wave-uniform loop (no BVH walk)
 };
 
 struct DevicePhotonMap {
@@ -81,10 +85,11 @@ struct RenderParams {
 // ------------------------------------------------------------------------------------------------
 // LDS carving
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
 struct LdsPlan {
-    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material,
+    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material,
         surf_kind, materials, light_surface, light_cdf, total;
 };
 
@@ -103,6 +108,8 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block)
     if (s.stage_all) {
         const uint32_t ns = s.num_surfaces;
         p.prim = off; off += ns * kPrimStride * 8;
+        p.flat_prim = off; off += s.flat ? ns * kPrimStride * 8 : 0;
+        p.flat_index = off; off = alignUp(off + (s.flat ? ns * 4 : 0), 16);
         p.surf_v = off; off += ns * 72;
         p.surf_normal = off; off += ns * 24;
         p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
@@ -113,7 +120,7 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block)
         p.light_cdf = off; off += s.num_lights * 8;
         p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
     } else {
-        p.prim = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
+        p.prim = p.flat_prim = p.flat_index = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
             p.light_cdf = p.light_surface = off;
     }
     p.total = off;
@@ -149,7 +156,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
     stk.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = total_lanes;
 
-    sv.num_nodes = s.num_nodes;
+    sv.num_nodes = s.flat ? 0u : s.num_nodes;
     sv.num_surfaces = s.num_surfaces;
     const uint32_t nn = kAll ? s.num_nodes : s.stage_nodes;
     MCRT_LDS_AS double* lnb = ldsAt<double>(lds, p.node_bounds);
@@ -169,6 +176,17 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
         stageCopy(lp, s.prim, ns * kPrimStride);
         sv.prim = lp;
+        sv.flat_tris = s.flat_tris;
+        sv.flat_prim = nullptr;
+        sv.flat_index = nullptr;
+        if (s.flat) {
+            MCRT_LDS_AS double* lfp = ldsAt<double>(lds, p.flat_prim);
+            stageCopy(lfp, s.flat_prim, ns * kPrimStride);
+            sv.flat_prim = lfp;
+            MCRT_LDS_AS uint32_t* lfi = ldsAt<uint32_t>(lds, p.flat_index);
+            stageCopy(lfi, s.flat_index, ns);
+            sv.flat_index = lfi;
+        }
         MCRT_LDS_AS double* lv = ldsAt<double>(lds, p.surf_v);
         stageCopy(lv, s.surf_v, ns * 9);
         sh.surf_v = lv;
@@ -200,6 +218,9 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         sv.node_bounds = s.node_bounds;
         sv.node_meta = s.node_meta;
         sv.prim = s.prim;
+        sv.flat_tris = 0;
+        sv.flat_prim = nullptr;
+        sv.flat_index = nullptr;
         sh.surf_v = s.surf_v;
         sh.surf_normal = s.surf_normal;
         sh.surf_vn = s.surf_vn;
@@ -257,7 +278,7 @@ __host__ __device__ inline uint32_t localToGlobalRow(const mcrt_camera_desc& cam
 // ------------------------------------------------------------------------------------------------
 // the integrator kernel
 // ------------------------------------------------------------------------------------------------
-template <int kIntegrator, bool kCount, bool kAll>
+template <int kIntegrator, bool kCount, bool kAll, bool kProf = false>
 __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
     extern __shared__ __align__(16) unsigned char lds[];
     SceneViewT<kAll> sv;
@@ -284,6 +305,8 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
 
     PathState st;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
+    PhaseProf<kProf> prof;
+    if constexpr (kProf) prof.begin();
     uint32_t paths = 0, searches = 0, octant_visits = 0;
     bool have_pixel = false, path_active = false, exhausted = false;
     uint32_t px = 0, py = 0, ly = 0, sample = 0;
@@ -291,6 +314,7 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
     const uint32_t W = prm.cam.width;
 
     for (;;) {
+        if (kProf) prof.mark(kPhLoop);
         const bool need = !have_pixel && !exhausted;
         if (__ballot(need)) {
             const unsigned long long w = wavePop(need, prm.work_counter);
@@ -318,6 +342,7 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
         }
         if (have_pixel) {
             if (!path_active) {
+                if (kProf) prof.mark(kPhRegen);
                 st.smp.setIndex(sample);  // camera.cpp:77
                 pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
                 path_active = true;
@@ -327,7 +352,8 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
             if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
                 done = photonMapperBounce<kCount, kAll>(st, rh, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
             else
-                done = pathTracerBounce<kCount, kAll>(st, rh, sv, sh, stk, cnt, tab);
+                done = pathTracerBounce<kCount, kAll, kProf>(st, rh, sv, sh, stk, cnt, tab, &prof);
+            if (kProf) prof.mark(kPhLoop);
             if (done) {
                 // Film::deposit, default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105)
                 acc0 += st.radiance.x * 1.0;
@@ -356,6 +382,13 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
     waveAccumulate(prm.stats + 4, searches);
     waveAccumulate(prm.stats + 5, cnt.overflow);
     waveAccumulate(prm.stats + 6, octant_visits);
+    if constexpr (kProf) {
+        prof.mark(kPhLoop);
+        for (int i = 0; i < kNumPhases; i++) {
+            atomicAdd(prm.stats + 8 + i, prof.wave_cycles[i]);
+            atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -477,7 +510,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -539,7 +572,7 @@ int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g)
 
 int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
-    if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(8 * sizeof(unsigned long long)));
+    if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
     if (ctx->spill_lanes < total_lanes) {
         HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
         ctx->spill_lanes = total_lanes;
@@ -585,6 +618,8 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         {{renderKernel<PT, false, false>, renderKernel<PT, false, true>}, {renderKernel<PT, true, false>, renderKernel<PT, true, true>}},
         {{renderKernel<PM, false, false>, renderKernel<PM, false, true>}, {renderKernel<PM, true, false>, renderKernel<PM, true, true>}}};
     KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
+    static const bool profile_phases = getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0;
+    if (profile_phases && !photon) kernel = all ? renderKernel<PT, false, true, true> : renderKernel<PT, false, false, true>;
 
     LaunchGeom g;
     if (int rc = launchGeometry(ctx, kernel, ctx->scene, g)) return rc;
@@ -618,7 +653,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         ctx->pending = true;
         ctx->launches = 0;
         ctx->t_begin = std::chrono::steady_clock::now();
-        HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
         return MCRT_OK;
@@ -629,7 +664,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
 
     ctx->t_begin = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
     HIP_TRY(ctx, hipGetLastError());
@@ -757,6 +792,8 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->node_bounds, bounds.data(), bounds.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_v, s->surf_v, ns * 9)) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_normal, normal.data(), normal.size())) return rc;
     if (any_vn) {
@@ -780,6 +817,9 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.node_bounds = ctx->node_bounds.as<double>();
     d.node_meta = ctx->node_meta.as<NodeMeta>();
     d.prim = ctx->prim.as<double>();
+    d.flat_prim = ctx->flat_prim.as<double>();
+    d.flat_index = ctx->flat_index.as<uint32_t>();
+    d.flat_tris = L.flat_tris;
     d.surf_v = ctx->surf_v.as<double>();
     d.surf_normal = ctx->surf_normal.as<double>();
     d.surf_vn = any_vn ? ctx->surf_vn.as<double>() : nullptr;
@@ -800,6 +840,13 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
         d.stage_all = 0;
         d.stage_nodes = std::min<uint32_t>(d.num_nodes, 512u);
     }
+    // Tiny scenes: a BVH of a few dozen primitives costs more in wavefront divergence (every lane walks
+    // its own node sequence) than it saves in tests. With <= MCRT_FLAT_MAX primitives (default 64) all
+    // lanes test all primitives in one wave-uniform loop, as Scene::intersect does without a "bvh" key
+    // (scene.cpp:161-173); the closest hit is the same.
+    const char* fm = getenv("MCRT_FLAT_MAX");
+    const uint32_t flat_max = fm ? (uint32_t)strtoul(fm, nullptr, 0) : 64u;
+    d.flat = (d.stage_all && d.num_surfaces <= flat_max) ? 1u : 0u;
     ctx->has_scene = true;
     return MCRT_OK;
 }
@@ -848,8 +895,16 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
     ctx->pending = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    unsigned long long h[8];
+    unsigned long long h[kStatsWords];
     HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0) {
+        static const char* names[kNumPhases] = {"regen", "traverse", "shade", "shadow", "sample", "loop"};
+        unsigned long long tw = 0;
+        for (int i = 0; i < kNumPhases; i++) tw += h[8 + i];
+        for (int i = 0; i < kNumPhases; i++)
+            fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
+                    h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
+    }
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (stats) {

@@ -19,6 +19,38 @@ struct PathState {
     Sampler smp;
 };
 
+// Optional phase profiler (MCRT_PROFILE_PHASES=1 selects the instrumented kernel): per phase, the
+// wave-cycles spent (accumulated by the first active lane) and the lane-cycles spent (every active
+// lane), whose ratio is the SIMD lane utilisation of that phase.
+enum : int { kPhRegen = 0, kPhTraverse = 1, kPhShade = 2, kPhShadow = 3, kPhSample = 4, kPhLoop = 5, kNumPhases = 6 };
+template <bool kProf>
+struct PhaseProf {
+    MCRT_HD void mark(int) {}
+};
+#if defined(__HIPCC__)
+template <>
+struct PhaseProf<true> {
+    unsigned long long wave_cycles[kNumPhases], lane_cycles[kNumPhases];
+    unsigned long long t0;
+    int cur;
+    __device__ void begin() {
+        for (int i = 0; i < kNumPhases; i++) wave_cycles[i] = lane_cycles[i] = 0ull;
+        t0 = clock64();
+        cur = kPhLoop;
+    }
+    // called by every active lane when it enters phase p
+    __device__ void mark(int p) {
+        const unsigned long long t = clock64();
+        const unsigned long long dt = t - t0;
+        const unsigned long long mask = __ballot(1);
+        lane_cycles[cur] += dt;
+        if ((int)__lane_id() == __ffsll((long long)mask) - 1) wave_cycles[cur] += dt;
+        t0 = t;
+        cur = p;
+    }
+};
+#endif
+
 // Start of sampleRay (path-tracer.cpp:16-19 / photon-mapper.cpp:281-284) for the ray samplePixel built.
 MCRT_HD void pathBegin(PathState& st, RefractionHistory& rh, const Ray& camera_ray) {
     st.ray = camera_ray;
@@ -32,11 +64,13 @@ MCRT_HD void pathBegin(PathState& st, RefractionHistory& rh, const Ray& camera_r
 
 // One iteration of the while(true) in PathTracer::sampleRay. Returns true when the path has ended;
 // st.radiance then holds sampleRay's return value.
-template <bool kCount, bool kAll>
+template <bool kCount, bool kAll, bool kProf = false>
 MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh, const LaneStack& stk,
-                              TraceCounters& cnt, SobolTab tab) {
+                              TraceCounters& cnt, SobolTab tab, PhaseProf<kProf>* prof = nullptr) {
+    if (kProf) prof->mark(kPhTraverse);
     st.smp.shuffle();                                                     // :23
     Hit isect = sceneIntersect<kAll, kCount, false>(sv, st.ray, stk, cnt);  // :25
+    if (kProf) prof->mark(kPhShade);
     if (isect.surface == kNoSurface) {                                    // :27-30
         st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
         return true;
@@ -47,9 +81,12 @@ MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneV
 
     DirectQuery dq;                                                       // :35 Integrator::sampleDirect
     if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+        if (kProf) prof->mark(kPhShadow);
         Hit shadow = sceneIntersect<kAll, kCount, true>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
+        if (kProf) prof->mark(kPhSample);
         st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
     }
+    if (kProf) prof->mark(kPhSample);
 
     d3 bsdf_absIdotN;
     if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return true;  // :37-40

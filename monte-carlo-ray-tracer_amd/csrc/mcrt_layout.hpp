@@ -17,6 +17,10 @@ struct HostLayout {
     std::vector<double> prim;          // [n][kPrimStride]
     std::vector<double> normal;        // [n][3] Triangle::normal_
     bool any_vn = false;
+    // kind-sorted copy for the flat (tiny-scene) loop: triangles first, then spheres
+    std::vector<double> flat_prim;     // [n][kPrimStride]
+    std::vector<uint32_t> flat_index;  // [n] sorted slot -> surface index
+    uint32_t flat_tris = 0;
 };
 
 // Reference LinearNode array (depth-first, sibling links, bvh/bvh.hpp:68-74) -> breadth-first order in
@@ -101,6 +105,19 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
         if (s->light_surface[i] >= s->num_surfaces) {
             err = "light surface index out of range";
             return MCRT_ERR_INVALID;
+        }
+    L.flat_prim.assign(ns * kPrimStride, 0.0);
+    L.flat_index.assign(ns, 0u);
+    L.flat_tris = 0;
+    size_t slot = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t i = 0; i < ns; i++) {
+            const bool sphere = s->surf_kind[i] == MCRT_SURF_SPHERE;
+            if (sphere != (pass == 1)) continue;
+            memcpy(&L.flat_prim[slot * kPrimStride], &L.prim[i * kPrimStride], kPrimStride * sizeof(double));
+            L.flat_index[slot] = (uint32_t)i;
+            slot++;
+            if (!sphere) L.flat_tris++;
         }
     return convertNodes(s, L.node_bounds, L.node_meta, err);
 }

@@ -89,6 +89,12 @@ struct SceneViewT {
     uint32_t lds_nodes;  // only meaningful when !kAll
     MCRT_LDS_AS const double* lds_node_bounds;
     MCRT_LDS_AS const NodeMeta* lds_node_meta;
+    // flat mode (tiny scenes, kAll only): num_nodes == 0 and a second copy of the intersection records
+    // sorted by kind (triangles [0, flat_tris), spheres [flat_tris, num_surfaces)); flat_index maps a
+    // sorted slot back to the surface index.
+    uint32_t flat_tris;
+    cptr<double, kAll> flat_prim;
+    cptr<uint32_t, kAll> flat_index;
 };
 
 struct LaneStack {
@@ -211,6 +217,50 @@ MCRT_HD bool primIntersect(P rec, const Ray& ray, Hit& out) {
     return true;
 }
 
+// Closest-hit update. The reference keeps the FIRST tested primitive among exact-t ties
+// (bvh.cpp:100, scene.cpp:166) and its test order is its heap order; here ties go to the LOWEST surface
+// index, which makes the result independent of the visiting order (flat loop, depth-first walk and any
+// sharding agree bit for bit). Both rules pick the same primitive unless two different surfaces are
+// hit at exactly the same t.
+MCRT_HD bool closer(double t, uint32_t surface, const Hit& best) {
+    return t < best.t || (t == best.t && surface < best.surface);
+}
+
+// Branch-free forms of the two primitive tests for the wave-uniform flat loop: the same arithmetic in
+// the same order, all comparisons folded into one accept flag (a primitive is accepted by exactly the
+// rays the early-return form accepts), so that independent tests can be interleaved by the compiler.
+template <class P>
+MCRT_HD bool triangleTestFlat(P rec, const Ray& ray, double& t, double& u, double& v) {
+    d3 v0 = ld3(rec), E1 = ld3(rec + 3), E2 = ld3(rec + 6);
+    d3 P_ = cross(ray.direction, E2);
+    double determinant = dot(P_, E1);
+    double inv_determinant = 1.0 / determinant;
+    d3 T = ray.start - v0;
+    u = dot(P_, T) * inv_determinant;
+    d3 Q = cross(T, E1);
+    v = dot(Q, ray.direction) * inv_determinant;
+    t = dot(Q, E2) * inv_determinant;
+    const bool parallel = determinant < kEpsilon && determinant > -kEpsilon;
+    const bool u_out = u > 1.0 || u < 0.0;
+    const bool v_out = v > 1.0 || v < 0.0 || u + v > 1.0;
+    return !parallel & !u_out & !v_out & !(t <= 0.0);
+}
+template <class P>
+MCRT_HD bool sphereTestFlat(P rec, const Ray& ray, double& t_hit) {
+    d3 so = ray.start - ld3(rec);
+    double b = 2.0 * dot(ray.direction, so);
+    double c = dot(so, so) - sq(rec[3]);
+    double d = b * b - 4.0 * 1.0 * c;
+    double sd = sqrt(d);
+    double t = -0.5 * (b + (b < 0.0 ? -sd : sd));
+    double t_min = t / 1.0;
+    double t_max = c / t;
+    const bool swap = t_min > t_max;
+    double lo = swap ? t_max : t_min, hi = swap ? t_min : t_max;
+    t_hit = lo < 0.0 ? hi : lo;
+    return !(d < 0.0) & (hi >= 0.0);
+}
+
 struct ShadowQuery {
     uint32_t light;  // surface the shadow ray was aimed at
     double t_near;   // d (1 - 1e-9): a closer hit of another surface decides the query
@@ -228,11 +278,46 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
     best.interpolate = false;
     cnt.rays++;
 
-    if (sv.num_nodes == 0) {  // brute force, scene.cpp:161-173
+    if (sv.num_nodes == 0) {  // every primitive, as scene.cpp:161-173 does without a BVH
+        if (kAll && sv.flat_prim) {
+            // wave-uniform loops over the kind-sorted copy: no per-lane control flow at all
+            const uint32_t nt = sv.flat_tris, ns = sv.num_surfaces;
+#pragma unroll 2
+            for (uint32_t i = 0; i < nt; i++) {
+                double t, u, v;
+                if (kCount) cnt.prim_tests++;
+                cptr<double, kAll> rec = sv.flat_prim + (size_t)i * kPrimStride;
+                const bool ok = triangleTestFlat(rec, ray, t, u, v);
+                const uint32_t idx = sv.flat_index[i];
+                if (ok && closer(t, idx, best)) {
+                    const bool interp = rec[9] >= 2.0;
+                    best.t = t;
+                    best.u = interp ? u : 0.0;
+                    best.v = interp ? v : 0.0;
+                    best.interpolate = interp;
+                    best.surface = idx;
+                }
+            }
+#pragma unroll 2
+            for (uint32_t i = nt; i < ns; i++) {
+                double t;
+                if (kCount) cnt.prim_tests++;
+                const bool ok = sphereTestFlat(sv.flat_prim + (size_t)i * kPrimStride, ray, t);
+                const uint32_t idx = sv.flat_index[i];
+                if (ok && closer(t, idx, best)) {
+                    best.t = t;
+                    best.u = 0.0;
+                    best.v = 0.0;
+                    best.interpolate = false;
+                    best.surface = idx;
+                }
+            }
+            return best;
+        }
         for (uint32_t i = 0; i < sv.num_surfaces; i++) {
             Hit h;
             if (kCount) cnt.prim_tests++;
-            if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && h.t < best.t) {
+            if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                 best = h;
                 best.surface = i;
                 if (kShadow && i != sq->light && h.t < sq->t_near) return best;
@@ -265,7 +350,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                 Box cb = loadBox(sv, c);
                 if (kCount) cnt.node_tests++;
                 const bool hit = fast ? boxIntersect<true>(cb, ray, t) : boxIntersect<false>(cb, ray, t);
-                if (hit && t < best.t) {
+                if (hit && t <= best.t) {
                     // keep the nearest child in registers, push the others
                     uint32_t push_node = c;
                     double push_t = t;
@@ -293,7 +378,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                 have = false;
                 while (sp > 0) {
                     StackEntry e = stk.get(--sp);
-                    if ((double)e.t < best.t) {
+                    if ((double)e.t <= best.t) {
                         node = e.node;
                         have = true;
                         break;
@@ -310,18 +395,18 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
             for (uint32_t i = m.a; i < end; i++) {
                 Hit h;
                 if (kCount) cnt.prim_tests++;
-                if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && h.t < best.t) {
+                if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                     best = h;
                     best.surface = i;
                     if (kShadow && i != sq->light && h.t < sq->t_near) return best;
                 }
             }
         }
-        // ---- pop, culling entries that can no longer beat the current closest hit
+        // ---- pop, culling entries that can no longer beat (or tie) the current closest hit
         have = false;
         while (sp > 0) {
             StackEntry e = stk.get(--sp);
-            if ((double)e.t < best.t) {
+            if ((double)e.t <= best.t) {
                 node = e.node;
                 have = true;
                 break;

@@ -96,3 +96,25 @@ def camera_for(image, render):
 def rel_error(a, ref):
     """per-pixel, per-channel |a-ref| / max(|ref|, 1e-3)  (SURVEY.md §8(d) parity metric)."""
     return np.abs(a - ref) / np.maximum(np.abs(ref), 1e-3)
+
+
+def check_hits_against_reference(oracle, img, kat_dir, t, surf, uv):
+    """t must equal the reference's bits for every ray. The surface must be the reference's unless two
+    different surfaces are hit at exactly the same t: the reference keeps whichever its best-first heap
+    order tested first (bvh.cpp:100), the HIP path keeps the lowest surface index (order independent).
+    Returns the number of such ties."""
+    rays = np.fromfile(os.path.join(kat_dir, "isect_rays.f64")).reshape(-1, 6)
+    t_ref = np.fromfile(os.path.join(kat_dir, "isect_t.f64"))
+    s_ref = np.fromfile(os.path.join(kat_dir, "isect_surface.u32"), dtype=np.uint32)
+    uv_ref = np.fromfile(os.path.join(kat_dir, "isect_uv.f64")).reshape(-1, 2)
+    np.testing.assert_array_equal(t, t_ref)
+    diff = np.nonzero(surf != s_ref)[0]
+    for i in diff:
+        o, d = rays[i:i + 1, :3].copy(), rays[i:i + 1, 3:].copy()
+        assert surf[i] < s_ref[i], "ray %d: tie must go to the lowest surface index" % i
+        assert oracle.single_surface_t(img, surf[i], o, d)[0] == t_ref[i], "ray %d: surface %d is not hit at the reference t" % (i, surf[i])
+        assert oracle.single_surface_t(img, s_ref[i], o, d)[0] == t_ref[i]
+    same = surf == s_ref
+    np.testing.assert_array_equal(uv[same], uv_ref[same])
+    assert len(diff) <= max(3, len(t) // 500)
+    return len(diff)

@@ -37,7 +37,8 @@ struct Emu {
     KnnScratch ks;
 };
 
-int setup(Emu& E, const mcrt_scene_desc* s, bool stage_lds) {
+int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
+    const bool stage_lds = stage_mode != 0;
     std::string err;
     if (int rc = buildLayout(s, E.L, err)) return rc;
     E.tab.resize(kSobolTableWords);
@@ -63,6 +64,9 @@ int setup(Emu& E, const mcrt_scene_desc* s, bool stage_lds) {
         sv.lds_nodes = s->num_nodes / 2;
         sv.lds_node_bounds = E.L.node_bounds.data();
         sv.lds_node_meta = E.L.node_meta.data();
+        sv.flat_tris = E.L.flat_tris;
+        sv.flat_prim = nullptr;
+        sv.flat_index = nullptr;
     };
     auto fillShade = [&](auto& sh) {
         sh.surf_v = s->surf_v;
@@ -81,6 +85,11 @@ int setup(Emu& E, const mcrt_scene_desc* s, bool stage_lds) {
     fillScene(E.sv_top);
     fillShade(E.sh_all);
     fillShade(E.sh_top);
+    if (stage_mode == 2) {  // flat (tiny-scene) mode of the "all" flavour
+        E.sv_all.num_nodes = 0;
+        E.sv_all.flat_prim = E.L.flat_prim.data();
+        E.sv_all.flat_index = E.L.flat_index.data();
+    }
     return 0;
 }
 
@@ -123,7 +132,7 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
                int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, uint32_t row0,
                uint32_t row1, int stage_lds, double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths */) {
     Emu E;
-    if (int rc = setup(E, scene, stage_lds != 0)) return rc;
+    if (int rc = setup(E, scene, stage_lds)) return rc;
     setupMap(E, 0, gmap, E.pv.global_map);
     setupMap(E, 1, cmap, E.pv.caustic_map);
     E.pv.k_nearest = k_nearest;
@@ -168,7 +177,7 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
 int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int stage_lds,
                   double* out_t, uint32_t* out_surface, double* out_uv) {
     Emu E;
-    if (int rc = setup(E, scene, stage_lds != 0)) return rc;
+    if (int rc = setup(E, scene, stage_lds)) return rc;
     TraceCounters cnt = {0, 0, 0, 0};
     for (uint64_t i = 0; i < n; i++) {
         Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
