@@ -39,6 +39,9 @@ WORKLOADS = {
     "c2": ("hexagon_room.mcrt", 1920, 1080, 16, "hexagon_room.json cam0 1920x1080 @ 256 spp (BASELINE configs[1])"),
     "c2_ggx": ("hexagon_room_ggx.mcrt", 1920, 1080, 16, "hexagon_room.json + GGX roughness, 1920x1080 @ 256 spp"),
     "c1": ("hexagon_room_diffuse.mcrt", 256, 256, 2, "hexagon_room_diffuse.json 256x256 @ 4 spp (BASELINE configs[0])"),
+    # secondary (not the headline): a real BVH that does not fit in LDS; image made by tests/large/make_large.py
+    "spaceship": ("../../oracle/_ref/images/spaceship.mcrt", 1920, 1080, 8,
+                  "spaceship.json (68 760 of 457 200 triangles present), quaternary SAH, 1920x1080 @ 64 spp"),
 }
 SEED = 0x12345678
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -202,7 +205,7 @@ def main():
         if counts is None:
             # per-ray counts of the reference-equivalent traversal measured on this workload by the oracle
             # (DESIGN.md "Measurement"); used when the CPU leg is skipped (N > 1)
-            counts = dict(node_per_ray=13.70, tri_per_ray=8.86, sphere_per_ray=5.85)
+            counts = dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31)
         b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
         launches = args.steps * 1  # one integrator launch per step per GPU
         kernel_ms = kernel_ms_sum / launches
