@@ -23,6 +23,7 @@
 
 #include "../../include/mcrt.h"
 #include "mcrt_integrator.hpp"
+#include "mcrt_lanesm.hpp"
 #include "mcrt_layout.hpp"
 
 using namespace mcrt;
@@ -37,6 +38,7 @@ struct DeviceScene {
     uint32_t num_nodes, num_surfaces, num_materials, num_lights;
     const double* node_bounds;
     const NodeMeta* node_meta;
+    const Node64* nodes64;
     const double* prim;
     const double* flat_prim;      // kind-sorted copy (flat mode)
     const uint32_t* flat_index;
@@ -80,6 +82,8 @@ struct RenderParams {
     uint32_t* knn_res_idx;
     double* knn_visit_d2;
     uint32_t* knn_visit_oct;
+    // lane-state-machine gating (renderKernelSM)
+    int sm_shade_lanes, sm_regen_lanes, sm_min_trav, sm_leaf_lanes, sm_min_inner;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -392,6 +396,267 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// the lane-state-machine integrator (scenes whose BVH is walked; see mcrt_lanesm.hpp)
+// ------------------------------------------------------------------------------------------------
+struct SmLdsPlan {
+    uint32_t sobol, stack, iors, nodes, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+        light_surface, light_cdf, total;
+};
+
+__host__ __device__ inline SmLdsPlan planSmLds(const DeviceScene& s, uint32_t block) {
+    SmLdsPlan p;
+    uint32_t off = 0;
+    p.sobol = off; off += kSobolTableWords * 4;
+    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(SmStackEntry);
+    p.iors = off; off += kMaxIors * block * 8u;
+    off = alignUp(off, 64);
+    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
+    p.nodes = off; off += nn * 64u;
+    if (s.stage_all) {
+        const uint32_t ns = s.num_surfaces;
+        p.prim = off; off += ns * kPrimStride * 8;
+        p.surf_v = off; off += ns * 72;
+        p.surf_normal = off; off += ns * 24;
+        p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
+        p.surf_area = off; off += ns * 8;
+        p.surf_material = off; off = alignUp(off + ns * 4, 16);
+        p.surf_kind = off; off = alignUp(off + ns, 16);
+        p.materials = off; off = alignUp(off + s.num_materials * (uint32_t)sizeof(mcrt_material), 16);
+        p.light_cdf = off; off += s.num_lights * 8;
+        p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
+    } else {
+        p.prim = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
+            p.light_cdf = p.light_surface = off;
+    }
+    p.total = off;
+    return p;
+}
+
+enum : int { kStRegen = 0, kStTrav = 1, kStShade = 2, kStDone = 3 };
+
+template <bool kCount, bool kAll, bool kProf = false>
+__global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene, const RenderParams prm) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const SmLdsPlan p = planSmLds(scene, blockDim.x);
+
+    // ---- staging
+    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
+    stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
+    const SobolTab tab = ltab;
+    SmStack stk;
+    stk.lds = ldsAt<SmStackEntry>(lds, p.stack) + threadIdx.x;
+    stk.lds_stride = blockDim.x;
+    stk.spill = reinterpret_cast<SmStackEntry*>(prm.spill) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    stk.spill_stride = prm.total_lanes;
+    RefractionHistory rh;
+    rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
+    rh.stride = blockDim.x;
+    rh.size = 0;
+
+    SmSceneView<kAll> sv;
+    ShadeViewT<kAll> sh;
+    sv.num_nodes = scene.num_nodes;
+    const uint32_t nn = kAll ? scene.num_nodes : scene.stage_nodes;
+    MCRT_LDS_AS uint64_t* lnodes = ldsAt<uint64_t>(lds, p.nodes);
+    stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.nodes64), nn * 8u);
+    sv.lds_nodes = nn;
+    sv.lds_node_ptr = (MCRT_LDS_AS const Node64*)lnodes;
+    sh.num_lights = scene.num_lights;
+    sh.scene_ior = scene.scene_ior;
+    if constexpr (kAll) {
+        const uint32_t ns = scene.num_surfaces;
+        sv.nodes = (MCRT_LDS_AS const Node64*)lnodes;
+        MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
+        stageCopy(lp, scene.prim, ns * kPrimStride);
+        sv.prim = lp;
+        MCRT_LDS_AS double* lv = ldsAt<double>(lds, p.surf_v);
+        stageCopy(lv, scene.surf_v, ns * 9);
+        sh.surf_v = lv;
+        MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
+        stageCopy(ln, scene.surf_normal, ns * 3);
+        sh.surf_normal = ln;
+        MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
+        if (scene.surf_vn) stageCopy(lvn, scene.surf_vn, ns * 9);
+        sh.surf_vn = lvn;
+        MCRT_LDS_AS double* la = ldsAt<double>(lds, p.surf_area);
+        stageCopy(la, scene.surf_area, ns);
+        sh.surf_area = la;
+        MCRT_LDS_AS uint32_t* lm = ldsAt<uint32_t>(lds, p.surf_material);
+        stageCopy(lm, scene.surf_material, ns);
+        sh.surf_material = lm;
+        MCRT_LDS_AS uint8_t* lk = ldsAt<uint8_t>(lds, p.surf_kind);
+        stageCopy(lk, scene.surf_kind, ns);
+        sh.surf_kind = lk;
+        MCRT_LDS_AS uint64_t* lmat = ldsAt<uint64_t>(lds, p.materials);
+        stageCopy(lmat, reinterpret_cast<const uint64_t*>(scene.materials), scene.num_materials * (uint32_t)(sizeof(mcrt_material) / 8));
+        sh.materials = (MCRT_LDS_AS const mcrt_material*)lmat;
+        MCRT_LDS_AS double* lc = ldsAt<double>(lds, p.light_cdf);
+        stageCopy(lc, scene.light_cdf, scene.num_lights);
+        sh.light_cdf = lc;
+        MCRT_LDS_AS uint32_t* ll = ldsAt<uint32_t>(lds, p.light_surface);
+        stageCopy(ll, scene.light_surface, scene.num_lights);
+        sh.light_surface = ll;
+    } else {
+        sv.nodes = scene.nodes64;
+        sv.prim = scene.prim;
+        sh.surf_v = scene.surf_v;
+        sh.surf_normal = scene.surf_normal;
+        sh.surf_vn = scene.surf_vn;
+        sh.surf_area = scene.surf_area;
+        sh.surf_material = scene.surf_material;
+        sh.surf_kind = scene.surf_kind;
+        sh.materials = scene.materials;
+        sh.light_surface = scene.light_surface;
+        sh.light_cdf = scene.light_cdf;
+    }
+    __syncthreads();
+
+    // ---- per-lane state
+    PathState st;
+    NeePending nee;
+    nee.pending = false;
+    Trav T;
+    T.active = false;
+    T.shadow = false;
+    T.sp = 0;
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    uint32_t paths = 0;
+    int state = kStRegen;
+    bool have_pixel = false, alive = false;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const uint32_t W = prm.cam.width;
+
+    // thresholds: the expensive blocks run when this many lanes wait for them, or when fewer than
+    // kMinTrav lanes are still traversing (so that nothing starves)
+    const int kShadeLanes = prm.sm_shade_lanes, kRegenLanes = prm.sm_regen_lanes, kMinTrav = prm.sm_min_trav;
+    const int kLeafLanes = prm.sm_leaf_lanes, kMinInner = prm.sm_min_inner;
+    PhaseProf<kProf> prof;  // phases here: regen, traverse = inner steps, shade, shadow = leaf steps, loop = transitions
+    if constexpr (kProf) prof.begin();
+
+    // path end: Film::deposit (box filter) + next sample / pixel bookkeeping
+    auto endPath = [&]() {
+        acc0 += st.radiance.x * 1.0;
+        acc1 += st.radiance.y * 1.0;
+        acc2 += st.radiance.z * 1.0;
+        if (++sample == prm.spp) {
+            const double wsum = (double)prm.spp;
+            double* o = prm.out + ((size_t)ly * W + px) * 3;
+            o[0] = gmax(acc0 / wsum, 0.0);
+            o[1] = gmax(acc1 / wsum, 0.0);
+            o[2] = gmax(acc2 / wsum, 0.0);
+            have_pixel = false;
+        }
+        state = kStRegen;
+    };
+
+    for (;;) {
+        unsigned long long tp = prof.now();
+        // ---- cheap transitions of lanes whose traversal has just finished
+        if (state == kStTrav && !T.active) {
+            if (T.shadow) {
+                smNeeFinish(st, sh, nee, T.best);
+                nee.pending = false;
+                if (alive) travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                else endPath();
+            } else {
+                state = kStShade;
+            }
+        }
+
+        if (kProf) { prof.span(kPhLoop, tp, true); tp = prof.now(); }
+        const unsigned long long m_trav = __ballot(state == kStTrav && T.active);
+        const int n_trav = __popcll(m_trav);
+        const unsigned long long m_shade = __ballot(state == kStShade);
+        const unsigned long long m_regen = __ballot(state == kStRegen);
+        if (!(m_trav | m_shade | m_regen)) break;  // every lane is done
+
+        // ---- regenerate: next sample of the lane's pixel, or a new pixel from the global counter
+        if (m_regen && (__popcll(m_regen) >= kRegenLanes || n_trav < kMinTrav)) {
+            const bool need = state == kStRegen && !have_pixel;
+            if (__ballot(need)) {
+                const unsigned long long w = wavePop(need, prm.work_counter);
+                if (need) {
+                    if (w >= prm.work_items) {
+                        state = kStDone;
+                    } else {
+                        const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
+                        const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
+                        ly = (tile / prm.tiles_x) * 8u + (in >> 3);
+                        if (lx < W && ly < prm.owned_rows) {
+                            px = lx;
+                            py = localToGlobalRow(prm.cam, ly);
+                            have_pixel = true;
+                            sample = 0;
+                            acc0 = acc1 = acc2 = 0.0;
+                            st.smp.initiate(prm.global_seed, py * W + px);
+                        }
+                    }
+                }
+            }
+            if (state == kStRegen && have_pixel) {
+                st.smp.setIndex(sample);
+                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                paths++;
+                st.smp.shuffle();  // path-tracer.cpp:23, first bounce
+                travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                state = kStTrav;
+            }
+        }
+
+        if (kProf) { prof.span(kPhRegen, tp, (m_regen >> __lane_id()) & 1ull); tp = prof.now(); }
+        // ---- shade
+        if (m_shade && (__popcll(m_shade) >= kShadeLanes || n_trav < kMinTrav)) {
+            if (state == kStShade) {
+                Ray shadow_ray;
+                ShadowQuery shadow_q;
+                alive = smShade(st, rh, sh, T.best, nee, shadow_ray, shadow_q, tab);
+                if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
+                if (nee.pending) {
+                    travBegin<kAll, kCount>(sv, T, shadow_ray.start, shadow_ray.direction, shadow_ray.inv_direction, true, &shadow_q, cnt);
+                    state = kStTrav;
+                } else if (alive) {
+                    travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                    state = kStTrav;
+                } else {
+                    endPath();
+                }
+            }
+        }
+
+        if (kProf) { prof.span(kPhShade, tp, (m_shade >> __lane_id()) & 1ull); tp = prof.now(); }
+        // ---- traversal steps: inner nodes first (all such lanes together), then leaves
+        {
+            const bool trav = state == kStTrav && T.active;
+            const bool inner = trav && (T.node_m & kSmInner);
+            if (inner) travInnerStep<kAll, kCount>(sv, T, stk, cnt);
+            if (kProf) { prof.span(kPhTraverse, tp, inner); tp = prof.now(); }
+            const bool leaf = state == kStTrav && T.active && !(T.node_m & kSmInner);
+            const unsigned long long m_leaf = __ballot(leaf);
+            const unsigned long long m_inner = __ballot(state == kStTrav && T.active && (T.node_m & kSmInner));
+            if (m_leaf && (__popcll(m_leaf) >= kLeafLanes || __popcll(m_inner) < kMinInner)) {
+                if (leaf) travLeafStep<kAll, kCount>(sv, T, stk, cnt);
+            }
+            if (kProf) prof.span(kPhShadow, tp, leaf);
+        }
+    }
+
+    waveAccumulate(prm.stats + 0, paths);
+    waveAccumulate(prm.stats + 1, cnt.rays);
+    if (kCount) {
+        waveAccumulate(prm.stats + 2, cnt.node_tests);
+        waveAccumulate(prm.stats + 3, cnt.prim_tests);
+    }
+    waveAccumulate(prm.stats + 5, cnt.overflow);
+    if constexpr (kProf) {
+        for (int i = 0; i < kNumPhases; i++) {
+            atomicAdd(prm.stats + 8 + i, prof.wave_cycles[i]);
+            atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // operator-level kernels
 // ------------------------------------------------------------------------------------------------
 template <bool kAll>
@@ -510,7 +775,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -556,9 +821,8 @@ struct LaunchGeom {
 };
 
 template <class K>
-int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g) {
-    const LdsPlan p = planLds(s, kBlock);
-    g.lds_bytes = p.total;
+int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g, bool sm = false) {
+    g.lds_bytes = sm ? planSmLds(s, kBlock).total : planLds(s, kBlock).total;
     if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)g.lds_bytes));
@@ -620,9 +884,19 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
     static const bool profile_phases = getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0;
     if (profile_phases && !photon) kernel = all ? renderKernel<PT, false, true, true> : renderKernel<PT, false, false, true>;
+    // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
+    // wave-synchronous one for A/B runs)
+    const char* kenv = getenv("MCRT_KERNEL");
+    const bool use_sm = !photon && !ctx->scene.flat && !(kenv && strcmp(kenv, "legacy") == 0);
+    if (use_sm) {
+        static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
+                                               {renderKernelSM<true, false>, renderKernelSM<true, true>}};
+        kernel = sm_table[count_tests ? 1 : 0][all ? 1 : 0];
+        if (profile_phases) kernel = all ? renderKernelSM<false, true, true> : renderKernelSM<false, false, true>;
+    }
 
     LaunchGeom g;
-    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g)) return rc;
+    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm)) return rc;
     if (int rc = ensureScratch(ctx, g.total_lanes, photon)) return rc;
 
     RenderParams prm;
@@ -639,6 +913,14 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     prm.stats = ctx->stats.as<unsigned long long>();
     prm.spill = ctx->spill.as<StackEntry>();
     prm.total_lanes = g.total_lanes;
+    {
+        auto envi = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
+        prm.sm_shade_lanes = envi("MCRT_SM_SHADE", 40);
+        prm.sm_regen_lanes = envi("MCRT_SM_REGEN", 16);
+        prm.sm_min_trav = envi("MCRT_SM_MINTRAV", 20);
+        prm.sm_leaf_lanes = envi("MCRT_SM_LEAF", 32);
+        prm.sm_min_inner = envi("MCRT_SM_MININNER", 8);
+    }
     if (photon) {
         prm.global_map = ctx->maps[0];
         prm.caustic_map = ctx->maps[1];
@@ -791,6 +1073,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
 
     if (int rc = uploadArray(ctx, ctx->node_bounds, bounds.data(), bounds.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
@@ -816,6 +1099,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.num_lights = s->num_lights;
     d.node_bounds = ctx->node_bounds.as<double>();
     d.node_meta = ctx->node_meta.as<NodeMeta>();
+    d.nodes64 = ctx->nodes64.as<Node64>();
     d.prim = ctx->prim.as<double>();
     d.flat_prim = ctx->flat_prim.as<double>();
     d.flat_index = ctx->flat_index.as<uint32_t>();
@@ -898,7 +1182,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
     unsigned long long h[kStatsWords];
     HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
     if (getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0) {
-        static const char* names[kNumPhases] = {"regen", "traverse", "shade", "shadow", "sample", "loop"};
+        static const char* names[kNumPhases] = {"regen", "trav/inner", "shade", "shadow/leaf", "sample", "loop"};
         unsigned long long tw = 0;
         for (int i = 0; i < kNumPhases; i++) tw += h[8 + i];
         for (int i = 0; i < kNumPhases; i++)

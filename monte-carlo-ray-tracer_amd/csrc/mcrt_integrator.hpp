@@ -26,6 +26,8 @@ enum : int { kPhRegen = 0, kPhTraverse = 1, kPhShade = 2, kPhShadow = 3, kPhSamp
 template <bool kProf>
 struct PhaseProf {
     MCRT_HD void mark(int) {}
+    MCRT_HD unsigned long long now() const { return 0ull; }
+    MCRT_HD void span(int, unsigned long long, bool) {}
 };
 #if defined(__HIPCC__)
 template <>
@@ -37,6 +39,14 @@ struct PhaseProf<true> {
         for (int i = 0; i < kNumPhases; i++) wave_cycles[i] = lane_cycles[i] = 0ull;
         t0 = clock64();
         cur = kPhLoop;
+    }
+    // wave-level form for blocks that only some lanes execute: call now() before and span() after the
+    // block from code that ALL lanes run; `participated` = this lane executed the block
+    __device__ unsigned long long now() const { return clock64(); }
+    __device__ void span(int p, unsigned long long t_begin, bool participated) {
+        const unsigned long long dt = clock64() - t_begin;
+        if (participated) lane_cycles[p] += dt;
+        if (__lane_id() == 0) wave_cycles[p] += dt;
     }
     // called by every active lane when it enters phase p
     __device__ void mark(int p) {

@@ -1,0 +1,329 @@
+// Per-lane STATE MACHINE form of the path tracer, for scenes whose BVH has to be walked (everything
+// that is not the tiny-scene flat loop).
+//
+// Why: in a BVH walk every lane follows its own node sequence and rays need very different numbers
+// of steps (spaceship.json: 34 node visits per ray on average, >150 for some). When a whole wave runs
+// "traverse until every lane is done, then shade", most lanes idle most of the time (measured VALU lane
+// utilisation 14 %, profiles/). Here each lane carries an explicit state
+//     REGEN -> TRAV(bounce ray) -> SHADE -> TRAV(shadow ray) -> [NEE finish] -> TRAV(next bounce ray) -> SHADE ...
+// and the wave executes ONE short block per loop iteration for the lanes that are in the matching
+// state: an inner-node step, a leaf step, or (only when enough lanes have queued up for it, or nothing
+// else can run) the expensive shade / regenerate blocks. Lanes that finish a traversal early start
+// their next one immediately instead of waiting for the slowest ray of the wave.
+//
+// The arithmetic of a path is exactly that of mcrt_integrator.hpp (same functions, same order); only
+// the interleaving between lanes changes. The next-event estimate is split around the shadow
+// traversal: everything that does not depend on the shadow hit (BSDF value/pdf towards the light,
+// area*cos of the light, throughput at that bounce) is computed in the shade block and parked in
+// NeePending, so the Interaction does not have to stay live across a traversal.
+//
+// Traversal data: 64-byte node records {bounds[6], a, b} with the children of a node contiguous, so a
+// child's meta arrives with its box and a node visit is ONE dependent memory round trip; stack
+// entries are 8 bytes {entry-distance key, a} with the node's flag/count packed into the low 9 bits
+// of the (rounded-down, therefore still conservative) float key.
+#pragma once
+
+#include "mcrt_integrator.hpp"
+
+namespace mcrt {
+
+template <bool kAll>
+struct SmSceneView {
+    uint32_t num_nodes;
+    cptr<Node64, kAll> nodes;
+    cptr<double, kAll> prim;
+    uint32_t lds_nodes;  // nodes [0, lds_nodes) are also in LDS (used when !kAll)
+    MCRT_LDS_AS const Node64* lds_node_ptr;
+};
+
+struct SmStackEntry {
+    uint32_t key;  // float bits of floor_f32(entry t) with the low 9 bits replaced by the node's m
+    uint32_t a;
+};
+
+struct SmStack {
+    MCRT_LDS_AS SmStackEntry* lds;
+    uint32_t lds_stride;
+    SmStackEntry* spill;
+    uint32_t spill_stride;
+    MCRT_HD void put(int sp, SmStackEntry e) const {
+        if (sp < kLdsStackDepth) lds[(uint32_t)sp * lds_stride] = e;
+        else spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride] = e;
+    }
+    MCRT_HD SmStackEntry get(int sp) const {
+        if (sp < kLdsStackDepth) return lds[(uint32_t)sp * lds_stride];
+        return spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
+    }
+};
+
+MCRT_HD uint32_t floatBits(float f) {
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.f = f;
+    return c.u;
+}
+MCRT_HD float bitsFloat(uint32_t u) {
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.u = u;
+    return c.f;
+}
+
+// One closest-hit query in progress.
+struct Trav {
+    d3 o, d, inv;      // the ray being traversed
+    Hit best;
+    uint32_t node_a, node_m;  // meta of the node to visit next
+    int sp;
+    bool active;       // a node is waiting to be visited
+    bool fast;         // v_min/v_max box test allowed (no NaN slab products possible)
+    bool shadow;
+    uint32_t light;    // shadow query: surface aimed at
+    double t_near;     // shadow query: a closer hit of another surface decides it
+};
+
+template <bool kAll>
+MCRT_HD Box smLoadBox(const SmSceneView<kAll>& sv, uint32_t i, uint32_t& a, uint32_t& m) {
+    Box b;
+    if (!kAll && i < sv.lds_nodes) {
+        MCRT_LDS_AS const Node64* n = sv.lds_node_ptr + i;
+        for (int k = 0; k < 6; k++) b.v[k] = n->b[k];
+        a = n->a;
+        m = n->m;
+    } else {
+        cptr<Node64, kAll> n = sv.nodes + i;
+        for (int k = 0; k < 6; k++) b.v[k] = n->b[k];
+        a = n->a;
+        m = n->m;
+    }
+    return b;
+}
+
+MCRT_HD Ray travRay(const Trav& T) {  // only start/direction/inv_direction are read by the tests
+    Ray r;
+    r.start = T.o;
+    r.direction = T.d;
+    r.inv_direction = T.inv;
+    r.medium_ior = 1.0;
+    r.refraction_scale = 1.0;
+    r.refraction_level = 0;
+    r.depth = 0;
+    r.diffuse_depth = 0;
+    r.dirac_delta = false;
+    r.refraction = false;
+    return r;
+}
+
+MCRT_HD void travPop(Trav& T, const SmStack& stk) {
+    T.active = false;
+    while (T.sp > 0) {
+        SmStackEntry e = stk.get(--T.sp);
+        if ((double)bitsFloat(e.key & ~0x1FFu) <= T.best.t) {
+            T.node_a = e.a;
+            T.node_m = e.key & 0x1FFu;
+            T.active = true;
+            break;
+        }
+    }
+}
+
+// Scene::intersect / BVH::intersect start (bvh.cpp:84-88): root box test.
+template <bool kAll, bool kCount>
+MCRT_HD void travBegin(const SmSceneView<kAll>& sv, Trav& T, d3 start, d3 direction, d3 inv_direction, bool shadow,
+                       const ShadowQuery* sq, TraceCounters& cnt) {
+    T.o = start;
+    T.d = direction;
+    T.inv = inv_direction;
+    T.best.t = shadow ? sq->t_far : kDblMax;
+    T.best.u = 0.0;
+    T.best.v = 0.0;
+    T.best.surface = kNoSurface;
+    T.best.interpolate = false;
+    T.shadow = shadow;
+    T.light = shadow ? sq->light : kNoSurface;
+    T.t_near = shadow ? sq->t_near : 0.0;
+    T.sp = 0;
+    T.fast = finite64(inv_direction.x) && finite64(inv_direction.y) && finite64(inv_direction.z);
+    cnt.rays++;
+    if (kCount) cnt.node_tests++;
+    uint32_t a, m;
+    Box rb = smLoadBox(sv, 0u, a, m);
+    double t;
+    const Ray r = travRay(T);
+    T.active = T.fast ? boxIntersect<true>(rb, r, t) : boxIntersect<false>(rb, r, t);
+    T.node_a = a;
+    T.node_m = m;
+}
+
+// Visit one INNER node: test its children (bvh.cpp:108-119), continue with the nearest hit child, push the rest.
+template <bool kAll, bool kCount>
+MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+    const uint32_t first = T.node_a, count = T.node_m & 0xFFu;
+    const Ray r = travRay(T);
+    double near_t = 0.0;
+    uint32_t near_a = 0, near_m = 0;
+    bool have_near = false;
+    for (uint32_t c = first; c < first + count; c++) {
+        uint32_t a, m;
+        Box cb = smLoadBox(sv, c, a, m);
+        if (kCount) cnt.node_tests++;
+        double t;
+        const bool hit = T.fast ? boxIntersect<true>(cb, r, t) : boxIntersect<false>(cb, r, t);
+        if (hit && t <= T.best.t) {
+            uint32_t push_a = a, push_m = m;
+            double push_t = t;
+            bool push = true;
+            if (!have_near || t < near_t) {
+                push = have_near;
+                push_a = near_a;
+                push_m = near_m;
+                push_t = near_t;
+                near_a = a;
+                near_m = m;
+                near_t = t;
+                have_near = true;
+            }
+            if (push) {
+                if (T.sp < kMaxStackDepth) {
+                    SmStackEntry e;
+                    e.key = (floatBits(floatBelow(push_t)) & ~0x1FFu) | push_m;
+                    e.a = push_a;
+                    stk.put(T.sp++, e);
+                } else {
+                    cnt.overflow = 1;
+                }
+            }
+        }
+    }
+    if (have_near) {
+        T.node_a = near_a;
+        T.node_m = near_m;
+    } else {
+        travPop(T, stk);
+    }
+}
+
+// One primitive record in registers.
+struct PrimRec {
+    double v[kPrimStride];
+};
+template <class P>
+MCRT_HD PrimRec loadPrim(P p) {
+    PrimRec r;
+    for (int k = 0; k < kPrimStride; k++) r.v[k] = p[k];
+    return r;
+}
+MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
+    if (rec.v[9] == 1.0) return primIntersect(rec.v, ray, h);  // sphere (rare in walked BVHs)
+    double t, u, v;
+    const bool ok = triangleTestFlat(rec.v, ray, t, u, v);
+    const bool interp = rec.v[9] >= 2.0;
+    h.t = t;
+    h.u = interp ? u : 0.0;
+    h.v = interp ? v : 0.0;
+    h.interpolate = interp;
+    return ok;
+}
+
+// Visit one LEAF: test its primitives (bvh.cpp:92-107), then pop. Primitives are fetched two at a time
+// (both records are requested before either is tested) so that a leaf of n primitives costs n/2
+// dependent memory round trips instead of n.
+template <bool kAll, bool kCount>
+MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+    const uint32_t start = T.node_a, end = start + T.node_m;
+    const Ray r = travRay(T);
+    bool decided = false;
+    for (uint32_t i = start; i < end; i += 2) {
+        const bool two = i + 1 < end;
+        const uint32_t j = two ? i + 1 : i;
+        const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
+        const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
+        Hit h0, h1;
+        if (kCount) cnt.prim_tests += two ? 2u : 1u;
+        const bool ok0 = primTestRec(r0, r, h0);
+        const bool ok1 = primTestRec(r1, r, h1) && two;
+        if (ok0 && closer(h0.t, i, T.best)) {
+            T.best = h0;
+            T.best.surface = i;
+            if (T.shadow && i != T.light && h0.t < T.t_near) decided = true;  // occluded for sure
+        }
+        if (ok1 && closer(h1.t, j, T.best)) {
+            T.best = h1;
+            T.best.surface = j;
+            if (T.shadow && j != T.light && h1.t < T.t_near) decided = true;
+        }
+    }
+    if (decided) {
+        T.sp = 0;
+        T.active = false;
+    } else {
+        travPop(T, stk);
+    }
+}
+
+// What the next-event estimate of a bounce needs once its shadow ray has been traced.
+struct NeePending {
+    bool pending;  // a shadow ray is being traced for this bounce
+    uint32_t light;
+    d3 bsdf_absIdotN;
+    double bsdf_pdf, area_cos;
+    d3 throughput;  // throughput the estimate is weighted with (before this bounce's BSDF update)
+};
+
+// Second half of Integrator::sampleDirect (integrator.cpp:68-86) from the parked data.
+template <bool L>
+MCRT_HD void smNeeFinish(PathState& st, const ShadeViewT<L>& sh, const NeePending& nee, const Hit& shadow_hit) {
+    if (shadow_hit.surface == kNoSurface || shadow_hit.surface != nee.light) return;
+    double light_pdf = sq(shadow_hit.t) / nee.area_cos;
+    double mis_weight = powerHeuristic(light_pdf, nee.bsdf_pdf);
+    const auto& lm = sh.materials[sh.surf_material[nee.light]];
+    d3 direct = mis_weight * nee.bsdf_absIdotN * ld3(lm.emittance) / (light_pdf * st.ls.select_probability);
+    st.radiance = st.radiance + direct * nee.throughput;
+}
+
+// The shade block: everything PathTracer::sampleRay does between two Scene::intersect calls of the
+// path (path-tracer.cpp:27-49), with sampleDirect cut at its shadow-ray trace. Returns true when the
+// path continues with st.ray; nee.pending says whether a shadow ray (returned in shadow_ray / shadow_q)
+// must be traced first.
+template <bool L>
+MCRT_HD bool smShade(PathState& st, RefractionHistory& rh, const ShadeViewT<L>& sh, const Hit& isect, NeePending& nee,
+                     Ray& shadow_ray, ShadowQuery& shadow_q, SobolTab tab) {
+    nee.pending = false;
+    if (isect.surface == kNoSurface) {  // :27-30
+        st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
+        return false;
+    }
+    InteractionT<L> ia;
+    interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);  // :32
+    st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;   // :34
+
+    DirectQuery dq;  // :35, integrator.cpp:31-66
+    if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+        // integrator.cpp:75-81 evaluated ahead of the trace: it does not depend on the shadow hit
+        d3 bsdf_absIdotN;
+        double bsdf_pdf;
+        if (interactionBSDF(ia, bsdf_absIdotN, dq.shadow_ray.direction, bsdf_pdf)) {
+            nee.pending = true;
+            nee.light = dq.sq.light;
+            shadow_ray = dq.shadow_ray;
+            shadow_q = dq.sq;
+            nee.bsdf_absIdotN = bsdf_absIdotN;
+            nee.bsdf_pdf = bsdf_pdf;
+            nee.area_cos = sh.surf_area[st.ls.light] * dq.cos_light_theta;
+            nee.throughput = st.throughput;
+        }
+    }
+
+    d3 bsdf_absIdotN;
+    if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) return false;  // :37-40
+    st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);                                           // :42
+    if (absorb(st.ray, st.throughput, st.smp, tab)) return false;                                               // :44-47
+    rh.update(st.ray);                                                                                          // :49
+    return true;
+}
+
+}  // namespace mcrt

@@ -21,6 +21,7 @@ struct HostLayout {
     std::vector<double> flat_prim;     // [n][kPrimStride]
     std::vector<uint32_t> flat_index;  // [n] sorted slot -> surface index
     uint32_t flat_tris = 0;
+    std::vector<Node64> nodes64;       // [n] box + meta records, same order as node_bounds
 };
 
 // Reference LinearNode array (depth-first, sibling links, bvh/bvh.hpp:68-74) -> breadth-first order in
@@ -119,7 +120,30 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             slot++;
             if (!sphere) L.flat_tris++;
         }
-    return convertNodes(s, L.node_bounds, L.node_meta, err);
+    if (int rc = convertNodes(s, L.node_bounds, L.node_meta, err)) return rc;
+    L.nodes64.assign(s->num_nodes, Node64{});
+    for (uint32_t i = 0; i < s->num_nodes; i++) {
+        Node64& n = L.nodes64[i];
+        memcpy(n.b, &L.node_bounds[(size_t)i * 6], 48);
+        const NodeMeta& m = L.node_meta[i];
+        n.a = m.a;
+        if (m.b & kInnerFlag) {
+            const uint32_t count = m.b & ~kInnerFlag;
+            if (count > 255) {
+                err = "BVH node with more than 255 children";
+                return MCRT_ERR_UNSUPPORTED;
+            }
+            n.m = kSmInner | count;
+        } else {
+            if (m.b > 255) {
+                err = "BVH leaf with more than 255 primitives";
+                return MCRT_ERR_UNSUPPORTED;
+            }
+            n.m = m.b;
+        }
+        n.pad0 = n.pad1 = 0;
+    }
+    return MCRT_OK;
 }
 
 }  // namespace mcrt

@@ -72,8 +72,23 @@ MCRT_HD double gmin(double x, double y) { return (y < x) ? y : x; }  // glm::min
 MCRT_HD double gmax(double x, double y) { return (x < y) ? y : x; }  // glm::max / std::max(x,y)
 // IEEE minNum/maxNum (one v_min_f64 / v_max_f64). Equal to gmin/gmax whenever neither input is NaN
 // (up to the sign of a zero result, which no comparison can observe).
+#if defined(__HIP_DEVICE_COMPILE__)
+// (spelled as the instruction: through llvm.minnum the compiler adds a canonicalising v_max x,x per
+// operand whenever the operands reach it through a phi)
+MCRT_HD double fastMin(double x, double y) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+MCRT_HD double fastMax(double x, double y) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+#else
 MCRT_HD double fastMin(double x, double y) { return fmin(x, y); }
 MCRT_HD double fastMax(double x, double y) { return fmax(x, y); }
+#endif
 MCRT_HD bool finite64(double x) { return fabs(x) <= kDblMax; }  // false for NaN and +-inf
 MCRT_HD double compMax(d3 v) { return gmax(gmax(v.x, v.y), v.z); }
 MCRT_HD double compMin(d3 v) { return gmin(gmin(v.x, v.y), v.z); }

@@ -43,6 +43,15 @@ struct NodeMeta {
     uint32_t a, b;
 };
 
+// 64-byte node record of the lane-state-machine traversal (mcrt_lanesm.hpp): a child's meta travels
+// with its box. leaf: a = start_surface, m = count (1..255); inner: a = first_child, m = 0x100 | child_count
+struct Node64 {
+    double b[6];
+    uint32_t a, m;
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t kSmInner = 0x100u;
+
 struct Ray {  // ray/ray.hpp:10-26
     d3 start, direction, inv_direction;
     double medium_ior, refraction_scale;

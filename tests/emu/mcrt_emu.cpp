@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
 
 using namespace mcrt;
@@ -171,6 +172,93 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
             for (int c = 0; c < 3; c++) o[c] = gmax(acc[c] / (double)spp, 0.0);
         }
     if (counters) memcpy(counters, totals, sizeof(totals));
+    return 0;
+}
+
+// The lane-state-machine integrator (mcrt_lanesm.hpp) driven for one lane at a time: the same
+// regenerate / traverse-step / shade / NEE-finish functions the gfx950 kernel calls, without the
+// wave-level gating (which only changes how lanes interleave, not what a lane computes).
+int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t row0, uint32_t row1,
+                  int stage_all, double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths */) {
+    Emu E;
+    if (int rc = setup(E, scene, stage_all ? 1 : 0)) return rc;
+    std::vector<SmStackEntry> s_lds(kLdsStackDepth), s_spill(kMaxStackDepth - kLdsStackDepth);
+    SmStack stk;
+    stk.lds = s_lds.data();
+    stk.lds_stride = 1;
+    stk.spill = s_spill.data();
+    stk.spill_stride = 1;
+    SmSceneView<true> sv_all;
+    SmSceneView<false> sv_top;
+    auto fill = [&](auto& sv) {
+        sv.num_nodes = scene->num_nodes;
+        sv.nodes = E.L.nodes64.data();
+        sv.prim = E.L.prim.data();
+        sv.lds_nodes = scene->num_nodes / 2;
+        sv.lds_node_ptr = E.L.nodes64.data();
+    };
+    fill(sv_all);
+    fill(sv_top);
+    if (scene->num_nodes == 0) return -200;  // the state machine is only used for scenes with a BVH
+    const uint32_t spp = cam->sqrtspp * cam->sqrtspp;
+    TraceCounters cnt = {0, 0, 0, 0};
+    uint64_t paths = 0;
+    auto begin = [&](Trav& T, d3 o, d3 d, d3 inv, bool shadow, const ShadowQuery* sq) {
+        if (stage_all) travBegin<true, true>(sv_all, T, o, d, inv, shadow, sq, cnt);
+        else travBegin<false, true>(sv_top, T, o, d, inv, shadow, sq, cnt);
+    };
+    for (uint32_t y = row0; y < row1; y++)
+        for (uint32_t x = 0; x < cam->width; x++) {
+            PathState st;
+            st.smp.initiate(global_seed, y * cam->width + x);
+            double acc[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < spp; i++) {
+                st.smp.setIndex(i);
+                pathBegin(st, E.rh, cameraRay(*cam, E.sh_all.scene_ior, x, y, st.smp, E.tab.data()));
+                paths++;
+                st.smp.shuffle();
+                Trav T;
+                NeePending nee;
+                nee.pending = false;
+                bool alive = false;
+                begin(T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr);
+                for (;;) {
+                    while (T.active) {
+                        if (T.node_m & kSmInner) {
+                            if (stage_all) travInnerStep<true, true>(sv_all, T, stk, cnt);
+                            else travInnerStep<false, true>(sv_top, T, stk, cnt);
+                        } else {
+                            if (stage_all) travLeafStep<true, true>(sv_all, T, stk, cnt);
+                            else travLeafStep<false, true>(sv_top, T, stk, cnt);
+                        }
+                    }
+                    if (T.shadow) {
+                        if (stage_all) smNeeFinish(st, E.sh_all, nee, T.best);
+                        else smNeeFinish(st, E.sh_top, nee, T.best);
+                        nee.pending = false;
+                        if (!alive) break;
+                        begin(T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr);
+                        continue;
+                    }
+                    Ray shadow_ray;
+                    ShadowQuery shadow_q;
+                    alive = stage_all ? smShade(st, E.rh, E.sh_all, T.best, nee, shadow_ray, shadow_q, E.tab.data())
+                                      : smShade(st, E.rh, E.sh_top, T.best, nee, shadow_ray, shadow_q, E.tab.data());
+                    if (alive) st.smp.shuffle();
+                    if (nee.pending) begin(T, shadow_ray.start, shadow_ray.direction, shadow_ray.inv_direction, true, &shadow_q);
+                    else if (alive) begin(T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr);
+                    else break;
+                }
+                acc[0] += st.radiance.x * 1.0;
+                acc[1] += st.radiance.y * 1.0;
+                acc[2] += st.radiance.z * 1.0;
+            }
+            double* o = out_rgb + ((size_t)(y - row0) * cam->width + x) * 3;
+            for (int c = 0; c < 3; c++) o[c] = gmax(acc[c] / (double)spp, 0.0);
+        }
+    if (counters) {
+        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
+    }
     return 0;
 }
 

@@ -42,6 +42,28 @@ def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, na
     assert cnt["rays"] == info["rays"] and cnt["paths"] == info["paths"]
 
 
+@pytest.mark.parametrize("name,stage_all", [("hexagon_room", 1), ("hexagon_room_ggx", 0), ("coffee_maker_qsah", 0),
+                                            ("coffee_maker_bsah", 0), ("veach_mis", 1), ("metals", 0), ("ggx_test", 1)])
+def test_lane_state_machine_equals_reference(pkg, emu, oracle, manifest, name, stage_all):
+    """mcrt_lanesm.hpp (the kernel used for every scene whose BVH is walked): split next-event
+    estimate, step-wise traversal with packed stack entries — same bits as the reference."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    r0, r1 = r["rows"]
+    out = np.zeros((r1 - r0, cam.width, 3))
+    cnt = (C.c_uint64 * 5)()
+    rc = emu.emu_render_sm(C.byref(img.scene), C.byref(cam), manifest["seed"], r0, r1, stage_all, out.ctypes.data, cnt)
+    assert rc == 0 and cnt[3] == 0
+    ref = load_radiance(r)
+    assert np.array_equal(out, ref), "max rel err %.3e" % rel_error(out, ref).max()
+    _, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
+    assert cnt[4] == info["paths"]
+    # shadow rays whose BSDF term is zero are not traced (the reference traces them and then discards them)
+    assert 0 <= info["rays"] - cnt[0] <= 0.03 * info["rays"]
+
+
 def test_photon_mapper_device_code(pkg, emu, manifest):
     case = manifest["cases"]["hexagon_room_pm"]
     img = pkg.SceneImage(golden_path(case["image"]))

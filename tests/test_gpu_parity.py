@@ -120,7 +120,8 @@ def test_flat_and_bvh_modes_agree(pkg, oracle, manifest):
     generic = np.all(rays[:, 3:] != 0.0, axis=1)  # a zero direction component makes NaN slabs (see emulation test)
     for a, b in zip(h0, h1):
         np.testing.assert_array_equal(a[generic], b[generic])
-    assert np.array_equal(f0, f1) and r0 == r1
+    assert np.array_equal(f0, f1)
+    assert 0 <= r0 - r1 <= 0.03 * r0  # the BVH kernel does not trace shadow rays whose BSDF term is zero
     _check(f0, load_radiance(case["renders"][0]), "hexagon_room flat mode")
 
 
