@@ -821,8 +821,8 @@ struct LaunchGeom {
 };
 
 template <class K>
-int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g, bool sm = false) {
-    g.lds_bytes = sm ? planSmLds(s, kBlock).total : planLds(s, kBlock).total;
+int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g, int plan = 0) {
+    g.lds_bytes = plan == 1 ? planSmLds(s, kBlock).total : planLds(s, kBlock).total;
     if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)g.lds_bytes));
@@ -896,7 +896,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     }
 
     LaunchGeom g;
-    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm)) return rc;
+    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : 0)) return rc;
     if (int rc = ensureScratch(ctx, g.total_lanes, photon)) return rc;
 
     RenderParams prm;

@@ -220,7 +220,7 @@ MCRT_HD PrimRec loadPrim(P p) {
 MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
     if (rec.v[9] == 1.0) return primIntersect(rec.v, ray, h);  // sphere (rare in walked BVHs)
     double t, u, v;
-    const bool ok = triangleTestFlat(rec.v, ray, t, u, v);
+    const bool ok = triangleTestFlat(rec.v, ray.start, ray.direction, t, u, v);
     const bool interp = rec.v[9] >= 2.0;
     h.t = t;
     h.u = interp ? u : 0.0;

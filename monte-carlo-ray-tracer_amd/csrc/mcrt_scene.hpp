@@ -239,15 +239,15 @@ MCRT_HD bool closer(double t, uint32_t surface, const Hit& best) {
 // the same order, all comparisons folded into one accept flag (a primitive is accepted by exactly the
 // rays the early-return form accepts), so that independent tests can be interleaved by the compiler.
 template <class P>
-MCRT_HD bool triangleTestFlat(P rec, const Ray& ray, double& t, double& u, double& v) {
+MCRT_HD bool triangleTestFlat(P rec, d3 start, d3 direction, double& t, double& u, double& v) {
     d3 v0 = ld3(rec), E1 = ld3(rec + 3), E2 = ld3(rec + 6);
-    d3 P_ = cross(ray.direction, E2);
+    d3 P_ = cross(direction, E2);
     double determinant = dot(P_, E1);
     double inv_determinant = 1.0 / determinant;
-    d3 T = ray.start - v0;
+    d3 T = start - v0;
     u = dot(P_, T) * inv_determinant;
     d3 Q = cross(T, E1);
-    v = dot(Q, ray.direction) * inv_determinant;
+    v = dot(Q, direction) * inv_determinant;
     t = dot(Q, E2) * inv_determinant;
     const bool parallel = determinant < kEpsilon && determinant > -kEpsilon;
     const bool u_out = u > 1.0 || u < 0.0;
@@ -255,9 +255,9 @@ MCRT_HD bool triangleTestFlat(P rec, const Ray& ray, double& t, double& u, doubl
     return !parallel & !u_out & !v_out & !(t <= 0.0);
 }
 template <class P>
-MCRT_HD bool sphereTestFlat(P rec, const Ray& ray, double& t_hit) {
-    d3 so = ray.start - ld3(rec);
-    double b = 2.0 * dot(ray.direction, so);
+MCRT_HD bool sphereTestFlat(P rec, d3 start, d3 direction, double& t_hit) {
+    d3 so = start - ld3(rec);
+    double b = 2.0 * dot(direction, so);
     double c = dot(so, so) - sq(rec[3]);
     double d = b * b - 4.0 * 1.0 * c;
     double sd = sqrt(d);
@@ -268,6 +268,14 @@ MCRT_HD bool sphereTestFlat(P rec, const Ray& ray, double& t_hit) {
     double lo = swap ? t_max : t_min, hi = swap ? t_min : t_max;
     t_hit = lo < 0.0 ? hi : lo;
     return !(d < 0.0) & (hi >= 0.0);
+}
+
+MCRT_HD void hitInit(Hit& h, double t_limit) {
+    h.t = t_limit;
+    h.u = 0.0;
+    h.v = 0.0;
+    h.surface = kNoSurface;
+    h.interpolate = false;
 }
 
 struct ShadowQuery {
@@ -296,7 +304,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                 double t, u, v;
                 if (kCount) cnt.prim_tests++;
                 cptr<double, kAll> rec = sv.flat_prim + (size_t)i * kPrimStride;
-                const bool ok = triangleTestFlat(rec, ray, t, u, v);
+                const bool ok = triangleTestFlat(rec, ray.start, ray.direction, t, u, v);
                 const uint32_t idx = sv.flat_index[i];
                 if (ok && closer(t, idx, best)) {
                     const bool interp = rec[9] >= 2.0;
@@ -311,7 +319,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
             for (uint32_t i = nt; i < ns; i++) {
                 double t;
                 if (kCount) cnt.prim_tests++;
-                const bool ok = sphereTestFlat(sv.flat_prim + (size_t)i * kPrimStride, ray, t);
+                const bool ok = sphereTestFlat(sv.flat_prim + (size_t)i * kPrimStride, ray.start, ray.direction, t);
                 const uint32_t idx = sv.flat_index[i];
                 if (ok && closer(t, idx, best)) {
                     best.t = t;
