@@ -54,7 +54,7 @@ struct Args {
     bool photon = false;
     long width = -1, height = -1, sqrtspp = -1, threads = -1;
     long row0 = 0, row1 = -1;
-    double emissions = -1, caustic_factor = -1;
+    double emissions = -1, caustic_factor = -1, f_stop = 0, focus_distance = 0;
     long knn_k = -1;
     std::string bvh;
     long bins = -1;
@@ -66,7 +66,7 @@ struct Args {
     std::fprintf(stderr,
         "usage: mcrt_ref <flatten|render|kat>[,<mode>...] --scene file.json [--camera N] [--photon]\n"
         "   [--width W --height H --sqrtspp S] [--bvh octree|binary_sah|quaternary_sah] [--bins B]\n"
-        "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K]\n"
+        "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K] [--f-stop X] [--focus-distance D]\n"
         "   [--specular-roughness material value]... [--n N]\n"
         "   --out image.mcrt (flatten) --out-radiance file.f64 [--out-samples file.f64] (render) --out-kat dir (kat)\n"
         "   several modes in one run share ONE Camera/Scene/photon map (photon order is thread-dependent)\n");
@@ -95,6 +95,8 @@ Args parse(int argc, char** argv) {
         else if (k == "--emissions") a.emissions = std::stod(next());
         else if (k == "--caustic-factor") a.caustic_factor = std::stod(next());
         else if (k == "--k") a.knn_k = std::stol(next());
+        else if (k == "--f-stop") a.f_stop = std::stod(next());
+        else if (k == "--focus-distance") a.focus_distance = std::stod(next());
         else if (k == "--bvh") a.bvh = next();
         else if (k == "--bins") a.bins = std::stol(next());
         else if (k == "--n") a.n = std::stol(next());
@@ -117,6 +119,8 @@ nlohmann::json loadScene(const Args& a) {
     if (a.width > 0) cam["image"]["width"] = a.width;
     if (a.height > 0) cam["image"]["height"] = a.height;
     if (a.sqrtspp > 0) cam["sqrtspp"] = a.sqrtspp;
+    if (a.f_stop != 0) cam["f_stop"] = a.f_stop;                       // thin lens (camera.cpp:41-42,63)
+    if (a.focus_distance != 0) cam["focus_distance"] = a.focus_distance;
     if (a.threads > 0) j["num_render_threads"] = a.threads;
     if (!a.bvh.empty()) {
         if (a.bvh == "none") j.erase("bvh");

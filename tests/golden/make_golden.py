@@ -35,6 +35,9 @@ CASES = [
          args=["--specular-roughness", "green", "0.1", "--specular-roughness", "crystal", "0.05"],
          image=dict(width=1920, height=1080, sqrtspp=16),
          renders=[dict(tag="c2ggx_192x108_s4", width=192, height=108, sqrtspp=4)]),
+    dict(name="hexagon_room_dof", scene="hexagon_room.json", args=["--f-stop", "1.8", "--focus-distance", "8"],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="dof_96x54_s3", width=96, height=54, sqrtspp=3)]),
     dict(name="hexagon_room_pm", scene="hexagon_room.json", photon=True, args=["--emissions", "4000"],
          image=dict(width=96, height=72, sqrtspp=2),
          renders=[dict(tag="pm_96x72_s2", width=96, height=72, sqrtspp=2)], kat=1000),

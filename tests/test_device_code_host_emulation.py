@@ -24,7 +24,7 @@ def _emu_render(emu, pkg, img, cam, seed, integ, rows, stage):
 
 
 @pytest.mark.parametrize("name,stage", [("hexagon_room_diffuse", 1), ("hexagon_room", 0), ("hexagon_room_ggx", 2),
-                                        ("hexagon_room", 2), ("ior_test", 2), ("veach_mis", 2),
+                                        ("hexagon_room", 2), ("ior_test", 2), ("veach_mis", 2), ("hexagon_room_dof", 2), ("hexagon_room_dof", 0),
                                         ("coffee_maker_qsah", 1), ("coffee_maker_bsah", 0), ("ior_test", 1),
                                         ("veach_mis", 1), ("metals", 0), ("oren_nayar_test", 1), ("ggx_test", 0)])
 def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, name, stage):

@@ -35,7 +35,7 @@ def _check(out, ref, what):
     return rel
 
 
-@pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "coffee_maker_qsah",
+@pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah",
                                   "coffee_maker_bsah", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test"])
 def test_path_tracer_matches_reference(pkg, ctx, manifest, name):
     case = manifest["cases"][name]

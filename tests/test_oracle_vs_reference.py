@@ -26,7 +26,7 @@ def test_c1_anchor_matches_survey_appendix_b2():
     assert h == "2d1014101b957ce88e988540e45f74d226992c5c57e1a188dd2577b50f0f7c26"
 
 
-@pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_pm",
+@pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_pm", "hexagon_room_dof",
                                   "coffee_maker_qsah", "coffee_maker_bsah", "ior_test", "veach_mis", "metals",
                                   "oren_nayar_test", "ggx_test"])
 def test_oracle_radiance_equals_reference(pkg, oracle, manifest, name):
