@@ -211,8 +211,15 @@ def main():
         kernel_ms = kernel_ms_sum / launches
         rays_per_launch = total_rays / args.steps / world
         achieved = rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if world == 1 and args.workload in tj:
+                traffic = tj[args.workload]["traffic_bytes"]
+        except Exception:
+            pass
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "kernel": "renderKernel<path_tracer>", "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
                               "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}

@@ -6,17 +6,15 @@
 Reads every *_results.db under the directory: kernel-trace databases give per-kernel call counts and
 average duration (the `--stats` view), PMC databases give per-kernel counter sums."""
 import glob
+import re
 import os
 import sqlite3
 import sys
 
 
 def short(name):
-    for k in ("renderKernel<0, false>", "renderKernel<0, true>", "renderKernel<1, false>", "renderKernel<1, true>",
-              "intersectKernel", "knnKernel", "samplerKernel"):
-        if k in name:
-            return k
-    return name[:60]
+    m = re.search(r"(renderKernelSM|renderKernel|intersectKernel|knnKernel|samplerKernel)(<[^>]*>)?", name)
+    return m.group(0) if m else name[:60]
 
 
 def main(root):
