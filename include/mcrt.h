@@ -188,6 +188,28 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);
 /* Number of rows owned by (shard_index, shard_count, shard_rows) of `cam`, and their indices. */
 uint32_t mcrt_shard_rows(const mcrt_camera_desc* cam, uint32_t* rows /* may be NULL */);
 
+/* Photon emission pass on the GPU. Replaces the thread fan-out of
+ * PhotonMapper::PhotonMapper (integrator/photon-mapper/photon-mapper.cpp:80-115: per emission
+ * Sampler::initiate(light), setIndex(offset+i), light point + cosine direction, emitPhoton :225-277) for
+ * the uploaded scene. `emissions` and `caustic_factor` are the "photon_map" JSON values (:31-38); the
+ * split of emissions over lights follows :43-78. The photons come back as two unordered lists in the
+ * reference's 32-byte Photon layout (photon.hpp:36-37) — the host then builds its octrees from them
+ * exactly as it does from the per-thread vectors (:190-207) and calls mcrt_upload_photons.
+ * keys (optional diagnostics) identify a photon: light << 48 | emission index << 16 | bounce.
+ * The arrays belong to the context and stay valid until the next mcrt_emit_photons / mcrt_destroy. */
+typedef struct mcrt_photon_emission {
+    uint64_t global_count, caustic_count;
+    const float* global_photons;    /* [global_count][8]  flux rgb, position xyz, phi, theta */
+    const float* caustic_photons;   /* [caustic_count][8]                                   */
+    const uint64_t* global_keys;    /* [global_count]  */
+    const uint64_t* caustic_keys;   /* [caustic_count] */
+    uint64_t emission_paths;        /* photon paths traced = emissions * caustic_factor, split per light */
+    uint64_t rays;                  /* Scene::intersect calls */
+    double kernel_ms;
+} mcrt_photon_emission;
+int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed,
+                      mcrt_photon_emission* out);
+
 /* ---- operator-level entry points (each mirrors one reference function; used by parity tests
  * and by hosts that only want the traversal / kNN engine) -------------------------------- */
 

@@ -99,6 +99,16 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class PhotonEmission(C.Structure):
+    """mcrt_photon_emission."""
+    _fields_ = [
+        ("global_count", C.c_uint64), ("caustic_count", C.c_uint64),
+        ("global_photons", _fp), ("caustic_photons", _fp),
+        ("global_keys", _u64p), ("caustic_keys", _u64p),
+        ("emission_paths", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double),
+    ]
+
+
 class McrtError(RuntimeError):
     pass
 
@@ -131,6 +141,7 @@ def lib():
     L.mcrt_render_finish.argtypes = [vp, C.POINTER(Stats)]
     L.mcrt_shard_rows.argtypes = [C.POINTER(CameraDesc), _u32p]
     L.mcrt_shard_rows.restype = C.c_uint32
+    L.mcrt_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.POINTER(PhotonEmission)]
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
@@ -247,6 +258,22 @@ class Context:
         st = Stats()
         self._check(self._lib.mcrt_render_finish(self._h, C.byref(st)), "mcrt_render_finish")
         return st.as_dict()
+
+    def emit_photons(self, emissions, caustic_factor, global_seed):
+        """mcrt_emit_photons -> dict(global_=(photons[n,8] f32, keys[n] u64), caustic=(...), paths, rays, kernel_ms)."""
+        pe = PhotonEmission()
+        self._check(self._lib.mcrt_emit_photons(self._h, float(emissions), float(caustic_factor), int(global_seed),
+                                                C.byref(pe)), "mcrt_emit_photons")
+
+        def grab(ptr, kptr, n):
+            if n == 0:
+                return np.zeros((0, 8), dtype=np.float32), np.zeros(0, dtype=np.uint64)
+            return (np.ctypeslib.as_array(ptr, shape=(n * 8,)).reshape(n, 8).copy(),
+                    np.ctypeslib.as_array(kptr, shape=(n,)).copy())
+
+        return dict(global_=grab(pe.global_photons, pe.global_keys, pe.global_count),
+                    caustic=grab(pe.caustic_photons, pe.caustic_keys, pe.caustic_count),
+                    paths=int(pe.emission_paths), rays=int(pe.rays), kernel_ms=pe.kernel_ms)
 
     def intersect(self, start, direction):
         start = np.ascontiguousarray(start, dtype=np.float64)

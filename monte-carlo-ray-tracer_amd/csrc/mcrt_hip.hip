@@ -657,6 +657,91 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
 }
 
 // ------------------------------------------------------------------------------------------------
+// photon emission pass (§8(f) rank 1): one photon path per lane at a time, regenerated like the eye paths
+// ------------------------------------------------------------------------------------------------
+struct EmitParams {
+    uint32_t num_lights;
+    const unsigned long long* light_first;  // [num_lights + 1] prefix sums of the per-light emission counts
+    const double* light_photon_flux;        // [num_lights][3]
+    unsigned long long total_emissions;
+    uint32_t global_seed;
+    double non_caustic_reject;
+    float* photons[2];                      // 0 global, 1 caustic: [capacity][8]
+    unsigned long long* keys[2];
+    unsigned long long capacity[2];
+    unsigned long long* counters;           // [0] work, [1] global count, [2] caustic count, [3] paths, [4] rays, [5] overflow
+    StackEntry* spill;
+    uint32_t total_lanes;
+};
+
+// wave-aggregated append: lanes with store == true get consecutive slots of the list
+__device__ inline unsigned long long waveAppend(bool store, unsigned long long* counter) { return wavePop(store, counter); }
+
+template <bool kAll>
+__global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, const EmitParams prm) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    SceneViewT<kAll> sv;
+    ShadeViewT<kAll> sh;
+    SobolTab tab;
+    LaneStack stk;
+    RefractionHistory rh;
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+
+    EmitState es;
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    uint32_t paths = 0;
+    bool active = false, exhausted = false;
+    for (;;) {
+        const bool need = !active && !exhausted;
+        if (__ballot(need)) {
+            const unsigned long long e = wavePop(need, prm.counters + 0);
+            if (need) {
+                if (e >= prm.total_emissions) {
+                    exhausted = true;
+                } else {
+                    // which light: largest i with light_first[i] <= e
+                    uint32_t lo = 0, hi = prm.num_lights - 1;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) / 2;
+                        if (prm.light_first[mid] <= e) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    const d3 pf = ld3(prm.light_photon_flux + 3 * (size_t)lo);
+                    emitBegin(es, rh, sh, lo, (uint32_t)(e - prm.light_first[lo]), pf, prm.global_seed, tab);
+                    active = true;
+                    paths++;
+                }
+            }
+        }
+        if (!__ballot(active)) {
+            if (!__ballot(!exhausted)) break;
+            continue;
+        }
+        PhotonOut out;
+        out.store = false;
+        out.caustic = false;
+        if (active) {
+            const bool done = emitBounce<false, kAll>(es, rh, sv, sh, stk, cnt, tab, prm.non_caustic_reject, out);
+            if (done) active = false;
+        }
+        for (int which = 0; which < 2; which++) {
+            const bool mine = out.store && (out.caustic == (which == 1));
+            if (__ballot(mine)) {
+                const unsigned long long slot = waveAppend(mine, prm.counters + 1 + which);
+                if (mine && slot < prm.capacity[which]) {
+                    float* o = prm.photons[which] + slot * 8ull;
+                    for (int k = 0; k < 8; k++) o[k] = out.rec[k];
+                    prm.keys[which][slot] = out.key;
+                }
+            }
+        }
+    }
+    waveAccumulate(prm.counters + 3, paths);
+    waveAccumulate(prm.counters + 4, cnt.rays);
+    waveAccumulate(prm.counters + 5, cnt.overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
 // operator-level kernels
 // ------------------------------------------------------------------------------------------------
 template <bool kAll>
@@ -786,6 +871,12 @@ struct mcrt_ctx {
 
     DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
     uint32_t spill_lanes = 0, knn_lanes = 0, knn_k = 0;
+
+    // photon emission pass
+    std::vector<double> host_light_flux;  // [num_lights][3] emittance * area (photon-mapper.cpp:64)
+    DevBuf emit_first, emit_flux, emit_counters, emit_photons[2], emit_keys[2];
+    std::vector<float> host_photons[2];
+    std::vector<uint64_t> host_keys[2];
 
     // in-flight render
     bool pending = false;
@@ -1116,6 +1207,12 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.sobol_tab = ctx->sobol_tab.as<uint32_t>();
     d.scene_ior = s->scene_ior;
 
+    ctx->host_light_flux.assign((size_t)s->num_lights * 3, 0.0);
+    for (uint32_t i = 0; i < s->num_lights; i++) {
+        const uint32_t ls = s->light_surface[i];
+        for (int c = 0; c < 3; c++) ctx->host_light_flux[(size_t)i * 3 + c] = s->materials[s->surf_material[ls]].emittance[c] * s->surf_area[ls];
+    }
+
     // Staging plan: whole scene when its LDS image is <= 48 KiB, else the top 512 nodes of the BVH.
     d.stage_all = 1;
     d.stage_nodes = 0;
@@ -1228,6 +1325,105 @@ int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed
     }
     st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
     if (stats) *stats = st;
+    return MCRT_OK;
+}
+
+int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, mcrt_photon_emission* out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
+    if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_emit_photons before mcrt_upload_scene");
+    if (!(emissions >= 0.0) || !(caustic_factor > 0.0)) return fail(ctx, MCRT_ERR_INVALID, "emissions must be >= 0 and caustic_factor > 0");
+    memset(out, 0, sizeof(*out));
+    const uint32_t nl = ctx->scene.num_lights;
+    if (nl == 0 || nl > 0xFFFFu) return nl == 0 ? MCRT_OK : fail(ctx, MCRT_ERR_UNSUPPORTED, "more than 65535 lights");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // work split, photon-mapper.cpp:31-78
+    const size_t photon_emissions = (size_t)((double)(size_t)emissions * caustic_factor);
+    double total_add_flux = 0.0;
+    for (uint32_t i = 0; i < nl; i++) {
+        const double* f = &ctx->host_light_flux[(size_t)i * 3];
+        total_add_flux += 0.0 + f[0] + f[1] + f[2];  // glm::compAdd
+    }
+    std::vector<unsigned long long> first(nl + 1, 0ull);
+    std::vector<double> pflux((size_t)nl * 3);
+    for (uint32_t i = 0; i < nl; i++) {
+        const double* f = &ctx->host_light_flux[(size_t)i * 3];
+        const double share = (0.0 + f[0] + f[1] + f[2]) / total_add_flux;
+        const size_t n = (size_t)((double)photon_emissions * share);
+        if (n > 0xFFFFFFFFull) return fail(ctx, MCRT_ERR_UNSUPPORTED, "more than 2^32 emissions from one light");
+        first[i + 1] = first[i] + n;
+        for (int c = 0; c < 3; c++) pflux[(size_t)i * 3 + c] = f[c] / (double)n;
+    }
+    const unsigned long long total = first[nl];
+    if (int rc = uploadArray(ctx, ctx->emit_first, first.data(), first.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->emit_flux, pflux.data(), pflux.size())) return rc;
+    if (!ctx->emit_counters.p) HIP_TRY(ctx, ctx->emit_counters.alloc(8 * sizeof(unsigned long long)));
+
+    auto kernel = ctx->scene.stage_all ? emitKernel<true> : emitKernel<false>;
+    DeviceScene scene = ctx->scene;
+    scene.flat = 0;  // the emission kernel walks the BVH
+    LaunchGeom g;
+    if (int rc = launchGeometry(ctx, kernel, scene, g)) return rc;
+    if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
+
+    unsigned long long cap[2] = {std::max<unsigned long long>(1ull << 16, total), std::max<unsigned long long>(1ull << 16, total)};
+    unsigned long long h[8] = {0};
+    float ms = 0.f;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        for (int w = 0; w < 2; w++) {
+            if (ctx->emit_photons[w].bytes < cap[w] * 32) HIP_TRY(ctx, ctx->emit_photons[w].alloc(cap[w] * 32));
+            if (ctx->emit_keys[w].bytes < cap[w] * 8) HIP_TRY(ctx, ctx->emit_keys[w].alloc(cap[w] * 8));
+        }
+        EmitParams prm;
+        memset(&prm, 0, sizeof(prm));
+        prm.num_lights = nl;
+        prm.light_first = ctx->emit_first.as<unsigned long long>();
+        prm.light_photon_flux = ctx->emit_flux.as<double>();
+        prm.total_emissions = total;
+        prm.global_seed = global_seed;
+        prm.non_caustic_reject = 1.0 / caustic_factor;
+        for (int w = 0; w < 2; w++) {
+            prm.photons[w] = ctx->emit_photons[w].as<float>();
+            prm.keys[w] = ctx->emit_keys[w].as<unsigned long long>();
+            prm.capacity[w] = cap[w];
+        }
+        prm.counters = ctx->emit_counters.as<unsigned long long>();
+        prm.spill = ctx->spill.as<StackEntry>();
+        prm.total_lanes = g.total_lanes;
+        const uint32_t grid = (uint32_t)std::min<unsigned long long>(g.grid, (total + kBlock - 1) / kBlock + 1);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->emit_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, ctx->stream, scene, prm);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        HIP_TRY(ctx, hipMemcpy(h, ctx->emit_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow in the emission pass");
+        if (h[1] <= cap[0] && h[2] <= cap[1]) break;
+        cap[0] = std::max(cap[0], h[1]);  // a list was too small: size it exactly and emit again
+        cap[1] = std::max(cap[1], h[2]);
+        if (attempt == 2) return fail(ctx, MCRT_ERR_HIP, "photon lists kept overflowing");
+    }
+    for (int w = 0; w < 2; w++) {
+        const size_t n = (size_t)h[1 + w];
+        ctx->host_photons[w].resize(n * 8);
+        ctx->host_keys[w].resize(n);
+        if (n) {
+            HIP_TRY(ctx, hipMemcpy(ctx->host_photons[w].data(), ctx->emit_photons[w].p, n * 32, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(ctx->host_keys[w].data(), ctx->emit_keys[w].p, n * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    out->global_count = h[1];
+    out->caustic_count = h[2];
+    out->global_photons = ctx->host_photons[0].data();
+    out->caustic_photons = ctx->host_photons[1].data();
+    out->global_keys = ctx->host_keys[0].data();
+    out->caustic_keys = ctx->host_keys[1].data();
+    out->emission_paths = h[3];
+    out->rays = h[4];
+    out->kernel_ms = ms;
     return MCRT_OK;
 }
 

@@ -106,6 +106,89 @@ MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneV
     return false;
 }
 
+// ------------------------------------------------------------------ photon emission pass (§8(f) rank 1)
+//   PhotonMapper::PhotonMapper per-emission set-up   photon-mapper.cpp:96-110
+//   PhotonMapper::emitPhoton                          photon-mapper.cpp:225-277
+//   Photon (FP32 record, polar direction)              photon.hpp:5-38
+struct EmitState {
+    Ray ray;
+    d3 flux;
+    Sampler smp;
+    uint64_t key;     // light << 48 | emission index << 16 (the bounce number is or-ed in per photon)
+    uint32_t bounce;
+};
+
+struct PhotonOut {
+    bool store, caustic;
+    float rec[8];     // flux rgb, position xyz, phi, theta
+    uint64_t key;
+};
+
+MCRT_HD void encodePhoton(PhotonOut& out, d3 flux, d3 position, d3 direction) {  // Photon ctor, photon.hpp:7-12
+    out.rec[0] = (float)flux.x;
+    out.rec[1] = (float)flux.y;
+    out.rec[2] = (float)flux.z;
+    out.rec[3] = (float)position.x;
+    out.rec[4] = (float)position.y;
+    out.rec[5] = (float)position.z;
+    out.rec[7] = (float)atan2(sqrt(direction.x * direction.x + direction.y * direction.y), direction.z);  // theta
+    out.rec[6] = (float)atan2(direction.y, direction.x);                                                   // phi
+}
+
+// photon-mapper.cpp:98-110: emission `index` of light number `light` (position in Scene::emissives).
+template <bool L>
+MCRT_HD void emitBegin(EmitState& es, RefractionHistory& rh, const ShadeViewT<L>& sh, uint32_t light, uint32_t index, d3 photon_flux,
+                       uint32_t global_seed, SobolTab tab) {
+    es.smp.initiate(global_seed, light);
+    es.smp.setIndex(index);
+    const double u0 = es.smp.get(0, tab), u1 = es.smp.get(1, tab), u2 = es.smp.get(2, tab), u3 = es.smp.get(3, tab);  // Dim::PM_LIGHT, 4D
+    const uint32_t surface = sh.light_surface[light];
+    d3 pos = surfSample(sh, surface, u0, u1);
+    d3 normal = surfNormal(sh, surface, pos);
+    d3 dir = csFrom(orthonormalBasis(normal), cosWeightedHemi(u2, u3));  // CoordinateSystem::from(v, N)
+    pos = pos + normal * kEpsilon;
+    es.ray = makeRay(pos, dir, sh.scene_ior);
+    es.flux = photon_flux;
+    es.key = ((uint64_t)light << 48) | ((uint64_t)index << 16);
+    es.bounce = 0;
+    rh.init(es.ray);
+}
+
+// One iteration of the while(true) in PhotonMapper::emitPhoton. Returns true when the photon path has
+// ended; out.store says whether this bounce deposited a photon (out.caustic: into which map).
+template <bool kCount, bool kAll>
+MCRT_HD bool emitBounce(EmitState& es, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh,
+                        const LaneStack& stk, TraceCounters& cnt, SobolTab tab, double non_caustic_reject, PhotonOut& out) {
+    out.store = false;
+    out.caustic = false;
+    es.smp.shuffle();                                                            // :233
+    Hit isect = sceneIntersect<kAll, kCount, false>(sv, es.ray, stk, cnt);       // :235
+    if (isect.surface == kNoSurface) return true;                                // :237-240
+    InteractionT<kAll> ia;
+    interactionInit(ia, sh, isect, es.ray, rh.externalIOR(es.ray), es.smp, tab);  // :242
+    if (!(ia.material->flags & MCRT_MAT_DIRAC_DELTA)) {                          // :245-255
+        if (es.ray.dirac_delta) {
+            out.store = true;
+            out.caustic = true;
+            encodePhoton(out, es.flux, ia.position, -es.ray.direction);
+        } else if (non_caustic_reject > es.smp.get(2 /* Dim::PM_REJECT */, tab)) {
+            out.store = true;
+            encodePhoton(out, es.flux / non_caustic_reject, ia.position, -es.ray.direction);
+        }
+        out.key = es.key | (uint64_t)(es.bounce & 0xFFFFu);
+    }
+    es.bounce++;
+    d3 bsdf_absIdotN;
+    double bsdf_pdf;
+    if (!interactionSampleBSDF(ia, bsdf_absIdotN, bsdf_pdf, es.ray, true, es.smp, tab)) return true;  // :257-260
+    bsdf_absIdotN = bsdf_absIdotN / bsdf_pdf;                                    // :262
+    double survive = gmin(compMax(bsdf_absIdotN), 0.95);                         // :267
+    if (survive == 0.0 || survive <= es.smp.get(kDimAbsorb, tab)) return true;   // :268-271
+    es.flux = es.flux * (bsdf_absIdotN / survive);                               // :273
+    rh.update(es.ray);                                                           // :275
+    return false;
+}
+
 // ------------------------------------------------------------------ photon map
 struct PhotonMapView {
     uint32_t num_octants;

@@ -1060,6 +1060,95 @@ void oracle_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* st
     free(ts.to_visit.H);
 }
 
+/* ------------------------------------------------------------------ photon emission (photon-mapper.cpp) */
+typedef struct {
+    float* photons; uint64_t* keys; uint64_t cap, count;
+} PhotonSink;
+
+static void sinkPhoton(PhotonSink* s, v3 flux, v3 position, v3 direction, uint64_t key) { /* Photon ctor, photon.hpp:7-12 */
+    if (s->count < s->cap) {
+        float* o = s->photons + 8 * s->count;
+        o[0] = (float)flux.x; o[1] = (float)flux.y; o[2] = (float)flux.z;
+        o[3] = (float)position.x; o[4] = (float)position.y; o[5] = (float)position.z;
+        o[7] = (float)atan2(sqrt(direction.x * direction.x + direction.y * direction.y), direction.z); /* theta */
+        o[6] = (float)atan2(direction.y, direction.x);                                                   /* phi   */
+        if (s->keys) s->keys[s->count] = key;
+    }
+    s->count++;
+}
+
+static void emitPhoton(Ctx* C, Ray ray, v3 flux, Sampler* smp, double non_caustic_reject, PhotonSink* gs, PhotonSink* cs, uint64_t key) { /* :225-277 */
+    const mcrt_scene_desc* s = C->S.s;
+    RefractionHistory rh; rhInit(&rh, &ray);
+    v3 bsdf_absIdotN; double bsdf_pdf;
+    for (uint64_t bounce = 0;; bounce++) {
+        samplerShuffle(smp);
+        Hit isect = sceneIntersect(&C->S, &ray, C->ts);
+        if (isect.surface == NO_SURFACE) return;
+        Interaction ia;
+        iaInit(&ia, s, &isect, &ray, rhExternalIOR(&rh, &ray), smp);
+        if (!(ia.material->flags & MCRT_MAT_DIRAC_DELTA)) {
+            if (ray.dirac_delta) sinkPhoton(cs, flux, ia.position, vneg(ray.direction), key | (bounce & 0xFFFFu));
+            else if (non_caustic_reject > samplerGet(smp, 2 /* Dim::PM_REJECT */))
+                sinkPhoton(gs, vdivs(flux, non_caustic_reject), ia.position, vneg(ray.direction), key | (bounce & 0xFFFFu));
+        }
+        if (!iaSampleBSDF(&ia, &bsdf_absIdotN, &bsdf_pdf, &ray, 1, smp)) return;
+        bsdf_absIdotN = vdivs(bsdf_absIdotN, bsdf_pdf);
+        double survive = smin(compMax(bsdf_absIdotN), 0.95);
+        if (survive == 0.0 || survive <= samplerGet(smp, DIM_ABSORB)) return;
+        flux = vmul(flux, vdivs(bsdf_absIdotN, survive));
+        rhUpdate(&rh, &ray);
+    }
+}
+
+int oracle_emit_photons(const mcrt_scene_desc* scene, double emissions, double caustic_factor, uint32_t global_seed,
+                        float* global_photons, uint64_t* global_keys, uint64_t global_capacity, uint64_t* global_count,
+                        float* caustic_photons, uint64_t* caustic_keys, uint64_t caustic_capacity, uint64_t* caustic_count,
+                        uint64_t* emission_paths, uint64_t* rays) {
+    pthread_once(&g_dirs_once, initDirections);
+    ThreadScratch ts; memset(&ts, 0, sizeof(ts));
+    oracle_counters cnt; memset(&cnt, 0, sizeof(cnt));
+    Ctx C; memset(&C, 0, sizeof(C)); C.S.s = scene; C.S.c = &cnt; C.ts = &ts;
+    PhotonSink gs = {global_photons, global_keys, global_capacity, 0}, cs = {caustic_photons, caustic_keys, caustic_capacity, 0};
+    /* photon-mapper.cpp:28-38 */
+    size_t photon_emissions0 = (size_t)emissions;
+    double non_caustic_reject = 1.0 / caustic_factor;
+    size_t photon_emissions = (size_t)((double)photon_emissions0 * caustic_factor);
+    double total_add_flux = 0.0; /* :43-47 */
+    for (uint32_t i = 0; i < scene->num_lights; i++) {
+        uint32_t ls = scene->light_surface[i];
+        v3 lf = vscale(ld3(scene->materials[scene->surf_material[ls]].emittance), scene->surf_area[ls]);
+        total_add_flux += 0.0 + lf.x + lf.y + lf.z; /* glm::compAdd: ((0 + x) + y) + z */
+    }
+    uint64_t paths = 0;
+    for (uint32_t i = 0; i < scene->num_lights; i++) { /* :62-78, 86-115 */
+        uint32_t ls = scene->light_surface[i];
+        v3 light_flux = vscale(ld3(scene->materials[scene->surf_material[ls]].emittance), scene->surf_area[ls]);
+        double share = (0.0 + light_flux.x + light_flux.y + light_flux.z) / total_add_flux;
+        size_t num_light_emissions = (size_t)((double)photon_emissions * share);
+        v3 photon_flux = vdivs(light_flux, (double)num_light_emissions);
+        Sampler smp; memset(&smp, 0, sizeof(smp)); smp.global_seed = global_seed;
+        samplerInitiate(&smp, i);
+        for (size_t j = 0; j < num_light_emissions; j++) {
+            samplerSetIndex(&smp, (uint32_t)j);
+            double u0 = samplerGet(&smp, 0), u1 = samplerGet(&smp, 1), u2 = samplerGet(&smp, 2), u3 = samplerGet(&smp, 3);
+            v3 pos = surfSample(scene, ls, u0, u1);
+            v3 normal = surfNormal(scene, ls, pos);
+            M3 T = orthonormalBasis(normal);
+            v3 dir = csFrom(&T, cosWeightedHemi(u2, u3)); /* CoordinateSystem::from(v, N) */
+            pos = vadd(pos, vscale(normal, EPSILON));
+            paths++;
+            emitPhoton(&C, rayDir(pos, dir, scene->scene_ior), photon_flux, &smp, non_caustic_reject, &gs, &cs,
+                       ((uint64_t)i << 48) | ((uint64_t)(uint32_t)j << 16));
+        }
+    }
+    *global_count = gs.count; *caustic_count = cs.count;
+    if (emission_paths) *emission_paths = paths;
+    if (rays) *rays = cnt.rays;
+    free(ts.to_visit.H);
+    return (gs.count > gs.cap || cs.count > cs.cap) ? -1 : 0;
+}
+
 void oracle_bsdf_kat(uint64_t n, const double* in, const double* consts, double* out) {
     mcrt_material rough; memset(&rough, 0, sizeof(rough));
     rough.roughness = consts[0];

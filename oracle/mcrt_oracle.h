@@ -49,6 +49,16 @@ int oracle_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* glob
                   uint32_t row0, uint32_t row1, int threads, double* out_rgb, double* out_samples,
                   oracle_counters* counters, double* seconds);
 
+/* Photon emission pass (integrator/photon-mapper/photon-mapper.cpp:24-115 work split and per-emission
+ * set-up, :225-277 emitPhoton). emissions / caustic_factor are the "photon_map" JSON values. Photons are
+ * written in (light, emission index, bounce) order as [n][8] floats (flux rgb, position xyz, phi, theta:
+ * photon.hpp:7-12,36-37) with keys = light << 48 | emission index << 16 | bounce. Returns 0, or -1 when
+ * a capacity was too small (counts then hold the required sizes). */
+int oracle_emit_photons(const mcrt_scene_desc* scene, double emissions, double caustic_factor, uint32_t global_seed,
+                        float* global_photons, uint64_t* global_keys, uint64_t global_capacity, uint64_t* global_count,
+                        float* caustic_photons, uint64_t* caustic_keys, uint64_t caustic_capacity, uint64_t* caustic_count,
+                        uint64_t* emission_paths, uint64_t* rays);
+
 /* Known-answer helpers for the BSDF building blocks (material/fresnel.cpp, material/ggx.cpp,
  * material/material.cpp). in[11] = wi(3) wo(3) n1 n2 alpha u v; consts[10] = roughness,
  * reflectance(3), complex ior real(3), imag(3); out[18] as written by oracle/ref_main.cpp doKat. */

@@ -74,6 +74,7 @@ def emu():
     L.emu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
     L.emu_intersect.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, vp, vp, vp]
     L.emu_render_sm.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
+    L.emu_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]
     L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L
@@ -119,3 +120,13 @@ def check_hits_against_reference(oracle, img, kat_dir, t, surf, uv):
     np.testing.assert_array_equal(uv[same], uv_ref[same])
     assert len(diff) <= max(3, len(t) // 500)
     return len(diff)
+
+
+def sort_by_key(photons, keys):
+    order = np.argsort(keys, kind="stable")
+    return photons[order], keys[order]
+
+
+def photon_set_bytes(photons):
+    """The photon list as a sorted array of opaque 32-byte records (order-free exact comparison)."""
+    return np.sort(np.ascontiguousarray(photons, dtype=np.float32).view("V32").ravel())

@@ -262,6 +262,54 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     return 0;
 }
 
+// Photon emission pass (emitBegin / emitBounce, the functions emitKernel runs), one photon path at a time.
+int emu_emit_photons(const mcrt_scene_desc* scene, double emissions, double caustic_factor, uint32_t global_seed, int stage_all,
+                     float* gph, uint64_t* gkeys, uint64_t gcap, uint64_t* gcount, float* cph, uint64_t* ckeys, uint64_t ccap,
+                     uint64_t* ccount, uint64_t* rays) {
+    Emu E;
+    if (int rc = setup(E, scene, stage_all ? 1 : 0)) return rc;
+    const size_t photon_emissions = (size_t)((double)(size_t)emissions * caustic_factor);
+    const double non_caustic_reject = 1.0 / caustic_factor;
+    std::vector<double> lf((size_t)scene->num_lights * 3);
+    double total = 0.0;
+    for (uint32_t i = 0; i < scene->num_lights; i++) {
+        const uint32_t ls = scene->light_surface[i];
+        for (int c = 0; c < 3; c++) lf[i * 3 + c] = scene->materials[scene->surf_material[ls]].emittance[c] * scene->surf_area[ls];
+        total += 0.0 + lf[i * 3] + lf[i * 3 + 1] + lf[i * 3 + 2];
+    }
+    TraceCounters cnt = {0, 0, 0, 0};
+    uint64_t ng = 0, nc = 0;
+    for (uint32_t i = 0; i < scene->num_lights; i++) {
+        const double share = (0.0 + lf[i * 3] + lf[i * 3 + 1] + lf[i * 3 + 2]) / total;
+        const size_t n = (size_t)((double)photon_emissions * share);
+        const d3 pf = d3{lf[i * 3] / (double)n, lf[i * 3 + 1] / (double)n, lf[i * 3 + 2] / (double)n};
+        for (size_t j = 0; j < n; j++) {
+            EmitState es;
+            if (stage_all) emitBegin(es, E.rh, E.sh_all, i, (uint32_t)j, pf, global_seed, E.tab.data());
+            else emitBegin(es, E.rh, E.sh_top, i, (uint32_t)j, pf, global_seed, E.tab.data());
+            for (;;) {
+                PhotonOut out;
+                const bool done = stage_all ? emitBounce<true, true>(es, E.rh, E.sv_all, E.sh_all, E.stk, cnt, E.tab.data(), non_caustic_reject, out)
+                                            : emitBounce<true, false>(es, E.rh, E.sv_top, E.sh_top, E.stk, cnt, E.tab.data(), non_caustic_reject, out);
+                if (out.store) {
+                    uint64_t& n_out = out.caustic ? nc : ng;
+                    const uint64_t cap = out.caustic ? ccap : gcap;
+                    if (n_out < cap) {
+                        memcpy((out.caustic ? cph : gph) + n_out * 8, out.rec, 32);
+                        (out.caustic ? ckeys : gkeys)[n_out] = out.key;
+                    }
+                    n_out++;
+                }
+                if (done) break;
+            }
+        }
+    }
+    *gcount = ng;
+    *ccount = nc;
+    *rays = cnt.rays;
+    return (ng > gcap || nc > ccap) ? -1 : (cnt.overflow ? -100 : 0);
+}
+
 int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int stage_lds,
                   double* out_t, uint32_t* out_surface, double* out_uv) {
     Emu E;

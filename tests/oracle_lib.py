@@ -40,6 +40,7 @@ def lib():
         L.oracle_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.oracle_bsdf_kat.argtypes = [C.c_uint64, vp, vp, vp]
         L.oracle_hardware_threads.restype = C.c_int
+        L.oracle_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -142,3 +143,21 @@ def single_surface_t(image, surface, start, direction):
 
     t, _, _, _ = intersect(_One, start, direction)
     return t
+
+
+def emit_photons(image, emissions, caustic_factor, seed):
+    """Photon emission pass of the oracle. Returns dict(global=(photons[n,8] f32, keys[n] u64), caustic=(...),
+    paths, rays), photons in (light, emission index, bounce) order."""
+    L = lib()
+    cap = max(1024, int(emissions * caustic_factor * 2))
+    while True:
+        g, gk = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+        c, ck = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+        ng, nc, paths, rays = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = L.oracle_emit_photons(C.byref(image.scene), float(emissions), float(caustic_factor), int(seed), g.ctypes.data,
+                                   gk.ctypes.data, cap, C.byref(ng), c.ctypes.data, ck.ctypes.data, cap, C.byref(nc),
+                                   C.byref(paths), C.byref(rays))
+        if rc == 0:
+            return dict(global_=(g[:ng.value], gk[:ng.value]), caustic=(c[:nc.value], ck[:nc.value]),
+                        paths=paths.value, rays=rays.value)
+        cap = int(max(ng.value, nc.value) * 1.1) + 16

@@ -1,0 +1,98 @@
+"""Photon emission pass: PhotonMapper's per-emission set-up and emitPhoton
+(integrator/photon-mapper/photon-mapper.cpp:24-115, 225-277). The reference's result is the photon
+content of the maps in tests/golden/hexagon_room_pm.mcrt (flattened from the reference's own
+LinearOctree<Photon>::ordered_data; 4000 emissions x caustic_factor 10 = 40 000 photon paths)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, photon_set_bytes, sort_by_key
+
+EMISSIONS, CAUSTIC_FACTOR = 4000, 10.0
+
+
+def _reference_maps(img):
+    out = []
+    for which in (0, 1):
+        pm = img.photons(which)
+        n = pm.num_photons
+        out.append(np.ctypeslib.as_array(pm.photons, shape=(n * 8,)).reshape(n, 8).copy())
+    return out
+
+
+def test_oracle_emission_equals_reference_photon_sets(pkg, oracle, manifest):
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    r = oracle.emit_photons(img, EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    ref_g, ref_c = _reference_maps(img)
+    assert r["paths"] == 40000
+    assert np.array_equal(photon_set_bytes(r["global_"][0]), photon_set_bytes(ref_g))
+    assert np.array_equal(photon_set_bytes(r["caustic"][0]), photon_set_bytes(ref_c))
+    # keys are unique and ordered (light, emission, bounce)
+    for name in ("global_", "caustic"):
+        k = r[name][1]
+        assert np.all(np.diff(k.astype(np.int64)) > 0)
+
+
+@pytest.mark.parametrize("stage_all", [0, 1])
+def test_emission_device_code_equals_oracle(pkg, emu, oracle, manifest, stage_all):
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    want = oracle.emit_photons(img, EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    cap = 1 << 17
+    g, gk = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+    c, ck = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+    ng, nc, rays = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = emu.emu_emit_photons(C.byref(img.scene), float(EMISSIONS), CAUSTIC_FACTOR, manifest["seed"], stage_all, g.ctypes.data,
+                              gk.ctypes.data, cap, C.byref(ng), c.ctypes.data, ck.ctypes.data, cap, C.byref(nc), C.byref(rays))
+    assert rc == 0
+    for (got, gotk, n), name in (((g, gk, ng.value), "global_"), ((c, ck, nc.value), "caustic")):
+        a, ak = sort_by_key(got[:n], gotk[:n])
+        b, bk = want[name]
+        np.testing.assert_array_equal(ak, bk)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))  # same libm on the host: same bits
+    assert rays.value == want["rays"]
+
+
+@pytest.mark.gpu
+def test_gpu_emission_matches_oracle(pkg, oracle, manifest):
+    """Through the C ABI on the GPU. Photons are matched by key (light, emission index, bounce). ocml and
+    glibc differ in the last ulp of sin/cos/atan2, which can move an FP32 field by one ulp and, rarely,
+    flip a branch of a photon path; tolerance: fields within 2e-6 relative, <= 0.2 % unmatched keys."""
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    want = oracle.emit_photons(img, EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    ctx = pkg.Context(0)
+    ctx.upload_scene(img.scene)
+    got = ctx.emit_photons(EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    assert got["paths"] == want["paths"] == 40000
+    assert abs(got["rays"] - want["rays"]) <= 0.002 * want["rays"]
+    for name in ("global_", "caustic"):
+        a, ak = sort_by_key(*got[name])
+        b, bk = want[name]
+        common, ia, ib = np.intersect1d(ak, bk, return_indices=True)
+        unmatched = (len(ak) - len(common)) + (len(bk) - len(common))
+        print("%s: %d photons, %d unmatched keys" % (name, len(bk), unmatched))
+        assert unmatched <= 0.002 * len(bk) + 2
+        x, y = a[ia].astype(np.float64), b[ib].astype(np.float64)
+        err = np.abs(x - y) / np.maximum(np.abs(y), 1e-3)
+        bad = int((err.max(axis=1) > 2e-6).sum())
+        print("%s: max field error %.3e, photons beyond 2e-6: %d" % (name, err.max(), bad))
+        assert bad <= 0.002 * len(common) + 2
+    # the emitted lists can be handed straight back as maps: same photon counts as the reference's maps
+    ref_g, ref_c = _reference_maps(img)
+    assert abs(len(got["global_"][0]) - len(ref_g)) <= 0.002 * len(ref_g) + 2
+    assert abs(len(got["caustic"][0]) - len(ref_c)) <= 0.002 * len(ref_c) + 2
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_emission_list_growth_and_errors(pkg, manifest):
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    ctx = pkg.Context(0)
+    with pytest.raises(pkg.McrtError):
+        ctx.emit_photons(100, 10.0, 1)  # no scene yet
+    ctx.upload_scene(img.scene)
+    small = ctx.emit_photons(100, 10.0, manifest["seed"])
+    assert small["paths"] == 1000 and len(small["caustic"][0]) > 0
+    with pytest.raises(pkg.McrtError):
+        ctx.emit_photons(100, 0.0, 1)
+    ctx.close()
