@@ -250,6 +250,17 @@ int mcrt_image_save(const char* path, const mcrt_scene_desc* scene, const mcrt_c
                     const mcrt_photon_map_desc* global_map, const mcrt_photon_map_desc* caustic_map,
                     const char* const* param_keys, const uint64_t* param_values, uint32_t num_params);
 
+/* Host-side photon-map builder: photon list (e.g. from mcrt_emit_photons) -> linear octree with the
+ * semantics of Octree<Photon>::insert + LinearOctree<Photon> (octree/octree.cpp:35-80,
+ * octree/linear-octree.cpp:202-244): root cell = Scene::BB(), a cell with more than
+ * max_photons_per_leaf photons is split into its 8 octants, empty octants are dropped, node boxes are
+ * tight. For hosts that do not carry the reference's builder; never touches the GPU. */
+typedef struct mcrt_photon_map mcrt_photon_map; /* opaque; owns the arrays its descriptor points into */
+int  mcrt_photon_map_build(const float* photons, uint64_t num_photons, const double bb_min[3], const double bb_max[3],
+                           uint32_t max_photons_per_leaf, mcrt_photon_map** out);
+const mcrt_photon_map_desc* mcrt_photon_map_get(const mcrt_photon_map* map);
+void mcrt_photon_map_free(mcrt_photon_map* map);
+
 uint32_t mcrt_abi_version(void);
 
 #ifdef __cplusplus

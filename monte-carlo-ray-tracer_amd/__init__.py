@@ -145,6 +145,11 @@ def lib():
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
+    L.mcrt_photon_map_build.argtypes = [_fp, C.c_uint64, _dp, _dp, C.c_uint32, C.POINTER(vp)]
+    L.mcrt_photon_map_get.argtypes = [vp]
+    L.mcrt_photon_map_get.restype = C.POINTER(PhotonMapDesc)
+    L.mcrt_photon_map_free.argtypes = [vp]
+    L.mcrt_photon_map_free.restype = None
     L.mcrt_image_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.mcrt_image_free.argtypes = [vp]
     L.mcrt_image_free.restype = None
@@ -196,6 +201,35 @@ class SceneImage:
     def close(self):
         if self._h:
             self._lib.mcrt_image_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PhotonMap:
+    """mcrt_photon_map: linear photon octree built on the host from a photon list (mcrt_photon_map_build)."""
+
+    def __init__(self, photons, bb_min, bb_max, max_photons_per_leaf=200):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        ph = np.ascontiguousarray(photons, dtype=np.float32).reshape(-1, 8)
+        lo = (C.c_double * 3)(*bb_min)
+        hi = (C.c_double * 3)(*bb_max)
+        rc = self._lib.mcrt_photon_map_build(_ptr(ph, C.c_float), ph.shape[0], lo, hi, int(max_photons_per_leaf), C.byref(self._h))
+        if rc != 0:
+            raise McrtError("mcrt_photon_map_build failed: %d" % rc)
+
+    @property
+    def desc(self):
+        return self._lib.mcrt_photon_map_get(self._h).contents
+
+    def close(self):
+        if self._h:
+            self._lib.mcrt_photon_map_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

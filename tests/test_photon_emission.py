@@ -96,3 +96,62 @@ def test_gpu_emission_list_growth_and_errors(pkg, manifest):
     with pytest.raises(pkg.McrtError):
         ctx.emit_photons(100, 0.0, 1)
     ctx.close()
+
+
+def _as_np(ptr, n, dtype):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy() if n else np.zeros(0, dtype=dtype)
+
+
+def test_host_map_builder_reproduces_reference_octree(pkg, oracle, manifest):
+    """mcrt_photon_map_build on the reference's own photon lists gives the reference's LinearOctree:
+    same octants (tight boxes, leaf flags, counts, links, data ranges); only the photon order inside a
+    leaf may differ."""
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    s = img.scene
+    for which in (0, 1):
+        ref = img.photons(which)
+        n, no = ref.num_photons, ref.num_octants
+        photons = np.ctypeslib.as_array(ref.photons, shape=(n * 8,)).reshape(n, 8).copy()
+        rng = np.random.default_rng(which)
+        built = pkg.PhotonMap(photons[rng.permutation(n)], s.bb_min[:], s.bb_max[:], 200)
+        d = built.desc
+        assert d.num_octants == no and d.num_photons == n
+        for field, dt, k in (("octant_bounds", np.float64, 6), ("octant_start_data", np.uint64, 1),
+                             ("octant_contained_data", np.uint64, 1), ("octant_next_sibling", np.uint32, 1), ("octant_leaf", np.uint8, 1)):
+            np.testing.assert_array_equal(_as_np(getattr(d, field), no * k, dt), _as_np(getattr(ref, field), no * k, dt), err_msg=field)
+        got = np.ctypeslib.as_array(d.photons, shape=(n * 8,)).reshape(n, 8)
+        start, cont, leaf = (_as_np(d.octant_start_data, no, np.int64), _as_np(d.octant_contained_data, no, np.int64),
+                             _as_np(d.octant_leaf, no, np.uint8))
+        for o in np.nonzero(leaf)[0]:  # every leaf holds the same photons
+            a = photon_set_bytes(got[start[o]:start[o] + cont[o]])
+            b = photon_set_bytes(photons[start[o]:start[o] + cont[o]])
+            assert np.array_equal(a, b)
+        # and queries agree with the reference map
+        pts = np.ctypeslib.as_array(ref.photons, shape=(n * 8,)).reshape(n, 8)[:200, 3:6].astype(np.float64) + 0.01
+        c0, i0, d0 = oracle.knn(ref, pts, 50)
+        c1, i1, d1 = oracle.knn(d, pts, 50)
+        np.testing.assert_array_equal(c0, c1)
+        np.testing.assert_array_equal(d0, d1)
+
+
+@pytest.mark.gpu
+def test_gpu_photon_mapping_end_to_end(pkg, manifest):
+    """emit on the GPU -> build the maps on the host -> upload -> photon-mapped render on the GPU, against
+    the reference's image (rendered by the reference from its own emission pass and octrees)."""
+    from conftest import camera_for, load_radiance, rel_error
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    s = img.scene
+    ctx = pkg.Context(0)
+    ctx.upload_scene(s)
+    em = ctx.emit_photons(EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    gmap = pkg.PhotonMap(em["global_"][0], s.bb_min[:], s.bb_max[:], 200)
+    cmap = pkg.PhotonMap(em["caustic"][0], s.bb_min[:], s.bb_max[:], 200)
+    ctx.upload_photons(gmap.desc, cmap.desc, 50, False)
+    r = case["renders"][0]
+    out, st = ctx.sample_image(camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    rel = rel_error(out, load_radiance(r)).max(axis=2)
+    bad = int((rel > 1e-4).sum())
+    print("end-to-end photon mapping: max rel %.3e, outliers %d / %d, %d kNN searches" % (rel.max(), bad, rel.size, st["knn_searches"]))
+    assert bad <= max(2, int(0.002 * rel.size))
+    ctx.close()
