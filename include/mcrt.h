@@ -209,6 +209,12 @@ typedef struct mcrt_photon_emission {
 } mcrt_photon_emission;
 int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed,
                       mcrt_photon_emission* out);
+/* Same, restricted to one shard of the photon paths (multi-GPU emission): the paths
+ * are numbered 0..emission_paths-1 in (light, emission index) order and shard k of n takes the k-th
+ * contiguous block, so the union of the n lists is exactly the unsharded result; the ranks then
+ * all-gather their lists (RCCL) and every rank builds/uploads the full maps. */
+int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed,
+                            uint32_t shard_index, uint32_t shard_count, mcrt_photon_emission* out);
 
 /* ---- operator-level entry points (each mirrors one reference function; used by parity tests
  * and by hosts that only want the traversal / kNN engine) -------------------------------- */

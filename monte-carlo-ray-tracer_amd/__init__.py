@@ -142,6 +142,7 @@ def lib():
     L.mcrt_shard_rows.argtypes = [C.POINTER(CameraDesc), _u32p]
     L.mcrt_shard_rows.restype = C.c_uint32
     L.mcrt_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.POINTER(PhotonEmission)]
+    L.mcrt_emit_photons_shard.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PhotonEmission)]
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
@@ -293,11 +294,11 @@ class Context:
         self._check(self._lib.mcrt_render_finish(self._h, C.byref(st)), "mcrt_render_finish")
         return st.as_dict()
 
-    def emit_photons(self, emissions, caustic_factor, global_seed):
-        """mcrt_emit_photons -> dict(global_=(photons[n,8] f32, keys[n] u64), caustic=(...), paths, rays, kernel_ms)."""
+    def emit_photons(self, emissions, caustic_factor, global_seed, shard_index=0, shard_count=1):
+        """mcrt_emit_photons[_shard] -> dict(global_=(photons[n,8] f32, keys[n] u64), caustic=(...), paths, rays, kernel_ms)."""
         pe = PhotonEmission()
-        self._check(self._lib.mcrt_emit_photons(self._h, float(emissions), float(caustic_factor), int(global_seed),
-                                                C.byref(pe)), "mcrt_emit_photons")
+        self._check(self._lib.mcrt_emit_photons_shard(self._h, float(emissions), float(caustic_factor), int(global_seed),
+                                                      int(shard_index), int(shard_count), C.byref(pe)), "mcrt_emit_photons")
 
         def grab(ptr, kptr, n):
             if n == 0:

@@ -663,7 +663,8 @@ struct EmitParams {
     uint32_t num_lights;
     const unsigned long long* light_first;  // [num_lights + 1] prefix sums of the per-light emission counts
     const double* light_photon_flux;        // [num_lights][3]
-    unsigned long long total_emissions;
+    unsigned long long total_emissions;     // this launch handles paths [first_emission, total_emissions)
+    unsigned long long first_emission;
     uint32_t global_seed;
     double non_caustic_reject;
     float* photons[2];                      // 0 global, 1 caustic: [capacity][8]
@@ -694,7 +695,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     for (;;) {
         const bool need = !active && !exhausted;
         if (__ballot(need)) {
-            const unsigned long long e = wavePop(need, prm.counters + 0);
+            const unsigned long long e = prm.first_emission + wavePop(need, prm.counters + 0);
             if (need) {
                 if (e >= prm.total_emissions) {
                     exhausted = true;
@@ -1329,8 +1330,14 @@ int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed
 }
 
 int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, mcrt_photon_emission* out) {
+    return mcrt_emit_photons_shard(ctx, emissions, caustic_factor, global_seed, 0, 1, out);
+}
+
+int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
+                            uint32_t shard_count, mcrt_photon_emission* out) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(ctx, MCRT_ERR_INVALID, "shard_index >= shard_count");
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_emit_photons before mcrt_upload_scene");
     if (!(emissions >= 0.0) || !(caustic_factor > 0.0)) return fail(ctx, MCRT_ERR_INVALID, "emissions must be >= 0 and caustic_factor > 0");
     memset(out, 0, sizeof(*out));
@@ -1355,7 +1362,9 @@ int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, ui
         first[i + 1] = first[i] + n;
         for (int c = 0; c < 3; c++) pflux[(size_t)i * 3 + c] = f[c] / (double)n;
     }
-    const unsigned long long total = first[nl];
+    const unsigned long long all_paths = first[nl];
+    const unsigned long long shard_begin = all_paths * shard_index / shard_count, shard_end = all_paths * (shard_index + 1ull) / shard_count;
+    const unsigned long long total = shard_end - shard_begin;  // paths of this shard
     if (int rc = uploadArray(ctx, ctx->emit_first, first.data(), first.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->emit_flux, pflux.data(), pflux.size())) return rc;
     if (!ctx->emit_counters.p) HIP_TRY(ctx, ctx->emit_counters.alloc(8 * sizeof(unsigned long long)));
@@ -1380,7 +1389,8 @@ int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, ui
         prm.num_lights = nl;
         prm.light_first = ctx->emit_first.as<unsigned long long>();
         prm.light_photon_flux = ctx->emit_flux.as<double>();
-        prm.total_emissions = total;
+        prm.total_emissions = shard_end;
+        prm.first_emission = shard_begin;
         prm.global_seed = global_seed;
         prm.non_caustic_reject = 1.0 / caustic_factor;
         for (int w = 0; w < 2; w++) {

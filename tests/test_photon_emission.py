@@ -85,6 +85,24 @@ def test_gpu_emission_matches_oracle(pkg, oracle, manifest):
 
 
 @pytest.mark.gpu
+def test_gpu_emission_shards_union_equals_whole(pkg, manifest):
+    img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
+    ctx = pkg.Context(0)
+    ctx.upload_scene(img.scene)
+    whole = ctx.emit_photons(EMISSIONS, CAUSTIC_FACTOR, manifest["seed"])
+    parts = [ctx.emit_photons(EMISSIONS, CAUSTIC_FACTOR, manifest["seed"], i, 3) for i in range(3)]
+    assert sum(p["paths"] for p in parts) == whole["paths"]
+    for name in ("global_", "caustic"):
+        ph = np.concatenate([p[name][0] for p in parts])
+        keys = np.concatenate([p[name][1] for p in parts])
+        a, ak = sort_by_key(ph, keys)
+        b, bk = sort_by_key(*whole[name])
+        np.testing.assert_array_equal(ak, bk)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_emission_list_growth_and_errors(pkg, manifest):
     img = pkg.SceneImage(golden_path("hexagon_room_pm.mcrt"))
     ctx = pkg.Context(0)
