@@ -24,6 +24,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
+#include "mcrt_waveknn.hpp"
 #include "mcrt_layout.hpp"
 
 using namespace mcrt;
@@ -657,6 +658,175 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
 }
 
 // ------------------------------------------------------------------------------------------------
+// photon-mapping eye pass with wave-cooperative radiance estimates (mcrt_waveknn.hpp)
+// ------------------------------------------------------------------------------------------------
+struct PmExtra {
+    PhotonMapViewW global_map, caustic_map;
+};
+
+template <bool kCount, bool kAll>
+__global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    SceneViewT<kAll> sv;
+    ShadeViewT<kAll> sh;
+    SobolTab tab;
+    LaneStack stk;
+    RefractionHistory rh;
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    // per-wave candidate buffer behind the common LDS plan
+    WaveKnnLds W;
+    {
+        const uint32_t base = alignUp(planLds(scene, blockDim.x).total, 16);
+        const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+        W.d2 = ldsAt<double>(lds, base) + wave * kWaveCand;
+        W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
+    }
+
+    PathState st;
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    uint32_t paths = 0, searches = 0, octant_visits = 0, knn_overflow = 0;
+    bool have_pixel = false, path_active = false, exhausted = false;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const uint32_t W_img = prm.cam.width;
+    const bool direct_visualization = prm.direct_visualization != 0;
+
+    for (;;) {
+        const bool need = !have_pixel && !exhausted;
+        if (__ballot(need)) {
+            const unsigned long long w = wavePop(need, prm.work_counter);
+            if (need) {
+                if (w >= prm.work_items) {
+                    exhausted = true;
+                } else {
+                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
+                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
+                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
+                    if (lx < W_img && ly < prm.owned_rows) {
+                        px = lx;
+                        py = localToGlobalRow(prm.cam, ly);
+                        have_pixel = true;
+                        sample = 0;
+                        acc0 = acc1 = acc2 = 0.0;
+                        st.smp.initiate(prm.global_seed, py * W_img + px);
+                    }
+                }
+            }
+        }
+        if (!__ballot(have_pixel)) {
+            if (!__ballot(!exhausted)) break;
+            continue;
+        }
+        if (have_pixel && !path_active) {
+            st.smp.setIndex(sample);
+            pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+            path_active = true;
+            paths++;
+        }
+
+        // ---- part 1 (per lane): PhotonMapper::sampleRay up to the radiance estimates (photon-mapper.cpp:288-313)
+        InteractionT<kAll> ia;
+        ia.material = sh.materials;
+        ia.position = ia.out = ia.shading_cs.c0 = ia.shading_cs.c1 = ia.shading_cs.c2 = splat(0.0);
+        ia.n1 = ia.n2 = ia.R = ia.T = 0.0;
+        ia.type = kDiffuse;
+        ia.inside = false;
+        ia.dirac_delta = false;
+        bool ended = false, needC = false, needG = false;
+        if (path_active) {
+            st.smp.shuffle();
+            Hit isect = sceneIntersect<kAll, kCount, false>(sv, st.ray, stk, cnt);
+            if (isect.surface == kNoSurface) {
+                ended = true;  // no sky in photon mode (:292-295)
+            } else {
+                interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);
+                st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;
+                if (ia.dirac_delta) {
+                    if (!st.ray.dirac_delta && st.ray.depth != 0) ended = true;  // :303-306
+                } else {
+                    needC = true;                                                                       // :315
+                    needG = !(!direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0));     // :317 / :327
+                }
+            }
+        }
+        // ---- part 2 (whole wave): caustic estimates, then global estimates
+        const d3 C = waveEstimate(needC, ia, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
+        if (needC) st.radiance = st.radiance + C * st.throughput;
+        const d3 G = waveEstimate(needG, ia, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
+        if (needG) {
+            st.radiance = st.radiance + G * st.throughput;  // :330, the path ends here
+            ended = true;
+        }
+        // ---- part 3 (per lane): next-event estimate, BSDF sampling, russian roulette (:308-311, :319-325, :334-339)
+        if (path_active && !ended) {
+            if (!ia.dirac_delta) {
+                DirectQuery dq;
+                if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+                    Hit shadow = sceneIntersect<kAll, kCount, true>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
+                    st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
+                }
+            }
+            d3 bsdf_absIdotN;
+            if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) {
+                ended = true;
+            } else {
+                st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);
+                if (absorb(st.ray, st.throughput, st.smp, tab)) ended = true;
+                else rh.update(st.ray);
+            }
+        }
+        if (path_active && ended) {
+            acc0 += st.radiance.x * 1.0;
+            acc1 += st.radiance.y * 1.0;
+            acc2 += st.radiance.z * 1.0;
+            path_active = false;
+            if (++sample == prm.spp) {
+                const double wsum = (double)prm.spp;
+                double* o = prm.out + ((size_t)ly * W_img + px) * 3;
+                o[0] = gmax(acc0 / wsum, 0.0);
+                o[1] = gmax(acc1 / wsum, 0.0);
+                o[2] = gmax(acc2 / wsum, 0.0);
+                have_pixel = false;
+            }
+        }
+    }
+    waveAccumulate(prm.stats + 0, paths);
+    waveAccumulate(prm.stats + 1, cnt.rays);
+    if (kCount) {
+        waveAccumulate(prm.stats + 2, cnt.node_tests);
+        waveAccumulate(prm.stats + 3, cnt.prim_tests);
+    }
+    waveAccumulate(prm.stats + 4, searches);
+    waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
+    waveAccumulate(prm.stats + 6, octant_visits);
+}
+
+// LinearOctree::knnSearch operator: one query at a time per wave
+__global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
+                                                     uint32_t* out_index, double* out_d2, unsigned long long* flags) {
+    __shared__ double s_d2[4 * kWaveCand];
+    __shared__ uint32_t s_idx[4 * kWaveCand];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    WaveKnnLds W;
+    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
+    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint32_t overflow = 0, visits = 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {
+        const d3 pt = ld3(p + 3 * q);
+        double r2;
+        const uint32_t c = waveKnnSearch(map, pt, k, W, r2, overflow, visits);
+        waveSortResult(W, c);
+        if (lane == 0) out_count[q] = c;
+        for (uint32_t j = lane; j < k; j += 64) {
+            out_index[q * k + j] = j < c ? W.idx[j] : 0xFFFFFFFFu;
+            out_d2[q * k + j] = j < c ? W.d2[j] : INFINITY;
+        }
+    }
+    if (overflow && lane == 0) atomicAdd(flags, 1ull);
+}
+
+// ------------------------------------------------------------------------------------------------
 // photon emission pass (§8(f) rank 1): one photon path per lane at a time, regenerated like the eye paths
 // ------------------------------------------------------------------------------------------------
 struct EmitParams {
@@ -866,7 +1036,8 @@ struct mcrt_ctx {
 
     bool has_photons = false;
     PhotonMapView maps[2]{};
-    DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2];
+    DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2];
+    const ChildRec* map_children_ptr[2] = {nullptr, nullptr};
     uint32_t k_nearest = 50;
     int direct_visualization = 0;
 
@@ -987,9 +1158,31 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         if (profile_phases) kernel = all ? renderKernelSM<false, true, true> : renderKernelSM<false, false, true>;
     }
 
+    // photon mapping: wave-cooperative estimates unless k is too large for the per-wave buffer
+    const bool use_pm_wave = photon && ctx->k_nearest <= 128 && !(kenv && strcmp(kenv, "legacy") == 0);
+    using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
+    PmKernelT pm_kernel = nullptr;
+    DeviceScene launch_scene = ctx->scene;
     LaunchGeom g;
-    if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : 0)) return rc;
-    if (int rc = ensureScratch(ctx, g.total_lanes, photon)) return rc;
+    if (use_pm_wave) {
+        static const PmKernelT pm_table[2][2] = {{renderKernelPM<false, false>, renderKernelPM<false, true>},
+                                                 {renderKernelPM<true, false>, renderKernelPM<true, true>}};
+        pm_kernel = pm_table[count_tests ? 1 : 0][all ? 1 : 0];
+        launch_scene.flat = 0;
+        if (!launch_scene.stage_all) launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, 128u);
+        const uint32_t extra = (kBlock / 64) * kWaveCand * 12u;
+        g.lds_bytes = alignUp(planLds(launch_scene, kBlock).total, 16) + extra;
+        if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pm_kernel, (int)kBlock, g.lds_bytes));
+        if (per_cu < 1) per_cu = 1;
+        g.grid = (uint32_t)(per_cu * ctx->num_cus);
+        g.total_lanes = g.grid * kBlock;
+    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : 0)) {
+        return rc;
+    }
+    if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
 
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
@@ -1040,7 +1233,16 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+    if (use_pm_wave) {
+        PmExtra pmx;
+        pmx.global_map.base = ctx->maps[0];
+        pmx.global_map.octant_children = ctx->map_children_ptr[0];
+        pmx.caustic_map.base = ctx->maps[1];
+        pmx.caustic_map.octant_children = ctx->map_children_ptr[1];
+        hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->pending = true;
@@ -1051,6 +1253,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
 int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     PhotonMapView& v = ctx->maps[which];
     memset(&v, 0, sizeof(v));
+    ctx->map_children_ptr[which] = nullptr;
     if (!m || m->num_octants == 0 || m->num_photons == 0) return MCRT_OK;
     if (m->num_photons > 0xFFFFFFFEull) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon map larger than 2^32-2 photons per GPU");
     if (!m->octant_bounds || !m->octant_start_data || !m->octant_contained_data || !m->octant_next_sibling || !m->octant_leaf || !m->photons)
@@ -1069,6 +1272,26 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     if (int rc = uploadArray(ctx, ctx->map_next[which], m->octant_next_sibling, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_leaf[which], m->octant_leaf, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_photons[which], m->photons, (size_t)m->num_photons * 8)) return rc;
+    {   // child lists for the wave-cooperative search: children of o are o+1 and its next_sibling chain
+        ChildRec none;
+        memset(&none, 0, sizeof(none));
+        none.octant = 0xFFFFFFFFu;
+        std::vector<ChildRec> children(n * 8, none);
+        for (size_t o = 0; o < n; o++) {
+            if (m->octant_leaf[o]) continue;
+            uint32_t c = (uint32_t)o + 1, slot = 0;
+            while (c != 0xFFFFFFFFu && c < n) {
+                if (slot >= 8) return fail(ctx, MCRT_ERR_INVALID, "photon octant with more than 8 children");
+                ChildRec& r = children[o * 8 + slot++];
+                memcpy(r.b, m->octant_bounds + (size_t)c * 6, 48);
+                r.octant = c;
+                r.contained = contained[c];
+                c = m->octant_next_sibling[c];
+            }
+        }
+        if (int rc = uploadArray(ctx, ctx->map_children[which], children.data(), children.size())) return rc;
+        ctx->map_children_ptr[which] = ctx->map_children[which].as<ChildRec>();
+    }
     v.num_octants = m->num_octants;
     v.num_photons = m->num_photons;
     v.octant_bounds = ctx->map_bounds[which].as<double>();
@@ -1493,6 +1716,31 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
     if (n == 0) return MCRT_OK;
     if (!p || !out_count || !out_index || !out_distance2) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const char* kenv = getenv("MCRT_KERNEL");
+    if (k <= 128 && !(kenv && strcmp(kenv, "legacy") == 0)) {  // wave-cooperative search (mcrt_waveknn.hpp)
+        DevBuf dp, dc, di, dd, flags;
+        if (int rc = uploadArray(ctx, dp, p, n * 3)) return rc;
+        HIP_TRY(ctx, dc.alloc(n * 4));
+        HIP_TRY(ctx, di.alloc(n * k * 4));
+        HIP_TRY(ctx, dd.alloc(n * k * 8));
+        HIP_TRY(ctx, flags.alloc(8));
+        HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
+        PhotonMapViewW mv;
+        mv.base = ctx->maps[which];
+        mv.octant_children = ctx->map_children_ptr[which];
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + 3) / 4);
+        hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
+                           di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long f = 0;
+        HIP_TRY(ctx, hipMemcpy(&f, flags.p, 8, hipMemcpyDeviceToHost));
+        if (f) return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow (octree deeper than the 128-entry wave frontier)");
+        HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));
+        return MCRT_OK;
+    }
     const uint32_t block = 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + block - 1) / block);
     const uint32_t lanes = grid * block;

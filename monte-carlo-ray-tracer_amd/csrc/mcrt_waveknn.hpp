@@ -1,0 +1,380 @@
+// Wave-cooperative photon-map radiance estimate (the §8 rows a23/a24) — device only.
+//
+//   LinearOctree<Photon>::knnSearch          octree/linear-octree.cpp:25-117
+//   PhotonMapper::estimate{Global,Caustic}Radiance   integrator/photon-mapper/photon-mapper.cpp:343-391
+//
+// A per-lane k-NN search keeps a k-entry heap and a frontier per lane; with k = 50 that is 600+ B per
+// lane, which does not fit in LDS, and in global memory every heap operation is a chain of dependent
+// DRAM/L2 round trips (measured: 21 M searches/s, slower than the CPU node). Here the 64 lanes of a
+// wavefront serve ONE query at a time:
+//   * the octree walk is wave-uniform; the frontier (octants still to visit) lives in registers, two
+//     entries per lane; pop = wave-wide argmin; the <= 8 children of an octant are tested by 8 lanes in
+//     parallel (child list precomputed at upload);
+//   * a leaf (or any octant with <= k photons, linear-octree.cpp:51) is scanned 64 photons at a time
+//     with coalesced 32-byte loads; photons within the current bound are appended to a per-wave
+//     candidate buffer in LDS by ballot/prefix compaction; when the buffer fills, the exact k smallest
+//     are kept (rank by counting) and the bound tightens to the k-th distance;
+//   * the pruning rules are the reference's (inclusive <=, "an octant holding >= k photons bounds the
+//     answer by its farthest corner"), so the k-set equals the reference's (ties at the k-th distance
+//     aside, which the reference resolves by insertion order);
+//   * the k photons are then evaluated by k lanes in parallel (BSDF towards the photon direction) with
+//     the query lane's Interaction broadcast by shuffles, and summed by a wave reduction. The order of
+//     that FP64 sum differs from the reference's heap-array order: a few ulp.
+#pragma once
+
+#include "mcrt_integrator.hpp"
+
+#if defined(__HIPCC__)
+
+namespace mcrt {
+
+constexpr uint32_t kWaveCand = 256;   // candidate buffer entries per wave (prune when > kWaveCand - 64)
+
+struct WaveKnnLds {
+    MCRT_LDS_AS double* d2;     // [kWaveCand] this wave's candidate distances
+    MCRT_LDS_AS uint32_t* idx;  // [kWaveCand] photon indices
+};
+
+// One child of an octant as the descent reads it: one 64-byte record per child, the 8 records of an
+// octant contiguous (a node visit is a single memory round trip for the 8 lanes that test the children).
+struct ChildRec {
+    double b[6];
+    uint32_t octant;     // 0xFFFFFFFF: no child in this slot
+    uint32_t contained;
+    uint32_t pad0, pad1;
+};
+
+struct PhotonMapViewW {
+    PhotonMapView base;
+    const ChildRec* octant_children;  // [n][8]
+};
+
+__device__ inline double waveShflD(double v, int src) {
+    union { double d; unsigned u[2]; } c;
+    c.d = v;
+    c.u[0] = __shfl(c.u[0], src, 64);
+    c.u[1] = __shfl(c.u[1], src, 64);
+    return c.d;
+}
+__device__ inline d3 waveShfl3(d3 v, int src) { return d3{waveShflD(v.x, src), waveShflD(v.y, src), waveShflD(v.z, src)}; }
+
+__device__ inline double waveMinD(double v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        union { double d; unsigned u[2]; } c;
+        c.d = v;
+        c.u[0] = __shfl_xor(c.u[0], off, 64);
+        c.u[1] = __shfl_xor(c.u[1], off, 64);
+        v = c.d < v ? c.d : v;
+    }
+    return v;
+}
+__device__ inline double waveSumD(double v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        union { double d; unsigned u[2]; } c;
+        c.d = v;
+        c.u[0] = __shfl_xor(c.u[0], off, 64);
+        c.u[1] = __shfl_xor(c.u[1], off, 64);
+        v = v + c.d;
+    }
+    return v;
+}
+
+// Keep the k smallest of the first `count` buffer entries, compacted (unordered) into slots [0, k);
+// returns min(count, k) and, in kth_d2, the largest distance kept. Exact selection by a bitwise radix
+// search for the k-th smallest key: squared distances are non-negative doubles, so their bit patterns
+// order like unsigned integers; 64 wave-uniform steps of "how many keys are <= prefix" (ballot +
+// popcount) instead of an all-pairs ranking. Entries equal to the k-th key are kept in buffer order
+// until k are reached (the reference resolves such ties by insertion order, linear-octree.cpp:58-77).
+// All lanes must call.
+__device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
+    const uint32_t lane = __lane_id();
+    unsigned long long key[4];
+    uint32_t my_i[4];
+    bool valid[4];
+    for (int s = 0; s < 4; s++) {
+        const uint32_t j = lane + 64u * s;
+        valid[s] = j < count;
+        union { double d; unsigned long long u; } c;
+        c.d = valid[s] ? W.d2[j] : 0.0;
+        key[s] = c.u;
+        my_i[s] = valid[s] ? W.idx[j] : 0xFFFFFFFFu;
+    }
+    if (count <= k) {  // nothing to drop: only the largest distance is needed
+        double mx = 0.0;
+        for (int s = 0; s < 4; s++) {
+            union { double d; unsigned long long u; } c;
+            c.u = key[s];
+            if (valid[s] && c.d > mx) mx = c.d;
+        }
+        kth_d2 = -waveMinD(-mx);
+        return count;
+    }
+    // T = the k-th smallest key: smallest T with #{key <= T} >= k, built from the top bit down
+    unsigned long long T = 0ull;
+    for (int bit = 63; bit >= 0; bit--) {
+        const unsigned long long trial = T | ((1ull << bit) - 1ull);  // all candidates with this bit clear
+        uint32_t n_le = 0;
+        for (int s = 0; s < 4; s++) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
+        if (n_le < k) T |= (1ull << bit);
+    }
+    uint32_t n_lt = 0;
+    for (int s = 0; s < 4; s++) n_lt += __popcll(__ballot(valid[s] && key[s] < T));
+    // compaction: everything below T, then entries equal to T until k are kept
+    uint32_t out = 0, eq_left = k - n_lt;
+    for (int s = 0; s < 4; s++) {
+        const bool lt = valid[s] && key[s] < T;
+        const bool eq = valid[s] && key[s] == T;
+        const unsigned long long m_lt = __ballot(lt), m_eq = __ballot(eq);
+        const uint32_t eq_rank = __popcll(m_eq & ((1ull << lane) - 1ull));
+        const bool keep_eq = eq && eq_rank < eq_left;
+        const unsigned long long m_keep = m_lt | __ballot(keep_eq);
+        const bool keep = lt || keep_eq;
+        if (keep) {
+            const uint32_t slot = out + __popcll(m_keep & ((1ull << lane) - 1ull));
+            union { double d; unsigned long long u; } c;
+            c.u = key[s];
+            W.d2[slot] = c.d;
+            W.idx[slot] = my_i[s];
+        }
+        out += __popcll(m_keep);
+        const uint32_t n_eq_kept = __popcll(__ballot(keep_eq));
+        eq_left -= n_eq_kept;
+    }
+    union { double d; unsigned long long u; } c;
+    c.u = T;
+    kth_d2 = c.d;
+    return k;
+}
+
+// Sort the first n (<= 64 per pass) result entries ascending by (distance2, index) in place (n <= 128).
+__device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
+    const uint32_t lane = __lane_id();
+    double my_d[2];
+    uint32_t my_i[2], rank[2];
+    for (int s = 0; s < 2; s++) {
+        const uint32_t j = lane + 64u * s;
+        my_d[s] = j < n ? W.d2[j] : INFINITY;
+        my_i[s] = j < n ? W.idx[j] : 0xFFFFFFFFu;
+        rank[s] = 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const double d = W.d2[i];
+        const uint32_t id = W.idx[i];
+        for (int s = 0; s < 2; s++) rank[s] += (d < my_d[s] || (d == my_d[s] && id < my_i[s])) ? 1u : 0u;
+    }
+    for (int s = 0; s < 2; s++) {
+        const uint32_t j = lane + 64u * s;
+        if (j < n) {
+            W.d2[rank[s]] = my_d[s];
+            W.idx[rank[s]] = my_i[s];
+        }
+    }
+}
+
+// k-NN of point p (wave-uniform) in `map`. On return the buffer holds the result (unordered) in slots
+// [0, n) and r2_max the largest of its distances; returns n. All 64 lanes must call with the same arguments.
+__device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
+                                         uint32_t& overflow, uint32_t& octant_visits) {
+    r2_max = 0.0;
+    const PhotonMapView& m = map.base;
+    if (m.num_octants == 0) return 0;
+    if ((uint64_t)k > m.num_photons) k = (uint32_t)m.num_photons;
+    if (k == 0) return 0;
+    const uint32_t lane = __lane_id();
+    // frontier: two (distance2, octant) entries per lane; octant == none marks a free slot
+    double f_d2[2] = {INFINITY, INFINITY};
+    uint32_t f_oct[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    double max_distance2 = kDblMax;
+    uint32_t count = 0;
+    bool dirty = false;  // candidates appended since the buffer was last reduced to the k best
+    bool exact = false;  // max_distance2 has been tightened to an exact k-th distance at least once
+    uint32_t cur = 0;    // root
+    for (;;) {
+        octant_visits++;
+        const uint32_t contained = m.octant_contained[cur];
+        if (m.octant_leaf[cur] || contained <= k) {
+            const uint32_t start = m.octant_start[cur];
+            // 4 x 64 photons per round trip: the four position loads of a lane are issued together
+            for (uint32_t base = 0; base < contained; base += 256) {
+                float px[4], py[4], pz[4];
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t i = base + 64u * c + lane;
+                    const uint32_t ii = i < contained ? i : contained - 1;  // clamp: keeps the loads unconditional
+                    const float* ph = m.photons + (size_t)(start + ii) * 8;
+                    px[c] = ph[3];
+                    py[c] = ph[4];
+                    pz[c] = ph[5];
+                }
+                for (int c = 0; c < 4; c++) {
+                    if (base + 64u * c >= contained) break;  // wave-uniform
+                    const uint32_t i = base + 64u * c + lane;
+                    d3 d = p - d3{(double)px[c], (double)py[c], (double)pz[c]};  // glm::distance2(data.pos(), p)
+                    const double d2v = dot(d, d);
+                    const bool cand = i < contained && d2v <= max_distance2;
+                    const unsigned long long mask = __ballot(cand);
+                    if (mask) {
+                        const uint32_t slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (cand) {
+                            W.d2[slot] = d2v;
+                            W.idx[slot] = start + i;
+                        }
+                        count += __popcll(mask);
+                        dirty = true;
+                        if (count > kWaveCand - 64u) {
+                            double kth;
+                            count = waveSelectK(W, count, k, kth);
+                            dirty = false;
+                            if (count == k) {
+                                max_distance2 = gmin(max_distance2, kth);
+                                exact = true;
+                            }
+                        }
+                    }
+                }
+            }
+            // The k-th best so far bounds the answer (linear-octree.cpp:79). The exact k-th distance is
+            // taken once, as soon as k candidates exist (it shrinks the bound from an octant diagonal to
+            // the k-photon radius); afterwards only when the buffer fills, since every later candidate
+            // already lies within that radius.
+            if (dirty && count >= k && !exact) {
+                double kth;
+                count = waveSelectK(W, count, k, kth);
+                dirty = false;
+                exact = true;
+                max_distance2 = gmin(max_distance2, kth);
+            }
+        } else {
+            // children: lanes 0..7 take one child each
+            uint32_t child = 0xFFFFFFFFu;
+            double cd2 = INFINITY;
+            bool push = false;
+            double corner = kDblMax;
+            if (lane < 8) {
+                const ChildRec* cr = map.octant_children + (size_t)cur * 8 + lane;
+                double cb[6];
+                for (int c = 0; c < 6; c++) cb[c] = cr->b[c];
+                child = cr->octant;
+                const uint32_t child_contained = cr->contained;
+                if (child != 0xFFFFFFFFu) {
+                    cd2 = boxDistance2(cb, p);
+                    push = cd2 <= max_distance2;
+                    if (push && child_contained >= k) corner = boxMaxDistance2(cb, p);  // linear-octree.cpp:96-100
+                }
+            }
+            const double best_corner = waveMinD(corner);
+            if (best_corner < max_distance2) max_distance2 = best_corner;
+            // place the pushed children into free frontier slots
+            unsigned long long pmask = __ballot(push);
+            while (pmask) {
+                const int src = __ffsll((long long)pmask) - 1;
+                pmask &= pmask - 1;
+                const double d = waveShflD(cd2, src);
+                const uint32_t o = __shfl(child, src, 64);
+                const unsigned long long free0 = __ballot(f_oct[0] == 0xFFFFFFFFu);
+                if (free0) {
+                    if ((int)lane == __ffsll((long long)free0) - 1) {
+                        f_d2[0] = d;
+                        f_oct[0] = o;
+                    }
+                } else {
+                    const unsigned long long free1 = __ballot(f_oct[1] == 0xFFFFFFFFu);
+                    if (free1) {
+                        if ((int)lane == __ffsll((long long)free1) - 1) {
+                            f_d2[1] = d;
+                            f_oct[1] = o;
+                        }
+                    } else {
+                        overflow = 1;
+                    }
+                }
+            }
+        }
+        // pop the nearest octant of the frontier
+        const double mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
+        const double best = waveMinD(mine);
+        if (!(best < INFINITY)) break;                // frontier empty
+        if (best > max_distance2) break;              // linear-octree.cpp:113
+        const unsigned long long owner = __ballot(mine == best);
+        const int ol = __ffsll((long long)owner) - 1;
+        const int which = f_d2[0] <= f_d2[1] ? 0 : 1;
+        const uint32_t my_oct = which == 0 ? f_oct[0] : f_oct[1];
+        cur = __shfl(my_oct, ol, 64);
+        if ((int)lane == ol) {
+            if (which == 0) { f_d2[0] = INFINITY; f_oct[0] = 0xFFFFFFFFu; }
+            else { f_d2[1] = INFINITY; f_oct[1] = 0xFFFFFFFFu; }
+        }
+    }
+    return waveSelectK(W, count, k, r2_max);
+}
+
+// estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) for every lane of the
+// wave that asks for one (`want`), served one query at a time by the whole wave. Returns the estimate
+// to the asking lane (zero elsewhere).
+template <bool L>
+__device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const PhotonMapViewW& map, uint32_t k, bool caustic,
+                                  const WaveKnnLds& W, uint32_t& searches, uint32_t& octant_visits, uint32_t& overflow) {
+    d3 result = splat(0.0);
+    const uint32_t lane = __lane_id();
+    unsigned long long mask = __ballot(want);
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        if ((int)lane == src) searches++;
+        // the asking lane's Interaction, as far as Interaction::BSDF reads it
+        InteractionT<L> q;
+        q.position = waveShfl3(ia.position, src);
+        q.out = waveShfl3(ia.out, src);
+        q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
+        q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
+        q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
+        q.n1 = waveShflD(ia.n1, src);
+        q.n2 = waveShflD(ia.n2, src);
+        q.R = waveShflD(ia.R, src);
+        q.T = waveShflD(ia.T, src);
+        q.type = __shfl(ia.type, src, 64);
+        q.inside = __shfl((int)ia.inside, src, 64) != 0;
+        {
+            // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
+            union { cptr<mcrt_material, L> p; unsigned long long u; } c;
+            c.u = 0ull;
+            c.p = ia.material;
+            unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
+            lo = __shfl(lo, src, 64);
+            hi = __shfl(hi, src, 64);
+            c.u = ((unsigned long long)hi << 32) | lo;
+            q.material = c.p;
+        }
+        double r2 = 0.0;
+        const uint32_t n = waveKnnSearch(map, q.position, k, W, r2, overflow, octant_visits);
+        d3 sum = splat(0.0);
+        if (n > 0) {  // r2 = photons.top().distance2: the farthest of the k
+            const double inv_max_squared_radius = 1.0 / r2;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t j = base + lane;
+                d3 contrib = splat(0.0);
+                if (j < n) {
+                    const float* ph = map.base.photons + (size_t)W.idx[j] * 8;
+                    d3 bsdf_absIdotN;
+                    double bsdf_pdf;
+                    if (interactionBSDF(q, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
+                        const d3 flux = d3{(double)ph[0], (double)ph[1], (double)ph[2]};
+                        if (caustic) {
+                            const double wp = gmax(0.0, 1.0 - sqrt(W.d2[j] * inv_max_squared_radius));
+                            contrib = (flux * bsdf_absIdotN * wp) / bsdf_pdf;
+                        } else {
+                            contrib = flux * bsdf_absIdotN / bsdf_pdf;
+                        }
+                    }
+                }
+                sum = sum + d3{waveSumD(contrib.x), waveSumD(contrib.y), waveSumD(contrib.z)};
+            }
+            sum = caustic ? 3.0 * sum * inv_max_squared_radius * kInvPi : sum / (r2 * kPi);
+        }
+        if ((int)lane == src) result = sum;
+    }
+    return result;
+}
+
+}  // namespace mcrt
+
+#endif  // __HIPCC__
