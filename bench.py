@@ -39,6 +39,9 @@ WORKLOADS = {
     "c2": ("hexagon_room.mcrt", 1920, 1080, 16, "hexagon_room.json cam0 1920x1080 @ 256 spp (BASELINE configs[1])"),
     "c2_ggx": ("hexagon_room_ggx.mcrt", 1920, 1080, 16, "hexagon_room.json + GGX roughness, 1920x1080 @ 256 spp"),
     "c1": ("hexagon_room_diffuse.mcrt", 256, 256, 2, "hexagon_room_diffuse.json 256x256 @ 4 spp (BASELINE configs[0])"),
+    # secondary: photon-mapped frame (BASELINE configs[4] class of work on the scene that is available):
+    # 1e7 photon paths emitted on the GPU, maps built on the host, then timed eye passes with kNN estimates
+    "pm": ("hexagon_room_pm.mcrt", 1920, 1080, 2, "hexagon_room.json photon mapping: 1e6 emissions x caustic_factor 10, k=50, 1920x1080 @ 4 spp"),
     # secondary (not the headline): a real BVH that does not fit in LDS; image made by tests/large/make_large.py
     "spaceship": ("../../oracle/_ref/images/spaceship.mcrt", 1920, 1080, 8,
                   "spaceship.json (68 760 of 457 200 triangles present), quaternary SAH, 1920x1080 @ 64 spp"),
@@ -48,7 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHARD_ROWS = 8
 
 
-def cpu_baseline(m, img, cam, budget_s=15.0):
+def cpu_baseline(m, img, cam, budget_s=15.0, integrator=0, pm_maps=None):
     """Times the CPU integrator on rows of the same frame. Prefers the reference itself
     (oracle/_ref/mcrt_ref + oracle/_ref/scenes, both produced by oracle/Makefile in the build
     container); otherwise the C restatement (oracle/, kind "port"). Also returns the per-ray
@@ -56,21 +59,40 @@ def cpu_baseline(m, img, cam, budget_s=15.0):
     import oracle_lib  # checker, cpu_baseline leg only
 
     threads = oracle_lib.hardware_threads()
+    if pm_maps is not None:
+        class _WithMaps:  # the scene image with the photon maps of this run (same maps the GPU uses)
+            scene = img.scene
+            path = img.path
+
+            @staticmethod
+            def photons(which):
+                return pm_maps[which].desc
+
+            @staticmethod
+            def param(key):
+                return {"k_nearest_photons": 50, "direct_visualization": 0}.get(key, 0)
+        img = _WithMaps
     mid = cam.height // 2
     # calibration: 2 rows
     t0 = time.time()
-    _, info = oracle_lib.render(img, cam, SEED, m.INTEGRATOR_PATH_TRACER, rows=(mid, mid + 2), threads=threads)
+    _, info = oracle_lib.render(img, cam, SEED, integrator, rows=(mid, mid + 2), threads=threads)
     per_row = max(info["seconds"] / 2.0, 1e-4)
     rows = int(max(2, min(cam.height, budget_s / per_row)))
     r0 = max(0, mid - rows // 2)
-    _, info = oracle_lib.render(img, cam, SEED, m.INTEGRATOR_PATH_TRACER, rows=(r0, r0 + rows), threads=threads)
+    _, info = oracle_lib.render(img, cam, SEED, integrator, rows=(r0, r0 + rows), threads=threads)
     rays = info["rays"]
     counts = dict(rays=rays, paths=info["paths"], node_per_ray=info["node_tests"] / rays,
                   tri_per_ray=(info["prim_tests"] - info["sphere_tests"]) / rays,
                   sphere_per_ray=info["sphere_tests"] / rays, rays_per_path=rays / info["paths"])
+    if info["knn_searches"]:
+        counts["knn_searches_per_s"] = info["knn_searches"] / info["seconds"]
+        counts["knn_octants_per_search"] = info["knn_octants"] / info["knn_searches"]
+        counts["knn_photons_per_search"] = info["knn_photons"] / info["knn_searches"]
     port = dict(value=rays / info["seconds"] / 1e6, unit="Mray/s", cores=threads, kind="port",
                 sample="rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)" % (r0, r0 + rows, cam.width, cam.height, cam.sqrtspp ** 2,
                                                                           info["paths"], info["seconds"]))
+    if "knn_searches_per_s" in counts:
+        port["knn_searches_per_s"] = counts["knn_searches_per_s"]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
     ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", "hexagon_room.json")
     base = port
@@ -126,6 +148,28 @@ def main():
     cam = tiling.shard_camera(full, rank, world, SHARD_ROWS)
     ctx = m.Context(local_rank)
     ctx.upload_image(img)  # scene resident in HBM before the timed region
+    integrator = m.INTEGRATOR_PATH_TRACER
+    pm_maps = None
+    if args.workload == "pm":
+        # emission pass on the GPU (sharded over the ranks and all-gathered), octrees on the host, upload
+        integrator = m.INTEGRATOR_PHOTON_MAPPER
+        em = ctx.emit_photons(1e6, 10.0, SEED, rank, world)
+        lists = []
+        for name in ("global_", "caustic"):
+            ph = torch.from_numpy(em[name][0]).to(torch.device("cuda", local_rank))
+            if world > 1:
+                sizes = [torch.zeros(1, dtype=torch.int64, device=ph.device) for _ in range(world)]
+                dist.all_gather(sizes, torch.tensor([ph.shape[0]], dtype=torch.int64, device=ph.device))
+                cap = int(max(int(x.item()) for x in sizes))
+                pad = torch.zeros((cap, 8), dtype=torch.float32, device=ph.device)
+                pad[: ph.shape[0]] = ph
+                parts = [torch.empty_like(pad) for _ in range(world)]
+                dist.all_gather(parts, pad)
+                ph = torch.cat([parts[r][: int(sizes[r].item())] for r in range(world)])
+            lists.append(ph.cpu().numpy())
+        sc = img.scene
+        pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200))
+        ctx.upload_photons(pm_maps[0].desc, pm_maps[1].desc, 50, False)
 
     my_rows = m.shard_rows(cam)
     max_rows = tiling.max_rows(full, world, SHARD_ROWS)
@@ -137,7 +181,7 @@ def main():
     stats_acc = []
 
     def step():
-        ctx.render_device(cam, SEED, m.INTEGRATOR_PATH_TRACER, tile.data_ptr(), stream)
+        ctx.render_device(cam, SEED, integrator, tile.data_ptr(), stream)
         st = ctx.render_finish()
         if world > 1:
             dist.gather(tile, gathered, dst=0)  # the single collective of the data path
@@ -158,15 +202,16 @@ def main():
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays = torch.tensor([float(sum(s["rays"] for s in stats_acc)), float(sum(s["paths"] for s in stats_acc)),
-                         float(sum(s["kernel_ms"] for s in stats_acc))], dtype=torch.float64, device=dev)
+                         float(sum(s["kernel_ms"] for s in stats_acc)), float(sum(s["knn_searches"] for s in stats_acc))],
+                        dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kmax = rays[2:].clone()
+        kmax = rays[2:3].clone()
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         rays[2] = kmax[0]
     elapsed = float(t.item())
-    total_rays, total_paths, kernel_ms_sum = float(rays[0]), float(rays[1]), float(rays[2])
+    total_rays, total_paths, kernel_ms_sum, total_knn = float(rays[0]), float(rays[1]), float(rays[2]), float(rays[3])
 
     if rank == 0:
         # sanity: the gathered frame is complete and finite
@@ -193,14 +238,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "path_tracer",
+            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "photon_mapper" if args.workload == "pm" else "path_tracer",
                        "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
                        "rays_per_step": total_rays / args.steps, "paths_per_step": total_paths / args.steps,
-                       "frame_mean_radiance": mean, "frame_finite": finite},
+                       "frame_mean_radiance": mean, "frame_finite": finite,
+                       "knn_searches_per_s": total_knn / elapsed if total_knn else None},
         }
         counts = None
         if world == 1 and not args.no_cpu:
-            base, counts = cpu_baseline(m, img, full, args.cpu_seconds)
+            base, counts = cpu_baseline(m, img, full, args.cpu_seconds, integrator, pm_maps)
             result["cpu_baseline"] = base
         if counts is None:
             # per-ray counts of the reference-equivalent traversal measured on this workload by the oracle
@@ -220,9 +266,16 @@ def main():
             pass
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                              "kernel": "renderKernel<path_tracer>", "kernel_ms": kernel_ms,
+                              "kernel": {"pm": "renderKernelPM", "spaceship": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
+                              "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
                               "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}
+        if counts.get("knn_photons_per_search"):
+            # B_knn = n_octant*128 + n_photon_scanned*32 + k*32 per search (reference-equivalent counts)
+            b_knn = counts["knn_octants_per_search"] * 128 + counts["knn_photons_per_search"] * 32 + 50 * 32
+            knn_rate = total_knn / args.steps / world / (kernel_ms * 1e-3)
+            result["roofline"]["knn"] = {"bytes_per_search": b_knn, "searches_per_s_in_kernel": knn_rate,
+                                          "achieved_GBs_incl_knn": achieved + knn_rate * b_knn / 1e9}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
