@@ -266,6 +266,9 @@ def main():
             pass
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time; "
+                                      "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/). Scenes that fit in LDS "
+                                      "move almost nothing through HBM, so frac can exceed 1 for them.",
                               "kernel": {"pm": "renderKernelPM", "spaceship": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
                               "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,

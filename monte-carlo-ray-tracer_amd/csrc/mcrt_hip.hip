@@ -1168,7 +1168,6 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         static const PmKernelT pm_table[2][2] = {{renderKernelPM<false, false>, renderKernelPM<false, true>},
                                                  {renderKernelPM<true, false>, renderKernelPM<true, true>}};
         pm_kernel = pm_table[count_tests ? 1 : 0][all ? 1 : 0];
-        launch_scene.flat = 0;
         if (!launch_scene.stage_all) launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, 128u);
         const uint32_t extra = (kBlock / 64) * kWaveCand * 12u;
         g.lds_bytes = alignUp(planLds(launch_scene, kBlock).total, 16) + extra;
