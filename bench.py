@@ -45,6 +45,16 @@ WORKLOADS = {
     # secondary (not the headline): a real BVH that does not fit in LDS; image made by tests/large/make_large.py
     "spaceship": ("../../oracle/_ref/images/spaceship.mcrt", 1920, 1080, 8,
                   "spaceship.json (68 760 of 457 200 triangles present), quaternary SAH, 1920x1080 @ 64 spp"),
+    # BASELINE configs[2] at full size; the Stanford bunny is not in the reference tree (.MISSING_LARGE_BLOBS), a
+    # synthetic 81 920-triangle stand-in is (tests/large/make_synthetic.py). The 120 MB image is flattened on this
+    # machine by the reference's loader + BVH builder (tests/large/make_large.py:ensure_c3_image)
+    "c3": ("../../oracle/_ref/images/metal_bunnies_c3.mcrt", 1920, 1080, 32,
+           "metal_bunnies.json (stand-in bunny mesh, 491 592 triangles), quaternary SAH, 1920x1080 @ 1024 spp (BASELINE configs[2])"),
+}
+# reference-side scene + flags for the cpu_baseline "reference" leg
+REF_SCENES = {
+    "hexagon_room.mcrt": ("hexagon_room.json", []),
+    "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
 }
 SEED = 0x12345678
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -94,11 +104,12 @@ def cpu_baseline(m, img, cam, budget_s=15.0, integrator=0, pm_maps=None):
     if "knn_searches_per_s" in counts:
         port["knn_searches_per_s"] = counts["knn_searches_per_s"]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
-    ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", "hexagon_room.json")
+    ref_name, ref_flags = REF_SCENES.get(os.path.basename(img.path), (None, []))
+    ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", ref_name or "-")
     base = port
-    if os.path.exists(ref_bin) and os.path.exists(ref_scene) and os.path.basename(img.path) == "hexagon_room.mcrt":
+    if os.path.exists(ref_bin) and ref_name and os.path.exists(ref_scene):
         try:
-            out = subprocess.run([ref_bin, "render", "--scene", ref_scene, "--width", str(cam.width), "--height", str(cam.height),
+            out = subprocess.run([ref_bin, "render", "--scene", ref_scene] + ref_flags + ["--width", str(cam.width), "--height", str(cam.height),
                                   "--sqrtspp", str(cam.sqrtspp), "--rows", str(r0), str(r0 + rows), "--out-radiance", "/dev/null"],
                                  capture_output=True, text=True, timeout=600, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
             line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -141,6 +152,13 @@ def main():
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
     tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
     image_file, W, H, sqrtspp, desc = WORKLOADS[args.workload]
+    if args.workload == "c3":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+        import make_large
+        if local_rank == 0 and make_large.ensure_c3_image() is None:
+            raise SystemExit("c3 needs oracle/_ref (python __graft_entry__.py build in the build container)")
+        if world > 1:
+            dist.barrier()
     img = m.SceneImage(os.path.join(ROOT, "tests", "golden", image_file))
     cam = img.camera
     cam.width, cam.height, cam.sqrtspp = W, H, sqrtspp
@@ -251,7 +269,10 @@ def main():
         if counts is None:
             # per-ray counts of the reference-equivalent traversal measured on this workload by the oracle
             # (DESIGN.md "Measurement"); used when the CPU leg is skipped (N > 1)
-            counts = dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31)
+            counts = {"spaceship": dict(node_per_ray=33.44, tri_per_ray=6.96, sphere_per_ray=0.0),
+                      "c3": dict(node_per_ray=46.28, tri_per_ray=7.17, sphere_per_ray=0.02),
+                      "pm": dict(node_per_ray=14.34, tri_per_ray=9.30, sphere_per_ray=7.40),
+                      }.get(args.workload, dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31))
         b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
         launches = args.steps * 1  # one integrator launch per step per GPU
         kernel_ms = kernel_ms_sum / launches
@@ -269,7 +290,7 @@ def main():
                               "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time; "
                                       "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/). Scenes that fit in LDS "
                                       "move almost nothing through HBM, so frac can exceed 1 for them.",
-                              "kernel": {"pm": "renderKernelPM", "spaceship": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
+                              "kernel": {"pm": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
                               "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
                               "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}
