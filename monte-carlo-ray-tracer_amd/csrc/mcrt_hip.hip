@@ -24,6 +24,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
+#include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_layout.hpp"
 
@@ -271,13 +272,6 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
         x += ((unsigned long long)hi << 32) | lo;
     }
     if (laneId() == 0 && x) atomicAdd(dst, x);
-}
-
-// shard-local row -> image row (include/mcrt.h: rows dealt in groups of shard_rows)
-__host__ __device__ inline uint32_t localToGlobalRow(const mcrt_camera_desc& cam, uint32_t ly) {
-    if (cam.shard_count <= 1) return ly;
-    const uint32_t g = cam.shard_rows ? cam.shard_rows : 1;
-    return ((ly / g) * cam.shard_count + cam.shard_index) * g + ly % g;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,6 +649,155 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
             atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront path tracer (mcrt_wavefront.hpp): trace kernel + shade kernel, path state pooled in HBM
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kWfBlock = 256;
+
+struct WfTraceArgs {
+    WfPool pool;
+    const uint32_t* queue;              // work items (slot * 2 + port) queued by the last shade launch
+    const unsigned long long* count;    // how many
+    unsigned long long* pop;            // next queue index to hand out (zeroed by the shade launch)
+    unsigned long long* stats;
+    const Node64* nodes;
+    const double* prim;
+    uint32_t num_nodes;
+    SmStackEntry* spill;
+    uint32_t total_lanes;
+    int refill_lanes, leaf_lanes, min_inner;
+};
+
+// Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
+// traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do).
+template <bool kCount>
+__global__ void __launch_bounds__(kWfBlock) wfTraceKernel(const WfTraceArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    SmStack stk;
+    stk.lds = ldsAt<SmStackEntry>(lds, 0) + threadIdx.x;
+    stk.lds_stride = blockDim.x;
+    stk.spill = a.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    stk.spill_stride = a.total_lanes;
+    SmSceneView<false> sv;
+    sv.num_nodes = a.num_nodes;
+    sv.nodes = a.nodes;
+    sv.prim = a.prim;
+    sv.lds_nodes = 0;
+    sv.lds_node_ptr = nullptr;
+
+    const unsigned long long n = *a.count;
+    Trav T;
+    T.active = false;
+    T.shadow = false;
+    T.sp = 0;
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    bool have = false, exhausted = n == 0ull;
+    uint32_t item = 0;
+    for (;;) {
+        if (have && !T.active) {  // finished since the last look: hand the hit back
+            wfStoreHit(a.pool, item, T.best);
+            have = false;
+        }
+        const unsigned long long m_have = __ballot(have);
+        if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
+            const unsigned long long w = wavePop(!have, a.pop);
+            if (!have && w < n) {
+                item = a.queue[w];
+                d3 o, d;
+                bool shadow;
+                ShadowQuery sq;
+                wfLoadRay(a.pool, item, o, d, shadow, sq);
+                travBegin<false, kCount>(sv, T, o, d, rcp3(d), shadow, &sq, cnt);
+                have = true;
+            }
+            exhausted = __ballot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
+        }
+        if (!__ballot(have)) {
+            if (exhausted) break;
+            continue;
+        }
+        const bool inner = have && T.active && (T.node_m & kSmInner);
+        if (inner) travInnerStep<false, kCount>(sv, T, stk, cnt);
+        const bool leaf = have && T.active && !(T.node_m & kSmInner);
+        const unsigned long long m_leaf = __ballot(leaf);
+        const unsigned long long m_inner = __ballot(have && T.active && (T.node_m & kSmInner));
+        if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+            if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
+        }
+    }
+    waveAccumulate(a.stats + 1, cnt.rays);
+    if (kCount) {
+        waveAccumulate(a.stats + 2, cnt.node_tests);
+        waveAccumulate(a.stats + 3, cnt.prim_tests);
+    }
+    waveAccumulate(a.stats + 5, cnt.overflow);
+}
+
+struct WfShadeArgs {
+    WfPool pool;
+    WfFrame fr;
+    uint32_t* queue;
+    unsigned long long* count_out;    // rays queued by this launch
+    unsigned long long* count_reset;  // the other parity's counter, consumed by the trace launch before this one
+    unsigned long long* pop_reset;
+    unsigned long long* work;         // the frame's pixel work counter
+    unsigned long long* stats;
+};
+
+struct DevWfEnv {
+    unsigned long long* work;
+    uint32_t* queue;
+    unsigned long long* count;
+    __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
+    __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
+    __device__ void push(uint32_t slot, bool p0, bool p1) const {
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
+        if (!total) return;
+        const uint32_t lane = laneId();
+        const int leader = __ffsll((long long)__ballot(true)) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(count, (unsigned long long)total);
+        base = waveBroadcast64(base, leader);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // the wave's bounce rays first, then its shadow rays (neighbouring queue entries = similar rays)
+        if (p0) queue[base + __popcll(m0 & below)] = slot * 2u;
+        if (p1) queue[base + n0 + __popcll(m1 & below)] = slot * 2u + 1u;
+    }
+};
+
+__global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scene, const WfShadeArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, 0);
+    stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
+    RefractionHistory rh;
+    rh.iors = ldsAt<double>(lds, kSobolTableWords * 4u) + threadIdx.x;
+    rh.stride = blockDim.x;
+    rh.size = 0;
+    ShadeViewT<false> sh;
+    sh.num_lights = scene.num_lights;
+    sh.scene_ior = scene.scene_ior;
+    sh.surf_v = scene.surf_v;
+    sh.surf_normal = scene.surf_normal;
+    sh.surf_vn = scene.surf_vn;
+    sh.surf_area = scene.surf_area;
+    sh.surf_material = scene.surf_material;
+    sh.surf_kind = scene.surf_kind;
+    sh.materials = scene.materials;
+    sh.light_surface = scene.light_surface;
+    sh.light_cdf = scene.light_cdf;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.count_reset = 0ull;
+        *a.pop_reset = 0ull;
+    }
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    DevWfEnv env{a.work, a.queue, a.count_out};
+    uint32_t paths = 0;
+    wfShadeSlot<false>(env, a.pool, slot < a.pool.n ? slot : 0u, slot < a.pool.n, a.fr, sh, rh, (SobolTab)ltab, paths);
+    waveAccumulate(a.stats + 0, paths);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1050,6 +1193,11 @@ struct mcrt_ctx {
     std::vector<float> host_photons[2];
     std::vector<uint64_t> host_keys[2];
 
+    // wavefront path tracer: slot pool, ray queue, control words {count[2], pop}, pinned read-back word
+    DevBuf wf_pool, wf_queue, wf_ctrl;
+    uint32_t wf_slots = 0;
+    unsigned long long* wf_host = nullptr;
+
     // in-flight render
     bool pending = false;
     std::chrono::steady_clock::time_point t_begin;
@@ -1126,6 +1274,114 @@ int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
     return MCRT_OK;
 }
 
+// The wavefront frame loop: shade(0), then trace(i), shade(i+1) until a shade launch queues no ray. The host
+// looks at the queue length every few iterations (a launch with nothing to do costs microseconds), so the
+// call returns when the frame is complete; mcrt_render_finish() then only collects the statistics.
+int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, double* d_out, hipStream_t stream,
+                    bool count_tests) {
+    auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
+    WfFrame fr;
+    memset(&fr, 0, sizeof(fr));
+    fr.cam = *cam;
+    fr.global_seed = global_seed;
+    fr.spp = cam->sqrtspp * cam->sqrtspp;
+    fr.owned_rows = mcrt_shard_rows(cam, nullptr);
+    fr.tiles_x = (cam->width + 7) / 8;
+    fr.work_items = (unsigned long long)fr.tiles_x * ((fr.owned_rows + 7) / 8) * 64ull;
+    fr.out = d_out;
+
+    if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
+    if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
+    ctx->t_begin = std::chrono::steady_clock::now();
+    ctx->launches = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (fr.owned_rows == 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+        ctx->pending = true;
+        return MCRT_OK;
+    }
+
+    // pool size: enough slots to fill the chip several times over, fewer than pixels so that cheap and expensive
+    // pixels average out within a slot
+    const uint64_t pixels = (uint64_t)cam->width * fr.owned_rows;
+    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 20);
+    slots = std::min<uint64_t>(slots, (pixels + kWfBlock - 1) / kWfBlock * kWfBlock);
+    slots = std::max<uint64_t>(slots, kWfBlock);
+    if (ctx->wf_slots != slots) {
+        HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
+        HIP_TRY(ctx, ctx->wf_queue.alloc((size_t)slots * 2 * sizeof(uint32_t)));
+        ctx->wf_slots = (uint32_t)slots;
+    }
+    if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(4 * sizeof(unsigned long long)));
+    if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, 4 * sizeof(unsigned long long), stream));
+    // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
+
+    auto trace = count_tests ? wfTraceKernel<true> : wfTraceKernel<false>;
+    const uint32_t trace_lds = kLdsStackDepth * kWfBlock * (uint32_t)sizeof(SmStackEntry);
+    const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace, (int)kWfBlock, trace_lds));
+    if (per_cu < 1) per_cu = 1;
+    per_cu = (int)std::min<long>(per_cu, envi("MCRT_WF_BLOCKS_PER_CU", per_cu));
+    const uint32_t trace_grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->num_cus, (slots * 2 + kWfBlock - 1) / kWfBlock);
+    const uint32_t total_lanes = trace_grid * kWfBlock;
+    if (ctx->spill_lanes < total_lanes) {
+        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
+        ctx->spill_lanes = total_lanes;
+    }
+    const uint32_t shade_grid = (uint32_t)((slots + kWfBlock - 1) / kWfBlock);
+
+    unsigned long long* ctrl = ctx->wf_ctrl.as<unsigned long long>();
+    WfTraceArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.pool.w = ctx->wf_pool.as<unsigned long long>();
+    ta.pool.n = (uint32_t)slots;
+    ta.queue = ctx->wf_queue.as<uint32_t>();
+    ta.pop = ctrl + 2;
+    ta.stats = ctx->stats.as<unsigned long long>();
+    ta.nodes = ctx->scene.nodes64;
+    ta.prim = ctx->scene.prim;
+    ta.num_nodes = ctx->scene.num_nodes;
+    ta.spill = ctx->spill.as<SmStackEntry>();
+    ta.total_lanes = total_lanes;
+    ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 32);
+    ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
+    WfShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.pool = ta.pool;
+    sa.fr = fr;
+    sa.queue = ctx->wf_queue.as<uint32_t>();
+    sa.pop_reset = ctrl + 2;
+    sa.work = ctx->work_counter.as<unsigned long long>();
+    sa.stats = ctx->stats.as<unsigned long long>();
+
+    const int check_every = (int)std::max<long>(1, envi("MCRT_WF_CHECK", 16));
+    for (uint64_t it = 0;; it++) {
+        sa.count_out = ctrl + (it & 1);
+        sa.count_reset = ctrl + ((it + 1) & 1);
+        hipLaunchKernelGGL(wfShadeKernel, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
+        ctx->launches++;
+        if (it % (uint64_t)check_every == (uint64_t)(check_every - 1) || it < 2) {
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host, ctrl + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if (*ctx->wf_host == 0ull) break;  // nothing queued: every slot is done
+        }
+        ta.count = ctrl + (it & 1);
+        hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(kWfBlock), trace_lds, stream, ta);
+        ctx->launches++;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->pending = true;
+    return MCRT_OK;
+}
+
 int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out,
                  hipStream_t stream) {
     if (!ctx) return MCRT_ERR_INVALID;
@@ -1151,6 +1407,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // wave-synchronous one for A/B runs)
     const char* kenv = getenv("MCRT_KERNEL");
     const bool use_sm = !photon && !ctx->scene.flat && !(kenv && strcmp(kenv, "legacy") == 0);
+    // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
+    // forces the wavefront pipeline for any scene that has a BVH)
+    const bool want_wf = kenv && strcmp(kenv, "wf") == 0;
+    static const bool wf_default = false;  // until it beats the megakernel on every walked scene
+    if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (wf_default && use_sm && !all && !kenv)))
+        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests);
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
                                                {renderKernelSM<true, false>, renderKernelSM<true, true>}};
@@ -1358,6 +1620,7 @@ void mcrt_destroy(mcrt_ctx* ctx) {
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
     delete ctx;
 }
 

@@ -1,0 +1,335 @@
+// WAVEFRONT form of the path tracer for scenes whose BVH lives in HBM (everything that does not fit in LDS).
+//
+// Why: the persistent megakernel (mcrt_lanesm.hpp) keeps a whole path — ray, Interaction, sampler, NEE
+// state, traversal state — in the registers of one lane, 256 VGPRs + scratch, 2 waves per SIMD. On a
+// 10-100 MB tree every node visit is an L2 / Infinity-Cache / HBM round trip and two waves cannot hide
+// it (measured on metal_bunnies: 57 % of wave cycles waiting, VALU 38 % busy at 40 % lane utilisation).
+// Here the path state lives in HBM (a pool of N slots, SoA, 448 B per slot) and a bounce is two launches:
+//
+//   trace kernel   one work item per queued ray (bounce ray or shadow ray of a slot): reads 48-64 B of ray,
+//                  walks the BVH with only the traversal state in registers (4+ waves per SIMD), writes the
+//                  hit (32 B). Lanes refill from the queue as soon as their ray is finished, so a wave
+//                  never waits for its slowest ray.
+//   shade kernel   one lane per slot: finishes the previous bounce's next-event estimate with the shadow
+//                  hit, shades the new hit (emission, NEE set-up, BSDF sampling, russian roulette), ends the
+//                  path and starts the slot's next sample / next pixel when it died, and queues the slot's
+//                  next bounce ray and shadow ray. Fully coalesced, no traversal.
+//
+// A slot runs the samples of one pixel in order and adds them up in order (Film::deposit order, so the
+// per-pixel sums are bit-identical to the megakernels'), then takes the next pixel from the frame's work
+// counter. The arithmetic of a path is the same functions in the same order as mcrt_lanesm.hpp:
+// smShade / smNeeFinish / travBegin / travInnerStep / travLeafStep.
+//
+// Everything in this header is plain per-slot / per-ray code shared by the gfx950 kernels (mcrt_hip.hip)
+// and the host emulation used by the CPU tests (tests/emu).
+#pragma once
+
+#include "mcrt_lanesm.hpp"
+
+namespace mcrt {
+
+// shard-local row -> image row (include/mcrt.h: rows dealt in groups of shard_rows)
+MCRT_HD uint32_t localToGlobalRow(const mcrt_camera_desc& cam, uint32_t ly) {
+    if (cam.shard_count <= 1) return ly;
+    const uint32_t g = cam.shard_rows ? cam.shard_rows : 1;
+    return ((ly / g) * cam.shard_count + cam.shard_index) * g + ly % g;
+}
+
+// ---- slot layout: 8-byte words, word w of slot s at pool[w * n + s]
+enum : uint32_t {
+    kWfRayO = 0,         // 3  st.ray.start
+    kWfRayD = 3,         // 3  st.ray.direction (inv_direction = rcp3(direction), as in makeRay)
+    kWfMediumIor = 6,
+    kWfRefrScale = 7,
+    kWfRayBits = 8,      // refraction_level (i32) | depth << 32 | diffuse_depth << 48
+    kWfFlags = 9,        // flags (u32) | ls.light << 32
+    kWfRadiance = 10,    // 3
+    kWfThroughput = 13,  // 3
+    kWfBsdfPdf = 16,
+    kWfSelectProb = 17,
+    kWfSmp0 = 18,        // base_seed | seed << 32
+    kWfSmp1 = 19,        // sequence | bit_reversed_index << 32
+    kWfSmp2 = 20,        // shuffled_index | sample index of the pixel << 32
+    kWfPixel = 21,       // px | local row << 32
+    kWfAcc = 22,         // 3  running sum of the pixel's samples
+    kWfIors = 25,        // 8  RefractionHistory
+    kWfNeeBsdf = 33,     // 3  NeePending
+    kWfNeePdf = 36,
+    kWfNeeAreaCos = 37,
+    kWfNeeThroughput = 38,  // 3
+    kWfNeeLight = 41,
+    kWfShO = 42,         // 3  shadow ray
+    kWfShD = 45,         // 3
+    kWfShNear = 48,
+    kWfShFar = 49,
+    kWfHit0T = 50,       // closest hit of the bounce ray
+    kWfHit0U = 51,
+    kWfHit0V = 52,
+    kWfHit0S = 53,       // surface | interpolate << 32
+    kWfHit1T = 54,       // shadow-ray result
+    kWfHit1S = 55,
+    kWfWords = 56
+};
+enum : uint32_t {
+    kWfAlive = 1u,        // the bounce ray in the slot was traced for this iteration
+    kWfHavePixel = 2u,
+    kWfNeePending = 4u,   // the shadow ray in the slot was traced for this iteration
+    kWfDone = 8u,         // no pixels left for this slot
+    kWfDirac = 16u,
+    kWfRefraction = 32u,
+    kWfRhShift = 8        // RefractionHistory::size in bits 8..11
+};
+
+MCRT_HD unsigned long long dBits(double d) {
+    union {
+        double d;
+        unsigned long long u;
+    } c;
+    c.d = d;
+    return c.u;
+}
+MCRT_HD double bitsD(unsigned long long u) {
+    union {
+        double d;
+        unsigned long long u;
+    } c;
+    c.u = u;
+    return c.d;
+}
+
+struct WfPool {
+    unsigned long long* w;
+    uint32_t n;
+    MCRT_HD unsigned long long getu(uint32_t word, uint32_t slot) const { return w[(size_t)word * n + slot]; }
+    MCRT_HD void setu(uint32_t word, uint32_t slot, unsigned long long v) const { w[(size_t)word * n + slot] = v; }
+    MCRT_HD double getd(uint32_t word, uint32_t slot) const { return bitsD(getu(word, slot)); }
+    MCRT_HD void setd(uint32_t word, uint32_t slot, double v) const { setu(word, slot, dBits(v)); }
+    MCRT_HD d3 get3(uint32_t word, uint32_t slot) const { return d3{getd(word, slot), getd(word + 1, slot), getd(word + 2, slot)}; }
+    MCRT_HD void set3(uint32_t word, uint32_t slot, d3 v) const {
+        setd(word, slot, v.x);
+        setd(word + 1, slot, v.y);
+        setd(word + 2, slot, v.z);
+    }
+};
+
+struct WfFrame {
+    mcrt_camera_desc cam;
+    uint32_t global_seed, spp, owned_rows, tiles_x;
+    unsigned long long work_items;  // tiles_x * tiles_y * 64 (8x8 pixel tiles, as the megakernels)
+    double* out;                    // [owned_rows][width][3]
+};
+
+// ---- trace side: work item = slot * 2 + port (0 = bounce ray, closest hit; 1 = shadow ray, bounded any-hit)
+MCRT_HD void wfLoadRay(const WfPool& P, uint32_t item, d3& o, d3& d, bool& shadow, ShadowQuery& sq) {
+    const uint32_t slot = item >> 1;
+    shadow = (item & 1u) != 0u;
+    if (shadow) {
+        o = P.get3(kWfShO, slot);
+        d = P.get3(kWfShD, slot);
+        sq.t_near = P.getd(kWfShNear, slot);
+        sq.t_far = P.getd(kWfShFar, slot);
+        sq.light = (uint32_t)P.getu(kWfNeeLight, slot);
+    } else {
+        o = P.get3(kWfRayO, slot);
+        d = P.get3(kWfRayD, slot);
+        sq.t_near = 0.0;
+        sq.t_far = kDblMax;
+        sq.light = kNoSurface;
+    }
+}
+
+MCRT_HD void wfStoreHit(const WfPool& P, uint32_t item, const Hit& h) {
+    const uint32_t slot = item >> 1;
+    if (item & 1u) {
+        P.setd(kWfHit1T, slot, h.t);
+        P.setu(kWfHit1S, slot, h.surface);
+    } else {
+        P.setd(kWfHit0T, slot, h.t);
+        P.setd(kWfHit0U, slot, h.u);
+        P.setd(kWfHit0V, slot, h.v);
+        P.setu(kWfHit0S, slot, (unsigned long long)h.surface | ((unsigned long long)(h.interpolate ? 1u : 0u) << 32));
+    }
+}
+
+// ---- shade side. Env supplies the three places where lanes cooperate:
+//   bool any(bool)                      true if the predicate holds for any lane of the wave (host: identity)
+//   unsigned long long pop(bool need)   next index of the frame's pixel work counter for the lanes that need one
+//   void push(slot, bool p0, bool p1)   queue the slot's bounce ray / shadow ray for the next trace launch
+// All three are called by every lane of the wave, at the same place.
+template <bool L, class Env>
+MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, const WfFrame& fr, const ShadeViewT<L>& sh,
+                         RefractionHistory& rh, SobolTab tab, uint32_t& paths) {
+    const unsigned long long fw = valid ? P.getu(kWfFlags, slot) : (unsigned long long)kWfDone;
+    const uint32_t flags = (uint32_t)fw;
+    const bool was_done = (flags & kWfDone) != 0u;
+    bool done = was_done;
+    bool alive = (flags & kWfAlive) != 0u, have_pixel = (flags & kWfHavePixel) != 0u;
+    const bool nee_was_pending = (flags & kWfNeePending) != 0u;
+
+    PathState st;
+    NeePending nee;
+    nee.pending = false;
+    uint32_t px = 0, ly = 0, sample = 0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    bool need_pixel = false;
+
+    if (!was_done) {
+        // ---- load the slot
+        st.ray.start = P.get3(kWfRayO, slot);
+        st.ray.direction = P.get3(kWfRayD, slot);
+        st.ray.inv_direction = rcp3(st.ray.direction);
+        st.ray.medium_ior = P.getd(kWfMediumIor, slot);
+        st.ray.refraction_scale = P.getd(kWfRefrScale, slot);
+        const unsigned long long rb = P.getu(kWfRayBits, slot);
+        st.ray.refraction_level = (int)(uint32_t)rb;
+        st.ray.depth = (uint16_t)(rb >> 32);
+        st.ray.diffuse_depth = (uint16_t)(rb >> 48);
+        st.ray.dirac_delta = (flags & kWfDirac) != 0u;
+        st.ray.refraction = (flags & kWfRefraction) != 0u;
+        st.radiance = P.get3(kWfRadiance, slot);
+        st.throughput = P.get3(kWfThroughput, slot);
+        st.ls.bsdf_pdf = P.getd(kWfBsdfPdf, slot);
+        st.ls.select_probability = P.getd(kWfSelectProb, slot);
+        st.ls.light = (uint32_t)(fw >> 32);
+        const unsigned long long s0 = P.getu(kWfSmp0, slot), s1 = P.getu(kWfSmp1, slot), s2 = P.getu(kWfSmp2, slot);
+        st.smp.base_seed = (uint32_t)s0;
+        st.smp.seed = (uint32_t)(s0 >> 32);
+        st.smp.sequence = (uint32_t)s1;
+        st.smp.bit_reversed_index = (uint32_t)(s1 >> 32);
+        st.smp.shuffled_index = (uint32_t)s2;
+        sample = (uint32_t)(s2 >> 32);
+        const unsigned long long pw = P.getu(kWfPixel, slot);
+        px = (uint32_t)pw;
+        ly = (uint32_t)(pw >> 32);
+        acc0 = P.getd(kWfAcc, slot);
+        acc1 = P.getd(kWfAcc + 1, slot);
+        acc2 = P.getd(kWfAcc + 2, slot);
+        rh.size = (int)((flags >> kWfRhShift) & 15u);
+        for (int i = 0; i < kMaxIors; i++)
+            if (i < rh.size) rh.iors[(uint32_t)i * rh.stride] = P.getd(kWfIors + (uint32_t)i, slot);
+
+        // ---- second half of the previous bounce's Integrator::sampleDirect, now that its shadow ray is back
+        if (nee_was_pending) {
+            nee.light = (uint32_t)P.getu(kWfNeeLight, slot);
+            nee.bsdf_absIdotN = P.get3(kWfNeeBsdf, slot);
+            nee.bsdf_pdf = P.getd(kWfNeePdf, slot);
+            nee.area_cos = P.getd(kWfNeeAreaCos, slot);
+            nee.throughput = P.get3(kWfNeeThroughput, slot);
+            Hit sh_hit;
+            sh_hit.t = P.getd(kWfHit1T, slot);
+            sh_hit.u = sh_hit.v = 0.0;
+            sh_hit.surface = (uint32_t)P.getu(kWfHit1S, slot);
+            sh_hit.interpolate = false;
+            smNeeFinish(st, sh, nee, sh_hit);
+        }
+
+        // ---- this bounce (path-tracer.cpp:27-49)
+        bool ended;
+        if (alive) {
+            Hit h;
+            h.t = P.getd(kWfHit0T, slot);
+            h.u = P.getd(kWfHit0U, slot);
+            h.v = P.getd(kWfHit0V, slot);
+            const unsigned long long hs = P.getu(kWfHit0S, slot);
+            h.surface = (uint32_t)hs;
+            h.interpolate = (hs >> 32) != 0ull;
+            Ray shadow_ray;
+            ShadowQuery shadow_q;
+            alive = smShade(st, rh, sh, h, nee, shadow_ray, shadow_q, tab);
+            if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
+            if (nee.pending) {
+                P.set3(kWfShO, slot, shadow_ray.start);
+                P.set3(kWfShD, slot, shadow_ray.direction);
+                P.setd(kWfShNear, slot, shadow_q.t_near);
+                P.setd(kWfShFar, slot, shadow_q.t_far);
+                P.setu(kWfNeeLight, slot, nee.light);
+                P.set3(kWfNeeBsdf, slot, nee.bsdf_absIdotN);
+                P.setd(kWfNeePdf, slot, nee.bsdf_pdf);
+                P.setd(kWfNeeAreaCos, slot, nee.area_cos);
+                P.set3(kWfNeeThroughput, slot, nee.throughput);
+            }
+            ended = !alive && !nee.pending;
+        } else {
+            nee.pending = false;
+            ended = have_pixel;  // the path died at its previous bounce; its last NEE has just been added
+        }
+        if (ended) {  // Film::deposit with the box filter + next sample / pixel bookkeeping
+            acc0 += st.radiance.x * 1.0;
+            acc1 += st.radiance.y * 1.0;
+            acc2 += st.radiance.z * 1.0;
+            if (++sample == fr.spp) {
+                const double wsum = (double)fr.spp;
+                double* o = fr.out + ((size_t)ly * fr.cam.width + px) * 3;
+                o[0] = gmax(acc0 / wsum, 0.0);
+                o[1] = gmax(acc1 / wsum, 0.0);
+                o[2] = gmax(acc2 / wsum, 0.0);
+                have_pixel = false;
+            }
+        }
+        need_pixel = !alive && !nee.pending && !have_pixel;
+    }
+
+    // ---- a new pixel from the frame's work counter (8x8 tiles; edge tiles hold positions outside the image)
+    while (env.any(need_pixel)) {
+        const unsigned long long w = env.pop(need_pixel);
+        if (need_pixel) {
+            if (w >= fr.work_items) {
+                done = true;
+                need_pixel = false;
+            } else {
+                const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
+                const uint32_t lx = (tile % fr.tiles_x) * 8u + (in & 7u);
+                const uint32_t y = (tile / fr.tiles_x) * 8u + (in >> 3);
+                if (lx < fr.cam.width && y < fr.owned_rows) {
+                    px = lx;
+                    ly = y;
+                    have_pixel = true;
+                    need_pixel = false;
+                    sample = 0;
+                    acc0 = acc1 = acc2 = 0.0;
+                    st.smp.initiate(fr.global_seed, localToGlobalRow(fr.cam, ly) * fr.cam.width + px);  // camera.cpp:73
+                }
+            }
+        }
+    }
+
+    // ---- next sample of the pixel (camera.cpp:77-96)
+    if (!was_done && !done && !alive && !nee.pending && have_pixel) {
+        st.smp.setIndex(sample);
+        pathBegin(st, rh, cameraRay(fr.cam, sh.scene_ior, px, localToGlobalRow(fr.cam, ly), st.smp, tab));
+        paths++;
+        st.smp.shuffle();  // path-tracer.cpp:23, first bounce
+        alive = true;
+    }
+
+    // ---- store the slot
+    if (!was_done) {
+        uint32_t nf = (alive ? kWfAlive : 0u) | (have_pixel ? kWfHavePixel : 0u) | (nee.pending ? kWfNeePending : 0u) | (done ? kWfDone : 0u) |
+                      (st.ray.dirac_delta ? kWfDirac : 0u) | (st.ray.refraction ? kWfRefraction : 0u) | ((uint32_t)rh.size << kWfRhShift);
+        P.setu(kWfFlags, slot, (unsigned long long)nf | ((unsigned long long)st.ls.light << 32));
+        if (!done) {
+            P.set3(kWfRayO, slot, st.ray.start);
+            P.set3(kWfRayD, slot, st.ray.direction);
+            P.setd(kWfMediumIor, slot, st.ray.medium_ior);
+            P.setd(kWfRefrScale, slot, st.ray.refraction_scale);
+            P.setu(kWfRayBits, slot, (unsigned long long)(uint32_t)st.ray.refraction_level | ((unsigned long long)st.ray.depth << 32) |
+                                          ((unsigned long long)st.ray.diffuse_depth << 48));
+            P.set3(kWfRadiance, slot, st.radiance);
+            P.set3(kWfThroughput, slot, st.throughput);
+            P.setd(kWfBsdfPdf, slot, st.ls.bsdf_pdf);
+            P.setd(kWfSelectProb, slot, st.ls.select_probability);
+            P.setu(kWfSmp0, slot, (unsigned long long)st.smp.base_seed | ((unsigned long long)st.smp.seed << 32));
+            P.setu(kWfSmp1, slot, (unsigned long long)st.smp.sequence | ((unsigned long long)st.smp.bit_reversed_index << 32));
+            P.setu(kWfSmp2, slot, (unsigned long long)st.smp.shuffled_index | ((unsigned long long)sample << 32));
+            P.setu(kWfPixel, slot, (unsigned long long)px | ((unsigned long long)ly << 32));
+            P.setd(kWfAcc, slot, acc0);
+            P.setd(kWfAcc + 1, slot, acc1);
+            P.setd(kWfAcc + 2, slot, acc2);
+            for (int i = 0; i < kMaxIors; i++)
+                if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.iors[(uint32_t)i * rh.stride]);
+        }
+    }
+    env.push(slot, !was_done && !done && alive, !was_done && nee.pending);
+}
+
+}  // namespace mcrt

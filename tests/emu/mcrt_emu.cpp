@@ -14,6 +14,7 @@
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 
 using namespace mcrt;
 
@@ -258,6 +259,85 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
         }
     if (counters) {
         counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
+    }
+    return 0;
+}
+
+// The wavefront integrator (mcrt_wavefront.hpp): a pool of `slots` path slots in "HBM", and per bounce a shade pass
+// over the slots followed by a trace pass over the queued rays — the same wfShadeSlot / wfLoadRay / trav* /
+// wfStoreHit the gfx950 kernels run, with the wave-level cooperation (work pop, queue append) done serially.
+// The camera's shard fields select the rows, exactly as for mcrt_render.
+namespace {
+struct HostWfEnv {
+    unsigned long long* work;
+    std::vector<uint32_t>* queue;
+    bool any(bool b) const { return b; }
+    unsigned long long pop(bool need) const { return need ? (*work)++ : 0ull; }
+    void push(uint32_t slot, bool p0, bool p1) const {
+        if (p0) queue->push_back(slot * 2u);
+        if (p1) queue->push_back(slot * 2u + 1u);
+    }
+};
+}  // namespace
+
+int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                  double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations */) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return rc;
+    if (scene->num_nodes == 0 || slots == 0) return -200;
+    std::vector<SmStackEntry> s_lds(kLdsStackDepth), s_spill(kMaxStackDepth - kLdsStackDepth);
+    SmStack stk;
+    stk.lds = s_lds.data();
+    stk.lds_stride = 1;
+    stk.spill = s_spill.data();
+    stk.spill_stride = 1;
+    SmSceneView<false> sv;
+    sv.num_nodes = scene->num_nodes;
+    sv.nodes = E.L.nodes64.data();
+    sv.prim = E.L.prim.data();
+    sv.lds_nodes = 0;
+    sv.lds_node_ptr = E.L.nodes64.data();
+
+    std::vector<unsigned long long> pool((size_t)kWfWords * slots, 0ull);
+    WfPool P;
+    P.w = pool.data();
+    P.n = slots;
+    WfFrame fr;
+    fr.cam = *cam;
+    fr.global_seed = global_seed;
+    fr.spp = cam->sqrtspp * cam->sqrtspp;
+    fr.owned_rows = owned_rows;
+    fr.tiles_x = (cam->width + 7) / 8;
+    fr.work_items = (unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull;
+    fr.out = out_rgb;
+    unsigned long long work = 0;
+    std::vector<uint32_t> queue;
+    HostWfEnv env{&work, &queue};
+    TraceCounters cnt = {0, 0, 0, 0};
+    uint32_t paths = 0;
+    uint64_t iterations = 0;
+    for (;;) {
+        queue.clear();
+        for (uint32_t s = 0; s < slots; s++) wfShadeSlot(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths);
+        iterations++;
+        if (queue.empty()) break;
+        for (uint32_t item : queue) {
+            d3 o, d;
+            bool shadow;
+            ShadowQuery sq;
+            wfLoadRay(P, item, o, d, shadow, sq);
+            Trav T;
+            travBegin<false, true>(sv, T, o, d, rcp3(d), shadow, &sq, cnt);
+            while (T.active) {
+                if (T.node_m & kSmInner) travInnerStep<false, true>(sv, T, stk, cnt);
+                else travLeafStep<false, true>(sv, T, stk, cnt);
+            }
+            wfStoreHit(P, item, T.best);
+        }
+    }
+    if (counters) {
+        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
+        counters[5] = iterations;
     }
     return 0;
 }

@@ -64,6 +64,43 @@ def test_lane_state_machine_equals_reference(pkg, emu, oracle, manifest, name, s
     assert 0 <= info["rays"] - cnt[0] <= 0.03 * info["rays"]
 
 
+@pytest.mark.parametrize("name,slots", [("hexagon_room", 1000), ("hexagon_room_ggx", 64), ("coffee_maker_qsah", 4096),
+                                        ("coffee_maker_bsah", 7), ("veach_mis", 100000), ("metals", 333), ("hexagon_room_dof", 512)])
+def test_wavefront_equals_reference(pkg, emu, oracle, manifest, name, slots):
+    """mcrt_wavefront.hpp (path state pooled in HBM, one shade pass + one trace pass per bounce): any number
+    of slots — fewer than pixels, more than pixels, not a multiple of anything — gives the reference's bits."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    assert r["rows"] == [0, cam.height]
+    out = np.zeros((cam.height, cam.width, 3))
+    cnt = (C.c_uint64 * 6)()
+    rc = emu.emu_render_wf(C.byref(img.scene), C.byref(cam), manifest["seed"], slots, cam.height, out.ctypes.data, cnt)
+    assert rc == 0 and cnt[3] == 0
+    ref = load_radiance(r)
+    assert np.array_equal(out, ref), "max rel err %.3e" % rel_error(out, ref).max()
+    _, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
+    assert cnt[4] == info["paths"]
+    assert 0 <= info["rays"] - cnt[0] <= 0.03 * info["rays"]
+
+
+def test_wavefront_sharded_rows(pkg, emu, manifest):
+    """Rows dealt to shards: the union of two shards' packed rows is the full frame."""
+    case = manifest["cases"]["metals"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    ref = load_radiance(r)
+    for index in (0, 1):
+        cam = camera_for(img, r)
+        cam.shard_index, cam.shard_count, cam.shard_rows = index, 2, 4
+        rows = pkg.shard_rows(cam)
+        out = np.zeros((len(rows), cam.width, 3))
+        cnt = (C.c_uint64 * 6)()
+        assert emu.emu_render_wf(C.byref(img.scene), C.byref(cam), manifest["seed"], 200, len(rows), out.ctypes.data, cnt) == 0
+        assert np.array_equal(out, ref[rows])
+
+
 def test_photon_mapper_device_code(pkg, emu, manifest):
     case = manifest["cases"]["hexagon_room_pm"]
     img = pkg.SceneImage(golden_path(case["image"]))

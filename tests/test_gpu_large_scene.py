@@ -104,8 +104,18 @@ def test_c3_traversal_equals_oracle(pkg, oracle, metal_bunnies):
     ctx.upload_image(img)
     t, surf, uv = ctx.intersect(start, d)
     t0, s0, uv0, cnt = oracle.intersect(img, start, d)
-    np.testing.assert_array_equal(t, t0)
+    # The shelf's back face and the back wall are coplanar (z = -1) and overlap: Möller-Trumbore gives the two
+    # triangles t values one ulp apart, the second one's leaf box starts exactly at the first one's t, and the
+    # reference's heap stops at `top.t >= intersect.t` (bvh.cpp:120) without looking inside. The HIP walk keeps
+    # boxes with t_box == t (that is what makes exact ties order independent) and returns the true minimum.
+    zfight = np.nonzero(t != t0)[0]
+    assert len(zfight) <= 5
+    for i in zfight:
+        assert surf[i] != s0[i]
+        ta = oracle.single_surface_t(img, int(surf[i]), start[i:i + 1], d[i:i + 1])[0]
+        tb = oracle.single_surface_t(img, int(s0[i]), start[i:i + 1], d[i:i + 1])[0]
+        assert ta == t[i] and tb == t0[i] and ta < tb and (tb - ta) <= 4 * np.spacing(tb)
     same = surf == s0
-    assert (~same).sum() <= 5  # exact-t ties only
+    assert (~same).sum() <= 5  # exact-t ties and the z-fight above only
     np.testing.assert_array_equal(uv[same], uv0[same])
     ctx.close()
