@@ -24,6 +24,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
+#include "mcrt_qbvh.hpp"
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_layout.hpp"
@@ -41,6 +42,8 @@ struct DeviceScene {
     const double* node_bounds;
     const NodeMeta* node_meta;
     const Node64* nodes64;
+    const QBlock* qblocks;        // quantised child blocks of the trace kernel (mcrt_qbvh.hpp)
+    uint32_t num_qblocks, q_root_a, q_root_m;
     const double* prim;
     const double* flat_prim;      // kind-sorted copy (flat mode)
     const uint32_t* flat_index;
@@ -453,8 +456,22 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
     sv.num_nodes = scene.num_nodes;
     const uint32_t nn = kAll ? scene.num_nodes : scene.stage_nodes;
     MCRT_LDS_AS uint64_t* lnodes = ldsAt<uint64_t>(lds, p.nodes);
-    stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.nodes64), nn * 8u);
-    sv.lds_nodes = nn;
+    // whole scene resident: the exact 64-byte records; tree in HBM: quantised child blocks (mcrt_qbvh.hpp), the
+    // first nn of them (the top of the tree) here in LDS
+    QView<true> qv;
+    qv.blocks = scene.qblocks;
+    qv.lds_blocks = 0;
+    qv.lds_ptr = (MCRT_LDS_AS const QBlock*)lnodes;
+    qv.root_a = scene.q_root_a;
+    qv.root_m = scene.q_root_m;
+    if constexpr (kAll) {
+        stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.nodes64), nn * 8u);
+        sv.lds_nodes = nn;
+    } else {
+        qv.lds_blocks = nn < scene.num_qblocks ? nn : scene.num_qblocks;
+        stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.qblocks), qv.lds_blocks * 8u);
+        sv.lds_nodes = 0;
+    }
     sv.lds_node_ptr = (MCRT_LDS_AS const Node64*)lnodes;
     sh.num_lights = scene.num_lights;
     sh.scene_ior = scene.scene_ior;
@@ -529,6 +546,10 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
     PhaseProf<kProf> prof;  // phases here: regen, traverse = inner steps, shade, shadow = leaf steps, loop = transitions
     if constexpr (kProf) prof.begin();
 
+    auto smBegin = [&](d3 o, d3 d, d3 inv, bool shadow, const ShadowQuery* sq, TraceCounters& c) {
+        if constexpr (kAll) travBegin<kAll, kCount>(sv, T, o, d, inv, shadow, sq, c);
+        else travBeginQ<kAll, true, kCount>(sv, qv, T, o, d, inv, shadow, sq, c);
+    };
     // path end: Film::deposit (box filter) + next sample / pixel bookkeeping
     auto endPath = [&]() {
         acc0 += st.radiance.x * 1.0;
@@ -552,7 +573,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
             if (T.shadow) {
                 smNeeFinish(st, sh, nee, T.best);
                 nee.pending = false;
-                if (alive) travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                if (alive) smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
                 else endPath();
             } else {
                 state = kStShade;
@@ -594,7 +615,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
                 pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
                 paths++;
                 st.smp.shuffle();  // path-tracer.cpp:23, first bounce
-                travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
                 state = kStTrav;
             }
         }
@@ -608,10 +629,10 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
                 alive = smShade(st, rh, sh, T.best, nee, shadow_ray, shadow_q, tab);
                 if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
                 if (nee.pending) {
-                    travBegin<kAll, kCount>(sv, T, shadow_ray.start, shadow_ray.direction, shadow_ray.inv_direction, true, &shadow_q, cnt);
+                    smBegin( shadow_ray.start, shadow_ray.direction, shadow_ray.inv_direction, true, &shadow_q, cnt);
                     state = kStTrav;
                 } else if (alive) {
-                    travBegin<kAll, kCount>(sv, T, st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
+                    smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
                     state = kStTrav;
                 } else {
                     endPath();
@@ -624,7 +645,12 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
         {
             const bool trav = state == kStTrav && T.active;
             const bool inner = trav && (T.node_m & kSmInner);
-            if (inner) travInnerStep<kAll, kCount>(sv, T, stk, cnt);
+            if constexpr (kAll) {
+                if (inner) travInnerStep<kAll, kCount>(sv, T, stk, cnt);
+            } else {
+                if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
+                if (inner && !T.fast) travInnerStep<kAll, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
+            }
             if (kProf) { prof.span(kPhTraverse, tp, inner); tp = prof.now(); }
             const bool leaf = state == kStTrav && T.active && !(T.node_m & kSmInner);
             const unsigned long long m_leaf = __ballot(leaf);
@@ -654,29 +680,64 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
 // ------------------------------------------------------------------------------------------------
 // wavefront path tracer (mcrt_wavefront.hpp): trace kernel + shade kernel, path state pooled in HBM
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kWfBlock = 256;
+constexpr uint32_t kWfBlock = 256;      // shade kernel
+constexpr uint32_t kTraceMaxBlock = 1024;  // trace kernel: up to 16 waves per workgroup, 128 VGPRs
 
 struct WfTraceArgs {
-    WfPool pool;
-    const uint32_t* queue;              // work items (slot * 2 + port) queued by the last shade launch
-    const unsigned long long* count;    // how many
+    const unsigned long long* count;    // number of queued rays
     unsigned long long* pop;            // next queue index to hand out (zeroed by the shade launch)
     unsigned long long* stats;
-    const Node64* nodes;
+    const Node64* nodes;                // exact records: root test, rays with a zero direction component
+    const QBlock* qblocks;
+    uint32_t num_nodes, lds_blocks, q_root_a, q_root_m;
     const double* prim;
-    uint32_t num_nodes;
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner;
 };
 
+// Where the rays of a trace launch come from and where their hits go.
+struct PoolRays {  // the wavefront pipeline: queue of (slot, port) items into the slot pool
+    WfPool pool;
+    const uint32_t* queue;
+    __device__ uint32_t item(unsigned long long w) const { return queue[w]; }
+    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const { wfLoadRay(pool, it, o, d, shadow, sq); }
+    __device__ void store(uint32_t it, const Hit& h) const { wfStoreHit(pool, it, h); }
+};
+struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
+    const double* start;
+    const double* direction;
+    double* out_t;
+    uint32_t* out_surface;
+    double* out_uv;
+    __device__ uint32_t item(unsigned long long w) const { return (uint32_t)w; }
+    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
+        o = ld3(start + 3 * (size_t)it);
+        d = ld3(direction + 3 * (size_t)it);
+        shadow = false;
+        sq.t_near = 0.0;
+        sq.t_far = kDblMax;
+        sq.light = kNoSurface;
+    }
+    __device__ void store(uint32_t it, const Hit& h) const {
+        out_t[it] = h.t;
+        out_surface[it] = h.surface;
+        out_uv[2 * (size_t)it] = h.u;
+        out_uv[2 * (size_t)it + 1] = h.v;
+    }
+};
+
 // Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
-// traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do).
-template <bool kCount>
-__global__ void __launch_bounds__(kWfBlock) wfTraceKernel(const WfTraceArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
+// traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
+// are visited through quantised child blocks, the top of the tree from LDS.
+template <class Rays, bool kCount>
+__global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
+    extern __shared__ __align__(64) unsigned char lds[];
+    MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
+    for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
+        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
     SmStack stk;
-    stk.lds = ldsAt<SmStackEntry>(lds, 0) + threadIdx.x;
+    stk.lds = ldsAt<SmStackEntry>(lds, a.lds_blocks * 64u) + threadIdx.x;
     stk.lds_stride = blockDim.x;
     stk.spill = a.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = a.total_lanes;
@@ -686,30 +747,38 @@ __global__ void __launch_bounds__(kWfBlock) wfTraceKernel(const WfTraceArgs a) {
     sv.prim = a.prim;
     sv.lds_nodes = 0;
     sv.lds_node_ptr = nullptr;
+    QView<true> qv;
+    qv.blocks = a.qblocks;
+    qv.lds_blocks = a.lds_blocks;
+    qv.lds_ptr = lq;
+    qv.root_a = a.q_root_a;
+    qv.root_m = a.q_root_m;
+    __syncthreads();
 
     const unsigned long long n = *a.count;
     Trav T;
     T.active = false;
     T.shadow = false;
+    T.fast = true;
     T.sp = 0;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     bool have = false, exhausted = n == 0ull;
     uint32_t item = 0;
     for (;;) {
         if (have && !T.active) {  // finished since the last look: hand the hit back
-            wfStoreHit(a.pool, item, T.best);
+            rays.store(item, T.best);
             have = false;
         }
         const unsigned long long m_have = __ballot(have);
         if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
             const unsigned long long w = wavePop(!have, a.pop);
             if (!have && w < n) {
-                item = a.queue[w];
+                item = rays.item(w);
                 d3 o, d;
                 bool shadow;
                 ShadowQuery sq;
-                wfLoadRay(a.pool, item, o, d, shadow, sq);
-                travBegin<false, kCount>(sv, T, o, d, rcp3(d), shadow, &sq, cnt);
+                rays.load(item, o, d, shadow, sq);
+                travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
                 have = true;
             }
             exhausted = __ballot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
@@ -719,7 +788,8 @@ __global__ void __launch_bounds__(kWfBlock) wfTraceKernel(const WfTraceArgs a) {
             continue;
         }
         const bool inner = have && T.active && (T.node_m & kSmInner);
-        if (inner) travInnerStep<false, kCount>(sv, T, stk, cnt);
+        if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
+        if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
         const bool leaf = have && T.active && !(T.node_m & kSmInner);
         const unsigned long long m_leaf = __ballot(leaf);
         const unsigned long long m_inner = __ballot(have && T.active && (T.node_m & kSmInner));
@@ -1174,7 +1244,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -1274,6 +1344,53 @@ int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
     return MCRT_OK;
 }
 
+// Launch geometry of the trace kernel: one workgroup per CU (MCRT_TRACE_WAVES waves, default 12), its LDS split
+// between the lanes' traversal stacks and as many top-of-tree child blocks as fit.
+struct TracePlan {
+    uint32_t grid, block, lds_bytes;
+    WfTraceArgs args;
+};
+
+template <class K>
+int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
+    auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
+    const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 12), 1), kTraceMaxBlock / 64);
+    tp.block = waves * 64u;
+    const uint32_t stack_bytes = kLdsStackDepth * tp.block * (uint32_t)sizeof(SmStackEntry);
+    const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
+    if ((long)stack_bytes > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
+    const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes) / 64u);
+    tp.lds_bytes = lds_blocks * 64u + stack_bytes;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)tp.block, tp.lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    tp.grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->num_cus, (max_items + tp.block - 1) / tp.block);
+    if (tp.grid < 1) tp.grid = 1;
+    const uint32_t total_lanes = tp.grid * tp.block;
+    if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
+    if (ctx->spill_lanes < total_lanes) {
+        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
+        ctx->spill_lanes = total_lanes;
+    }
+    WfTraceArgs& ta = tp.args;
+    memset(&ta, 0, sizeof(ta));
+    ta.stats = ctx->stats.as<unsigned long long>();
+    ta.nodes = ctx->scene.nodes64;
+    ta.qblocks = ctx->scene.qblocks;
+    ta.num_nodes = ctx->scene.num_nodes;
+    ta.lds_blocks = lds_blocks;
+    ta.q_root_a = ctx->scene.q_root_a;
+    ta.q_root_m = ctx->scene.q_root_m;
+    ta.prim = ctx->scene.prim;
+    ta.spill = ctx->spill.as<SmStackEntry>();
+    ta.total_lanes = total_lanes;
+    ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 32);
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 32);
+    ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
+    return MCRT_OK;
+}
+
 // The wavefront frame loop: shade(0), then trace(i), shade(i+1) until a shade launch queues no ray. The host
 // looks at the queue length every few iterations (a launch with nothing to do costs microseconds), so the
 // call returns when the frame is complete; mcrt_render_finish() then only collects the statistics.
@@ -1320,40 +1437,22 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
 
-    auto trace = count_tests ? wfTraceKernel<true> : wfTraceKernel<false>;
-    const uint32_t trace_lds = kLdsStackDepth * kWfBlock * (uint32_t)sizeof(SmStackEntry);
+    auto trace = count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
-    int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace, (int)kWfBlock, trace_lds));
-    if (per_cu < 1) per_cu = 1;
-    per_cu = (int)std::min<long>(per_cu, envi("MCRT_WF_BLOCKS_PER_CU", per_cu));
-    const uint32_t trace_grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->num_cus, (slots * 2 + kWfBlock - 1) / kWfBlock);
-    const uint32_t total_lanes = trace_grid * kWfBlock;
-    if (ctx->spill_lanes < total_lanes) {
-        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
-        ctx->spill_lanes = total_lanes;
-    }
+    TracePlan tp;
+    if (int rc = planTrace(ctx, trace, slots * 2, tp)) return rc;
     const uint32_t shade_grid = (uint32_t)((slots + kWfBlock - 1) / kWfBlock);
 
     unsigned long long* ctrl = ctx->wf_ctrl.as<unsigned long long>();
-    WfTraceArgs ta;
-    memset(&ta, 0, sizeof(ta));
-    ta.pool.w = ctx->wf_pool.as<unsigned long long>();
-    ta.pool.n = (uint32_t)slots;
-    ta.queue = ctx->wf_queue.as<uint32_t>();
+    WfTraceArgs ta = tp.args;
     ta.pop = ctrl + 2;
-    ta.stats = ctx->stats.as<unsigned long long>();
-    ta.nodes = ctx->scene.nodes64;
-    ta.prim = ctx->scene.prim;
-    ta.num_nodes = ctx->scene.num_nodes;
-    ta.spill = ctx->spill.as<SmStackEntry>();
-    ta.total_lanes = total_lanes;
-    ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);
-    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 32);
-    ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
+    PoolRays pr;
+    pr.pool.w = ctx->wf_pool.as<unsigned long long>();
+    pr.pool.n = (uint32_t)slots;
+    pr.queue = ctx->wf_queue.as<uint32_t>();
     WfShadeArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.pool = ta.pool;
+    sa.pool = pr.pool;
     sa.fr = fr;
     sa.queue = ctx->wf_queue.as<uint32_t>();
     sa.pop_reset = ctrl + 2;
@@ -1373,7 +1472,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             if (*ctx->wf_host == 0ull) break;  // nothing queued: every slot is done
         }
         ta.count = ctrl + (it & 1);
-        hipLaunchKernelGGL(trace, dim3(trace_grid), dim3(kWfBlock), trace_lds, stream, ta);
+        hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, stream, ta, pr);
         ctx->launches++;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1651,6 +1750,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->node_bounds, bounds.data(), bounds.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
@@ -1677,6 +1777,10 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.node_bounds = ctx->node_bounds.as<double>();
     d.node_meta = ctx->node_meta.as<NodeMeta>();
     d.nodes64 = ctx->nodes64.as<Node64>();
+    d.qblocks = ctx->qblocks.as<QBlock>();
+    d.num_qblocks = (uint32_t)L.qblocks.size();
+    d.q_root_a = L.q_root_a;
+    d.q_root_m = L.q_root_m;
     d.prim = ctx->prim.as<double>();
     d.flat_prim = ctx->flat_prim.as<double>();
     d.flat_index = ctx->flat_index.as<uint32_t>();
@@ -1929,6 +2033,36 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     if (n == 0) return MCRT_OK;
     if (!start || !direction || !out_t || !out_surface) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFFFFFFFull) {
+        // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
+        auto trace = wfTraceKernel<ArrayRays, false>;
+        TracePlan tp;
+        if (int rc = planTrace(ctx, trace, n, tp)) return rc;
+        DevBuf ds, dd, dt, dsf, duv;
+        if (int rc = uploadArray(ctx, ds, start, n * 3)) return rc;
+        if (int rc = uploadArray(ctx, dd, direction, n * 3)) return rc;
+        HIP_TRY(ctx, dt.alloc(n * 8));
+        HIP_TRY(ctx, dsf.alloc(n * 4));
+        HIP_TRY(ctx, duv.alloc(n * 16));
+        if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(4 * sizeof(unsigned long long)));
+        const unsigned long long ctrl_init[4] = {n, 0ull, 0ull, 0ull};
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_ctrl.p, ctrl_init, sizeof(ctrl_init), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), ctx->stream));
+        WfTraceArgs ta = tp.args;
+        ta.count = ctx->wf_ctrl.as<unsigned long long>();
+        ta.pop = ctx->wf_ctrl.as<unsigned long long>() + 2;
+        ArrayRays ar{ds.as<double>(), dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>()};
+        hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, ctx->stream, ta, ar);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long h[kStatsWords];
+        HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
+        HIP_TRY(ctx, hipMemcpy(out_t, dt.p, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out_surface, dsf.p, n * 4, hipMemcpyDeviceToHost));
+        if (out_uv) HIP_TRY(ctx, hipMemcpy(out_uv, duv.p, n * 16, hipMemcpyDeviceToHost));
+        return MCRT_OK;
+    }
     LaunchGeom g;
     auto ikernel = ctx->scene.stage_all ? intersectKernel<true> : intersectKernel<false>;
     if (int rc = launchGeometry(ctx, ikernel, ctx->scene, g)) return rc;

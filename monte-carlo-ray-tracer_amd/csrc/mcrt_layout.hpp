@@ -2,12 +2,15 @@
 // layout the gfx950 kernels read (mcrt_scene.hpp). Used by mcrt_upload_scene; host only.
 #pragma once
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/mcrt.h"
 #include "mcrt_scene.hpp"
+#include "mcrt_qbvh.hpp"
 
 namespace mcrt {
 
@@ -22,7 +25,118 @@ struct HostLayout {
     std::vector<uint32_t> flat_index;  // [n] sorted slot -> surface index
     uint32_t flat_tris = 0;
     std::vector<Node64> nodes64;       // [n] box + meta records, same order as node_bounds
+    std::vector<QBlock> qblocks;       // quantised child blocks (mcrt_qbvh.hpp), breadth-first over the inner nodes
+    uint32_t q_root_a = 0, q_root_m = 0;
 };
+
+// One axis of one block: origin (float, rounded down), cell exponent and the cell coordinates of every child,
+// chosen so that qDecode(lower) <= lo and qDecode(upper) >= hi hold in the kernels' own arithmetic.
+inline bool quantiseAxis(const double* lo, const double* hi, int n, float& origin, uint8_t& exp_out, uint8_t* qlo, uint8_t* qhi) {
+    double lo_min = lo[0], hi_max = hi[0];
+    for (int c = 1; c < n; c++) {
+        lo_min = lo[c] < lo_min ? lo[c] : lo_min;
+        hi_max = hi[c] > hi_max ? hi[c] : hi_max;
+    }
+    if (!(fabs(lo_min) <= 3.0e38) || !(fabs(hi_max) <= 3.0e38)) return false;  // not representable around a float origin
+    float o = (float)lo_min;
+    if ((double)o > lo_min) o = nextafterf(o, -INFINITY);
+    origin = o;
+    const double extent = hi_max - (double)o;
+    int e = -kQExpBias;  // smallest cell
+    if (extent > 0.0) {
+        int ex;
+        frexp(extent / 255.0, &ex);  // extent/255 = f * 2^ex, f in [0.5, 1)  ->  2^ex >= extent/255
+        e = ex;
+    }
+    for (;; e++) {
+        if (e < -kQExpBias) e = -kQExpBias;
+        if (e > 255 - kQExpBias) return false;
+        const double cell = qCell((uint32_t)(e + kQExpBias));
+        bool ok = true;
+        for (int c = 0; c < n && ok; c++) {
+            double ql = floor((lo[c] - (double)o) / cell), qh = ceil((hi[c] - (double)o) / cell);
+            if (ql < 0.0) ql = 0.0;
+            if (ql > 255.0) ql = 255.0;
+            if (qh < 0.0) qh = 0.0;
+            while (ql > 0.0 && qDecode(o, (uint32_t)ql, cell) > lo[c]) ql -= 1.0;
+            while (qh <= 255.0 && qDecode(o, (uint32_t)qh, cell) < hi[c]) qh += 1.0;
+            if (qh > 255.0 || qDecode(o, (uint32_t)ql, cell) > lo[c]) {
+                ok = false;
+                break;
+            }
+            qlo[c] = (uint8_t)ql;
+            qhi[c] = (uint8_t)qh;
+        }
+        if (ok) {
+            exp_out = (uint8_t)(e + kQExpBias);
+            return true;
+        }
+    }
+}
+
+// Blocks for every inner node of the breadth-first Node64 array, in node order (so the top of the tree is a
+// prefix of the block array too).
+inline int buildQBlocks(HostLayout& L, std::string& err) {
+    const uint32_t n = (uint32_t)L.nodes64.size();
+    L.qblocks.clear();
+    L.q_root_a = L.q_root_m = 0;
+    if (n == 0) return MCRT_OK;
+    std::vector<uint32_t> first_block(n, 0);
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (L.nodes64[i].m & kSmInner) {
+            first_block[i] = total;
+            total += ((L.nodes64[i].m & 0xFFu) + 3u) / 4u;
+        }
+    L.qblocks.assign(total, QBlock{});
+    auto link = [&](uint32_t node, uint32_t& a, uint32_t& m) {
+        m = L.nodes64[node].m;
+        a = (m & kSmInner) ? first_block[node] : L.nodes64[node].a;
+    };
+    link(0, L.q_root_a, L.q_root_m);
+    for (uint32_t i = 0; i < n; i++) {
+        const Node64& nd = L.nodes64[i];
+        if (!(nd.m & kSmInner)) continue;
+        const uint32_t count = nd.m & 0xFFu, nb = (count + 3u) / 4u;
+        if (count == 0) {
+            err = "BVH inner node without children";
+            return MCRT_ERR_INVALID;
+        }
+        for (uint32_t b = 0; b < nb; b++) {
+            QBlock& q = L.qblocks[first_block[i] + b];
+            const uint32_t c0 = nd.a + b * 4u, nc = std::min<uint32_t>(4u, count - b * 4u);
+            uint8_t exps[3], qlo[3][4], qhi[3][4];
+            for (int ax = 0; ax < 3; ax++) {
+                double lo[4], hi[4];
+                for (uint32_t c = 0; c < nc; c++) {
+                    lo[c] = L.nodes64[c0 + c].b[ax];
+                    hi[c] = L.nodes64[c0 + c].b[3 + ax];
+                }
+                float o;
+                if (!quantiseAxis(lo, hi, (int)nc, o, exps[ax], qlo[ax], qhi[ax])) {
+                    err = "BVH bounds cannot be quantised (non-finite or beyond float range)";
+                    return MCRT_ERR_UNSUPPORTED;
+                }
+                memcpy(&q.w[ax], &o, 4);
+            }
+            q.w[3] = (uint32_t)exps[0] | ((uint32_t)exps[1] << 8) | ((uint32_t)exps[2] << 16) | ((nc | (b + 1 < nb ? 0x80u : 0u)) << 24);
+            uint8_t bytes[24] = {0};
+            for (uint32_t c = 0; c < nc; c++)
+                for (int ax = 0; ax < 3; ax++) {
+                    bytes[c * 6 + ax] = qlo[ax][c];
+                    bytes[c * 6 + 3 + ax] = qhi[ax][c];
+                }
+            memcpy(&q.w[4], bytes, 24);
+            for (uint32_t c = 0; c < nc; c++) {
+                uint32_t a, m;
+                link(c0 + c, a, m);
+                q.w[10 + c] = a;
+                q.w[14 + c / 2] |= m << (16 * (c % 2));
+            }
+        }
+    }
+    return MCRT_OK;
+}
 
 // Reference LinearNode array (depth-first, sibling links, bvh/bvh.hpp:68-74) -> breadth-first order in
 // which the children of a node are contiguous and the top of the tree is a prefix of the array.
@@ -143,7 +257,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
         }
         n.pad0 = n.pad1 = 0;
     }
-    return MCRT_OK;
+    return buildQBlocks(L, err);
 }
 
 }  // namespace mcrt

@@ -89,6 +89,23 @@ MCRT_HD double fastMax(double x, double y) {
 MCRT_HD double fastMin(double x, double y) { return fmin(x, y); }
 MCRT_HD double fastMax(double x, double y) { return fmax(x, y); }
 #endif
+MCRT_HD unsigned long long dBits(double d) {
+    union {
+        double d;
+        unsigned long long u;
+    } c;
+    c.d = d;
+    return c.u;
+}
+MCRT_HD double bitsD(unsigned long long u) {
+    union {
+        double d;
+        unsigned long long u;
+    } c;
+    c.u = u;
+    return c.d;
+}
+
 MCRT_HD bool finite64(double x) { return fabs(x) <= kDblMax; }  // false for NaN and +-inf
 MCRT_HD double compMax(d3 v) { return gmax(gmax(v.x, v.y), v.z); }
 MCRT_HD double compMin(d3 v) { return gmin(gmin(v.x, v.y), v.z); }

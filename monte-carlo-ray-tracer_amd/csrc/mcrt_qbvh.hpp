@@ -1,0 +1,143 @@
+// Quantised child blocks for the trace kernel of the wavefront pipeline.
+//
+// Why: with the tree in HBM the trace kernel is bound by the number of 16-byte lane requests the CU's
+// L1 (TCP) can look up, not by latency or arithmetic (measured on metal_bunnies: 266 requests per ray,
+// TCP active 90 % of the time, VALU 33 %, no gain from more waves). A node visit with 64-byte FP64 child
+// records costs 4 requests per child. Here the children of an inner node share ONE 64-byte block: a
+// float origin, a power-of-two cell size per axis and 8-bit cell coordinates of every child box, plus the
+// children's links — 4 requests per node visit instead of 16.
+//
+// Exactness: a decoded box is an FP64 box that CONTAINS the reference's FP64 box of that child (the
+// host rounds lower bounds down and upper bounds up and verifies the decode with the device's own
+// expression), and the slab test run on it is the reference's (BoundingBox::intersect, bounding-box.cpp:9-17).
+// Every operation of that test is monotone in the bounds, so a decoded box is hit whenever the exact box
+// is, with an entry distance that is not larger: the walk visits a superset of the nodes the exact walk
+// visits and therefore tests a superset of the primitives. Primitive tests are unchanged (FP64,
+// Triangle::intersect / Sphere::intersect) and the result is the minimum over the tested primitives, so
+// it equals the exact walk's result. Rays with a zero direction component (0 * inf = NaN slabs, where
+// "monotone" does not hold) never use the blocks; they walk the exact 64-byte records (Trav::fast == false).
+#pragma once
+
+#include "mcrt_lanesm.hpp"
+
+namespace mcrt {
+
+// 64 bytes, up to 4 children of one inner node:
+//   w[0..2]   float origin x,y,z            (<= every child's lower bound)
+//   w[3]      ex | ey << 8 | ez << 16 | n << 24     cell size per axis = 2^(e - 128); n = children in this
+//             block (1..4) | 0x80 when the node's next block follows (node with more than 4 children)
+//   w[4..9]   24 bytes: child c, byte c*6+k = lower x,y,z (k=0..2), upper x,y,z (k=3..5) in cells
+//   w[10..13] child c: inner -> index of its first block, leaf -> first primitive
+//   w[14..15] child c (16 bits each): inner -> 0x100 | number of children, leaf -> number of primitives
+struct alignas(64) QBlock {
+    uint32_t w[16];
+};
+constexpr int kQExpBias = 128;
+
+MCRT_HD double qCell(uint32_t e) { return bitsD((unsigned long long)((int)e - kQExpBias + 1023) << 52); }
+// the one decode expression, used by the host builder's verification and by the kernels
+MCRT_HD double qDecode(float origin, uint32_t q, double cell) { return (double)origin + (double)q * cell; }
+MCRT_HD uint32_t qByte(const QBlock& b, int byte) { return (b.w[4 + byte / 4] >> (8 * (byte % 4))) & 0xFFu; }
+
+template <bool kLds>
+struct QView {
+    const QBlock* blocks;                 // every block, HBM
+    uint32_t lds_blocks;                  // blocks [0, lds_blocks) are also in LDS (top of the tree)
+    MCRT_LDS_AS const QBlock* lds_ptr;
+    uint32_t root_a, root_m;              // the root as a child: inner -> block 0, leaf -> its primitives
+};
+
+template <bool kLds>
+MCRT_HD QBlock qFetch(const QView<kLds>& qv, uint32_t i) {
+    QBlock b;
+    if (kLds && i < qv.lds_blocks) {
+        MCRT_LDS_AS const QBlock* p = qv.lds_ptr + i;
+        for (int k = 0; k < 16; k++) b.w[k] = p->w[k];
+    } else {
+        const QBlock* p = qv.blocks + i;
+        for (int k = 0; k < 16; k++) b.w[k] = p->w[k];
+    }
+    return b;
+}
+
+// Scene::intersect / BVH::intersect start (bvh.cpp:84-88): the root box is tested exactly (one record).
+template <bool kAll, bool kLds, bool kCount>
+MCRT_HD void travBeginQ(const SmSceneView<kAll>& sv, const QView<kLds>& qv, Trav& T, d3 start, d3 direction, d3 inv_direction,
+                        bool shadow, const ShadowQuery* sq, TraceCounters& cnt) {
+    travBegin<kAll, kCount>(sv, T, start, direction, inv_direction, shadow, sq, cnt);
+    if (T.fast) {  // from here on node_a / node_m are block links
+        T.node_a = qv.root_a;
+        T.node_m = qv.root_m;
+    }
+}
+
+// Visit one INNER node through its block(s): decode and test the children (bvh.cpp:108-119), continue
+// with the nearest hit child, push the rest.
+template <bool kLds, bool kCount>
+MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+    const Ray r = travRay(T);
+    double near_t = 0.0;
+    uint32_t near_a = 0, near_m = 0;
+    bool have_near = false;
+    uint32_t bi = T.node_a;
+    bool more = true;
+    while (more) {
+        const QBlock b = qFetch(qv, bi++);
+        const uint32_t n = (b.w[3] >> 24) & 0x7Fu;
+        more = (b.w[3] >> 31) != 0u;
+        const float ox = bitsFloat(b.w[0]), oy = bitsFloat(b.w[1]), oz = bitsFloat(b.w[2]);
+        const double cx = qCell(b.w[3] & 0xFFu), cy = qCell((b.w[3] >> 8) & 0xFFu), cz = qCell((b.w[3] >> 16) & 0xFFu);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int c = 0; c < 4; c++) {
+            if ((uint32_t)c < n) {
+                Box cb;
+                cb.v[0] = qDecode(ox, qByte(b, c * 6 + 0), cx);
+                cb.v[1] = qDecode(oy, qByte(b, c * 6 + 1), cy);
+                cb.v[2] = qDecode(oz, qByte(b, c * 6 + 2), cz);
+                cb.v[3] = qDecode(ox, qByte(b, c * 6 + 3), cx);
+                cb.v[4] = qDecode(oy, qByte(b, c * 6 + 4), cy);
+                cb.v[5] = qDecode(oz, qByte(b, c * 6 + 5), cz);
+                const uint32_t a = b.w[10 + c];
+                const uint32_t m = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0xFFFFu;
+                if (kCount) cnt.node_tests++;
+                double t;
+                const bool hit = boxIntersect<true>(cb, r, t);
+                if (hit && t <= T.best.t) {
+                    uint32_t push_a = a, push_m = m;
+                    double push_t = t;
+                    bool push = true;
+                    if (!have_near || t < near_t) {
+                        push = have_near;
+                        push_a = near_a;
+                        push_m = near_m;
+                        push_t = near_t;
+                        near_a = a;
+                        near_m = m;
+                        near_t = t;
+                        have_near = true;
+                    }
+                    if (push) {
+                        if (T.sp < kMaxStackDepth) {
+                            SmStackEntry e;
+                            e.key = (floatBits(floatBelow(push_t)) & ~0x1FFu) | push_m;
+                            e.a = push_a;
+                            stk.put(T.sp++, e);
+                        } else {
+                            cnt.overflow = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (have_near) {
+        T.node_a = near_a;
+        T.node_m = near_m;
+    } else {
+        travPop(T, stk);
+    }
+}
+
+}  // namespace mcrt

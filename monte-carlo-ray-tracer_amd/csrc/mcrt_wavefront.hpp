@@ -80,23 +80,6 @@ enum : uint32_t {
     kWfRhShift = 8        // RefractionHistory::size in bits 8..11
 };
 
-MCRT_HD unsigned long long dBits(double d) {
-    union {
-        double d;
-        unsigned long long u;
-    } c;
-    c.d = d;
-    return c.u;
-}
-MCRT_HD double bitsD(unsigned long long u) {
-    union {
-        double d;
-        unsigned long long u;
-    } c;
-    c.u = u;
-    return c.d;
-}
-
 struct WfPool {
     unsigned long long* w;
     uint32_t n;

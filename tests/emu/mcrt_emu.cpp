@@ -14,6 +14,7 @@
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_qbvh.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 
 using namespace mcrt;
@@ -176,6 +177,48 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
     return 0;
 }
 
+// One ray through the trace kernel's per-lane code: quantised child blocks (mcrt_qbvh.hpp) with the first
+// half of the blocks on the "LDS" side, exact records for rays with a zero direction component.
+namespace {
+struct QTrace {
+    SmSceneView<false> sv;
+    QView<true> qv;
+    std::vector<SmStackEntry> s_lds, s_spill;
+    SmStack stk;
+    void init(Emu& E, const mcrt_scene_desc* scene) {
+        s_lds.resize(kLdsStackDepth);
+        s_spill.resize(kMaxStackDepth - kLdsStackDepth);
+        stk.lds = s_lds.data();
+        stk.lds_stride = 1;
+        stk.spill = s_spill.data();
+        stk.spill_stride = 1;
+        sv.num_nodes = scene->num_nodes;
+        sv.nodes = E.L.nodes64.data();
+        sv.prim = E.L.prim.data();
+        sv.lds_nodes = 0;
+        sv.lds_node_ptr = E.L.nodes64.data();
+        qv.blocks = E.L.qblocks.data();
+        qv.lds_blocks = (uint32_t)E.L.qblocks.size() / 2;
+        qv.lds_ptr = E.L.qblocks.data();
+        qv.root_a = E.L.q_root_a;
+        qv.root_m = E.L.q_root_m;
+    }
+    Hit run(d3 o, d3 d, bool shadow, const ShadowQuery* sq, TraceCounters& cnt) {
+        Trav T;
+        travBeginQ<false, true, true>(sv, qv, T, o, d, rcp3(d), shadow, sq, cnt);
+        while (T.active) {
+            if (T.node_m & kSmInner) {
+                if (T.fast) travInnerStepQ<true, true>(qv, T, stk, cnt);
+                else travInnerStep<false, true>(sv, T, stk, cnt);
+            } else {
+                travLeafStep<false, true>(sv, T, stk, cnt);
+            }
+        }
+        return T.best;
+    }
+};
+}  // namespace
+
 // The lane-state-machine integrator (mcrt_lanesm.hpp) driven for one lane at a time: the same
 // regenerate / traverse-step / shade / NEE-finish functions the gfx950 kernel calls, without the
 // wave-level gating (which only changes how lanes interleave, not what a lane computes).
@@ -204,9 +247,11 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     const uint32_t spp = cam->sqrtspp * cam->sqrtspp;
     TraceCounters cnt = {0, 0, 0, 0};
     uint64_t paths = 0;
+    QTrace qt;  // tree not resident: quantised child blocks, as renderKernelSM<kAll = false>
+    qt.init(E, scene);
     auto begin = [&](Trav& T, d3 o, d3 d, d3 inv, bool shadow, const ShadowQuery* sq) {
         if (stage_all) travBegin<true, true>(sv_all, T, o, d, inv, shadow, sq, cnt);
-        else travBegin<false, true>(sv_top, T, o, d, inv, shadow, sq, cnt);
+        else travBeginQ<false, true, true>(sv_top, qt.qv, T, o, d, inv, shadow, sq, cnt);
     };
     for (uint32_t y = row0; y < row1; y++)
         for (uint32_t x = 0; x < cam->width; x++) {
@@ -227,6 +272,7 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
                     while (T.active) {
                         if (T.node_m & kSmInner) {
                             if (stage_all) travInnerStep<true, true>(sv_all, T, stk, cnt);
+                            else if (T.fast) travInnerStepQ<true, true>(qt.qv, T, stk, cnt);
                             else travInnerStep<false, true>(sv_top, T, stk, cnt);
                         } else {
                             if (stage_all) travLeafStep<true, true>(sv_all, T, stk, cnt);
@@ -263,6 +309,7 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     return 0;
 }
 
+
 // The wavefront integrator (mcrt_wavefront.hpp): a pool of `slots` path slots in "HBM", and per bounce a shade pass
 // over the slots followed by a trace pass over the queued rays — the same wfShadeSlot / wfLoadRay / trav* /
 // wfStoreHit the gfx950 kernels run, with the wave-level cooperation (work pop, queue append) done serially.
@@ -285,18 +332,8 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     Emu E;
     if (int rc = setup(E, scene, 0)) return rc;
     if (scene->num_nodes == 0 || slots == 0) return -200;
-    std::vector<SmStackEntry> s_lds(kLdsStackDepth), s_spill(kMaxStackDepth - kLdsStackDepth);
-    SmStack stk;
-    stk.lds = s_lds.data();
-    stk.lds_stride = 1;
-    stk.spill = s_spill.data();
-    stk.spill_stride = 1;
-    SmSceneView<false> sv;
-    sv.num_nodes = scene->num_nodes;
-    sv.nodes = E.L.nodes64.data();
-    sv.prim = E.L.prim.data();
-    sv.lds_nodes = 0;
-    sv.lds_node_ptr = E.L.nodes64.data();
+    QTrace qt;
+    qt.init(E, scene);
 
     std::vector<unsigned long long> pool((size_t)kWfWords * slots, 0ull);
     WfPool P;
@@ -326,13 +363,8 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
             bool shadow;
             ShadowQuery sq;
             wfLoadRay(P, item, o, d, shadow, sq);
-            Trav T;
-            travBegin<false, true>(sv, T, o, d, rcp3(d), shadow, &sq, cnt);
-            while (T.active) {
-                if (T.node_m & kSmInner) travInnerStep<false, true>(sv, T, stk, cnt);
-                else travLeafStep<false, true>(sv, T, stk, cnt);
-            }
-            wfStoreHit(P, item, T.best);
+            const Hit h = qt.run(o, d, shadow, &sq, cnt);
+            wfStoreHit(P, item, h);
         }
     }
     if (counters) {
@@ -393,11 +425,17 @@ int emu_emit_photons(const mcrt_scene_desc* scene, double emissions, double caus
 int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int stage_lds,
                   double* out_t, uint32_t* out_surface, double* out_uv) {
     Emu E;
-    if (int rc = setup(E, scene, stage_lds)) return rc;
+    if (int rc = setup(E, scene, stage_lds == 3 ? 0 : stage_lds)) return rc;
     TraceCounters cnt = {0, 0, 0, 0};
+    QTrace qt;
+    if (stage_lds == 3) {
+        if (scene->num_nodes == 0) return -200;
+        qt.init(E, scene);
+    }
     for (uint64_t i = 0; i < n; i++) {
         Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
-        Hit h = E.stage_all ? sceneIntersect<true, true, false>(E.sv_all, ray, E.stk, cnt)
+        Hit h = stage_lds == 3 ? qt.run(ray.start, ray.direction, false, nullptr, cnt)
+                : E.stage_all ? sceneIntersect<true, true, false>(E.sv_all, ray, E.stk, cnt)
                             : sceneIntersect<false, true, false>(E.sv_top, ray, E.stk, cnt);
         out_t[i] = h.t;
         out_surface[i] = h.surface;

@@ -130,14 +130,15 @@ def test_traversal_device_code_kat(pkg, emu, oracle, manifest, name):
     n = rays.shape[0]
     start, direction = rays[:, :3].copy(), rays[:, 3:].copy()
     results = []
-    for stage in (0, 1, 2):  # top-of-tree staged / whole scene staged / flat loop
+    # top-of-tree staged / whole scene staged / flat loop / quantised child blocks of the trace kernel
+    for stage in (0, 1, 2, 3) if img.scene.num_nodes else (0, 1, 2):
         t, surf, uv = np.empty(n), np.empty(n, dtype=np.uint32), np.empty((n, 2))
         rc = emu.emu_intersect(C.byref(img.scene), n, start.ctypes.data, direction.ctypes.data, stage, t.ctypes.data,
                                surf.ctypes.data, uv.ctypes.data)
         assert rc == 0
         check_hits_against_reference(oracle, img, d, t, surf, uv)
         results.append((t, surf, uv))
-    # The three traversal flavours agree bit for bit, ties included — except for rays with an exactly
+    # The traversal flavours agree bit for bit, ties included — except for rays with an exactly
     # zero direction component, where a slab product can be 0*inf = NaN and BoundingBox::intersect
     # (bounding-box.cpp:9-17) rejects a box that does contain a hit; there the BVH walk follows the
     # reference's BVH result and the flat loop follows the reference's brute-force result.
