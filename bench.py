@@ -50,11 +50,20 @@ WORKLOADS = {
     # machine by the reference's loader + BVH builder (tests/large/make_large.py:ensure_c3_image)
     "c3": ("../../oracle/_ref/images/metal_bunnies_c3.mcrt", 1920, 1080, 32,
            "metal_bunnies.json (stand-in bunny mesh, 491 592 triangles), quaternary SAH, 1920x1080 @ 1024 spp (BASELINE configs[2])"),
+    # BASELINE configs[3] on ONE GPU (the 8-GPU figure is the driver's scaling run): the two missing hull meshes replaced by
+    # stand-ins of the same triangle counts (tests/large/gen_mesh.c), 457 200 triangles in total
+    "c4": ("../../oracle/_ref/images/spaceship_c4.mcrt", 3840, 2160, 32,
+           "spaceship.json (stand-in hull meshes, 457 200 triangles), quaternary SAH, 3840x2160 @ 1024 spp (BASELINE configs[3])"),
+    # BASELINE configs[4]: water.obj replaced by a 6 734 450-triangle heightfield; photons emitted on the GPU
+    # (--emissions x caustic_factor 10 paths), octrees built on the host, timed eye passes with k = 50 estimates
+    "c5": ("../../oracle/_ref/images/water_caustics_c5.mcrt", 1000, 1000, 16,
+           "water_caustics.json (stand-in water surface, 6 898 815 triangles), octree BVH, photon map, 1000x1000 @ 256 spp (BASELINE configs[4])"),
 }
 # reference-side scene + flags for the cpu_baseline "reference" leg
 REF_SCENES = {
     "hexagon_room.mcrt": ("hexagon_room.json", []),
     "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
+    "spaceship_c4.mcrt": ("spaceship.json", []),
 }
 SEED = 0x12345678
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -131,6 +140,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (roofline then uses stored counts)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--emissions", type=float, default=1e6, help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths)")
     args = ap.parse_args()
 
     import torch
@@ -152,11 +162,11 @@ def main():
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
     tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
     image_file, W, H, sqrtspp, desc = WORKLOADS[args.workload]
-    if args.workload == "c3":
+    if args.workload in ("c3", "c4", "c5"):
         sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
         import make_large
-        if local_rank == 0 and make_large.ensure_c3_image() is None:
-            raise SystemExit("c3 needs oracle/_ref (python __graft_entry__.py build in the build container)")
+        if local_rank == 0 and make_large.ensure_image(args.workload) is None:
+            raise SystemExit("%s needs oracle/_ref (python __graft_entry__.py build in the build container)" % args.workload)
         if world > 1:
             dist.barrier()
     img = m.SceneImage(os.path.join(ROOT, "tests", "golden", image_file))
@@ -168,10 +178,13 @@ def main():
     ctx.upload_image(img)  # scene resident in HBM before the timed region
     integrator = m.INTEGRATOR_PATH_TRACER
     pm_maps = None
-    if args.workload == "pm":
+    emit_info = None
+    photon_workload = args.workload in ("pm", "c5")
+    if photon_workload:
         # emission pass on the GPU (sharded over the ranks and all-gathered), octrees on the host, upload
         integrator = m.INTEGRATOR_PHOTON_MAPPER
-        em = ctx.emit_photons(1e6, 10.0, SEED, rank, world)
+        em = ctx.emit_photons(args.emissions, 10.0, SEED, rank, world)
+        emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
         lists = []
         for name in ("global_", "caustic"):
             ph = torch.from_numpy(em[name][0]).to(torch.device("cuda", local_rank))
@@ -186,7 +199,11 @@ def main():
                 ph = torch.cat([parts[r][: int(sizes[r].item())] for r in range(world)])
             lists.append(ph.cpu().numpy())
         sc = img.scene
+        t_build = time.perf_counter()
         pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200))
+        emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
+                         octree_build_s=time.perf_counter() - t_build,
+                         emission_Mray_per_s=emit_info["rays"] / max(emit_info["kernel_ms"], 1e-9) / 1e3)
         ctx.upload_photons(pm_maps[0].desc, pm_maps[1].desc, 50, False)
 
     my_rows = m.shard_rows(cam)
@@ -256,11 +273,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "photon_mapper" if args.workload == "pm" else "path_tracer",
+            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "photon_mapper" if photon_workload else "path_tracer",
                        "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
                        "rays_per_step": total_rays / args.steps, "paths_per_step": total_paths / args.steps,
                        "frame_mean_radiance": mean, "frame_finite": finite,
-                       "knn_searches_per_s": total_knn / elapsed if total_knn else None},
+                       "knn_searches_per_s": total_knn / elapsed if total_knn else None,
+                       "photon_pass": emit_info if photon_workload else None},
         }
         counts = None
         if world == 1 and not args.no_cpu:
@@ -290,7 +308,7 @@ def main():
                               "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time; "
                                       "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/). Scenes that fit in LDS "
                                       "move almost nothing through HBM, so frac can exceed 1 for them.",
-                              "kernel": {"pm": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
+                              "kernel": {"pm": "renderKernelPM", "c5": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "renderKernelSM", "c4": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
                               "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
                               "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}

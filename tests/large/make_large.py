@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """Large-scene fixtures (too big for git). Everything here is produced by the REFERENCE (oracle/_ref/mcrt_ref
-= the reference's translation units compiled in place + oracle/ref_main.cpp) under oracle/_ref/ (git-ignored).
+= the reference's translation units compiled in place + oracle/ref_main.cpp) under oracle/_ref/ (git-ignored),
+from scene copies whose missing meshes (.MISSING_LARGE_BLOBS) are replaced by deterministic synthetic stand-ins
+(tests/large/make_synthetic.py, tests/large/gen_mesh.c).
 
-Build container (/root/reference present; called from __graft_entry__.build()):
-  oracle/_ref/images/spaceship.mcrt (+ .480x270_s2.f64)   spaceship.json as far as its meshes are present
-                              (68 760 of 457 200 triangles, .MISSING_LARGE_BLOBS), quaternary SAH, 23 187 nodes
-  oracle/_ref/scenes/metal_bunnies.json + data/            scene copy for BASELINE configs[2] with the synthetic
-                              stand-in bunny.obj (tests/large/make_synthetic.py), shelf.obj, backwall.obj
-  tests/golden/metal_bunnies_c3.rows540_542.f64             the reference's radiance for two full-width rows of
-                              the C3 frame (1920x1080 @ 1024 spp, quaternary SAH) — committed (92 KB)
-Any machine that has oracle/_ref/ (build container and GPU box):
-  oracle/_ref/images/metal_bunnies_c3.mcrt                  flattened C3 scene, 491 592 primitives (about 120 MB:
-                              listed in .gpurunignore, rebuilt on the GPU box by ensure_c3_image() in ~10 s)
+Build container (/root/reference present; main(), called from __graft_entry__.build()):
+  oracle/_ref/bin/gen_mesh                              the C mesh generator
+  oracle/_ref/scenes/{metal_bunnies,spaceship,water_caustics}.json + data/   scene copies with the meshes that exist
+  oracle/_ref/images/spaceship.mcrt (+ .480x270_s2.f64)  spaceship.json as far as its meshes are present (68 760 tris)
+  tests/golden/<config>.rows*.f64                         the reference's radiance for a few full-width rows of each
+                                                        BASELINE config at full size — committed (<= 100 KB each)
+Any machine that has oracle/_ref/ (build container and GPU box; ensure_image(name)):
+  stand-in meshes + oracle/_ref/images/<config>.mcrt      flattened scene (120 MB - 1.7 GB: listed in .gpurunignore,
+                                                        rebuilt on the GPU box in 5-60 s)
 """
 import hashlib
 import os
@@ -22,20 +23,66 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 REF = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
+GEN = os.path.join(ROOT, "oracle", "_ref", "bin", "gen_mesh")
 OUT = os.path.join(ROOT, "oracle", "_ref", "images")
 SCENES_OUT = os.path.join(ROOT, "oracle", "_ref", "scenes")
 SCENES = "/root/reference/scenes"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 SEED = 0x12345678
 BUNNY_MD5 = "3379d5cae7668b436c4a00c1a9e4bd74"
-C3 = dict(width=1920, height=1080, sqrtspp=32, rows=(540, 542), bvh="quaternary_sah", bins=8,
-          golden=os.path.join(ROOT, "tests", "golden", "metal_bunnies_c3.rows540_542.f64"),
-          image=os.path.join(OUT, "metal_bunnies_c3.mcrt"))
 
 sys.path.insert(0, HERE)
 
 
+def _bunny(path):
+    import make_synthetic
+    make_synthetic.write_bunny(path)
+
+
+def _gen(*args):
+    return lambda path: subprocess.check_call([GEN] + [str(a) for a in args] + [path])
+
+
+# BASELINE configs[2..4] at full size. "meshes": generated file -> (generator, md5 of its bytes).
+CONFIGS = {
+    "c3": dict(scene="metal_bunnies.json", copy=["data/shelf.obj", "data/backwall.obj"],
+               meshes={"data/bunny.obj": (_bunny, BUNNY_MD5)},
+               flags=["--bvh", "quaternary_sah", "--bins", "8", "--width", "1920", "--height", "1080", "--sqrtspp", "32"],
+               width=1920, height=1080, sqrtspp=32, rows=(540, 542), photon=False,
+               golden="metal_bunnies_c3.rows540_542.f64", image="metal_bunnies_c3.mcrt",
+               surfaces=491593, nodes=169162),
+    "c4": dict(scene="spaceship.json", copy=["data/spaceship", "data/spectral-distributions"],
+               meshes={"data/spaceship/aluminium.obj": (_gen("bowl", 500, 300, -0.385, 0.73, 0, 1.6, 1.0, 1.6, 0.65, -0.76, 21),
+                                                        "313e7f20fc8507667801e81c30b1721c"),
+                       "data/spaceship/steel.obj": (_gen("bowl", 220, 201, -0.385, 0.73, 0, 1.45, 0.9, 1.45, 0.65, -0.76, 22),
+                                                    "7f8d2185b55dcc6c6c7fbdb591330556")},
+               flags=["--width", "3840", "--height", "2160", "--sqrtspp", "32"],
+               width=3840, height=2160, sqrtspp=32, rows=(1080, 1081), photon=False,
+               golden="spaceship_c4.rows1080_1081.f64", image="spaceship_c4.mcrt",
+               surfaces=457200, nodes=153801),
+    # photon map of the parity image: 1e5 emissions x caustic_factor 10 traced by the reference; the timing run
+    # (bench.py --workload c5) emits on the GPU
+    "c5": dict(scene="water_caustics.json", copy=["data/water_caustics"],
+               meshes={"data/water_caustics/water.obj": (_gen("water", 1835), "3728d20d4225dd8617842d74e25a4f6e"),
+                       "data/bunny.obj": (_bunny, BUNNY_MD5)},
+               flags=["--photon", "--emissions", "100000", "--width", "1000", "--height", "1000", "--sqrtspp", "4"],
+               width=1000, height=1000, sqrtspp=4, rows=(500, 504), photon=True,
+               golden="water_caustics_c5.rows500_504.f64", image="water_caustics_c5.mcrt",
+               surfaces=6898815, nodes=1925901),
+}
+C3 = dict(CONFIGS["c3"], golden=os.path.join(GOLDEN, CONFIGS["c3"]["golden"]), image=os.path.join(OUT, CONFIGS["c3"]["image"]))
+
+
 def _run(cmd):
     subprocess.check_call(cmd, env=dict(os.environ, MCRT_REF_SEED=str(SEED)), stdout=subprocess.DEVNULL)
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, CONFIGS[name]["golden"])
+
+
+def image_path(name):
+    return os.path.join(OUT, CONFIGS[name]["image"])
 
 
 def spaceship(force=False):
@@ -48,53 +95,101 @@ def spaceship(force=False):
     return img, rad
 
 
-def prepare_c3_scene(force=False):
-    """Scene directory for metal_bunnies with the synthetic bunny (needs /root/reference)."""
-    import make_synthetic
-    data = os.path.join(SCENES_OUT, "data")
-    os.makedirs(data, exist_ok=True)
-    shutil.copy(os.path.join(SCENES, "metal_bunnies.json"), os.path.join(SCENES_OUT, "metal_bunnies.json"))
-    for f in ("shelf.obj", "backwall.obj"):
-        shutil.copy(os.path.join(SCENES, "data", f), os.path.join(data, f))
-    bunny = os.path.join(data, "bunny.obj")
-    if force or not os.path.exists(bunny):
-        make_synthetic.write_bunny(bunny)
-    md5 = hashlib.md5(open(bunny, "rb").read()).hexdigest()
-    if md5 != BUNNY_MD5:
-        raise RuntimeError("synthetic bunny.obj differs from the committed fingerprint: %s" % md5)
+def build_generator():
+    os.makedirs(os.path.dirname(GEN), exist_ok=True)
+    src = os.path.join(HERE, "gen_mesh.c")
+    if not os.path.exists(GEN) or os.path.getmtime(src) > os.path.getmtime(GEN):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", GEN, src, "-lm"])
 
 
-def c3_flags():
-    return ["--scene", os.path.join(SCENES_OUT, "metal_bunnies.json"), "--bvh", C3["bvh"], "--bins", str(C3["bins"]),
-            "--width", str(C3["width"]), "--height", str(C3["height"]), "--sqrtspp", str(C3["sqrtspp"])]
+def prepare_scene(name):
+    """Scene copy with the meshes the reference tree does have (needs /root/reference)."""
+    c = CONFIGS[name]
+    os.makedirs(os.path.join(SCENES_OUT, "data"), exist_ok=True)
+    shutil.copy(os.path.join(SCENES, c["scene"]), os.path.join(SCENES_OUT, c["scene"]))
+    for rel in c["copy"]:
+        src, dst = os.path.join(SCENES, rel), os.path.join(SCENES_OUT, rel)
+        if os.path.isdir(src):
+            shutil.copytree(src, dst, dirs_exist_ok=True)
+        else:
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            shutil.copy(src, dst)
+    for root, dirs, files in os.walk(SCENES_OUT):  # the reference tree is read-only; the copies must not be
+        for f in files:
+            os.chmod(os.path.join(root, f), 0o644)
+        for d in dirs:
+            os.chmod(os.path.join(root, d), 0o755)
 
 
-def c3_golden(force=False):
-    """Two full-width rows of the C3 frame rendered by the reference (about 4 M paths)."""
-    if force or not os.path.exists(C3["golden"]):
-        _run([REF, "render"] + c3_flags() + ["--rows", str(C3["rows"][0]), str(C3["rows"][1]), "--out-radiance", C3["golden"]])
-    return C3["golden"]
+def ensure_meshes(name):
+    """Writes the stand-in meshes of a config if missing and checks their fingerprints."""
+    c = CONFIGS[name]
+    if not os.path.exists(os.path.join(SCENES_OUT, c["scene"])):
+        return False
+    for rel, (gen, md5) in c["meshes"].items():
+        path = os.path.join(SCENES_OUT, rel)
+        if not os.path.exists(path):
+            if gen is not _bunny and not os.path.exists(GEN):
+                return False
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            gen(path)
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        if h.hexdigest() != md5:
+            raise RuntimeError("%s differs from the committed fingerprint: %s" % (rel, h.hexdigest()))
+    return True
+
+
+def scene_flags(name):
+    c = CONFIGS[name]
+    return ["--scene", os.path.join(SCENES_OUT, c["scene"])] + c["flags"]
+
+
+def make_golden(name, force=False):
+    """A few full-width rows of the config's frame rendered by the reference at full resolution and spp."""
+    c = CONFIGS[name]
+    g = golden_path(name)
+    if force or not os.path.exists(g):
+        ensure_meshes(name)
+        if c["photon"]:
+            # the rows and the image must come from the same process (one photon map): keep the image too
+            os.makedirs(OUT, exist_ok=True)
+            _run([REF, "flatten,render"] + scene_flags(name) + ["--rows", str(c["rows"][0]), str(c["rows"][1]), "--out", image_path(name),
+                                                                "--out-radiance", g])
+        else:
+            _run([REF, "render"] + scene_flags(name) + ["--rows", str(c["rows"][0]), str(c["rows"][1]), "--out-radiance", g])
+    return g
+
+
+def ensure_image(name):
+    """Flatten the config's scene with the reference's loader and BVH builder (and, for c5, its photon pass).
+    Returns the path, or None when the reference binary / scene copy is not on this machine."""
+    p = image_path(name)
+    if os.path.exists(p):
+        return p
+    if not os.path.exists(REF) or not ensure_meshes(name):
+        return None
+    os.makedirs(OUT, exist_ok=True)
+    _run([REF, "flatten"] + scene_flags(name) + ["--out", p])
+    return p
 
 
 def ensure_c3_image():
-    """Flatten the C3 scene with the reference's loader and BVH builder. Returns the path, or None when
-    the reference binary / scene copy is not on this machine."""
-    if os.path.exists(C3["image"]):
-        return C3["image"]
-    if not (os.path.exists(REF) and os.path.exists(os.path.join(SCENES_OUT, "metal_bunnies.json"))
-            and os.path.exists(os.path.join(SCENES_OUT, "data", "bunny.obj"))):
-        return None
-    os.makedirs(OUT, exist_ok=True)
-    _run([REF, "flatten"] + c3_flags() + ["--out", C3["image"]])
-    return C3["image"]
+    return ensure_image("c3")
 
 
 def main(force=False):
+    build_generator()
     spaceship(force)
-    prepare_c3_scene(force)
-    c3_golden(force)
+    for name in CONFIGS:
+        prepare_scene(name)
+        make_golden(name, force)
 
 
 if __name__ == "__main__":
     main(force="--force" in sys.argv)
-    print(ensure_c3_image())
+    for n in sys.argv[1:]:
+        if n in CONFIGS:
+            print(ensure_image(n))
