@@ -35,8 +35,9 @@ struct alignas(64) QBlock {
 constexpr int kQExpBias = 128;
 
 MCRT_HD double qCell(uint32_t e) { return bitsD((unsigned long long)((int)e - kQExpBias + 1023) << 52); }
-// the one decode expression, used by the host builder's verification and by the kernels
-MCRT_HD double qDecode(float origin, uint32_t q, double cell) { return (double)origin + (double)q * cell; }
+// The one decode expression, used by the host builder's verification and by the kernels. q * cell is exact (8 bits
+// times a power of two), so the fused form rounds once, exactly like multiply-then-add would: one instruction.
+MCRT_HD double qDecode(float origin, uint32_t q, double cell) { return fma((double)q, cell, (double)origin); }
 MCRT_HD uint32_t qByte(const QBlock& b, int byte) { return (b.w[4 + byte / 4] >> (8 * (byte % 4))) & 0xFFu; }
 
 template <bool kLds>
