@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (roofline then uses stored counts)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--host-octree", action="store_true", help="build the photon octrees with the host builder instead of the GPU-assisted one")
     ap.add_argument("--emissions", type=float, default=1e6, help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths)")
     args = ap.parse_args()
 
@@ -200,9 +201,11 @@ def main():
             lists.append(ph.cpu().numpy())
         sc = img.scene
         t_build = time.perf_counter()
-        pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200))
+        # octrees: cell codes + radix sort + gather + leaf boxes on the GPU, octant assembly on the host (--host-octree: all on the host)
+        bctx = None if args.host_octree else ctx
+        pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx))
         emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
-                         octree_build_s=time.perf_counter() - t_build,
+                         octree_build_s=time.perf_counter() - t_build, octree_builder="host" if args.host_octree else "gpu",
                          emission_Mray_per_s=emit_info["rays"] / max(emit_info["kernel_ms"], 1e-9) / 1e3)
         ctx.upload_photons(pm_maps[0].desc, pm_maps[1].desc, 50, False)
 

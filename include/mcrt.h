@@ -264,6 +264,13 @@ int mcrt_image_save(const char* path, const mcrt_scene_desc* scene, const mcrt_c
 typedef struct mcrt_photon_map mcrt_photon_map; /* opaque; owns the arrays its descriptor points into */
 int  mcrt_photon_map_build(const float* photons, uint64_t num_photons, const double bb_min[3], const double bb_max[3],
                            uint32_t max_photons_per_leaf, mcrt_photon_map** out);
+/* The same tree (same octants, boxes and photons per leaf; photons of a leaf in cell-code order instead of input
+ * order) built with the GPU of `ctx`: per-photon octant path codes, radix sort, gather and leaf boxes on the device,
+ * octant assembly from the sorted codes on the host (replaces the serial insert loop of
+ * PhotonMapper::PhotonMapper, photon-mapper.cpp:169-203, and LinearOctree's compaction, linear-octree.cpp:202-244).
+ * Falls back to mcrt_photon_map_build when more than max_photons_per_leaf photons share one 2^-21 cell. */
+int  mcrt_photon_map_build_gpu(mcrt_ctx* ctx, const float* photons, uint64_t num_photons, const double bb_min[3],
+                               const double bb_max[3], uint32_t max_photons_per_leaf, mcrt_photon_map** out);
 const mcrt_photon_map_desc* mcrt_photon_map_get(const mcrt_photon_map* map);
 void mcrt_photon_map_free(mcrt_photon_map* map);
 

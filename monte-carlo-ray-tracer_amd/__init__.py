@@ -147,6 +147,7 @@ def lib():
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
     L.mcrt_photon_map_build.argtypes = [_fp, C.c_uint64, _dp, _dp, C.c_uint32, C.POINTER(vp)]
+    L.mcrt_photon_map_build_gpu.argtypes = [vp, _fp, C.c_uint64, _dp, _dp, C.c_uint32, C.POINTER(vp)]
     L.mcrt_photon_map_get.argtypes = [vp]
     L.mcrt_photon_map_get.restype = C.POINTER(PhotonMapDesc)
     L.mcrt_photon_map_free.argtypes = [vp]
@@ -212,17 +213,33 @@ class SceneImage:
 
 
 class PhotonMap:
-    """mcrt_photon_map: linear photon octree built on the host from a photon list (mcrt_photon_map_build)."""
+    """mcrt_photon_map: linear photon octree built from a photon list — on the host (mcrt_photon_map_build) or,
+    given a Context, with its GPU (mcrt_photon_map_build_gpu: cell codes, radix sort, gather, leaf boxes)."""
 
-    def __init__(self, photons, bb_min, bb_max, max_photons_per_leaf=200):
+    def __init__(self, photons, bb_min, bb_max, max_photons_per_leaf=200, ctx=None):
         self._lib = lib()
         self._h = C.c_void_p()
         ph = np.ascontiguousarray(photons, dtype=np.float32).reshape(-1, 8)
         lo = (C.c_double * 3)(*bb_min)
         hi = (C.c_double * 3)(*bb_max)
-        rc = self._lib.mcrt_photon_map_build(_ptr(ph, C.c_float), ph.shape[0], lo, hi, int(max_photons_per_leaf), C.byref(self._h))
-        if rc != 0:
-            raise McrtError("mcrt_photon_map_build failed: %d" % rc)
+        if ctx is None:
+            rc = self._lib.mcrt_photon_map_build(_ptr(ph, C.c_float), ph.shape[0], lo, hi, int(max_photons_per_leaf), C.byref(self._h))
+            if rc != 0:
+                raise McrtError("mcrt_photon_map_build failed: %d" % rc)
+        else:
+            ctx._check(self._lib.mcrt_photon_map_build_gpu(ctx._h, _ptr(ph, C.c_float), ph.shape[0], lo, hi, int(max_photons_per_leaf),
+                                                           C.byref(self._h)), "mcrt_photon_map_build_gpu")
+
+    def arrays(self):
+        """The descriptor as numpy copies: dict(bounds[n,6], start[n], contained[n], next[n], leaf[n], photons[m,8])."""
+        d = self.desc
+        n, m = d.num_octants, d.num_photons
+
+        def grab(ptr, count, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True) if count else np.zeros(0, dtype)
+        return dict(bounds=grab(d.octant_bounds, n * 6, np.float64).reshape(n, 6), start=grab(d.octant_start_data, n, np.uint64),
+                    contained=grab(d.octant_contained_data, n, np.uint64), next=grab(d.octant_next_sibling, n, np.uint32),
+                    leaf=grab(d.octant_leaf, n, np.uint8), photons=grab(d.photons, m * 8, np.float32).reshape(m, 8))
 
     @property
     def desc(self):

@@ -28,6 +28,7 @@
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_layout.hpp"
+#include "mcrt_internal.hpp"
 
 using namespace mcrt;
 
@@ -2161,3 +2162,8 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
 }
 
 }  // extern "C"
+
+namespace mcrt {
+int ctxDevice(const mcrt_ctx* ctx) { return ctx->device; }
+int ctxFail(mcrt_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
+}  // namespace mcrt

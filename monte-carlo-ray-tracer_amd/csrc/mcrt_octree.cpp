@@ -10,16 +10,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/mcrt.h"
-
-struct mcrt_photon_map {
-    std::vector<double> bounds;
-    std::vector<uint64_t> start, contained;
-    std::vector<uint32_t> next;
-    std::vector<uint8_t> leaf;
-    std::vector<float> photons;
-    mcrt_photon_map_desc desc;
-};
+#include "mcrt_octree_shared.hpp"
 
 namespace {
 
@@ -42,7 +33,7 @@ struct Builder {
         M->bounds.resize(M->bounds.size() + 6);
         double bb[6] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308,
                         -1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
-        const bool is_leaf = idx.size() <= max_node_data || depth > 60;
+        const bool is_leaf = idx.size() <= max_node_data || depth > mcrt::kMaxOctreeDepth;
         uint64_t contained = 0;
         if (is_leaf) {
             for (uint64_t i : idx) {
@@ -108,7 +99,6 @@ int mcrt_photon_map_build(const float* photons, uint64_t num_photons, const doub
                           uint32_t max_photons_per_leaf, mcrt_photon_map** out) {
     if (!out || (num_photons && !photons) || !bb_min || !bb_max || max_photons_per_leaf == 0) return MCRT_ERR_INVALID;
     mcrt_photon_map* M = new mcrt_photon_map();
-    memset(&M->desc, 0, sizeof(M->desc));
     if (num_photons) {
         M->photons.reserve((size_t)num_photons * 8);
         std::vector<uint64_t> idx(num_photons);
@@ -122,14 +112,7 @@ int mcrt_photon_map_build(const float* photons, uint64_t num_photons, const doub
         double bb[6];
         b.compact(idx, root, true, 0, bb);
     }
-    M->desc.num_octants = (uint32_t)M->start.size();
-    M->desc.octant_bounds = M->bounds.data();
-    M->desc.octant_start_data = M->start.data();
-    M->desc.octant_contained_data = M->contained.data();
-    M->desc.octant_next_sibling = M->next.data();
-    M->desc.octant_leaf = M->leaf.data();
-    M->desc.num_photons = M->photons.size() / 8;
-    M->desc.photons = M->photons.data();
+    mcrt::finishMapDesc(M);
     *out = M;
     return MCRT_OK;
 }

@@ -76,6 +76,10 @@ def emu():
     L.emu_render_sm.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
     L.emu_render_wf.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.emu_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]
+    L.emu_octree_build.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.emu_octree_desc.argtypes = [vp]
+    L.emu_octree_desc.restype = vp
+    L.emu_octree_free.argtypes = [vp]
     L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L
@@ -121,6 +125,20 @@ def check_hits_against_reference(oracle, img, kat_dir, t, surf, uv):
     np.testing.assert_array_equal(uv[same], uv_ref[same])
     assert len(diff) <= max(3, len(t) // 500)
     return len(diff)
+
+
+def assert_same_octree(a, b):
+    """Two photon maps (PhotonMap.arrays() dicts) are the same tree: identical octant arrays, and in every leaf the same
+    photons (compared as sets of 32-byte records: the order inside a leaf is builder specific and no query depends on it)."""
+    for k in ("bounds", "start", "contained", "next", "leaf"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["photons"].shape == b["photons"].shape
+    pa, pb = a["photons"].view(np.uint32), b["photons"].view(np.uint32)  # bit patterns: NaN-safe, -0.0 != 0.0
+    for i in np.nonzero(a["leaf"])[0]:
+        s, n = int(a["start"][i]), int(a["contained"][i])
+        ra = np.sort(np.ascontiguousarray(pa[s:s + n]).view("V32").ravel())
+        rb = np.sort(np.ascontiguousarray(pb[s:s + n]).view("V32").ravel())
+        assert ra.tobytes() == rb.tobytes(), "leaf %d holds different photons" % i
 
 
 def sort_by_key(photons, keys):

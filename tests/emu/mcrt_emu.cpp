@@ -14,6 +14,7 @@
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_octree_shared.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_qbvh.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 
@@ -444,6 +445,58 @@ int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start,
     }
     return cnt.overflow ? -100 : 0;
 }
+
+// mcrt_photon_map_build_gpu with its device steps done on the host: the same per-photon cell code
+// (photonCellCode), a stable sort standing in for the radix sort, the same assembler, the leaf boxes by a plain loop.
+// Returns 1 when the builder would fall back to the recursive host builder (cell deeper than the codes).
+int emu_octree_build(const float* photons, uint64_t n, const double* bb_min, const double* bb_max, uint32_t max_per_leaf,
+                     mcrt_photon_map** out) {
+    mcrt_photon_map* M = new mcrt_photon_map();
+    if (n == 0) {
+        finishMapDesc(M);
+        *out = M;
+        return 0;
+    }
+    std::vector<unsigned long long> code(n);
+    std::vector<uint32_t> index(n);
+    for (uint64_t i = 0; i < n; i++) {
+        code[i] = photonCellCode(photons + i * 8, bb_min, bb_max);
+        index[i] = (uint32_t)i;
+    }
+    std::stable_sort(index.begin(), index.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    std::vector<unsigned long long> keys(n);
+    M->photons.resize(n * 8);
+    for (uint64_t i = 0; i < n; i++) {
+        keys[i] = code[index[i]];
+        memcpy(&M->photons[i * 8], photons + (size_t)index[i] * 8, 32);
+    }
+    OctreeAssembler A;
+    A.keys = keys.data();
+    A.max_node_data = max_per_leaf;
+    A.M = M;
+    A.node(0, n, 0, true, 0xFFFFFFFFu);
+    M->bounds.assign(M->start.size() * 6, 0.0);
+    for (uint32_t l : A.leaves) {
+        double* bb = &M->bounds[(size_t)l * 6];
+        for (int c = 0; c < 3; c++) {
+            bb[c] = 1.7976931348623157e308;
+            bb[3 + c] = -1.7976931348623157e308;
+        }
+        for (uint64_t i = M->start[l]; i < M->start[l] + M->contained[l]; i++)
+            for (int c = 0; c < 3; c++) {
+                const double v = (double)M->photons[i * 8 + 3 + c];
+                if (bb[c] > v) bb[c] = v;
+                if (bb[3 + c] < v) bb[3 + c] = v;
+            }
+    }
+    A.mergeBounds();
+    finishMapDesc(M);
+    *out = M;
+    return A.too_deep ? 1 : 0;
+}
+
+const mcrt_photon_map_desc* emu_octree_desc(const mcrt_photon_map* m) { return &m->desc; }
+void emu_octree_free(mcrt_photon_map* m) { delete m; }
 
 void emu_sampler(uint32_t global_seed, uint32_t pixel, uint32_t index, uint32_t shuffles, double* out) {
     static std::vector<uint32_t> tab;

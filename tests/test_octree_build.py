@@ -1,0 +1,132 @@
+"""Photon-octree builders. mcrt_photon_map_build is the reference's tree
+(tests/test_photon_emission.py checks it against LinearOctree<Photon> dumps); here the GPU-assisted builder's
+algorithm — per-photon cell codes, sort, octants from code prefixes, leaf boxes — must give that same tree:
+on the host build of its code (always) and on the device (-m gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_same_octree, golden_path
+
+
+def _clouds():
+    rng = np.random.default_rng(5)
+    lo, hi = np.array([-2.0, -1.0, -3.0]), np.array([2.5, 3.0, 1.0])
+
+    def photons(pos):
+        ph = rng.random((len(pos), 8)).astype(np.float32)
+        ph[:, 3:6] = pos.astype(np.float32)
+        return ph
+    uniform = lo + (hi - lo) * rng.random((30000, 3))
+    # caustic-like: most photons in a few tight clusters, some exactly coincident, some on cell centres
+    centres = lo + (hi - lo) * rng.random((6, 3))
+    clustered = np.concatenate([c + 1e-3 * rng.normal(size=(6000, 3)) for c in centres] + [uniform[:4000]])
+    clustered = np.clip(clustered, lo, hi)
+    coincident = np.concatenate([np.repeat(uniform[:7], 150, axis=0), uniform[:500], np.tile((lo + hi) / 2, (180, 1))])
+    return [("uniform", photons(uniform), lo, hi, 200), ("clustered", photons(clustered), lo, hi, 200),
+            ("tiny-leaves", photons(uniform[:5000]), lo, hi, 3), ("coincident", photons(coincident), lo, hi, 200),
+            ("single", photons(uniform[:1]), lo, hi, 200)]
+
+
+class EmuMap:
+    def __init__(self, emu, pkg, ph, lo, hi, cap):
+        self.emu, self.h = emu, C.c_void_p()
+        self.rc = emu.emu_octree_build(ph.ctypes.data, ph.shape[0], (C.c_double * 3)(*lo), (C.c_double * 3)(*hi), cap, C.byref(self.h))
+        self.desc = C.cast(emu.emu_octree_desc(self.h), C.POINTER(pkg.PhotonMapDesc)).contents
+
+    def arrays(self, pkg):
+        d = self.desc
+        n, m = d.num_octants, d.num_photons
+
+        def grab(ptr, count, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True) if count else np.zeros(0, dtype)
+        return dict(bounds=grab(d.octant_bounds, n * 6, np.float64).reshape(n, 6), start=grab(d.octant_start_data, n, np.uint64),
+                    contained=grab(d.octant_contained_data, n, np.uint64), next=grab(d.octant_next_sibling, n, np.uint32),
+                    leaf=grab(d.octant_leaf, n, np.uint8), photons=grab(d.photons, m * 8, np.float32).reshape(m, 8))
+
+    def close(self):
+        self.emu.emu_octree_free(self.h)
+
+
+@pytest.mark.parametrize("case", _clouds(), ids=lambda c: c[0])
+def test_code_sort_assembly_gives_the_reference_tree(pkg, emu, case):
+    name, ph, lo, hi, cap = case
+    host = pkg.PhotonMap(ph, lo, hi, cap)
+    e = EmuMap(emu, pkg, ph, lo, hi, cap)
+    assert e.rc == 0  # "coincident": 150 photons at one point / 180 on a cell centre fit a leaf of 200
+    assert_same_octree(host.arrays(), e.arrays(pkg))
+    e.close()
+    host.close()
+
+
+def test_cells_deeper_than_the_codes_are_reported(pkg, emu):
+    """More photons than a leaf holds inside one 2^-21 cell: the code-based assembly cannot split them (the recursive
+    host builder goes on to depth 60); the builder must notice so that mcrt_photon_map_build_gpu can fall back."""
+    rng = np.random.default_rng(6)
+    lo, hi = np.zeros(3), np.ones(3)
+    pos = np.full((50, 3), 0.3) + 1e-9 * rng.random((50, 3))
+    ph = rng.random((50, 8)).astype(np.float32)
+    ph[:, 3:6] = pos.astype(np.float32)
+    e = EmuMap(emu, pkg, ph, lo, hi, 8)
+    assert e.rc == 1
+    e.close()
+
+
+def test_golden_photon_map_rebuilt(pkg, emu, manifest):
+    """The reference's own caustic map of the photon-mapped golden case: rebuilding it from its photon list with the
+    code/sort/assemble algorithm returns the reference's octants."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    for which in (0, 1):
+        d = img.photons(which)
+        n = d.num_photons
+        ph = np.ctypeslib.as_array(d.photons, shape=(n * 8,)).reshape(n, 8).copy()
+        s = img.scene
+        e = EmuMap(emu, pkg, ph, s.bb_min[:], s.bb_max[:], 200)
+        a = e.arrays(pkg)
+        assert e.rc == 0 and a["bounds"].shape[0] == d.num_octants
+        np.testing.assert_array_equal(a["bounds"].ravel(), np.ctypeslib.as_array(d.octant_bounds, shape=(d.num_octants * 6,)))
+        np.testing.assert_array_equal(a["contained"], np.ctypeslib.as_array(d.octant_contained_data, shape=(d.num_octants,)))
+        np.testing.assert_array_equal(a["next"], np.ctypeslib.as_array(d.octant_next_sibling, shape=(d.num_octants,)))
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _clouds(), ids=lambda c: c[0])
+def test_gpu_builder_gives_the_reference_tree(pkg, case):
+    name, ph, lo, hi, cap = case
+    ctx = pkg.Context(0)
+    host = pkg.PhotonMap(ph, lo, hi, cap)
+    dev = pkg.PhotonMap(ph, lo, hi, cap, ctx=ctx)
+    assert_same_octree(host.arrays(), dev.arrays())
+    dev.close()
+    host.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_builder_on_emitted_photons(pkg, manifest):
+    """1e6 emission paths of the photon-mapped golden scene: emitted on the GPU, both maps built by both builders,
+    identical trees; a render with the GPU-built maps equals the render with the host-built ones bit for bit."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    em = ctx.emit_photons(1e5, 10.0, manifest["seed"])
+    s = img.scene
+    frames = []
+    for use_gpu in (False, True):
+        maps = [pkg.PhotonMap(em[k][0], s.bb_min[:], s.bb_max[:], 200, ctx=ctx if use_gpu else None) for k in ("global_", "caustic")]
+        frames.append((maps, None))
+    for a, b in zip(frames[0][0], frames[1][0]):
+        assert_same_octree(a.arrays(), b.arrays())
+    cam = img.camera
+    cam.width, cam.height, cam.sqrtspp = 96, 72, 2
+    outs = []
+    for maps, _ in frames:
+        ctx.upload_photons(maps[0].desc, maps[1].desc, 50, False)
+        out, _ = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        outs.append(out)
+    # same k nearest sets; photons of a leaf arrive in another order, so equal-distance ties and the summation order
+    # inside an estimate may differ in the last bits
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-12 * max(1.0, np.abs(outs[0]).max())
+    ctx.close()
