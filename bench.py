@@ -292,6 +292,8 @@ def main():
             # (DESIGN.md "Measurement"); used when the CPU leg is skipped (N > 1)
             counts = {"spaceship": dict(node_per_ray=33.44, tri_per_ray=6.96, sphere_per_ray=0.0),
                       "c3": dict(node_per_ray=46.28, tri_per_ray=7.17, sphere_per_ray=0.02),
+                      "c4": dict(node_per_ray=71.99, tri_per_ray=14.22, sphere_per_ray=0.0),
+                      "c5": dict(node_per_ray=45.05, tri_per_ray=7.28, sphere_per_ray=0.0),
                       "pm": dict(node_per_ray=14.34, tri_per_ray=9.30, sphere_per_ray=7.40),
                       }.get(args.workload, dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31))
         b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
