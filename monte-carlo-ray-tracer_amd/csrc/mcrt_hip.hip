@@ -249,10 +249,9 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
 // ------------------------------------------------------------------------------------------------
 __device__ inline uint32_t laneId() { return __lane_id(); }
 
-__device__ inline unsigned long long waveBroadcast64(unsigned long long v, int src) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl(lo, src, 64);
-    hi = __shfl(hi, src, 64);
+__device__ inline unsigned long long waveBroadcast64(unsigned long long v, int src) {  // src wave-uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -1252,6 +1251,7 @@ struct mcrt_ctx {
     PhotonMapView maps[2]{};
     DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2];
     const ChildRec* map_children_ptr[2] = {nullptr, nullptr};
+    uint32_t map_root_contained[2] = {0, 0}, map_root_leaf[2] = {0, 0};
     uint32_t k_nearest = 50;
     int direct_visualization = 0;
 
@@ -1333,6 +1333,15 @@ int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
         ctx->knn_k = k;
     }
     return MCRT_OK;
+}
+
+PhotonMapViewW waveMapView(const mcrt_ctx* ctx, int which) {
+    PhotonMapViewW v;
+    v.base = ctx->maps[which];
+    v.octant_children = ctx->map_children_ptr[which];
+    v.root_contained = ctx->map_root_contained[which];
+    v.root_leaf = ctx->map_root_leaf[which];
+    return v;
 }
 
 int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
@@ -1596,10 +1605,8 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (use_pm_wave) {
         PmExtra pmx;
-        pmx.global_map.base = ctx->maps[0];
-        pmx.global_map.octant_children = ctx->map_children_ptr[0];
-        pmx.caustic_map.base = ctx->maps[1];
-        pmx.caustic_map.octant_children = ctx->map_children_ptr[1];
+        pmx.global_map = waveMapView(ctx, 0);
+        pmx.caustic_map = waveMapView(ctx, 1);
         hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
     } else {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
@@ -1647,11 +1654,15 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
                 memcpy(r.b, m->octant_bounds + (size_t)c * 6, 48);
                 r.octant = c;
                 r.contained = contained[c];
+                r.start = (uint32_t)m->octant_start_data[c];
+                r.leaf = m->octant_leaf[c] ? 1u : 0u;
                 c = m->octant_next_sibling[c];
             }
         }
         if (int rc = uploadArray(ctx, ctx->map_children[which], children.data(), children.size())) return rc;
         ctx->map_children_ptr[which] = ctx->map_children[which].as<ChildRec>();
+        ctx->map_root_contained[which] = contained[0];
+        ctx->map_root_leaf[which] = m->octant_leaf[0] ? 1u : 0u;
     }
     v.num_octants = m->num_octants;
     v.num_photons = m->num_photons;
@@ -2122,9 +2133,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         HIP_TRY(ctx, dd.alloc(n * k * 8));
         HIP_TRY(ctx, flags.alloc(8));
         HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
-        PhotonMapViewW mv;
-        mv.base = ctx->maps[which];
-        mv.octant_children = ctx->map_children_ptr[which];
+        const PhotonMapViewW mv = waveMapView(ctx, which);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + 3) / 4);
         hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
                            di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());

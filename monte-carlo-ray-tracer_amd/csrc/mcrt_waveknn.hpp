@@ -23,6 +23,7 @@
 #pragma once
 
 #include "mcrt_integrator.hpp"
+#include "mcrt_lanesm.hpp"
 
 #if defined(__HIPCC__)
 
@@ -41,19 +42,22 @@ struct ChildRec {
     double b[6];
     uint32_t octant;     // 0xFFFFFFFF: no child in this slot
     uint32_t contained;
-    uint32_t pad0, pad1;
+    uint32_t start;      // first photon of the child's subtree
+    uint32_t leaf;       // 1: the child is a leaf
 };
 
 struct PhotonMapViewW {
     PhotonMapView base;
     const ChildRec* octant_children;  // [n][8]
+    uint32_t root_contained, root_leaf;
 };
 
+// Broadcast from lane `src` (wave-uniform): v_readlane, no LDS round trip.
 __device__ inline double waveShflD(double v, int src) {
-    union { double d; unsigned u[2]; } c;
+    union { double d; int u[2]; } c;
     c.d = v;
-    c.u[0] = __shfl(c.u[0], src, 64);
-    c.u[1] = __shfl(c.u[1], src, 64);
+    c.u[0] = __builtin_amdgcn_readlane(c.u[0], src);
+    c.u[1] = __builtin_amdgcn_readlane(c.u[1], src);
     return c.d;
 }
 __device__ inline d3 waveShfl3(d3 v, int src) { return d3{waveShflD(v.x, src), waveShflD(v.y, src), waveShflD(v.z, src)}; }
@@ -68,16 +72,56 @@ __device__ inline double waveMinD(double v) {
     }
     return v;
 }
+// Wave-wide FP64 sum through the DPP cross-lane network (pairs in quads, half rows, rows, then the four rows into
+// lane 63). Lanes outside a step's row mask add 0.
+#define MCRT_DPP_ADD_F64(v, ctrl, row_mask)                                               \
+    do {                                                                                  \
+        union { double d; int u[2]; } a_, b_;                                             \
+        a_.d = (v);                                                                       \
+        b_.u[0] = __builtin_amdgcn_update_dpp(0, a_.u[0], ctrl, row_mask, 0xF, false);    \
+        b_.u[1] = __builtin_amdgcn_update_dpp(0, a_.u[1], ctrl, row_mask, 0xF, false);    \
+        (v) = (v) + b_.d;                                                                 \
+    } while (0)
 __device__ inline double waveSumD(double v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        union { double d; unsigned u[2]; } c;
-        c.d = v;
-        c.u[0] = __shfl_xor(c.u[0], off, 64);
-        c.u[1] = __shfl_xor(c.u[1], off, 64);
-        v = v + c.d;
-    }
-    return v;
+    MCRT_DPP_ADD_F64(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    MCRT_DPP_ADD_F64(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    MCRT_DPP_ADD_F64(v, 0x141, 0xF);  // row_half_mirror
+    MCRT_DPP_ADD_F64(v, 0x140, 0xF);  // row_mirror
+    MCRT_DPP_ADD_F64(v, 0x142, 0xA);  // row_bcast15 -> rows 1, 3
+    MCRT_DPP_ADD_F64(v, 0x143, 0xC);  // row_bcast31 -> rows 2, 3
+    union { double d; int u[2]; } c;
+    c.d = v;
+    c.u[0] = __builtin_amdgcn_readlane(c.u[0], 63);
+    c.u[1] = __builtin_amdgcn_readlane(c.u[1], 63);
+    return c.d;
 }
+
+// Wave-wide minimum of a u32 through the DPP cross-lane network (no LDS round trips, unlike __shfl): swap within
+// quads, mirror within half rows and rows, then fold the four rows of 16 into lane 63.
+__device__ inline uint32_t waveMinU32(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
+    v = t < v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Non-negative floats order like their bit patterns.
+__device__ inline float waveMinPosF(float v) { return bitsFloat(waveMinU32(floatBits(v))); }
+__device__ inline float floatAbove(double t) {  // smallest float >= t (t >= 0)
+    float f = (float)t;
+    if ((double)f < t) f = bitsFloat(floatBits(f) + 1u);
+    return f;
+}
+__device__ inline uint32_t waveRead(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }  // src wave-uniform
 
 // Keep the k smallest of the first `count` buffer entries, compacted (unordered) into slots [0, k);
 // returns min(count, k) and, in kth_d2, the largest distance kept. Exact selection by a bitwise radix
@@ -88,6 +132,7 @@ __device__ inline double waveSumD(double v) {
 // All lanes must call.
 __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
     const uint32_t lane = __lane_id();
+    const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
     unsigned long long key[4];
     uint32_t my_i[4];
     bool valid[4];
@@ -111,10 +156,11 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
     }
     // T = the k-th smallest key: smallest T with #{key <= T} >= k, built from the top bit down
     unsigned long long T = 0ull;
-    for (int bit = 63; bit >= 0; bit--) {
+    for (int bit = 62; bit >= 0; bit--) {  // bit 63 (sign) is clear in every key
         const unsigned long long trial = T | ((1ull << bit) - 1ull);  // all candidates with this bit clear
         uint32_t n_le = 0;
-        for (int s = 0; s < 4; s++) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
+        for (int s = 0; s < 4; s++)
+            if (s < rows) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
         if (n_le < k) T |= (1ull << bit);
     }
     uint32_t n_lt = 0;
@@ -146,6 +192,54 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
     return k;
 }
 
+// Pruning only needs AN upper bound of the k-th smallest distance, and room in the buffer: the same radix search
+// stopped after the top `kCoarseBits` bits gives T = (prefix of the k-th key) | (all lower bits set) >= k-th key.
+// Every entry <= T is kept (at least k, plus the few that share the k-th key's prefix: 8 mantissa bits = 0.4 %
+// in distance2), the rest can never be among the k nearest. 19 wave-uniform steps instead of 63; the exact
+// selection runs once, at the end of the search. Returns the new count; all lanes must call.
+constexpr int kCoarseBits = 20;
+__device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2) {
+    const uint32_t lane = __lane_id();
+    const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
+    unsigned long long key[4];
+    uint32_t my_i[4];
+    bool valid[4];
+    for (int s = 0; s < 4; s++) {
+        const uint32_t j = lane + 64u * s;
+        valid[s] = j < count;
+        union { double d; unsigned long long u; } c;
+        c.d = valid[s] ? W.d2[j] : 0.0;
+        key[s] = c.u;
+        my_i[s] = valid[s] ? W.idx[j] : 0xFFFFFFFFu;
+    }
+    unsigned long long T = 0ull;
+    for (int bit = 62; bit >= 64 - kCoarseBits; bit--) {  // bit 63 (sign) is clear in every key
+        const unsigned long long trial = T | ((1ull << bit) - 1ull);
+        uint32_t n_le = 0;
+        for (int s = 0; s < 4; s++)
+            if (s < rows) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
+        if (n_le < k) T |= (1ull << bit);
+    }
+    T |= (1ull << (64 - kCoarseBits)) - 1ull;
+    uint32_t out = 0;
+    for (int s = 0; s < 4; s++) {
+        const bool keep = valid[s] && key[s] <= T;
+        const unsigned long long m_keep = __ballot(keep);
+        if (keep) {
+            const uint32_t slot = out + __popcll(m_keep & ((1ull << lane) - 1ull));
+            union { double d; unsigned long long u; } c;
+            c.u = key[s];
+            W.d2[slot] = c.d;
+            W.idx[slot] = my_i[s];
+        }
+        out += __popcll(m_keep);
+    }
+    union { double d; unsigned long long u; } c;
+    c.u = T;
+    bound_d2 = c.d;
+    return out;
+}
+
 // Sort the first n (<= 64 per pass) result entries ascending by (distance2, index) in place (n <= 128).
 __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
     const uint32_t lane = __lane_id();
@@ -173,6 +267,12 @@ __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
 
 // k-NN of point p (wave-uniform) in `map`. On return the buffer holds the result (unordered) in slots
 // [0, n) and r2_max the largest of its distances; returns n. All 64 lanes must call with the same arguments.
+//
+// A frontier entry carries everything the visit of its octant needs — {distance2, a, b}: scannable octant (leaf,
+// or <= k photons, linear-octree.cpp:51) a = first photon, b = 0x80000000 | count; inner octant a = octant index —
+// so that popping an octant costs no memory access and a visit is ONE round trip (its 8 child records, or its
+// photons). The 8 lanes that test the children rotate with the step number and drop the children they keep into
+// their own two frontier slots; only when a lane's slots are both taken does the wave look for a free slot elsewhere.
 __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
                                          uint32_t& overflow, uint32_t& octant_visits) {
     r2_max = 0.0;
@@ -181,19 +281,22 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     if ((uint64_t)k > m.num_photons) k = (uint32_t)m.num_photons;
     if (k == 0) return 0;
     const uint32_t lane = __lane_id();
-    // frontier: two (distance2, octant) entries per lane; octant == none marks a free slot
-    double f_d2[2] = {INFINITY, INFINITY};
-    uint32_t f_oct[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    constexpr uint32_t kNone = 0xFFFFFFFFu, kScan = 0x80000000u;
+    // distances in the frontier are rounded DOWN to float: they only order the visits and end the search, and a
+    // smaller key can only postpone the end (linear-octree.cpp:113 stays conservative)
+    float f_d2[2] = {INFINITY, INFINITY};
+    uint32_t f_a[2] = {kNone, kNone}, f_b[2] = {0u, 0u};  // b == 0 marks a free slot (an inner entry has b = 1)
     double max_distance2 = kDblMax;
     uint32_t count = 0;
-    bool dirty = false;  // candidates appended since the buffer was last reduced to the k best
-    bool exact = false;  // max_distance2 has been tightened to an exact k-th distance at least once
-    uint32_t cur = 0;    // root
-    for (;;) {
+    bool dirty = false;    // candidates appended since the buffer was last reduced
+    bool bounded = false;  // max_distance2 has been tightened to a k-photon radius at least once
+    // root
+    uint32_t cur_a = (map.root_leaf || map.root_contained <= k) ? 0u : 0u;
+    uint32_t cur_b = (map.root_leaf || map.root_contained <= k) ? (kScan | map.root_contained) : 1u;
+    for (uint32_t step = 0;; step++) {
         octant_visits++;
-        const uint32_t contained = m.octant_contained[cur];
-        if (m.octant_leaf[cur] || contained <= k) {
-            const uint32_t start = m.octant_start[cur];
+        if (cur_b & kScan) {
+            const uint32_t start = cur_a, contained = cur_b & ~kScan;
             // 4 x 64 photons per round trip: the four position loads of a lane are issued together
             for (uint32_t base = 0; base < contained; base += 256) {
                 float px[4], py[4], pz[4];
@@ -220,68 +323,76 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         }
                         count += __popcll(mask);
                         dirty = true;
-                        if (count > kWaveCand - 64u) {
-                            double kth;
-                            count = waveSelectK(W, count, k, kth);
+                        if (count > kWaveCand - 64u) {  // make room: drop what cannot be among the k nearest
+                            double bound;
+                            count = waveSelectBound(W, count, k, bound);
+                            if (count > kWaveCand - 64u) count = waveSelectK(W, count, k, bound);  // a crowd inside 0.4 %
                             dirty = false;
-                            if (count == k) {
-                                max_distance2 = gmin(max_distance2, kth);
-                                exact = true;
-                            }
+                            bounded = true;
+                            max_distance2 = gmin(max_distance2, bound);
                         }
                     }
                 }
             }
-            // The k-th best so far bounds the answer (linear-octree.cpp:79). The exact k-th distance is
-            // taken once, as soon as k candidates exist (it shrinks the bound from an octant diagonal to
-            // the k-photon radius); afterwards only when the buffer fills, since every later candidate
-            // already lies within that radius.
-            if (dirty && count >= k && !exact) {
-                double kth;
-                count = waveSelectK(W, count, k, kth);
+            // The k-th best so far bounds the answer (linear-octree.cpp:79): taken once, as soon as k candidates
+            // exist (it shrinks the bound from an octant diagonal to the k-photon radius); afterwards only when
+            // the buffer fills, since every later candidate already lies within that radius.
+            if (dirty && count >= k && !bounded) {
+                double bound;
+                count = waveSelectBound(W, count, k, bound);
                 dirty = false;
-                exact = true;
-                max_distance2 = gmin(max_distance2, kth);
+                bounded = true;
+                max_distance2 = gmin(max_distance2, bound);
             }
         } else {
-            // children: lanes 0..7 take one child each
-            uint32_t child = 0xFFFFFFFFu;
-            double cd2 = INFINITY;
+            // children: this step's 8 lanes take one child each
+            const uint32_t g = (step & 7u) * 8u;
+            const bool tester = lane >= g && lane < g + 8u;
+            float cd2 = INFINITY, corner = INFINITY;
+            uint32_t ca = kNone, cb = 0u;
             bool push = false;
-            double corner = kDblMax;
-            if (lane < 8) {
-                const ChildRec* cr = map.octant_children + (size_t)cur * 8 + lane;
-                double cb[6];
-                for (int c = 0; c < 6; c++) cb[c] = cr->b[c];
-                child = cr->octant;
-                const uint32_t child_contained = cr->contained;
-                if (child != 0xFFFFFFFFu) {
-                    cd2 = boxDistance2(cb, p);
-                    push = cd2 <= max_distance2;
-                    if (push && child_contained >= k) corner = boxMaxDistance2(cb, p);  // linear-octree.cpp:96-100
+            if (tester) {
+                const ChildRec* cr = map.octant_children + (size_t)cur_a * 8 + (lane - g);
+                double bb[6];
+                for (int c = 0; c < 6; c++) bb[c] = cr->b[c];
+                const uint32_t child = cr->octant, child_contained = cr->contained, child_start = cr->start, child_leaf = cr->leaf;
+                if (child != kNone) {
+                    const double d2c = boxDistance2(bb, p);
+                    push = d2c <= max_distance2;
+                    cd2 = floatBelow(d2c);
+                    // linear-octree.cpp:96-100; rounded UP to float: still an upper bound of the k-th distance
+                    if (push && child_contained >= k) corner = floatAbove(boxMaxDistance2(bb, p));
+                    const bool scan = child_leaf != 0u || child_contained <= k;
+                    ca = scan ? child_start : child;
+                    cb = scan ? (kScan | child_contained) : 1u;
                 }
             }
-            const double best_corner = waveMinD(corner);
+            const double best_corner = (double)waveMinPosF(corner);
             if (best_corner < max_distance2) max_distance2 = best_corner;
-            // place the pushed children into free frontier slots
-            unsigned long long pmask = __ballot(push);
+            // keep the pushed children: own slots first
+            if (push && f_b[0] == 0u) {
+                f_d2[0] = cd2; f_a[0] = ca; f_b[0] = cb;
+                push = false;
+            } else if (push && f_b[1] == 0u) {
+                f_d2[1] = cd2; f_a[1] = ca; f_b[1] = cb;
+                push = false;
+            }
+            unsigned long long pmask = __ballot(push);  // (rare) both slots of the tester taken: any free slot of the wave
             while (pmask) {
                 const int src = __ffsll((long long)pmask) - 1;
                 pmask &= pmask - 1;
-                const double d = waveShflD(cd2, src);
-                const uint32_t o = __shfl(child, src, 64);
-                const unsigned long long free0 = __ballot(f_oct[0] == 0xFFFFFFFFu);
+                const float d = bitsFloat(waveRead(floatBits(cd2), src));
+                const uint32_t a = waveRead(ca, src), b = waveRead(cb, src);
+                const unsigned long long free0 = __ballot(f_b[0] == 0u);
                 if (free0) {
                     if ((int)lane == __ffsll((long long)free0) - 1) {
-                        f_d2[0] = d;
-                        f_oct[0] = o;
+                        f_d2[0] = d; f_a[0] = a; f_b[0] = b;
                     }
                 } else {
-                    const unsigned long long free1 = __ballot(f_oct[1] == 0xFFFFFFFFu);
+                    const unsigned long long free1 = __ballot(f_b[1] == 0u);
                     if (free1) {
                         if ((int)lane == __ffsll((long long)free1) - 1) {
-                            f_d2[1] = d;
-                            f_oct[1] = o;
+                            f_d2[1] = d; f_a[1] = a; f_b[1] = b;
                         }
                     } else {
                         overflow = 1;
@@ -290,19 +401,24 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
             }
         }
         // pop the nearest octant of the frontier
-        const double mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
-        const double best = waveMinD(mine);
+        const float mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
+        const float best = waveMinPosF(mine);
         if (!(best < INFINITY)) break;                // frontier empty
-        if (best > max_distance2) break;              // linear-octree.cpp:113
+        if ((double)best > max_distance2) break;      // linear-octree.cpp:113
         const unsigned long long owner = __ballot(mine == best);
         const int ol = __ffsll((long long)owner) - 1;
         const int which = f_d2[0] <= f_d2[1] ? 0 : 1;
-        const uint32_t my_oct = which == 0 ? f_oct[0] : f_oct[1];
-        cur = __shfl(my_oct, ol, 64);
+        cur_a = waveRead(which == 0 ? f_a[0] : f_a[1], ol);
+        cur_b = waveRead(which == 0 ? f_b[0] : f_b[1], ol);
         if ((int)lane == ol) {
-            if (which == 0) { f_d2[0] = INFINITY; f_oct[0] = 0xFFFFFFFFu; }
-            else { f_d2[1] = INFINITY; f_oct[1] = 0xFFFFFFFFu; }
+            if (which == 0) { f_d2[0] = INFINITY; f_b[0] = 0u; }
+            else { f_d2[1] = INFINITY; f_b[1] = 0u; }
         }
+    }
+    // exact selection, once: first shrink to the entries that can still matter, so that it runs on one buffer row
+    if (count > 64u) {
+        double bound;
+        count = waveSelectBound(W, count, k, bound);
     }
     return waveSelectK(W, count, k, r2_max);
 }
@@ -331,16 +447,16 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
         q.n2 = waveShflD(ia.n2, src);
         q.R = waveShflD(ia.R, src);
         q.T = waveShflD(ia.T, src);
-        q.type = __shfl(ia.type, src, 64);
-        q.inside = __shfl((int)ia.inside, src, 64) != 0;
+        q.type = __builtin_amdgcn_readlane(ia.type, src);
+        q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
         {
             // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
             union { cptr<mcrt_material, L> p; unsigned long long u; } c;
             c.u = 0ull;
             c.p = ia.material;
             unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
-            lo = __shfl(lo, src, 64);
-            hi = __shfl(hi, src, 64);
+            lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+            hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
             c.u = ((unsigned long long)hi << 32) | lo;
             q.material = c.p;
         }
