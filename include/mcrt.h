@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MCRT_ABI_VERSION 1u
+#define MCRT_ABI_VERSION 2u
 
 typedef enum mcrt_status {
     MCRT_OK = 0,
@@ -47,7 +47,7 @@ typedef enum mcrt_status {
  * fields the hot path reads.
  * ---------------------------------------------------------------------------------------- */
 
-enum { MCRT_SURF_TRIANGLE = 0, MCRT_SURF_SPHERE = 1 };
+enum { MCRT_SURF_TRIANGLE = 0, MCRT_SURF_SPHERE = 1, MCRT_SURF_QUADRIC = 2 };
 
 /* Material flag bits = the bools of class Material (material/material.hpp:41-44) as they stand
  * AFTER scene construction (scene/scene.cpp:83-89 copies materials without recomputing them). */
@@ -94,7 +94,7 @@ typedef struct mcrt_scene_desc {
     const uint8_t*  surf_interpolate;   /* 1 ⇔ Triangle::N != nullptr (surface/triangle.cpp:56) */
     const uint32_t* surf_material;      /* index into materials                                 */
     const double*   surf_area;          /* Base::area_                                          */
-    const double*   surf_v;             /* [n][9] triangle: v0,v1,v2 · sphere: origin,radius,0… */
+    const double*   surf_v;             /* [n][9] triangle: v0,v1,v2 · sphere: origin,radius,0… · quadric: record index,0… */
     const double*   surf_e;             /* [n][9] triangle: E1,E2,normal_ · sphere: unused      */
     const double*   surf_vn;            /* [n][9] vertex normals N[0..2], or NULL if none       */
 
@@ -108,6 +108,14 @@ typedef struct mcrt_scene_desc {
 
     double scene_ior;                   /* Scene::ior (scene/scene.cpp:22)   */
     double bb_min[3], bb_max[3];        /* Scene::BB()                        */
+
+    /* Surface::Quadric (surface/surface.hpp:99-116, surface/quadric.cpp). One record of 22 doubles per quadric:
+     * Q as glm stores it (column-major: Q[c][r] at 4*c + r; the gradient matrix G is 2 * its upper 3 rows,
+     * quadric.cpp:38-45), then BB_.min, BB_.max — the box that slices the quadric (quadric.cpp:36,72-76,92).
+     * Surface i of kind MCRT_SURF_QUADRIC names its record in surf_v[9*i] (an integer stored as a double).
+     * Quadrics cannot be emissive (scene/scene.cpp:125). */
+    uint32_t num_quadrics;
+    const double*   quadrics;           /* [num_quadrics][22] */
 } mcrt_scene_desc;
 
 /* ------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmcrt_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
@@ -55,6 +55,7 @@ class SceneDesc(C.Structure):
         ("num_materials", C.c_uint32), ("materials", C.POINTER(Material)),
         ("num_lights", C.c_uint32), ("light_surface", _u32p), ("light_cdf", _dp),
         ("scene_ior", C.c_double), ("bb_min", C.c_double * 3), ("bb_max", C.c_double * 3),
+        ("num_quadrics", C.c_uint32), ("quadrics", _dp),
     ]
 
 

@@ -1244,7 +1244,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, qblocks, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, quadrics, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -1763,10 +1763,20 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
+    // quadric records first: the primitive records and surf_v of quadric surfaces carry their device addresses
+    if (L.num_quadric_surfaces) {
+        for (uint32_t i = 0; i < s->num_lights; i++)
+            if (s->surf_kind[s->light_surface[i]] == MCRT_SURF_QUADRIC)
+                return fail(ctx, MCRT_ERR_UNSUPPORTED, "emissive quadrics are not supported (scene/scene.cpp:125)");
+        if (int rc = uploadArray(ctx, ctx->quadrics, s->quadrics, (size_t)s->num_quadrics * 22)) return rc;
+        patchQuadricAddresses(s, L, ctx->quadrics.as<double>());
+    } else {
+        ctx->quadrics.release();
+    }
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
-    if (int rc = uploadArray(ctx, ctx->surf_v, s->surf_v, ns * 9)) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_v, L.num_quadric_surfaces ? L.surf_v_patched.data() : s->surf_v, ns * 9)) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_normal, normal.data(), normal.size())) return rc;
     if (any_vn) {
         if (int rc = uploadArray(ctx, ctx->surf_vn, s->surf_vn, ns * 9)) return rc;
@@ -1829,7 +1839,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     // (scene.cpp:161-173); the closest hit is the same.
     const char* fm = getenv("MCRT_FLAT_MAX");
     const uint32_t flat_max = fm ? (uint32_t)strtoul(fm, nullptr, 0) : 64u;
-    d.flat = (d.stage_all && d.num_surfaces <= flat_max) ? 1u : 0u;
+    d.flat = (d.stage_all && d.num_surfaces <= flat_max && L.num_quadric_surfaces == 0) ? 1u : 0u;  // the flat loop knows triangles and spheres
     ctx->has_scene = true;
     return MCRT_OK;
 }

@@ -19,6 +19,7 @@ struct Chunk {
 };
 
 const char kMagic[8] = {'M', 'C', 'R', 'T', 'I', 'M', 'G', '1'};
+const uint32_t kImageVersion = 1;  // container version (chunks are optional and named; independent of MCRT_ABI_VERSION)
 
 struct ParamKV {
     char key[24];
@@ -113,7 +114,7 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
     uint32_t abi = 0, num_chunks = 0;
     bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0;
     ok = ok && fread(&abi, 4, 1, f) == 1 && fread(&num_chunks, 4, 1, f) == 1;
-    if (!ok || abi != MCRT_ABI_VERSION) {
+    if (!ok || abi != kImageVersion) {
         fclose(f);
         return MCRT_ERR_IO;
     }
@@ -166,6 +167,8 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
             s.bb_max[i] = sc[4 + i];
         }
     }
+    s.quadrics = chunkPtr<double>(img, "quadrics", &n);
+    s.num_quadrics = (uint32_t)(n / 22);
     const mcrt_camera_desc* cam = chunkPtr<mcrt_camera_desc>(img, "camera", &n);
     if (cam && n >= 1) img->camera = *cam;
     else memset(&img->camera, 0, sizeof(img->camera));
@@ -217,7 +220,7 @@ int mcrt_image_save(const char* path, const mcrt_scene_desc* s, const mcrt_camer
     if (!path || !s) return MCRT_ERR_INVALID;
     FILE* f = fopen(path, "wb");
     if (!f) return MCRT_ERR_IO;
-    uint32_t abi = MCRT_ABI_VERSION, zero = 0;
+    uint32_t abi = kImageVersion, zero = 0;
     fwrite(kMagic, 1, 8, f);
     fwrite(&abi, 4, 1, f);
     fwrite(&zero, 4, 1, f);  // chunk count patched below
@@ -240,6 +243,7 @@ int mcrt_image_save(const char* path, const mcrt_scene_desc* s, const mcrt_camer
     double sc[7] = {s->scene_ior, s->bb_min[0], s->bb_min[1], s->bb_min[2],
                     s->bb_max[0], s->bb_max[1], s->bb_max[2]};
     w.put("scene_scalars", sc, sizeof(sc));
+    if (s->num_quadrics) w.put("quadrics", s->quadrics, (size_t)s->num_quadrics * 22 * sizeof(double));
     if (cam) w.put("camera", cam, sizeof(*cam));
     writeMap(w, "g_", global_map);
     writeMap(w, "c_", caustic_map);

@@ -218,7 +218,7 @@ MCRT_HD PrimRec loadPrim(P p) {
     return r;
 }
 MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
-    if (rec.v[9] == 1.0) return primIntersect(rec.v, ray, h);  // sphere (rare in walked BVHs)
+    if (rec.v[9] == 1.0 || rec.v[9] == 3.0) return primIntersect(rec.v, ray, h);  // sphere / quadric (rare in walked BVHs)
     double t, u, v;
     const bool ok = triangleTestFlat(rec.v, ray.start, ray.direction, t, u, v);
     const bool interp = rec.v[9] >= 2.0;

@@ -27,6 +27,8 @@ struct HostLayout {
     std::vector<Node64> nodes64;       // [n] box + meta records, same order as node_bounds
     std::vector<QBlock> qblocks;       // quantised child blocks (mcrt_qbvh.hpp), breadth-first over the inner nodes
     uint32_t q_root_a = 0, q_root_m = 0;
+    uint32_t num_quadric_surfaces = 0;
+    std::vector<double> surf_v_patched;  // surf_v with quadric record addresses (only when the scene has quadrics)
 };
 
 // One axis of one block: origin (float, rounded down), cell exponent and the cell coordinates of every child,
@@ -191,6 +193,8 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
     L.prim.assign(ns * kPrimStride, 0.0);
     L.normal.assign(ns * 3, 0.0);
     L.any_vn = false;
+    L.num_quadric_surfaces = 0;
+    L.surf_v_patched.clear();
     for (size_t i = 0; i < ns; i++) {
         if (s->surf_material[i] >= s->num_materials) {
             err = "surface material index out of range";
@@ -211,8 +215,17 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             }
             L.any_vn = L.any_vn || interp;
             r[9] = interp ? 2.0 : 0.0;
+        } else if (s->surf_kind[i] == MCRT_SURF_QUADRIC) {
+            const double idx = s->surf_v[i * 9];
+            if (!s->quadrics || !(idx >= 0.0) || idx >= (double)s->num_quadrics || idx != (double)(uint32_t)idx) {
+                err = "quadric surface names a record outside the quadrics array";
+                return MCRT_ERR_INVALID;
+            }
+            r[0] = idx;  // replaced by the record's address once its home is known (patchQuadricAddresses)
+            r[9] = 3.0;
+            L.num_quadric_surfaces++;
         } else {
-            err = "unsupported surface kind (only triangles and spheres)";
+            err = "unsupported surface kind";
             return MCRT_ERR_UNSUPPORTED;
         }
     }
@@ -258,6 +271,20 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
         n.pad0 = n.pad1 = 0;
     }
     return buildQBlocks(L, err);
+}
+
+// Quadric surfaces: put the address of each one's record (`records` = where the [n][22] array lives for the code that
+// will read it: device memory for the kernels, host memory for the CPU harness) into its primitive record and into a
+// copy of surf_v.
+inline void patchQuadricAddresses(const mcrt_scene_desc* s, HostLayout& L, const double* records) {
+    if (L.num_quadric_surfaces == 0) return;
+    L.surf_v_patched.assign(s->surf_v, s->surf_v + (size_t)s->num_surfaces * 9);
+    for (size_t i = 0; i < s->num_surfaces; i++)
+        if (s->surf_kind[i] == MCRT_SURF_QUADRIC) {
+            const double slot = quadricSlot(records + (size_t)s->surf_v[i * 9] * 22);
+            L.prim[i * kPrimStride] = slot;
+            L.surf_v_patched[i * 9] = slot;
+        }
 }
 
 }  // namespace mcrt

@@ -179,10 +179,84 @@ MCRT_HD bool boxIntersect(const Box& b, const Ray& ray, double& t) {
     return compMin(hi) >= t;
 }
 
-// Triangle::intersect (triangle.cpp:23-63) / Sphere::intersect (sphere.cpp:13-26) on one record.
+// ---- Surface::Quadric (surface/quadric.cpp). Record = 22 doubles: Q as glm stores it (Q[c][r] at 4c + r), BB_.min,
+// BB_.max. Primitive records and the device copy of surf_v carry the ADDRESS of a quadric's record (64 bits stored
+// in the double's slot; patched in by the host when the records' home is known), so that no view needs another
+// pointer for a primitive kind no BASELINE scene uses.
+MCRT_HD const double* quadricPtr(double slot) { return reinterpret_cast<const double*>((uintptr_t)dBits(slot)); }
+MCRT_HD double quadricSlot(const double* record) { return bitsD((unsigned long long)(uintptr_t)record); }
+
+// solveQuadratic, common/util.hpp:60-83
+MCRT_HD bool solveQuadratic(double a, double b, double c, double& t_min, double& t_max) {
+    if (a != 0.0) {
+        double d = b * b - 4.0 * a * c;
+        if (d < 0.0) return false;
+        double sd = sqrt(d);
+        double t = -0.5 * (b + (b < 0.0 ? -sd : sd));
+        t_min = t / a;
+        t_max = c / t;
+        if (t_min > t_max) {
+            double tmp = t_min;
+            t_min = t_max;
+            t_max = tmp;
+        }
+        return true;
+    }
+    if (b != 0.0) {
+        t_min = t_max = -c / b;
+        return true;
+    }
+    return false;
+}
+
+// Quadric::intersect, quadric.cpp:69-100: clip to the slicing box first, solve transpose(r) Q r = 0 from the box
+// entry point. glm::dmat4 * dvec4 adds its four column products pairwise, (c0 + c1) + (c2 + c3), and so does the
+// dvec4 dot (lib/glm/glm/detail/type_mat4x4.inl:561-573, func_geometric.inl:58-65).
+MCRT_HD bool quadricIntersect(const double* q, const Ray& ray, Hit& out) {
+    Box bb;
+    for (int k = 0; k < 6; k++) bb.v[k] = q[16 + k];
+    double t_bb = 0.0;
+    if (!boxIntersect<false>(bb, ray, t_bb)) return false;
+    const d3 o = ray.start + ray.direction * t_bb;  // Ray::operator()(t_bb), w = 1
+    const d3 d = ray.direction;                      // w = 0
+    double Qo[4], Qd[4];
+    for (int r = 0; r < 4; r++) {
+        Qo[r] = (q[0 + r] * o.x + q[4 + r] * o.y) + (q[8 + r] * o.z + q[12 + r] * 1.0);
+        Qd[r] = (q[0 + r] * d.x + q[4 + r] * d.y) + (q[8 + r] * d.z + q[12 + r] * 0.0);
+    }
+    const double a = (d.x * Qd[0] + d.y * Qd[1]) + (d.z * Qd[2] + 0.0 * Qd[3]);
+    const double b = ((d.x * Qo[0] + d.y * Qo[1]) + (d.z * Qo[2] + 0.0 * Qo[3])) * 2.0;
+    const double c = (o.x * Qo[0] + o.y * Qo[1]) + (o.z * Qo[2] + 1.0 * Qo[3]);
+    double t_min, t_max;
+    if (solveQuadratic(a, b, c, t_min, t_max) && t_max >= 0.0) {
+        const double t = t_bb + (t_min < 0.0 ? t_max : t_min);
+        const d3 p = ray.start + ray.direction * t;  // BB_.contains(ray(t)), bounding-box.cpp:19-23
+        if (!(p.x >= bb.v[0] && p.y >= bb.v[1] && p.z >= bb.v[2] && p.x <= bb.v[3] && p.y <= bb.v[4] && p.z <= bb.v[5])) return false;
+        out.t = t;
+        out.u = 0.0;
+        out.v = 0.0;
+        out.interpolate = false;
+        return true;
+    }
+    return false;
+}
+
+// Quadric::normal, quadric.cpp:127-130: normalize(G * (pos, 1)), G = 2 * the upper three rows of Q (quadric.cpp:38-45);
+// dmat4x3 * dvec4 adds left to right (type_mat4x3.inl:469-478).
+MCRT_HD d3 quadricNormal(const double* q, d3 pos) {
+    d3 g;
+    g.x = (2.0 * q[0]) * pos.x + (2.0 * q[4]) * pos.y + (2.0 * q[8]) * pos.z + (2.0 * q[12]) * 1.0;
+    g.y = (2.0 * q[1]) * pos.x + (2.0 * q[5]) * pos.y + (2.0 * q[9]) * pos.z + (2.0 * q[13]) * 1.0;
+    g.z = (2.0 * q[2]) * pos.x + (2.0 * q[6]) * pos.y + (2.0 * q[10]) * pos.z + (2.0 * q[14]) * 1.0;
+    return normalize(g);
+}
+
+// Triangle::intersect (triangle.cpp:23-63) / Sphere::intersect (sphere.cpp:13-26) / Quadric::intersect on one record
+// (tag = rec[9]: 0 triangle, 2 triangle with vertex normals, 1 sphere, 3 quadric).
 template <class P>
 MCRT_HD bool primIntersect(P rec, const Ray& ray, Hit& out) {
     const double tag = rec[9];
+    if (tag == 3.0) return quadricIntersect(quadricPtr(rec[0]), ray, out);
     if (tag == 1.0) {  // sphere
         d3 so = ray.start - ld3(rec);
         double b = 2.0 * dot(ray.direction, so);

@@ -223,8 +223,46 @@ static int sphIntersect(const mcrt_scene_desc* s, uint32_t i, const Ray* ray, Hi
     return 0;
 }
 
+/* Surface::Quadric, surface/quadric.cpp. Record: Q as glm stores it (Q[c][r] at 4c + r), BB_.min, BB_.max. */
+static const double* quadricRecord(const mcrt_scene_desc* s, uint32_t i) { return s->quadrics + 22 * (size_t)s->surf_v[9 * (size_t)i]; }
+
+static int quadricIntersect(const mcrt_scene_desc* s, uint32_t i, const Ray* ray, Hit* out) { /* quadric.cpp:69-100 */
+    const double* q = quadricRecord(s, i);
+    double t_bb = 0.0;
+    if (!bbIntersect(q + 16, ray, &t_bb)) return 0;
+    v3 o = rayAt(ray, t_bb), d = ray->direction; /* dvec4 o(ray(t_bb), 1.0), d(ray.direction, 0.0) */
+    double Qo[4], Qd[4];
+    for (int r = 0; r < 4; r++) { /* dmat4 * dvec4 = (col0*x + col1*y) + (col2*z + col3*w), type_mat4x4.inl:561-573 */
+        Qo[r] = (q[0 + r] * o.x + q[4 + r] * o.y) + (q[8 + r] * o.z + q[12 + r] * 1.0);
+        Qd[r] = (q[0 + r] * d.x + q[4 + r] * d.y) + (q[8 + r] * d.z + q[12 + r] * 0.0);
+    }
+    /* dvec4 dot = (x*x' + y*y') + (z*z' + w*w'), func_geometric.inl:58-65 */
+    double a = (d.x * Qd[0] + d.y * Qd[1]) + (d.z * Qd[2] + 0.0 * Qd[3]);
+    double b = ((d.x * Qo[0] + d.y * Qo[1]) + (d.z * Qo[2] + 0.0 * Qo[3])) * 2.0;
+    double c = (o.x * Qo[0] + o.y * Qo[1]) + (o.z * Qo[2] + 1.0 * Qo[3]);
+    double t_min, t_max;
+    if (solveQuadratic(a, b, c, &t_min, &t_max) && t_max >= 0.0) {
+        double t = t_bb + (t_min < 0.0 ? t_max : t_min);
+        v3 p = rayAt(ray, t); /* BB_.contains, bounding-box.cpp:19-23 */
+        if (!(p.x >= q[16] && p.y >= q[17] && p.z >= q[18] && p.x <= q[19] && p.y <= q[20] && p.z <= q[21])) return 0;
+        out->t = t; out->u = out->v = 0.0; out->interpolate = 0;
+        return 1;
+    }
+    return 0;
+}
+
+static v3 quadricNormal(const mcrt_scene_desc* s, uint32_t i, v3 pos) { /* quadric.cpp:127-130, G = 2 * Q's upper rows (:38-45) */
+    const double* q = quadricRecord(s, i);
+    v3 g; /* dmat4x3 * dvec4 adds left to right, type_mat4x3.inl:469-478 */
+    g.x = (2.0 * q[0]) * pos.x + (2.0 * q[4]) * pos.y + (2.0 * q[8]) * pos.z + (2.0 * q[12]) * 1.0;
+    g.y = (2.0 * q[1]) * pos.x + (2.0 * q[5]) * pos.y + (2.0 * q[9]) * pos.z + (2.0 * q[13]) * 1.0;
+    g.z = (2.0 * q[2]) * pos.x + (2.0 * q[6]) * pos.y + (2.0 * q[10]) * pos.z + (2.0 * q[14]) * 1.0;
+    return vnormalize(g);
+}
+
 static int surfIntersect(const SceneRef* S, uint32_t i, const Ray* ray, Hit* out) {
     if (S->c) { S->c->prim_tests++; if (S->s->surf_kind[i] == MCRT_SURF_SPHERE) S->c->sphere_tests++; }
+    if (S->s->surf_kind[i] == MCRT_SURF_QUADRIC) return quadricIntersect(S->s, i, ray, out);
     return S->s->surf_kind[i] == MCRT_SURF_SPHERE ? sphIntersect(S->s, i, ray, out) : triIntersect(S->s, i, ray, out);
 }
 
@@ -311,6 +349,7 @@ static v3 surfNormal(const mcrt_scene_desc* s, uint32_t i, v3 pos) { /* triangle
         const double* p = s->surf_v + 9 * (size_t)i;
         return vdivs(vsub(pos, ld3(p)), p[3]);
     }
+    if (s->surf_kind[i] == MCRT_SURF_QUADRIC) return quadricNormal(s, i, pos);
     return ld3(s->surf_e + 9 * (size_t)i + 6);
 }
 static v3 surfInterpolatedNormal(const mcrt_scene_desc* s, uint32_t i, double u, double v) { /* triangle.cpp:109-113 */

@@ -143,7 +143,7 @@ struct Flat {
     std::vector<uint32_t> node_start, node_count, node_next;
     std::vector<uint8_t> kind, interp;
     std::vector<uint32_t> surf_material;
-    std::vector<double> area, v, e, vn;
+    std::vector<double> area, v, e, vn, quadrics;
     std::vector<mcrt_material> materials;
     std::vector<uint32_t> light_surface;
     std::vector<double> light_cdf;
@@ -223,8 +223,18 @@ void flattenScene(const Scene& scene, Flat& F) {
             F.v.push_back(sph->radius);
             for (int i = 0; i < 5; i++) F.v.push_back(0.0);
             for (int i = 0; i < 9; i++) { F.e.push_back(0.0); F.vn.push_back(0.0); }
+        } else if (auto q = dynamic_cast<const Surface::Quadric*>(s)) {
+            F.kind.push_back(MCRT_SURF_QUADRIC);
+            F.interp.push_back(0);
+            F.v.push_back((double)(F.quadrics.size() / 22));
+            for (int i = 0; i < 8; i++) F.v.push_back(0.0);
+            for (int i = 0; i < 9; i++) { F.e.push_back(0.0); F.vn.push_back(0.0); }
+            for (int c = 0; c < 4; c++)
+                for (int rr = 0; rr < 4; rr++) F.quadrics.push_back(q->Q[c][rr]);
+            put3(F.quadrics, q->BB_.min);
+            put3(F.quadrics, q->BB_.max);
         } else {
-            std::fprintf(stderr, "flatten: unsupported surface type (quadric)\n");
+            std::fprintf(stderr, "flatten: unsupported surface type\n");
             std::exit(3);
         }
     }
@@ -256,6 +266,8 @@ void flattenScene(const Scene& scene, Flat& F) {
     d.scene_ior = scene.ior;
     BoundingBox bb = scene.BB();
     for (int c = 0; c < 3; c++) { d.bb_min[c] = bb.min[c]; d.bb_max[c] = bb.max[c]; }
+    d.num_quadrics = (uint32_t)(F.quadrics.size() / 22);
+    d.quadrics = F.quadrics.data();
 }
 
 struct FlatMap {

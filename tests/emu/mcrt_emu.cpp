@@ -45,6 +45,7 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     const bool stage_lds = stage_mode != 0;
     std::string err;
     if (int rc = buildLayout(s, E.L, err)) return rc;
+    patchQuadricAddresses(s, E.L, s->quadrics);  // quadric records are read where the descriptor keeps them
     E.tab.resize(kSobolTableWords);
     buildSobolByteTables(E.tab.data());
     E.stack_lds.resize(kLdsStackDepth);
@@ -73,7 +74,7 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
         sv.flat_index = nullptr;
     };
     auto fillShade = [&](auto& sh) {
-        sh.surf_v = s->surf_v;
+        sh.surf_v = E.L.num_quadric_surfaces ? E.L.surf_v_patched.data() : s->surf_v;
         sh.surf_normal = E.L.normal.data();
         sh.surf_vn = s->surf_vn;
         sh.surf_area = s->surf_area;

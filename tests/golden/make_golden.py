@@ -59,6 +59,10 @@ CASES = [
     dict(name="oren_nayar_test", scene="oren_nayar_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="on_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    # Surface::Quadric (no BASELINE config uses it): 13 sliced quadrics, octree BVH, thin lens, sky light
+    dict(name="quadric", scene="quadric.json", args=[],
+         image=dict(width=96, height=72, sqrtspp=3),
+         renders=[dict(tag="quadric_96x72_s3", width=96, height=72, sqrtspp=3)], kat=3000),
     dict(name="ggx_test", scene="ggx_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="ggx_96x54_s3", width=96, height=54, sqrtspp=3)]),

@@ -26,7 +26,8 @@ def _emu_render(emu, pkg, img, cam, seed, integ, rows, stage):
 @pytest.mark.parametrize("name,stage", [("hexagon_room_diffuse", 1), ("hexagon_room", 0), ("hexagon_room_ggx", 2),
                                         ("hexagon_room", 2), ("ior_test", 2), ("veach_mis", 2), ("hexagon_room_dof", 2), ("hexagon_room_dof", 0),
                                         ("coffee_maker_qsah", 1), ("coffee_maker_bsah", 0), ("ior_test", 1),
-                                        ("veach_mis", 1), ("metals", 0), ("oren_nayar_test", 1), ("ggx_test", 0)])
+                                        ("veach_mis", 1), ("metals", 0), ("oren_nayar_test", 1), ("ggx_test", 0),
+                                        ("quadric", 0), ("quadric", 1)])
 def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, name, stage):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
@@ -43,7 +44,8 @@ def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, na
 
 
 @pytest.mark.parametrize("name,stage_all", [("hexagon_room", 1), ("hexagon_room_ggx", 0), ("coffee_maker_qsah", 0),
-                                            ("coffee_maker_bsah", 0), ("veach_mis", 1), ("metals", 0), ("ggx_test", 1)])
+                                            ("coffee_maker_bsah", 0), ("veach_mis", 1), ("metals", 0), ("ggx_test", 1),
+                                            ("quadric", 0), ("quadric", 1)])
 def test_lane_state_machine_equals_reference(pkg, emu, oracle, manifest, name, stage_all):
     """mcrt_lanesm.hpp (the kernel used for every scene whose BVH is walked): split next-event
     estimate, step-wise traversal with packed stack entries — same bits as the reference."""
@@ -65,7 +67,8 @@ def test_lane_state_machine_equals_reference(pkg, emu, oracle, manifest, name, s
 
 
 @pytest.mark.parametrize("name,slots", [("hexagon_room", 1000), ("hexagon_room_ggx", 64), ("coffee_maker_qsah", 4096),
-                                        ("coffee_maker_bsah", 7), ("veach_mis", 100000), ("metals", 333), ("hexagon_room_dof", 512)])
+                                        ("coffee_maker_bsah", 7), ("veach_mis", 100000), ("metals", 333), ("hexagon_room_dof", 512),
+                                        ("quadric", 300)])
 def test_wavefront_equals_reference(pkg, emu, oracle, manifest, name, slots):
     """mcrt_wavefront.hpp (path state pooled in HBM, one shade pass + one trace pass per bounce): any number
     of slots — fewer than pixels, more than pixels, not a multiple of anything — gives the reference's bits."""
@@ -121,7 +124,7 @@ def test_sampler_byte_tables_equal_reference(emu, manifest):
         np.testing.assert_array_equal(out, want)
 
 
-@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "ior_test"])
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "ior_test", "quadric"])
 def test_traversal_device_code_kat(pkg, emu, oracle, manifest, name):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
@@ -131,7 +134,10 @@ def test_traversal_device_code_kat(pkg, emu, oracle, manifest, name):
     start, direction = rays[:, :3].copy(), rays[:, 3:].copy()
     results = []
     # top-of-tree staged / whole scene staged / flat loop / quantised child blocks of the trace kernel
-    for stage in (0, 1, 2, 3) if img.scene.num_nodes else (0, 1, 2):
+    stages = (0, 1, 2, 3) if img.scene.num_nodes else (0, 1, 2)
+    if img.scene.num_quadrics:
+        stages = (0, 1, 3)  # the flat loop knows triangles and spheres only
+    for stage in stages:
         t, surf, uv = np.empty(n), np.empty(n, dtype=np.uint32), np.empty((n, 2))
         rc = emu.emu_intersect(C.byref(img.scene), n, start.ctypes.data, direction.ctypes.data, stage, t.ctypes.data,
                                surf.ctypes.data, uv.ctypes.data)

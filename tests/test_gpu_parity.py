@@ -36,7 +36,7 @@ def _check(out, ref, what):
 
 
 @pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah",
-                                  "coffee_maker_bsah", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test"])
+                                  "coffee_maker_bsah", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test", "quadric"])
 def test_path_tracer_matches_reference(pkg, ctx, manifest, name):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
@@ -64,7 +64,7 @@ def kernel_env():
 
 
 @pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah", "coffee_maker_bsah",
-                                  "veach_mis", "metals", "ggx_test"])
+                                  "veach_mis", "metals", "ggx_test", "quadric"])
 def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, name):
     """The wavefront pipeline (mcrt_wavefront.hpp; default for scenes whose BVH stays in HBM) forced onto the
     golden scenes: the reference's radiance, and the megakernel's bits (same per-path arithmetic, same
@@ -120,7 +120,7 @@ def test_sampler_bits_exact(pkg, ctx, manifest):
         np.testing.assert_array_equal(out, ref[sel])
 
 
-@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_diffuse", "coffee_maker_qsah", "ior_test"])
+@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_diffuse", "coffee_maker_qsah", "ior_test", "quadric"])
 def test_intersect_exact(pkg, ctx, oracle, manifest, name):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
