@@ -13,8 +13,9 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(renderKernelSM|renderKernel|intersectKernel|knnKernel|samplerKernel)(<[^>]*>)?", name)
-    return m.group(0) if m else name[:60]
+    m = re.search(r"(renderKernelSM|renderKernelPM|renderKernel|wfTraceKernel|wfShadeKernel|emitKernel|intersectKernel|knnWaveKernel|"
+                  r"knnKernel|samplerKernel|cellCodeKernel|gatherKernel|leafBoundsKernel)(<[^(]*>)?", name)
+    return m.group(0).replace("(anonymous namespace)::", "") if m else name[:60]
 
 
 def main(root):
@@ -26,7 +27,7 @@ def main(root):
             rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
         except sqlite3.Error:
             rows = []
-        rows = [r for r in rows if "mcrt" in r[0] or "renderKernel" in r[0] or "Kernel" in r[0] and "anonymous" in r[0]]
+        rows = [r for r in rows if "mcrt" in r[0] or "Kernel" in r[0] and "anonymous" in r[0]]
         if rows:
             print("## kernel trace: %s\n" % rel)
             print("| kernel | calls | total ms | avg ms | % |")
@@ -35,7 +36,7 @@ def main(root):
                 print("| `%s` | %d | %.3f | %.3f | %.2f |" % (short(n), c, tot / 1e3, avg / 1e3, pct))
             try:
                 k = list(con.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
-                                     "from kernels where name like '%renderKernel%' limit 1"))
+                                     "from kernels where name like '%renderKernel%' or name like '%wfTraceKernel%' limit 2"))
                 for n, g, w, lds, scr, v, a, s in k:
                     print("\nlaunch: grid %d threads, block %d, LDS %d B/block, scratch %d B/lane, VGPR %d, AGPR %d, SGPR %d\n" % (g, w, lds, scr, v, a, s))
             except sqlite3.Error:
@@ -45,7 +46,7 @@ def main(root):
                                     "group by kernel_name, counter_name"))
         except sqlite3.Error:
             rows = []
-        rows = [r for r in rows if "renderKernel" in r[0] or "intersectKernel" in r[0] or "knnKernel" in r[0]]
+        rows = [r for r in rows if "Kernel" in r[0] and "anonymous" in r[0]]
         if rows:
             print("## counters: %s\n" % rel)
             print("| kernel | counter | sum over dispatches | dispatches |")
