@@ -1829,7 +1829,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.stage_all = 1;
     d.stage_nodes = 0;
     const uint32_t fixed = planLds(DeviceScene{}, kBlock).total;
-    if (planLds(d, kBlock).total - fixed > 48u * 1024u) {
+    if (planLds(d, kBlock).total - fixed > 48u * 1024u || L.num_quadric_surfaces) {  // quadric code lives in the kAll == false kernels
         d.stage_all = 0;
         d.stage_nodes = std::min<uint32_t>(d.num_nodes, 512u);
     }

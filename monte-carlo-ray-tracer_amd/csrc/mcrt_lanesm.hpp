@@ -217,8 +217,9 @@ MCRT_HD PrimRec loadPrim(P p) {
     for (int k = 0; k < kPrimStride; k++) r.v[k] = p[k];
     return r;
 }
+template <bool kQuadrics>
 MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
-    if (rec.v[9] == 1.0 || rec.v[9] == 3.0) return primIntersect(rec.v, ray, h);  // sphere / quadric (rare in walked BVHs)
+    if (rec.v[9] == 1.0 || (kQuadrics && rec.v[9] == 3.0)) return primIntersect<kQuadrics>(rec.v, ray, h);  // sphere / quadric (rare in walked BVHs)
     double t, u, v;
     const bool ok = triangleTestFlat(rec.v, ray.start, ray.direction, t, u, v);
     const bool interp = rec.v[9] >= 2.0;
@@ -244,8 +245,8 @@ MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& s
         const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
         Hit h0, h1;
         if (kCount) cnt.prim_tests += two ? 2u : 1u;
-        const bool ok0 = primTestRec(r0, r, h0);
-        const bool ok1 = primTestRec(r1, r, h1) && two;
+        const bool ok0 = primTestRec<QuadricsIn<kAll>::value>(r0, r, h0);
+        const bool ok1 = primTestRec<QuadricsIn<kAll>::value>(r1, r, h1) && two;
         if (ok0 && closer(h0.t, i, T.best)) {
             T.best = h0;
             T.best.surface = i;

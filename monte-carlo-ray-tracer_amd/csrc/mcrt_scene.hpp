@@ -183,6 +183,19 @@ MCRT_HD bool boxIntersect(const Box& b, const Ray& ray, double& t) {
 // BB_.max. Primitive records and the device copy of surf_v carry the ADDRESS of a quadric's record (64 bits stored
 // in the double's slot; patched in by the host when the records' home is known), so that no view needs another
 // pointer for a primitive kind no BASELINE scene uses.
+// Quadric code is compiled only into the device kernels of scenes that are NOT staged whole in LDS (kAll == false):
+// no BASELINE scene has quadrics and the LDS-resident kernels (configs C1/C2) sit at their register limit — the extra
+// branch cost the headline kernel 3 % through spills. mcrt_upload_scene never stages a scene with quadrics whole. The
+// host build (tests/emu) keeps the code everywhere.
+template <bool kAll>
+struct QuadricsIn {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static constexpr bool value = !kAll;
+#else
+    static constexpr bool value = true;
+#endif
+};
+
 MCRT_HD const double* quadricPtr(double slot) { return reinterpret_cast<const double*>((uintptr_t)dBits(slot)); }
 MCRT_HD double quadricSlot(const double* record) { return bitsD((unsigned long long)(uintptr_t)record); }
 
@@ -253,10 +266,12 @@ MCRT_HD d3 quadricNormal(const double* q, d3 pos) {
 
 // Triangle::intersect (triangle.cpp:23-63) / Sphere::intersect (sphere.cpp:13-26) / Quadric::intersect on one record
 // (tag = rec[9]: 0 triangle, 2 triangle with vertex normals, 1 sphere, 3 quadric).
-template <class P>
+template <bool kQuadrics, class P>
 MCRT_HD bool primIntersect(P rec, const Ray& ray, Hit& out) {
     const double tag = rec[9];
-    if (tag == 3.0) return quadricIntersect(quadricPtr(rec[0]), ray, out);
+    if constexpr (kQuadrics) {
+        if (tag == 3.0) return quadricIntersect(quadricPtr(rec[0]), ray, out);
+    }
     if (tag == 1.0) {  // sphere
         d3 so = ray.start - ld3(rec);
         double b = 2.0 * dot(ray.direction, so);
@@ -408,7 +423,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
         for (uint32_t i = 0; i < sv.num_surfaces; i++) {
             Hit h;
             if (kCount) cnt.prim_tests++;
-            if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
+            if (primIntersect<QuadricsIn<kAll>::value>(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                 best = h;
                 best.surface = i;
                 if (kShadow && i != sq->light && h.t < sq->t_near) return best;
@@ -486,7 +501,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
             for (uint32_t i = m.a; i < end; i++) {
                 Hit h;
                 if (kCount) cnt.prim_tests++;
-                if (primIntersect(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
+                if (primIntersect<QuadricsIn<kAll>::value>(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                     best = h;
                     best.surface = i;
                     if (kShadow && i != sq->light && h.t < sq->t_near) return best;

@@ -152,7 +152,9 @@ MCRT_HD d3 surfNormal(const ShadeViewT<L>& sh, uint32_t i, d3 pos) {  // triangl
         cptr<double, L> p = sh.surf_v + (size_t)i * 9;
         return (pos - ld3(p)) / p[3];
     }
-    if (sh.surf_kind[i] == MCRT_SURF_QUADRIC) return quadricNormal(quadricPtr(sh.surf_v[(size_t)i * 9]), pos);  // quadric.cpp:127-130
+    if constexpr (QuadricsIn<L>::value) {
+        if (sh.surf_kind[i] == MCRT_SURF_QUADRIC) return quadricNormal(quadricPtr(sh.surf_v[(size_t)i * 9]), pos);  // quadric.cpp:127-130
+    }
     return ld3(sh.surf_normal + (size_t)i * 3);
 }
 template <bool L>

@@ -25,3 +25,7 @@ prof kt_pm --kernel-trace --stats -- --workload pm --steps 3 --warmup 1
 prof pmc_pm_fetch --kernel-trace --pmc FETCH_SIZE -- --workload pm --steps 1 --warmup 0
 prof pmc_pm_write --kernel-trace --pmc WRITE_SIZE -- --workload pm --steps 1 --warmup 0
 prof pmc_pm_sq --kernel-trace --pmc $SQ -- --workload pm --steps 1 --warmup 0
+# keep the summaries only: the rocpd databases are tens of MB each and gpurun_out/ is capped at 64 MiB
+python $R/tools/summarize_rocprof.py $O > $O/summary.md
+find $O -name "*.db" -delete
+find $O -type d -empty -delete
