@@ -313,7 +313,8 @@ def main():
                               "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time; "
                                       "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/). Scenes that fit in LDS "
                                       "move almost nothing through HBM, so frac can exceed 1 for them.",
-                              "kernel": {"pm": "renderKernelPM", "c5": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "renderKernelSM", "c4": "renderKernelSM"}.get(args.workload, "renderKernel<path_tracer, flat>"),
+                              "kernel": {"pm": "renderKernelPM", "c5": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "wfTraceKernel + wfShadeKernel (all launches of the frame)",
+                                         "c4": "wfTraceKernel + wfShadeKernel (all launches of the frame)"}.get(args.workload, "renderKernel<path_tracer, flat>"),
                               "kernel_ms": kernel_ms,
                               "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
                               "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}

@@ -188,7 +188,9 @@ int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed
 /* Same, but the image stays in DEVICE memory owned by the caller (e.g. the buffer RCCL gathers
  * from) and the launch is asynchronous on `stream` (a hipStream_t; NULL = the context's stream).
  * d_out_rgb holds owned rows only, packed in ascending row order: mcrt_shard_rows() rows of
- * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. */
+ * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. (Scenes whose tree is walked by the
+ * wavefront pipeline — BVHs of 65 536 nodes or more — run as a host-driven sequence of launches on `stream`; for them
+ * the call returns when the frame is complete and mcrt_render_finish() only collects the statistics.) */
 int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed,
                        int integrator, double* d_out_rgb, void* stream);
 int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);

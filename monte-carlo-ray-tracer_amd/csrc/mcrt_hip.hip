@@ -1354,7 +1354,7 @@ int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
     return MCRT_OK;
 }
 
-// Launch geometry of the trace kernel: one workgroup per CU (MCRT_TRACE_WAVES waves, default 12), its LDS split
+// Launch geometry of the trace kernel: one workgroup per CU (MCRT_TRACE_WAVES waves, default 16), its LDS split
 // between the lanes' traversal stacks and as many top-of-tree child blocks as fit.
 struct TracePlan {
     uint32_t grid, block, lds_bytes;
@@ -1364,7 +1364,7 @@ struct TracePlan {
 template <class K>
 int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
-    const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 12), 1), kTraceMaxBlock / 64);
+    const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
     const uint32_t stack_bytes = kLdsStackDepth * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
@@ -1430,10 +1430,11 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         return MCRT_OK;
     }
 
-    // pool size: enough slots to fill the chip several times over, fewer than pixels so that cheap and expensive
-    // pixels average out within a slot
+    // pool size: one slot per pixel up to 4 M slots (1.8 GB). More slots = fewer, longer trace launches (their tails
+    // amortised); the chip only needs ~262 k rays in flight, so the late phase of a frame, when only the expensive
+    // pixels are still running, stays full as well
     const uint64_t pixels = (uint64_t)cam->width * fr.owned_rows;
-    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 20);
+    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 22);
     slots = std::min<uint64_t>(slots, (pixels + kWfBlock - 1) / kWfBlock * kWfBlock);
     slots = std::max<uint64_t>(slots, kWfBlock);
     if (ctx->wf_slots != slots) {
@@ -1519,8 +1520,11 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
     const bool want_wf = kenv && strcmp(kenv, "wf") == 0;
-    static const bool wf_default = false;  // until it beats the megakernel on every walked scene
-    if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (wf_default && use_sm && !all && !kenv)))
+    // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
+    // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
+    const char* mn = getenv("MCRT_WF_MIN_NODES");
+    const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
+    if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests);
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},

@@ -16,9 +16,9 @@ def main():
     sqrtspp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
-    if name == "c3":
+    if name in ("c3", "c4", "c5"):
         import make_large
-        path = make_large.ensure_c3_image()
+        path = make_large.ensure_image(name)
     elif name == "spaceship":
         path = os.path.join(ROOT, "oracle", "_ref", "images", "spaceship.mcrt")
     else:
