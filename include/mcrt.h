@@ -284,6 +284,35 @@ int  mcrt_photon_map_build_gpu(mcrt_ctx* ctx, const float* photons, uint64_t num
 const mcrt_photon_map_desc* mcrt_photon_map_get(const mcrt_photon_map* map);
 void mcrt_photon_map_free(mcrt_photon_map* map);
 
+/* ------------------------------------------------------------------------------------------
+ * BVH builder for hosts that do not carry the reference's: the reference's DEFAULT hierarchy ("bvh": {"type":
+ * "octree"}, bvh/bvh.cpp:41-56,130-163,428-449) — an octree over the surfaces' box centroids, leaves of at most 8
+ * surfaces, one node per non-empty octant with the union of its surfaces' boxes — built by sorting per-surface octant
+ * path codes instead of inserting one surface at a time. The result is the reference's tree
+ * bit for bit: same LinearNode arrays, same surface order (tests/test_bvh_build.py rebuilds every golden octree BVH,
+ * up to the 6.9 M-triangle C5 scene). `scene` needs its surface arrays, quadrics, bb_min/bb_max; its node arrays are
+ * ignored. ctx != NULL: boxes, codes and the radix sort run on the GPU of ctx; ctx == NULL: host only.
+ * MCRT_ERR_UNSUPPORTED when more than 8 centroids share one 2^-21 cell of the root cube. */
+typedef struct mcrt_bvh_desc {
+    uint32_t num_nodes;
+    const double*   node_bounds;        /* as mcrt_scene_desc */
+    const uint32_t* node_start_surface;
+    const uint32_t* node_num_surfaces;
+    const uint32_t* node_next_sibling;
+    uint32_t num_surfaces;
+    const uint32_t* order;              /* [num_surfaces] BVH::ordered_surfaces: new position -> index in `scene` */
+} mcrt_bvh_desc;
+typedef struct mcrt_bvh mcrt_bvh;       /* opaque; owns the arrays its descriptor points into */
+int  mcrt_bvh_build_octree(mcrt_ctx* ctx /* may be NULL */, const mcrt_scene_desc* scene, mcrt_bvh** out);
+const mcrt_bvh_desc* mcrt_bvh_get(const mcrt_bvh* bvh);
+void mcrt_bvh_free(mcrt_bvh* bvh);
+/* `scene` with its surfaces put in bvh->order, its lights re-indexed and the node arrays of `bvh`: an owning copy whose
+ * descriptor can go to mcrt_upload_scene / mcrt_image_save. */
+typedef struct mcrt_scene mcrt_scene;
+int  mcrt_scene_with_bvh(const mcrt_scene_desc* scene, const mcrt_bvh_desc* bvh, mcrt_scene** out);
+const mcrt_scene_desc* mcrt_scene_get(const mcrt_scene* scene);
+void mcrt_scene_free(mcrt_scene* scene);
+
 uint32_t mcrt_abi_version(void);
 
 #ifdef __cplusplus

@@ -59,6 +59,14 @@ class SceneDesc(C.Structure):
     ]
 
 
+class BvhDesc(C.Structure):
+    """mcrt_bvh_desc."""
+    _fields_ = [
+        ("num_nodes", C.c_uint32), ("node_bounds", _dp), ("node_start_surface", _u32p), ("node_num_surfaces", _u32p),
+        ("node_next_sibling", _u32p), ("num_surfaces", C.c_uint32), ("order", _u32p),
+    ]
+
+
 class PhotonMapDesc(C.Structure):
     """mcrt_photon_map_desc."""
     _fields_ = [
@@ -147,6 +155,14 @@ def lib():
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
+    L.mcrt_bvh_build_octree.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.mcrt_bvh_get.argtypes = [vp]
+    L.mcrt_bvh_get.restype = C.POINTER(BvhDesc)
+    L.mcrt_bvh_free.argtypes = [vp]
+    L.mcrt_scene_with_bvh.argtypes = [C.POINTER(SceneDesc), C.POINTER(BvhDesc), C.POINTER(vp)]
+    L.mcrt_scene_get.argtypes = [vp]
+    L.mcrt_scene_get.restype = C.POINTER(SceneDesc)
+    L.mcrt_scene_free.argtypes = [vp]
     L.mcrt_photon_map_build.argtypes = [_fp, C.c_uint64, _dp, _dp, C.c_uint32, C.POINTER(vp)]
     L.mcrt_photon_map_build_gpu.argtypes = [vp, _fp, C.c_uint64, _dp, _dp, C.c_uint32, C.POINTER(vp)]
     L.mcrt_photon_map_get.argtypes = [vp]
@@ -204,6 +220,74 @@ class SceneImage:
     def close(self):
         if self._h:
             self._lib.mcrt_image_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Bvh:
+    """mcrt_bvh: the reference's default ("octree") BVH of a scene's surfaces, built by sorting centroid path codes
+    (mcrt_bvh_build_octree; with a Context the per-surface work and the sort run on its GPU)."""
+
+    def __init__(self, scene_desc, ctx=None):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        rc = self._lib.mcrt_bvh_build_octree(ctx._h if ctx is not None else None, C.byref(scene_desc), C.byref(self._h))
+        if rc != 0:
+            if ctx is not None:
+                ctx._check(rc, "mcrt_bvh_build_octree")
+            raise McrtError("mcrt_bvh_build_octree failed: %d" % rc)
+
+    @property
+    def desc(self):
+        return self._lib.mcrt_bvh_get(self._h).contents
+
+    def arrays(self):
+        d = self.desc
+        n = d.num_nodes
+
+        def grab(ptr, count, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True) if count else np.zeros(0, dtype)
+        return dict(bounds=grab(d.node_bounds, n * 6, np.float64).reshape(n, 6), start=grab(d.node_start_surface, n, np.uint32),
+                    count=grab(d.node_num_surfaces, n, np.uint32), next=grab(d.node_next_sibling, n, np.uint32),
+                    order=grab(d.order, d.num_surfaces, np.uint32))
+
+    def apply(self, scene_desc):
+        """mcrt_scene_with_bvh -> OwnedScene (surfaces in BVH order, lights re-indexed, this BVH's nodes)."""
+        return OwnedScene(scene_desc, self)
+
+    def close(self):
+        if self._h:
+            self._lib.mcrt_bvh_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OwnedScene:
+    def __init__(self, scene_desc, bvh):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        self._keep = (scene_desc, bvh)  # the copy still points into their material / light / quadric / node arrays
+        rc = self._lib.mcrt_scene_with_bvh(C.byref(scene_desc), C.byref(bvh.desc), C.byref(self._h))
+        if rc != 0:
+            raise McrtError("mcrt_scene_with_bvh failed: %d" % rc)
+
+    @property
+    def desc(self):
+        return self._lib.mcrt_scene_get(self._h).contents
+
+    def close(self):
+        if self._h:
+            self._lib.mcrt_scene_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 
+#include "mcrt_bvh_shared.hpp"
 #include "mcrt_internal.hpp"
 #include "mcrt_octree_shared.hpp"
 
@@ -152,4 +153,75 @@ extern "C" int mcrt_photon_map_build_gpu(mcrt_ctx* ctx, const float* photons, ui
     finishMapDesc(M);
     *out = M;
     return MCRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Octree BVH (mcrt_bvh_shared.hpp): per-surface boxes + centroid path codes, radix sort and the gather of the boxes
+// on the device; octant assembly, leaf boxes (8 surfaces each at most) and in-leaf ordering on the host.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void surfaceCodeKernel(const uint8_t* kind, const double* surf_v, const double* quadrics, uint64_t n, BoxArgs cube, double* bb,
+                                  unsigned long long* keys, uint32_t* index) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double b[6];
+    surfaceBounds(kind[i], surf_v + 9 * i, quadrics, b);
+    for (int c = 0; c < 6; c++) bb[i * 6 + c] = b[c];
+    keys[i] = cellCode((b[3] + b[0]) / 2.0, (b[4] + b[1]) / 2.0, (b[5] + b[2]) / 2.0, cube.mn, cube.mx);
+    index[i] = (uint32_t)i;
+}
+
+__global__ void gatherBoxKernel(const double* in, const uint32_t* index, uint64_t n, double* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t src = index[i];
+    for (int c = 0; c < 6; c++) out[i * 6 + c] = in[src * 6 + c];
+}
+
+#define BVH_TRY(call)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) return ctxFail(ctx, MCRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+int mcrt::bvhOctreeGpu(mcrt_ctx* ctx, const mcrt_scene_desc* s, mcrt_bvh* B) {
+    BVH_TRY(hipSetDevice(ctxDevice(ctx)));
+    const uint64_t n = s->num_surfaces;
+    Dev d_kind, d_v, d_q, d_bb, d_bb2, d_keys, d_keys2, d_idx, d_idx2, d_tmp;
+    BVH_TRY(d_kind.alloc(n));
+    BVH_TRY(d_v.alloc(n * 72));
+    BVH_TRY(d_q.alloc((size_t)s->num_quadrics * 22 * 8));
+    BVH_TRY(d_bb.alloc(n * 48));
+    BVH_TRY(d_bb2.alloc(n * 48));
+    BVH_TRY(d_keys.alloc(n * 8));
+    BVH_TRY(d_keys2.alloc(n * 8));
+    BVH_TRY(d_idx.alloc(n * 4));
+    BVH_TRY(d_idx2.alloc(n * 4));
+    BVH_TRY(hipMemcpy(d_kind.p, s->surf_kind, n, hipMemcpyHostToDevice));
+    BVH_TRY(hipMemcpy(d_v.p, s->surf_v, n * 72, hipMemcpyHostToDevice));
+    if (s->num_quadrics) BVH_TRY(hipMemcpy(d_q.p, s->quadrics, (size_t)s->num_quadrics * 22 * 8, hipMemcpyHostToDevice));
+    BoxArgs cube;
+    bvhRootCube(s, cube.mn, cube.mx);
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(surfaceCodeKernel, dim3(grid), dim3(256), 0, 0, d_kind.as<uint8_t>(), d_v.as<double>(), d_q.as<double>(), n, cube,
+                       d_bb.as<double>(), d_keys.as<unsigned long long>(), d_idx.as<uint32_t>());
+    BVH_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    BVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+                                               d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (int)n, 0, 3 * kCodeLevels));
+    BVH_TRY(d_tmp.alloc(tmp_bytes));
+    BVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(),
+                                               d_idx.as<uint32_t>(), d_idx2.as<uint32_t>(), (int)n, 0, 3 * kCodeLevels));
+    hipLaunchKernelGGL(gatherBoxKernel, dim3(grid), dim3(256), 0, 0, d_bb.as<double>(), d_idx2.as<uint32_t>(), n, d_bb2.as<double>());
+    BVH_TRY(hipGetLastError());
+    std::vector<unsigned long long> keys(n);
+    std::vector<uint32_t> index(n);
+    std::vector<double> sorted_bb(n * 6);
+    BVH_TRY(hipMemcpy(keys.data(), d_keys2.p, n * 8, hipMemcpyDeviceToHost));
+    BVH_TRY(hipMemcpy(index.data(), d_idx2.p, n * 4, hipMemcpyDeviceToHost));
+    BVH_TRY(hipMemcpy(sorted_bb.data(), d_bb2.p, n * 48, hipMemcpyDeviceToHost));
+    return assembleOctreeBvh(keys.data(), index.data(), sorted_bb.data(), n, B) ? MCRT_OK : MCRT_ERR_UNSUPPORTED;
 }

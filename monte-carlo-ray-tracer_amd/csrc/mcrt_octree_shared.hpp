@@ -34,15 +34,16 @@ namespace mcrt {
 constexpr int kCodeLevels = 21;   // 63-bit codes
 constexpr int kMaxOctreeDepth = 60;  // the host builder's recursion guard (same rule here)
 
-// Root-to-level-21 octant path of one photon position (ph[3..5]), cells exactly as octree.cpp:46-58,71-80.
-MCRT_HD unsigned long long photonCellCode(const float* ph, const double* bb_min, const double* bb_max) {
+// Root-to-level-21 octant path of a position, cells exactly as octree.cpp:46-58,71-80.
+MCRT_HD unsigned long long cellCode(double px, double py, double pz, const double* bb_min, const double* bb_max) {
+    const double pos[3] = {px, py, pz};
     double mn[3] = {bb_min[0], bb_min[1], bb_min[2]}, mx[3] = {bb_max[0], bb_max[1], bb_max[2]};
     unsigned long long code = 0ull;
     for (int level = 0; level < kCodeLevels; level++) {
         unsigned o = 0;
         for (int c = 0; c < 3; c++) {
             const double origin = (mx[c] + mn[c]) / 2.0, half = (mx[c] - mn[c]) / 2.0;
-            const bool up = (double)ph[3 + c] >= origin;
+            const bool up = pos[c] >= origin;
             if (up) o |= (4u >> c);
             const double no = origin + half * (up ? 0.5 : -0.5);
             mn[c] = no - half * 0.5;
@@ -51,6 +52,9 @@ MCRT_HD unsigned long long photonCellCode(const float* ph, const double* bb_min,
         code = (code << 3) | o;
     }
     return code;
+}
+MCRT_HD unsigned long long photonCellCode(const float* ph, const double* bb_min, const double* bb_max) {  // position = ph[3..5]
+    return cellCode((double)ph[3], (double)ph[4], (double)ph[5], bb_min, bb_max);
 }
 
 inline void finishMapDesc(mcrt_photon_map* M) {
