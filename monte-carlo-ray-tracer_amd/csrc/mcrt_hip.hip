@@ -807,6 +807,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
 
 struct WfShadeArgs {
     WfPool pool;
+    uint32_t slot_base, slot_count;   // the slots this launch serves (one half of the pool per stream)
     WfFrame fr;
     uint32_t* queue;
     unsigned long long* count_out;    // rays queued by this launch
@@ -863,10 +864,11 @@ __global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scen
         *a.pop_reset = 0ull;
     }
     __syncthreads();
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = local < a.slot_count;
     DevWfEnv env{a.work, a.queue, a.count_out};
     uint32_t paths = 0;
-    wfShadeSlot<false>(env, a.pool, slot < a.pool.n ? slot : 0u, slot < a.pool.n, a.fr, sh, rh, (SobolTab)ltab, paths);
+    wfShadeSlot<false>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths);
     waveAccumulate(a.stats + 0, paths);
 }
 
@@ -1267,7 +1269,9 @@ struct mcrt_ctx {
     // wavefront path tracer: slot pool, ray queue, control words {count[2], pop}, pinned read-back word
     DevBuf wf_pool, wf_queue, wf_ctrl;
     uint32_t wf_slots = 0;
-    unsigned long long* wf_host = nullptr;
+    unsigned long long* wf_host = nullptr;   // pinned: one read-back word per half
+    hipStream_t wf_stream[2] = {nullptr, nullptr};
+    hipEvent_t wf_ev[3] = {nullptr, nullptr, nullptr};
 
     // in-flight render
     bool pending = false;
@@ -1379,9 +1383,9 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     if (tp.grid < 1) tp.grid = 1;
     const uint32_t total_lanes = tp.grid * tp.block;
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-    if (ctx->spill_lanes < total_lanes) {
-        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
-        ctx->spill_lanes = total_lanes;
+    if (ctx->spill_lanes < 2 * total_lanes) {  // two trace launches (the two halves of the wavefront pool) can be resident at once
+        HIP_TRY(ctx, ctx->spill.alloc((size_t)2 * total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
+        ctx->spill_lanes = 2 * total_lanes;
     }
     WfTraceArgs& ta = tp.args;
     memset(&ta, 0, sizeof(ta));
@@ -1439,12 +1443,12 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     slots = std::max<uint64_t>(slots, kWfBlock);
     if (ctx->wf_slots != slots) {
         HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
-        HIP_TRY(ctx, ctx->wf_queue.alloc((size_t)slots * 2 * sizeof(uint32_t)));
+        HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * sizeof(uint32_t)));
         ctx->wf_slots = (uint32_t)slots;
     }
-    if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(4 * sizeof(unsigned long long)));
-    if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, 4 * sizeof(unsigned long long), stream));
+    if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(8 * sizeof(unsigned long long)));
+    if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), 2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, 8 * sizeof(unsigned long long), stream));
     // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
 
@@ -1452,41 +1456,81 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
     TracePlan tp;
     if (int rc = planTrace(ctx, trace, slots * 2, tp)) return rc;
-    const uint32_t shade_grid = (uint32_t)((slots + kWfBlock - 1) / kWfBlock);
 
-    unsigned long long* ctrl = ctx->wf_ctrl.as<unsigned long long>();
-    WfTraceArgs ta = tp.args;
-    ta.pop = ctrl + 2;
-    PoolRays pr;
-    pr.pool.w = ctx->wf_pool.as<unsigned long long>();
-    pr.pool.n = (uint32_t)slots;
-    pr.queue = ctx->wf_queue.as<uint32_t>();
-    WfShadeArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.pool = pr.pool;
-    sa.fr = fr;
-    sa.queue = ctx->wf_queue.as<uint32_t>();
-    sa.pop_reset = ctrl + 2;
-    sa.work = ctx->work_counter.as<unsigned long long>();
-    sa.stats = ctx->stats.as<unsigned long long>();
-
-    const int check_every = (int)std::max<long>(1, envi("MCRT_WF_CHECK", 16));
-    for (uint64_t it = 0;; it++) {
-        sa.count_out = ctrl + (it & 1);
-        sa.count_reset = ctrl + ((it + 1) & 1);
-        hipLaunchKernelGGL(wfShadeKernel, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
-        ctx->launches++;
-        if (it % (uint64_t)check_every == (uint64_t)(check_every - 1) || it < 2) {
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host, ctrl + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(ctx, hipStreamSynchronize(stream));
-            if (*ctx->wf_host == 0ull) break;  // nothing queued: every slot is done
+    // MCRT_WF_HALVES=2 (experiment, off by default): two halves of the pool on two streams, so that while one half's trace
+    // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
+    // gain (C3 1074 vs 1101 Mray/s, C4 619 vs 681): a trace workgroup owns a CU's whole LDS, so the halves mostly
+    // alternate, and each now pays its tail on half as many rays.
+    const int halves = (slots >= 4u * kWfBlock && envi("MCRT_WF_HALVES", 1) >= 2) ? 2 : 1;
+    hipStream_t hs[2] = {stream, stream};
+    if (halves == 2) {
+        for (int i = 0; i < 2; i++)
+            if (!ctx->wf_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[i], hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++)
+            if (!ctx->wf_ev[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[2], stream));  // the setup above precedes both halves
+        for (int i = 0; i < 2; i++) {
+            hs[i] = ctx->wf_stream[i];
+            HIP_TRY(ctx, hipStreamWaitEvent(hs[i], ctx->wf_ev[2], 0));
         }
-        ta.count = ctrl + (it & 1);
-        hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, stream, ta, pr);
-        ctx->launches++;
+    }
+    unsigned long long* ctrl = ctx->wf_ctrl.as<unsigned long long>();
+    WfTraceArgs ta[2];
+    PoolRays pr[2];
+    WfShadeArgs sa[2];
+    uint32_t shade_grid[2];
+    const uint32_t half_slots = halves == 2 ? (uint32_t)((slots / 2 + kWfBlock - 1) / kWfBlock * kWfBlock) : (uint32_t)slots;
+    for (int h = 0; h < halves; h++) {
+        unsigned long long* c = ctrl + 4 * h;  // {count[2], pop} of this half
+        ta[h] = tp.args;
+        ta[h].pop = c + 2;
+        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * (kMaxStackDepth - kLdsStackDepth);
+        pr[h].pool.w = ctx->wf_pool.as<unsigned long long>();
+        pr[h].pool.n = (uint32_t)slots;
+        pr[h].queue = ctx->wf_queue.as<uint32_t>() + (size_t)h * 2 * half_slots;
+        memset(&sa[h], 0, sizeof(WfShadeArgs));
+        sa[h].pool = pr[h].pool;
+        sa[h].slot_base = (uint32_t)h * half_slots;
+        sa[h].slot_count = h == 0 ? std::min<uint32_t>(half_slots, (uint32_t)slots) : (uint32_t)slots - half_slots;
+        sa[h].fr = fr;
+        sa[h].queue = ctx->wf_queue.as<uint32_t>() + (size_t)h * 2 * half_slots;
+        sa[h].pop_reset = c + 2;
+        sa[h].work = ctx->work_counter.as<unsigned long long>();
+        sa[h].stats = ctx->stats.as<unsigned long long>();
+        shade_grid[h] = (sa[h].slot_count + kWfBlock - 1) / kWfBlock;
+    }
+
+    const uint64_t check_every = (uint64_t)std::max<long>(2, envi("MCRT_WF_CHECK", 16));
+    bool done[2] = {false, halves == 1};
+    for (uint64_t it = 0; !(done[0] && done[1]); it++) {
+        for (int h = 0; h < halves; h++) {
+            if (done[h]) continue;
+            unsigned long long* c = ctrl + 4 * h;
+            sa[h].count_out = c + (it & 1);
+            sa[h].count_reset = c + ((it + 1) & 1);
+            hipLaunchKernelGGL(wfShadeKernel, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
+            ctx->launches++;
+            // the two halves look at their queue length at different iterations, so that one stream always has work queued
+            if (it % check_every == (h == 0 ? check_every - 1 : check_every / 2 - 1) || it < 2) {
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + h, c + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
+                HIP_TRY(ctx, hipStreamSynchronize(hs[h]));
+                if (ctx->wf_host[h] == 0ull) {  // nothing queued: every slot of this half is done
+                    done[h] = true;
+                    continue;
+                }
+            }
+            ta[h].count = c + (it & 1);
+            hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h]);
+            ctx->launches++;
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (halves == 2)
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[i], hs[i]));
+            HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev[i], 0));
+        }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->pending = true;
     return MCRT_OK;
@@ -1736,6 +1780,10 @@ void mcrt_destroy(mcrt_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
+    for (int i = 0; i < 2; i++)
+        if (ctx->wf_stream[i]) (void)hipStreamDestroy(ctx->wf_stream[i]);
+    for (int i = 0; i < 3; i++)
+        if (ctx->wf_ev[i]) (void)hipEventDestroy(ctx->wf_ev[i]);
     delete ctx;
 }
 
