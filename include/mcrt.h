@@ -304,6 +304,10 @@ typedef struct mcrt_bvh_desc {
 } mcrt_bvh_desc;
 typedef struct mcrt_bvh mcrt_bvh;       /* opaque; owns the arrays its descriptor points into */
 int  mcrt_bvh_build_octree(mcrt_ctx* ctx /* may be NULL */, const mcrt_scene_desc* scene, mcrt_bvh** out);
+/* The reference's other two hierarchies, "binary_sah" (arity 2) and "quaternary_sah" (arity 4): its binned surface-area
+ * builders (bvh/bvh.cpp:165-426) restated with the same arithmetic and tie rules — same tree — and run on `threads` host
+ * threads (0 = all), one subtree per thread. bins_per_axis 0 = the reference's default (16 / 8). Host only. */
+int  mcrt_bvh_build_sah(const mcrt_scene_desc* scene, int arity, uint32_t bins_per_axis, uint32_t threads, mcrt_bvh** out);
 const mcrt_bvh_desc* mcrt_bvh_get(const mcrt_bvh* bvh);
 void mcrt_bvh_free(mcrt_bvh* bvh);
 /* `scene` with its surfaces put in bvh->order, its lights re-indexed and the node arrays of `bvh`: an owning copy whose

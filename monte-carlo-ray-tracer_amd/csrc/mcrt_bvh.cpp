@@ -1,7 +1,11 @@
 // Octree BVH builder, host path and the scene re-ordering helper (include/mcrt.h: mcrt_bvh_build_octree,
 // mcrt_scene_with_bvh). Algorithm and its equivalence with the reference's builder: mcrt_bvh_shared.hpp. The GPU path
 // (boxes, codes, radix sort on the device) is bvhOctreeGpu in mcrt_octree_gpu.hip.
+#include <atomic>
+#include <cmath>
+#include <memory>
 #include <numeric>
+#include <thread>
 
 #include "mcrt_bvh_shared.hpp"
 #include "mcrt_internal.hpp"
@@ -49,6 +53,290 @@ int buildHost(const mcrt_scene_desc* s, mcrt_bvh* B) {
     return assembleOctreeBvh(keys.data(), index.data(), sorted_bb.data(), n, B) ? MCRT_OK : MCRT_ERR_UNSUPPORTED;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The reference's binned-SAH builders, restated (bvh/bvh.cpp:165-288 binary, :290-426 quaternary, :451-473
+// arbitrarySplit, :428-449 compact) with the same arithmetic and the same tie rules, so that the tree is the
+// reference's: top-down, per node a histogram of the surfaces' box centroids over `bins` bins (one axis) or
+// bins x bins (two axes), every split position costed with the surface-area heuristic against the node's box, an
+// order-preserving partition. What differs is the execution: subtrees are independent once their surface lists exist,
+// so they are built by as many host threads as there are, and the depth-first numbering is a second pass.
+// ------------------------------------------------------------------------------------------------
+struct Box6 {
+    double mn[3], mx[3];
+    Box6() {  // BoundingBox(), bounding-box.hpp:25-26
+        for (int c = 0; c < 3; c++) {
+            mn[c] = 1.7976931348623157e308;
+            mx[c] = -1.7976931348623157e308;
+        }
+    }
+    void merge(const double* b) {  // bounding-box.cpp:56-63
+        for (int c = 0; c < 3; c++) {
+            if (mn[c] > b[c]) mn[c] = b[c];
+            if (mx[c] < b[3 + c]) mx[c] = b[3 + c];
+        }
+    }
+    void merge(const Box6& o) {
+        for (int c = 0; c < 3; c++) {
+            if (mn[c] > o.mn[c]) mn[c] = o.mn[c];
+            if (mx[c] < o.mx[c]) mx[c] = o.mx[c];
+        }
+    }
+    void mergePoint(const double* p) {  // bounding-box.cpp:65-72
+        for (int c = 0; c < 3; c++) {
+            if (mn[c] > p[c]) mn[c] = p[c];
+            if (mx[c] < p[c]) mx[c] = p[c];
+        }
+    }
+    double area() const {  // bounding-box.cpp:35-40
+        for (int c = 0; c < 3; c++)
+            if (mn[c] > mx[c]) return 0.0;
+        const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return 2.0 * (dx * dy + dx * dz + dy * dz);
+    }
+};
+
+struct SahNode {
+    Box6 bb;
+    std::vector<uint32_t> surfaces;
+    std::vector<std::unique_ptr<SahNode>> children;
+};
+
+struct SahBuilder {
+    const double* bb;        // [n][6] surface boxes
+    const double* centroid;  // [n][3]
+    int bins;
+    std::atomic<int> free_threads;
+    static constexpr size_t kLeaf = 8, kMaxLeaf = 0xFF;  // BVH::leaf_surfaces, max_leaf_surfaces (bvh.hpp:91-92)
+    static constexpr size_t kSpawn = 20000;              // subtrees smaller than this stay on the current thread
+
+    void arbitrarySplit(SahNode* node, size_t N) {  // bvh.cpp:451-473
+        auto& S = node->surfaces;
+        N = std::min(N, S.size());
+        for (size_t i = 0; i < N; i++) node->children.emplace_back(new SahNode());
+        for (size_t i = 0; i < S.size(); i++) {
+            SahNode* c = node->children[i % N].get();
+            c->surfaces.push_back(S[i]);
+            c->bb.merge(bb + (size_t)S[i] * 6);
+        }
+        S.clear();
+    }
+
+    template <class F>
+    void forChildren(SahNode* node, F recurse) {
+        std::vector<std::thread> spawned;
+        for (auto& c : node->children) {
+            SahNode* child = c.get();
+            if (child->surfaces.size() >= kSpawn && free_threads.fetch_sub(1) > 0) {
+                spawned.emplace_back([this, child, recurse]() {
+                    recurse(child);
+                    free_threads.fetch_add(1);
+                });
+            } else {
+                if (child->surfaces.size() >= kSpawn) free_threads.fetch_add(1);  // undo the failed claim
+                recurse(child);
+            }
+        }
+        for (auto& t : spawned) t.join();
+    }
+
+    void binary(SahNode* node) {  // recursiveBuildBinarySAH, bvh.cpp:165-288
+        auto& S = node->surfaces;
+        if (S.size() <= kLeaf) return;
+        Box6 ce;
+        for (uint32_t s : S) ce.mergePoint(centroid + (size_t)s * 3);
+        const double dims[3] = {ce.mx[0] - ce.mn[0], ce.mx[1] - ce.mn[1], ce.mx[2] - ce.mn[2]};
+        const int axis = dims[0] > dims[1] ? (dims[0] > dims[2] ? 0 : 2) : (dims[1] > dims[2] ? 1 : 2);
+        auto recurse = [this](SahNode* n) { binary(n); };
+        if (dims[axis] < 1e-9) {
+            if (S.size() > kMaxLeaf) {
+                arbitrarySplit(node, 2);
+                forChildren(node, recurse);
+            }
+            return;
+        }
+        auto getIdx = [&](uint32_t s) {
+            const double f = (centroid[(size_t)s * 3 + axis] - ce.mn[axis]) / dims[axis];
+            const int idx = (int)std::floor(f * bins);
+            return std::min(idx, bins - 1);
+        };
+        std::vector<size_t> count(bins, 0);
+        std::vector<Box6> bbox(bins);
+        for (uint32_t s : S) {
+            const int idx = getIdx(s);
+            count[idx]++;
+            bbox[idx].merge(bb + (size_t)s * 6);
+        }
+        double min_cost = 1.7976931348623157e308;
+        size_t split_bin = 0;
+        const double node_area = node->bb.area();
+        for (size_t i = 0; i + 1 < (size_t)bins; i++) {
+            size_t a_count = 0, b_count = 0;
+            Box6 a_bb, b_bb;
+            for (size_t j = 0; j < i + 1; j++) {
+                a_count += count[j];
+                a_bb.merge(bbox[j]);
+            }
+            for (size_t j = i + 1; j < (size_t)bins; j++) {
+                b_count += count[j];
+                b_bb.merge(bbox[j]);
+            }
+            const double cost = 1.0 + ((double)a_count * a_bb.area() + (double)b_count * b_bb.area()) / node_area;
+            if (cost < min_cost) {
+                split_bin = i;
+                min_cost = cost;
+            }
+        }
+        if (min_cost > (double)S.size()) {
+            if (S.size() > kMaxLeaf) {
+                arbitrarySplit(node, 2);
+                forChildren(node, recurse);
+            }
+            return;
+        }
+        std::unique_ptr<SahNode> A(new SahNode()), B(new SahNode());
+        for (uint32_t s : S) {
+            SahNode* side = (size_t)getIdx(s) <= split_bin ? A.get() : B.get();
+            side->surfaces.push_back(s);
+            side->bb.merge(bb + (size_t)s * 6);
+        }
+        std::vector<uint32_t>().swap(S);
+        if (!A->surfaces.empty()) node->children.push_back(std::move(A));
+        if (!B->surfaces.empty()) node->children.push_back(std::move(B));
+        forChildren(node, recurse);
+    }
+
+    void quaternary(SahNode* node) {  // recursiveBuildQuaternarySAH, bvh.cpp:290-426
+        auto& S = node->surfaces;
+        if (S.size() <= kLeaf) return;
+        Box6 ce;
+        for (uint32_t s : S) ce.mergePoint(centroid + (size_t)s * 3);
+        const double dims[3] = {ce.mx[0] - ce.mn[0], ce.mx[1] - ce.mn[1], ce.mx[2] - ce.mn[2]};
+        int ax, ay;
+        if (dims[0] > dims[1]) {
+            ax = 0;
+            ay = dims[1] > dims[2] ? 1 : 2;
+        } else {
+            if (dims[0] > dims[2]) { ax = 0; ay = 1; } else { ax = 1; ay = 2; }
+        }
+        if (dims[ax] < 1e-9 || dims[ay] < 1e-9) {  // one usable axis: the binary rule, same node (bvh.cpp:313-318)
+            binary(node);
+            return;
+        }
+        auto getIdx = [&](uint32_t s, int& ix, int& iy) {
+            const double fx = (centroid[(size_t)s * 3 + ax] - ce.mn[ax]) / dims[ax];
+            const double fy = (centroid[(size_t)s * 3 + ay] - ce.mn[ay]) / dims[ay];
+            ix = std::min((int)std::floor(fx * (double)bins), bins - 1);
+            iy = std::min((int)std::floor(fy * (double)bins), bins - 1);
+        };
+        std::vector<size_t> count((size_t)bins * bins, 0);
+        std::vector<Box6> bbox((size_t)bins * bins);
+        for (uint32_t s : S) {
+            int ix, iy;
+            getIdx(s, ix, iy);
+            count[(size_t)ix * bins + iy]++;
+            bbox[(size_t)ix * bins + iy].merge(bb + (size_t)s * 6);
+        }
+        double min_cost = 1.7976931348623157e308;
+        int split_x = 0, split_y = 0;
+        const double node_area = node->bb.area();
+        for (int i = 0; i < bins - 1; i++)
+            for (int j = 0; j < bins - 1; j++) {
+                double cost = 0.0;
+                for (int v = 0; v < 4; v++) {
+                    const int x0 = (v & 1) ? i + 1 : 0, x1 = (v & 1) ? bins : i + 1;
+                    const int y0 = (v & 2) ? j + 1 : 0, y1 = (v & 2) ? bins : j + 1;
+                    size_t n = 0;
+                    Box6 q;
+                    for (int x = x0; x < x1; x++)
+                        for (int y = y0; y < y1; y++) {
+                            n += count[(size_t)x * bins + y];
+                            q.merge(bbox[(size_t)x * bins + y]);
+                        }
+                    cost += q.area() * (double)n;
+                }
+                cost = 1.0 + cost / node_area;
+                if (cost < min_cost) {
+                    split_x = i;
+                    split_y = j;
+                    min_cost = cost;
+                }
+            }
+        auto recurse = [this](SahNode* n) { quaternary(n); };
+        if (min_cost > (double)S.size()) {
+            if (S.size() > kMaxLeaf) {
+                arbitrarySplit(node, 4);
+                forChildren(node, recurse);
+            }
+            return;
+        }
+        std::unique_ptr<SahNode> quad[4];
+        for (uint32_t s : S) {
+            int ix, iy;
+            getIdx(s, ix, iy);
+            const int ci = (ix > split_x ? 1 : 0) | (iy > split_y ? 2 : 0);
+            if (!quad[ci]) quad[ci].reset(new SahNode());
+            quad[ci]->surfaces.push_back(s);
+            quad[ci]->bb.merge(bb + (size_t)s * 6);
+        }
+        std::vector<uint32_t>().swap(S);
+        for (auto& q : quad)
+            if (q) node->children.push_back(std::move(q));
+        forChildren(node, recurse);
+    }
+};
+
+// BVH::compact, bvh.cpp:428-449: depth-first numbering, surfaces of the leaves in visiting order.
+size_t countNodes(const SahNode* n) {
+    size_t c = 1;
+    for (const auto& ch : n->children) c += countNodes(ch.get());
+    return c;
+}
+
+void compact(const SahNode* node, uint32_t next_sibling, mcrt_bvh* B) {
+    B->start.push_back((uint32_t)B->order.size());
+    B->count.push_back((uint32_t)(uint8_t)node->surfaces.size());  // LinearNode::num_surfaces is a uint8_t (bvh.cpp:433)
+    B->next.push_back(next_sibling);
+    for (int c = 0; c < 3; c++) B->bounds.push_back(node->bb.mn[c]);
+    for (int c = 0; c < 3; c++) B->bounds.push_back(node->bb.mx[c]);
+    for (uint32_t s : node->surfaces) B->order.push_back(s);
+    const size_t nc = node->children.size();
+    for (size_t i = 0; i < nc; i++) {
+        // a child's next sibling sits right after the child's subtree in depth-first order; 0 = none (bvh.cpp:443-447)
+        const uint32_t my_id = (uint32_t)B->start.size();
+        const uint32_t sibling = i + 1 < nc ? my_id + (uint32_t)countNodes(node->children[i].get()) : 0u;
+        compact(node->children[i].get(), sibling, B);
+    }
+}
+
+int buildSah(const mcrt_scene_desc* s, int arity, uint32_t bins, uint32_t threads, mcrt_bvh* B) {
+    const uint64_t n = s->num_surfaces;
+    std::vector<double> bb(n * 6), centroid(n * 3);
+    for (uint64_t i = 0; i < n; i++) {
+        double* b = &bb[i * 6];
+        surfaceBounds(s->surf_kind[i], s->surf_v + 9 * i, s->quadrics, b);
+        for (int c = 0; c < 3; c++) centroid[i * 3 + c] = (b[3 + c] + b[c]) / 2.0;  // BB().centroid()
+    }
+    SahBuilder sb;
+    sb.bb = bb.data();
+    sb.centroid = centroid.data();
+    sb.bins = (int)(bins ? bins : (arity == 4 ? 8u : 16u));  // bvh.cpp:29,36
+    unsigned hw = threads ? threads : std::thread::hardware_concurrency();
+    sb.free_threads.store((int)(hw > 1 ? hw - 1 : 0));
+    SahNode root;
+    for (int c = 0; c < 3; c++) {  // root->BB = the scene box handed to the builder (bvh.cpp:20)
+        root.bb.mn[c] = s->bb_min[c];
+        root.bb.mx[c] = s->bb_max[c];
+    }
+    root.surfaces.resize(n);
+    std::iota(root.surfaces.begin(), root.surfaces.end(), 0u);
+    if (arity == 4) sb.quaternary(&root);
+    else sb.binary(&root);
+    compact(&root, 0, B);
+    finishBvhDesc(B);
+    return MCRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -60,6 +348,18 @@ int mcrt_bvh_build_octree(mcrt_ctx* ctx, const mcrt_scene_desc* scene, mcrt_bvh*
     if (rc != MCRT_OK) {
         delete B;
         if (ctx && rc == MCRT_ERR_UNSUPPORTED) return ctxFail(ctx, rc, "more than 8 surface centroids inside one 2^-21 cell of the scene cube");
+        return rc;
+    }
+    *out = B;
+    return MCRT_OK;
+}
+
+int mcrt_bvh_build_sah(const mcrt_scene_desc* scene, int arity, uint32_t bins_per_axis, uint32_t threads, mcrt_bvh** out) {
+    if (!out || !sceneUsable(scene) || (arity != 2 && arity != 4) || bins_per_axis == 1 || bins_per_axis > 1024) return MCRT_ERR_INVALID;
+    mcrt_bvh* B = new mcrt_bvh();
+    const int rc = buildSah(scene, arity, bins_per_axis, threads, B);
+    if (rc != MCRT_OK) {
+        delete B;
         return rc;
     }
     *out = B;

@@ -22,9 +22,9 @@ def _image_nodes(img):
                 count=g(s.node_num_surfaces, n, np.uint32), next=g(s.node_next_sibling, n, np.uint32))
 
 
-def _check_same_tree(pkg, img, ctx=None):
+def _check_same_tree(pkg, img, ctx=None, kind="octree", threads=0):
     ref = _image_nodes(img)
-    bvh = pkg.Bvh(img.scene, ctx=ctx)
+    bvh = pkg.Bvh(img.scene, ctx=ctx, kind=kind, threads=threads)
     got = bvh.arrays()
     for k in ("bounds", "start", "count", "next"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
@@ -37,6 +37,29 @@ def _check_same_tree(pkg, img, ctx=None):
 def test_rebuilds_the_reference_octree_bvh(pkg, manifest, name):
     img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
     assert _check_same_tree(pkg, img) == img.scene.num_nodes > 0
+
+
+@pytest.mark.parametrize("name,kind", [("coffee_maker_qsah", "quaternary_sah"), ("coffee_maker_bsah", "binary_sah")])
+@pytest.mark.parametrize("threads", [1, 0])
+def test_rebuilds_the_reference_sah_bvh(pkg, manifest, name, kind, threads):
+    """The binned-SAH builders restated (mcrt_bvh_build_sah): same tree as the reference's, on one thread and on all."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    assert _check_same_tree(pkg, img, kind=kind, threads=threads) == img.scene.num_nodes > 0
+
+
+@pytest.mark.parametrize("name,nodes", [("c3", 169162), ("c4", 153801), ("spaceship", 23187)])
+def test_large_scene_sah(pkg, name, nodes):
+    """Quaternary SAH trees of the full-size C3 / C4 stand-ins and of the spaceship cockpit, all host threads."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    import make_large
+    p = make_large.image_path(name) if name != "spaceship" else os.path.join(ROOT, "oracle", "_ref", "images", "spaceship.mcrt")
+    if not os.path.exists(p):
+        pytest.skip("%s image not built on this machine" % name)
+    img = pkg.SceneImage(p)
+    t = time.perf_counter()
+    assert _check_same_tree(pkg, img, kind="quaternary_sah") == nodes
+    print("%s: quaternary SAH of %d surfaces rebuilt and compared in %.2f s" % (name, img.scene.num_surfaces, time.perf_counter() - t))
 
 
 def test_shuffled_surfaces_give_the_same_hits(pkg, oracle, manifest):
