@@ -148,8 +148,19 @@ typedef struct mcrt_camera_desc {
      * seeding stays hashCombine(global_seed, hash(y*width+x)) (camera.cpp:73, sampler.hpp:32-35)
      * so the image is independent of the split. */
     uint32_t shard_index, shard_count, shard_rows;
+    /* Film reconstruction filter (camera/film.cpp:19-58, camera/filter.hpp): MCRT_FILM_BOX is the reference's default
+     * Film(width, height): radius 0.5, every sample lands in its own pixel with weight 1. Any other filter makes every
+     * sample a splat over the pixels within film_radius (0 = the filter's default radius, film.cpp:31-44), weights from
+     * the filter function or, when film_cache_size > 0, from a table of that many samples of it (film.cpp:49-57,86-97);
+     * such frames are rendered by the wavefront pipeline (path tracer, scenes with a BVH, shard_count <= 1). */
+    uint32_t film_filter;
+    double   film_radius;
+    uint32_t film_cache_size;
     uint32_t reserved;
 } mcrt_camera_desc;
+
+enum { MCRT_FILM_BOX = 0, MCRT_FILM_MITCHELL_NETRAVALI = 1, MCRT_FILM_CATMULL_ROM = 2, MCRT_FILM_B_SPLINE = 3, MCRT_FILM_HERMITE = 4,
+       MCRT_FILM_GAUSSIAN = 5, MCRT_FILM_LANCZOS = 6 };
 
 enum { MCRT_INTEGRATOR_PATH_TRACER = 0, MCRT_INTEGRATOR_PHOTON_MAPPER = 1 };
 

@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmcrt_hip.so")
 ABI_VERSION = 2
 
+FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
 SURF_TRIANGLE, SURF_SPHERE = 0, 1
@@ -86,7 +87,7 @@ class CameraDesc(C.Structure):
         ("thin_lens", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
         ("sqrtspp", C.c_uint32),
         ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("shard_rows", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("film_filter", C.c_uint32), ("film_radius", C.c_double), ("film_cache_size", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
     def copy(self):

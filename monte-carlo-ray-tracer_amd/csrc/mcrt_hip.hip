@@ -823,6 +823,7 @@ struct DevWfEnv {
     unsigned long long* count;
     __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
+    __device__ void filmAdd(double* a, double v) const { atomicAdd(a, v); }  // std::atomic<double> of Film::Splat
     __device__ void push(uint32_t slot, bool p0, bool p1) const {
         const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
         const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
@@ -870,6 +871,12 @@ __global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scen
     uint32_t paths = 0;
     wfShadeSlot<false>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths);
     waveAccumulate(a.stats + 0, paths);
+}
+
+// Film::scan over the frame (film.cpp:81-84,107-113): the splats of a reconstruction-filter frame -> image.
+__global__ void filmResolveKernel(const double* blob, uint64_t pixels, double* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pixels) filmResolve(blob + i * 4, out + i * 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1267,7 +1274,7 @@ struct mcrt_ctx {
     std::vector<uint64_t> host_keys[2];
 
     // wavefront path tracer: slot pool, ray queue, control words {count[2], pop}, pinned read-back word
-    DevBuf wf_pool, wf_queue, wf_ctrl;
+    DevBuf wf_pool, wf_queue, wf_ctrl, wf_film, wf_film_cache;
     uint32_t wf_slots = 0;
     unsigned long long* wf_host = nullptr;   // pinned: one read-back word per half
     hipStream_t wf_stream[2] = {nullptr, nullptr};
@@ -1420,6 +1427,33 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     fr.tiles_x = (cam->width + 7) / 8;
     fr.work_items = (unsigned long long)fr.tiles_x * ((fr.owned_rows + 7) / 8) * 64ull;
     fr.out = d_out;
+    fr.film.type = MCRT_FILM_BOX;
+    if (cam->film_filter != MCRT_FILM_BOX) {  // Film::Film(width, height, json), film.cpp:19-58
+        if (cam->film_filter > MCRT_FILM_LANCZOS) return fail(ctx, MCRT_ERR_INVALID, "camera: unknown film filter");
+        if (cam->shard_count > 1)
+            return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters splat across row groups: render them unsharded (shard_count <= 1)");
+        FilmView& f = fr.film;
+        f.type = cam->film_filter;
+        f.width = cam->width;
+        f.height = cam->height;
+        f.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);
+        f.two_inv_radius = 2.0 / f.radius;
+        f.cache_size = cam->film_cache_size;
+        f.inv_dx = 0.0;
+        f.cache = nullptr;
+        if (f.cache_size) {
+            if (f.cache_size < 2) return fail(ctx, MCRT_ERR_INVALID, "camera: film_cache_size must be 0 or at least 2");
+            std::vector<double> table(f.cache_size);
+            for (uint32_t i = 0; i < f.cache_size; i++) table[i] = filmFilterFunction(f.type, (2.0 * (int)i) / (double)(f.cache_size - 1));
+            if (int rc = uploadArray(ctx, ctx->wf_film_cache, table.data(), table.size())) return rc;
+            f.cache = ctx->wf_film_cache.as<double>();
+            f.inv_dx = (double)(f.cache_size - 1) / f.radius;
+        }
+        const size_t blob_bytes = (size_t)cam->width * cam->height * 4 * sizeof(double);
+        if (ctx->wf_film.bytes < blob_bytes) HIP_TRY(ctx, ctx->wf_film.alloc(blob_bytes));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_film.p, 0, blob_bytes, stream));
+        f.blob = ctx->wf_film.as<double>();
+    }
 
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
@@ -1531,6 +1565,12 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[i], hs[i]));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev[i], 0));
         }
+    if (fr.film.type != MCRT_FILM_BOX) {
+        const uint64_t pixels = (uint64_t)cam->width * cam->height;
+        hipLaunchKernelGGL(filmResolveKernel, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream, fr.film.blob, pixels, d_out);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->launches++;
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->pending = true;
     return MCRT_OK;
@@ -1563,7 +1603,10 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     const bool use_sm = !photon && !ctx->scene.flat && !(kenv && strcmp(kenv, "legacy") == 0);
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
-    const bool want_wf = kenv && strcmp(kenv, "wf") == 0;
+    const bool filtered = cam->film_filter != MCRT_FILM_BOX;  // per-sample splats: the wavefront pipeline's shade kernel has them
+    if (filtered && (photon || ctx->scene.num_nodes == 0))
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for path-traced scenes with a BVH");
+    const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
     const char* mn = getenv("MCRT_WF_MIN_NODES");

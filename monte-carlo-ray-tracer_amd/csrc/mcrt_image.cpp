@@ -5,6 +5,7 @@
 // Layout: "MCRTIMG1" | u32 abi | u32 num_chunks | { char name[24]; u64 nbytes; data; pad to 8 }*
 #include "../../include/mcrt.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -169,9 +170,13 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
     }
     s.quadrics = chunkPtr<double>(img, "quadrics", &n);
     s.num_quadrics = (uint32_t)(n / 22);
-    const mcrt_camera_desc* cam = chunkPtr<mcrt_camera_desc>(img, "camera", &n);
-    if (cam && n >= 1) img->camera = *cam;
-    else memset(&img->camera, 0, sizeof(img->camera));
+    // the camera record has grown over time (film filter fields): take what the file has, the rest stays zero (= box filter)
+    memset(&img->camera, 0, sizeof(img->camera));
+    {
+        auto it = img->chunks.find("camera");
+        if (it != img->chunks.end())
+            memcpy(&img->camera, it->second.bytes.data(), std::min(it->second.bytes.size(), sizeof(img->camera)));
+    }
     img->has_map[0] = loadMap(img, "g_", &img->maps[0]);
     img->has_map[1] = loadMap(img, "c_", &img->maps[1]);
     const ParamKV* kv = chunkPtr<ParamKV>(img, "params", &n);

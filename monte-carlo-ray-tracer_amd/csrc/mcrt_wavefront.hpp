@@ -24,6 +24,7 @@
 // and the host emulation used by the CPU tests (tests/emu).
 #pragma once
 
+#include "mcrt_film.hpp"
 #include "mcrt_lanesm.hpp"
 
 namespace mcrt {
@@ -100,6 +101,7 @@ struct WfFrame {
     uint32_t global_seed, spp, owned_rows, tiles_x;
     unsigned long long work_items;  // tiles_x * tiles_y * 64 (8x8 pixel tiles, as the megakernels)
     double* out;                    // [owned_rows][width][3]
+    FilmView film;                  // type != MCRT_FILM_BOX: samples are splatted into film.blob instead (mcrt_film.hpp)
 };
 
 // ---- trace side: work item = slot * 2 + port (0 = bounce ray, closest hit; 1 = shadow ray, bounded any-hit)
@@ -138,7 +140,8 @@ MCRT_HD void wfStoreHit(const WfPool& P, uint32_t item, const Hit& h) {
 //   bool any(bool)                      true if the predicate holds for any lane of the wave (host: identity)
 //   unsigned long long pop(bool need)   next index of the frame's pixel work counter for the lanes that need one
 //   void push(slot, bool p0, bool p1)   queue the slot's bounce ray / shadow ray for the next trace launch
-// All three are called by every lane of the wave, at the same place.
+//   void filmAdd(double*, double)       accumulate into a film splat (any lane, any time; atomic on the GPU)
+// The first three are called by every lane of the wave, at the same place.
 template <bool L, class Env>
 MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, const WfFrame& fr, const ShadeViewT<L>& sh,
                          RefractionHistory& rh, SobolTab tab, uint32_t& paths) {
@@ -236,7 +239,13 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             nee.pending = false;
             ended = have_pixel;  // the path died at its previous bounce; its last NEE has just been added
         }
-        if (ended) {  // Film::deposit with the box filter + next sample / pixel bookkeeping
+        if (ended && fr.film.type != MCRT_FILM_BOX) {  // Film::deposit with a reconstruction filter: a splat per sample
+            Sampler at_start = st.smp;  // the sample's pixel position: the two draws of camera.cpp:79-80, sampler as it was then
+            at_start.setIndex(sample);
+            const double fx = (double)px + at_start.get(kDimPixel, tab), fy = (double)ly + at_start.get(kDimPixel + 1, tab);
+            filmDeposit(fr.film, fx, fy, st.radiance, [&](double* a, double v) { env.filmAdd(a, v); });
+            if (++sample == fr.spp) have_pixel = false;
+        } else if (ended) {  // Film::deposit with the box filter + next sample / pixel bookkeeping
             acc0 += st.radiance.x * 1.0;
             acc1 += st.radiance.y * 1.0;
             acc2 += st.radiance.z * 1.0;

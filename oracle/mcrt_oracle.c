@@ -981,12 +981,66 @@ static v3 photonMapperSampleRay(Ctx* C, Ray ray, Sampler* smp) { /* :279-341 */
 }
 
 /* ------------------------------------------------------------------ Camera::samplePixel + Film (camera/camera.cpp:66-99) */
+/* ---- Film with a reconstruction filter (camera/film.cpp:19-113, camera/filter.hpp). The default box film needs no
+ * buffer (a sample lands in its own pixel with weight 1); every other filter splats into job->film. */
+static double mitchellNetravali(double B, double C_, double x) { /* filter.hpp:16-40 */
+    double k = 6.0 / (6.0 - 2.0 * B);
+    if (x < 1.0) {
+        double a = k * (12.0 - 9.0 * B - 6.0 * C_) / 6.0, b = k * (-18.0 + 12.0 * B + 6.0 * C_) / 6.0, d = k * (6.0 - 2.0 * B) / 6.0;
+        return d + (b + a * x) * x * x;
+    }
+    double a = k * (-B - 6.0 * C_) / 6.0, b = k * (6.0 * B + 30.0 * C_) / 6.0, c = k * (-12.0 * B - 48.0 * C_) / 6.0, d = k * (8.0 * B + 24.0 * C_) / 6.0;
+    return d + (c + (b + a * x) * x) * x;
+}
+static double filmFilterFunction(uint32_t type, double x) {
+    switch (type) {
+        case MCRT_FILM_MITCHELL_NETRAVALI: return mitchellNetravali(1.0 / 3.0, 1.0 / 3.0, x);
+        case MCRT_FILM_CATMULL_ROM: return mitchellNetravali(0.0, 0.5, x);
+        case MCRT_FILM_B_SPLINE: return mitchellNetravali(1.0, 0.0, x);
+        case MCRT_FILM_HERMITE: return mitchellNetravali(0.0, 0.0, x * 0.5);
+        case MCRT_FILM_GAUSSIAN: return exp(-2.0 * x * x) - exp(-2.0 * 2.0 * 2.0);
+        case MCRT_FILM_LANCZOS: return x == 0.0 ? 1.0 : 2.0 * sin(PI * x) * sin(PI * x / 2.0) / (PI * PI * x * x);
+        default: return 1.0;
+    }
+}
+typedef struct { uint32_t type, cache_size, width, height; double radius, two_inv_radius, inv_dx; double* cache; double* blob; } Film;
+static double filmFilter(const Film* f, double x) { /* film.cpp:86-97 */
+    if (f->cache_size == 0) return filmFilterFunction(f->type, f->two_inv_radius * fabs(x));
+    return f->cache[(size_t)(f->inv_dx * fabs(x) + 0.5)];
+}
+static void filmDeposit(Film* f, double px, double py, v3 v) { /* film.cpp:61-79 */
+    long long min_x = (long long)(px + 0.5 - f->radius), min_y = (long long)(py + 0.5 - f->radius);
+    long long max_x = (long long)(px - 0.5 + f->radius), max_y = (long long)(py - 0.5 + f->radius);
+    if (min_x < 0) min_x = 0;
+    if (min_y < 0) min_y = 0;
+    if (max_x > (long long)f->width - 1) max_x = (long long)f->width - 1;
+    if (max_y > (long long)f->height - 1) max_y = (long long)f->height - 1;
+    for (long long y = min_y; y <= max_y; y++) {
+        double weight_y = filmFilter(f, (double)y + 0.5 - py);
+        for (long long x = min_x; x <= max_x; x++) {
+            double weight = weight_y * filmFilter(f, (double)x + 0.5 - px);
+            double* s = f->blob + ((size_t)y * f->width + (size_t)x) * 4;
+            s[0] += v.x * weight; s[1] += v.y * weight; s[2] += v.z * weight; s[3] += weight;
+        }
+    }
+}
+static double filmDefaultRadius(uint32_t type) { /* film.cpp:31-44 */
+    switch (type) {
+        case MCRT_FILM_MITCHELL_NETRAVALI: case MCRT_FILM_CATMULL_ROM: case MCRT_FILM_LANCZOS: return 2.0;
+        case MCRT_FILM_B_SPLINE: return 1.39;
+        case MCRT_FILM_HERMITE: return 1.0;
+        case MCRT_FILM_GAUSSIAN: return 1.71;
+        default: return 0.5;
+    }
+}
+
 typedef struct {
     const mcrt_scene_desc* scene; const mcrt_photon_map_desc* maps[2];
     uint32_t k_nearest; int direct_visualization;
     const mcrt_camera_desc* cam; uint32_t global_seed; int integrator;
     uint32_t row0, row1;
     double* out_rgb; double* out_samples;
+    Film* film; /* non-box reconstruction filter: splats (single-threaded) */
     volatile uint32_t next_row;
     oracle_counters total; pthread_mutex_t lock;
 } Job;
@@ -1020,12 +1074,14 @@ static void samplePixel(Job* job, Ctx* C, uint32_t x, uint32_t y) {
         v3 L = job->integrator == MCRT_INTEGRATOR_PHOTON_MAPPER ? photonMapperSampleRay(C, ray, &smp)
                                                                 : pathTracerSampleRay(C, ray, &smp);
         /* Film::deposit with the default box filter, radius 0.5: the sample's own pixel, weight 1 (film.cpp:13-17,61-79) */
+        if (job->film) filmDeposit(job->film, px, py, L);
         sum[0] += L.x * 1.0; sum[1] += L.y * 1.0; sum[2] += L.z * 1.0; weight_sum += 1.0;
         if (job->out_samples) {
             double* o = job->out_samples + ((((size_t)(y - job->row0) * cam->width + x) * spp + i) * 3);
             o[0] = L.x; o[1] = L.y; o[2] = L.z;
         }
     }
+    if (job->film) return; /* the frame is read from the film when every sample has been deposited */
     double* o = job->out_rgb + ((size_t)(y - job->row0) * cam->width + x) * 3;
     for (int c = 0; c < 3; c++) o[c] = weight_sum == 0.0 ? 0.0 : gmax(sum[c] / weight_sum, 0.0); /* Splat::get, film.cpp:107-113 */
 }
@@ -1071,6 +1127,21 @@ int oracle_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* glob
     pthread_mutex_init(&job.lock, NULL);
     if (threads <= 0) threads = oracle_hardware_threads();
     if (threads > 1024) threads = 1024;
+    Film film; memset(&film, 0, sizeof(film));
+    if (cam->film_filter != MCRT_FILM_BOX) { /* Film::Film(width, height, json), film.cpp:19-58 */
+        film.type = cam->film_filter; film.width = cam->width; film.height = cam->height;
+        film.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);
+        film.two_inv_radius = 2.0 / film.radius;
+        film.cache_size = cam->film_cache_size;
+        if (film.cache_size) {
+            film.cache = (double*)malloc(sizeof(double) * film.cache_size);
+            for (uint32_t i = 0; i < film.cache_size; i++) film.cache[i] = filmFilterFunction(film.type, (2.0 * (int)i) / (double)(film.cache_size - 1));
+            film.inv_dx = (double)(film.cache_size - 1) / film.radius;
+        }
+        film.blob = (double*)calloc((size_t)cam->width * cam->height * 4, sizeof(double));
+        job.film = &film;
+        threads = 1; /* plain adds into shared splats; the reference's atomics make its own sums order dependent too */
+    }
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1079,6 +1150,15 @@ int oracle_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* glob
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
     pthread_mutex_destroy(&job.lock);
+    if (job.film) { /* Film::scan of the rendered rows, film.cpp:81-84,107-113 */
+        for (uint32_t y = row0; y < row1; y++)
+            for (uint32_t x = 0; x < cam->width; x++) {
+                const double* s = film.blob + ((size_t)y * cam->width + x) * 4;
+                double* o2 = out_rgb + ((size_t)(y - row0) * cam->width + x) * 3;
+                for (int c = 0; c < 3; c++) o2[c] = s[3] == 0.0 ? 0.0 : gmax(s[c] / s[3], 0.0);
+            }
+        free(film.blob); free(film.cache);
+    }
     if (counters) *counters = job.total;
     if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     return 0;

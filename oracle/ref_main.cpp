@@ -55,6 +55,9 @@ struct Args {
     long width = -1, height = -1, sqrtspp = -1, threads = -1;
     long row0 = 0, row1 = -1;
     double emissions = -1, caustic_factor = -1, f_stop = 0, focus_distance = 0;
+    std::string film_filter;  // camera "film": {"filter", "radius", "cache_size"} (camera.cpp:34-35, film.cpp:19-58)
+    double film_radius = 0;
+    int film_cache = 0;
     long knn_k = -1;
     std::string bvh;
     long bins = -1;
@@ -67,6 +70,7 @@ struct Args {
         "usage: mcrt_ref <flatten|render|kat>[,<mode>...] --scene file.json [--camera N] [--photon]\n"
         "   [--width W --height H --sqrtspp S] [--bvh octree|binary_sah|quaternary_sah] [--bins B]\n"
         "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K] [--f-stop X] [--focus-distance D]\n"
+        "   [--film-filter mitchell-netravali|catmull-rom|b-spline|hermite|gaussian|lanczos] [--film-radius R] [--film-cache N]\n"
         "   [--specular-roughness material value]... [--n N]\n"
         "   --out image.mcrt (flatten) --out-radiance file.f64 [--out-samples file.f64] (render) --out-kat dir (kat)\n"
         "   several modes in one run share ONE Camera/Scene/photon map (photon order is thread-dependent)\n");
@@ -97,6 +101,9 @@ Args parse(int argc, char** argv) {
         else if (k == "--k") a.knn_k = std::stol(next());
         else if (k == "--f-stop") a.f_stop = std::stod(next());
         else if (k == "--focus-distance") a.focus_distance = std::stod(next());
+        else if (k == "--film-filter") a.film_filter = next();
+        else if (k == "--film-radius") a.film_radius = std::stod(next());
+        else if (k == "--film-cache") a.film_cache = std::stoi(next());
         else if (k == "--bvh") a.bvh = next();
         else if (k == "--bins") a.bins = std::stol(next());
         else if (k == "--n") a.n = std::stol(next());
@@ -121,6 +128,11 @@ nlohmann::json loadScene(const Args& a) {
     if (a.sqrtspp > 0) cam["sqrtspp"] = a.sqrtspp;
     if (a.f_stop != 0) cam["f_stop"] = a.f_stop;                       // thin lens (camera.cpp:41-42,63)
     if (a.focus_distance != 0) cam["focus_distance"] = a.focus_distance;
+    if (!a.film_filter.empty()) {
+        cam["film"] = {{"filter", a.film_filter}};
+        if (a.film_radius > 0) cam["film"]["radius"] = a.film_radius;
+        if (a.film_cache > 0) cam["film"]["cache_size"] = a.film_cache;
+    }
     if (a.threads > 0) j["num_render_threads"] = a.threads;
     if (!a.bvh.empty()) {
         if (a.bvh == "none") j.erase("bvh");
@@ -308,7 +320,7 @@ void flattenMap(const LinearOctree<Photon>& map, FlatMap& M) {
     M.desc.photons = M.photons.data();
 }
 
-mcrt_camera_desc flattenCamera(const Camera& c) {
+mcrt_camera_desc flattenCamera(const Camera& c, const Args& a) {
     mcrt_camera_desc d;
     std::memset(&d, 0, sizeof(d));
     for (int i = 0; i < 3; i++) {
@@ -323,6 +335,15 @@ mcrt_camera_desc flattenCamera(const Camera& c) {
     d.height = (uint32_t)c.image.height;
     d.sqrtspp = (uint32_t)c.sqrtspp;
     d.shard_index = 0; d.shard_count = 1; d.shard_rows = 1;
+    // Film keeps its filter as a std::function: the kind comes from the scene description, radius and table size from the object
+    static const char* names[] = {"box", "mitchell-netravali", "catmull-rom", "b-spline", "hermite", "gaussian", "lanczos"};
+    d.film_filter = MCRT_FILM_BOX;
+    for (uint32_t i = 1; i < 7; i++)
+        if (a.film_filter == names[i]) d.film_filter = i;
+    if (d.film_filter != MCRT_FILM_BOX) {
+        d.film_radius = c.film.radius;
+        d.film_cache_size = (uint32_t)c.film.filter_cache.size();
+    }
     return d;
 }
 
@@ -335,7 +356,7 @@ void writeRaw(const std::string& path, const void* data, size_t nbytes) {
 int doFlatten(const Args& a, Camera& camera) {
     Flat F;
     flattenScene(camera.integrator->scene, F);
-    mcrt_camera_desc cd = flattenCamera(camera);
+    mcrt_camera_desc cd = flattenCamera(camera, a);
     FlatMap G, C;
     const mcrt_photon_map_desc *gp = nullptr, *cp = nullptr;
     std::vector<const char*> keys = {"global_seed", "photon_mapping"};

@@ -322,6 +322,7 @@ struct HostWfEnv {
     std::vector<uint32_t>* queue;
     bool any(bool b) const { return b; }
     unsigned long long pop(bool need) const { return need ? (*work)++ : 0ull; }
+    void filmAdd(double* a, double v) const { *a += v; }
     void push(uint32_t slot, bool p0, bool p1) const {
         if (p0) queue->push_back(slot * 2u);
         if (p1) queue->push_back(slot * 2u + 1u);
@@ -349,6 +350,27 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     fr.tiles_x = (cam->width + 7) / 8;
     fr.work_items = (unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull;
     fr.out = out_rgb;
+    fr.film.type = MCRT_FILM_BOX;
+    std::vector<double> blob, cache;
+    if (cam->film_filter != MCRT_FILM_BOX) {  // as launchWavefront sets the film up
+        FilmView& f = fr.film;
+        f.type = cam->film_filter;
+        f.width = cam->width;
+        f.height = cam->height;
+        f.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);
+        f.two_inv_radius = 2.0 / f.radius;
+        f.cache_size = cam->film_cache_size;
+        f.inv_dx = 0.0;
+        f.cache = nullptr;
+        if (f.cache_size) {
+            cache.resize(f.cache_size);
+            for (uint32_t i = 0; i < f.cache_size; i++) cache[i] = filmFilterFunction(f.type, (2.0 * (int)i) / (double)(f.cache_size - 1));
+            f.cache = cache.data();
+            f.inv_dx = (double)(f.cache_size - 1) / f.radius;
+        }
+        blob.assign((size_t)cam->width * cam->height * 4, 0.0);
+        f.blob = blob.data();
+    }
     unsigned long long work = 0;
     std::vector<uint32_t> queue;
     HostWfEnv env{&work, &queue};
@@ -369,6 +391,8 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
             wfStoreHit(P, item, h);
         }
     }
+    if (fr.film.type != MCRT_FILM_BOX)
+        for (size_t i = 0; i < (size_t)cam->width * cam->height; i++) filmResolve(&blob[i * 4], out_rgb + i * 3);
     if (counters) {
         counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
         counters[5] = iterations;

@@ -63,6 +63,16 @@ CASES = [
     dict(name="quadric", scene="quadric.json", args=[],
          image=dict(width=96, height=72, sqrtspp=3),
          renders=[dict(tag="quadric_96x72_s3", width=96, height=72, sqrtspp=3)], kat=3000),
+    # Film reconstruction filters (no shipped scene has a "film" key): splats instead of per-pixel sums
+    dict(name="film_mitchell", scene="hexagon_room.json", args=["--film-filter", "mitchell-netravali"],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="mitchell_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    dict(name="film_gaussian_cached", scene="metals.json", args=["--film-filter", "gaussian", "--film-cache", "64"],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="gaussian_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    dict(name="film_lanczos", scene="quadric.json", args=["--film-filter", "lanczos", "--film-radius", "1.5"],
+         image=dict(width=96, height=72, sqrtspp=2),
+         renders=[dict(tag="lanczos_96x72_s2", width=96, height=72, sqrtspp=2)]),
     dict(name="ggx_test", scene="ggx_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="ggx_96x54_s3", width=96, height=54, sqrtspp=3)]),
