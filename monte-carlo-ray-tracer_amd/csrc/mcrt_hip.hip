@@ -815,12 +815,30 @@ struct WfShadeArgs {
     unsigned long long* pop_reset;
     unsigned long long* work;         // the frame's pixel work counter
     unsigned long long* stats;
+    // photon mapper: estimate requests (slot | need_global << 31) for the next kNN launch, and the results of the last one
+    uint32_t* requests;
+    unsigned long long* rcount_out;
+    unsigned long long* rcount_reset;
+    unsigned long long* rpop_reset;
+    WfPmView pm;
 };
 
 struct DevWfEnv {
     unsigned long long* work;
     uint32_t* queue;
     unsigned long long* count;
+    uint32_t* requests;
+    unsigned long long* rcount;
+    __device__ void request(uint32_t slot, bool want, bool global) const {
+        const unsigned long long m = __ballot(want);
+        if (!m) return;
+        const uint32_t lane = laneId();
+        const int leader = __ffsll((long long)__ballot(true)) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(rcount, (unsigned long long)__popcll(m));
+        base = waveBroadcast64(base, leader);
+        if (want) requests[base + __popcll(m & ((1ull << lane) - 1ull))] = slot | (global ? 0x80000000u : 0u);
+    }
     __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
     __device__ void filmAdd(double* a, double v) const { atomicAdd(a, v); }  // std::atomic<double> of Film::Splat
@@ -840,6 +858,7 @@ struct DevWfEnv {
     }
 };
 
+template <bool kPhoton>
 __global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scene, const WfShadeArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, 0);
@@ -863,13 +882,17 @@ __global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scen
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *a.count_reset = 0ull;
         *a.pop_reset = 0ull;
+        if (kPhoton) {
+            *a.rcount_reset = 0ull;
+            *a.rpop_reset = 0ull;
+        }
     }
     __syncthreads();
     const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = local < a.slot_count;
-    DevWfEnv env{a.work, a.queue, a.count_out};
+    DevWfEnv env{a.work, a.queue, a.count_out, a.requests, a.rcount_out};
     uint32_t paths = 0;
-    wfShadeSlot<false>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths);
+    wfShadeSlot<false, kPhoton>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
     waveAccumulate(a.stats + 0, paths);
 }
 
@@ -877,6 +900,63 @@ __global__ void __launch_bounds__(kWfBlock) wfShadeKernel(const DeviceScene scen
 __global__ void filmResolveKernel(const double* blob, uint64_t pixels, double* out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < pixels) filmResolve(blob + i * 4, out + i * 3);
+}
+
+// kNN launch of the wavefront photon mapper: one estimate request per wave at a time (mcrt_waveknn.hpp), the k photons
+// of every search written out for the next shade launch. 80 VGPRs: 6 waves per SIMD.
+struct WfKnnArgs {
+    WfPool pool;
+    const uint32_t* requests;
+    const unsigned long long* count;
+    unsigned long long* pop;
+    unsigned long long* stats;
+    PhotonMapViewW maps[2];  // global, caustic
+    uint32_t k;
+    uint32_t* res_n;
+    double* res_r2;
+    uint32_t* res_idx;
+    double* res_d2;
+};
+
+__global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
+    __shared__ double s_d2[4 * kWaveCand];
+    __shared__ uint32_t s_idx[4 * kWaveCand];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    WaveKnnLds W;
+    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
+    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    const unsigned long long n = *a.count;
+    const uint32_t slots = a.pool.n;
+    uint32_t overflow = 0, visits = 0, searches = 0;
+    for (;;) {
+        unsigned long long w = 0ull;
+        if (lane == 0) w = atomicAdd(a.pop, 1ull);
+        w = waveBroadcast64(w, 0);
+        if (w >= n) break;
+        const uint32_t req = a.requests[w];
+        const uint32_t slot = req & 0x7FFFFFFFu;
+        // Interaction::position = ray(t) (interaction.cpp:15)
+        const d3 p = a.pool.get3(kWfRayO, slot) + a.pool.get3(kWfRayD, slot) * a.pool.getd(kWfHit0T, slot);
+        for (int map = 1; map >= ((req >> 31) ? 0 : 1); map--) {  // caustic map always, global map on request
+            double r2;
+            const uint32_t c = waveKnnSearch(a.maps[map], p, a.k, W, r2, overflow, visits);
+            searches++;
+            if (lane == 0) {
+                a.res_n[(size_t)map * slots + slot] = c;
+                a.res_r2[(size_t)map * slots + slot] = r2;
+            }
+            for (uint32_t j = lane; j < c; j += 64) {
+                const size_t at = ((size_t)map * a.k + j) * slots + slot;
+                a.res_idx[at] = W.idx[j];
+                a.res_d2[at] = W.d2[j];
+            }
+        }
+    }
+    if (lane == 0) {
+        if (searches) atomicAdd(a.stats + 4, (unsigned long long)searches);
+        if (visits) atomicAdd(a.stats + 6, (unsigned long long)visits);
+        if (overflow) atomicAdd(a.stats + 5, 1ull);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1274,7 +1354,8 @@ struct mcrt_ctx {
     std::vector<uint64_t> host_keys[2];
 
     // wavefront path tracer: slot pool, ray queue, control words {count[2], pop}, pinned read-back word
-    DevBuf wf_pool, wf_queue, wf_ctrl, wf_film, wf_film_cache;
+    DevBuf wf_pool, wf_queue, wf_ctrl, wf_film, wf_film_cache, wf_requests, wf_res_n, wf_res_r2, wf_res_idx, wf_res_d2;
+    uint32_t wf_res_slots = 0, wf_res_k = 0;
     uint32_t wf_slots = 0;
     unsigned long long* wf_host = nullptr;   // pinned: one read-back word per half
     hipStream_t wf_stream[2] = {nullptr, nullptr};
@@ -1416,7 +1497,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
 // looks at the queue length every few iterations (a launch with nothing to do costs microseconds), so the
 // call returns when the frame is complete; mcrt_render_finish() then only collects the statistics.
 int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, double* d_out, hipStream_t stream,
-                    bool count_tests) {
+                    bool count_tests, bool photon) {
     auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
     WfFrame fr;
     memset(&fr, 0, sizeof(fr));
@@ -1495,7 +1576,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
     // gain (C3 1074 vs 1101 Mray/s, C4 619 vs 681): a trace workgroup owns a CU's whole LDS, so the halves mostly
     // alternate, and each now pays its tail on half as many rays.
-    const int halves = (slots >= 4u * kWfBlock && envi("MCRT_WF_HALVES", 1) >= 2) ? 2 : 1;
+    const int halves = (!photon && slots >= 4u * kWfBlock && envi("MCRT_WF_HALVES", 1) >= 2) ? 2 : 1;
     hipStream_t hs[2] = {stream, stream};
     if (halves == 2) {
         for (int i = 0; i < 2; i++)
@@ -1534,6 +1615,46 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         shade_grid[h] = (sa[h].slot_count + kWfBlock - 1) / kWfBlock;
     }
 
+    // photon mapper: estimate requests and the kNN launch that serves them (control words 4..6 = {rcount[2], rpop})
+    WfKnnArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    uint32_t knn_grid = 0;
+    if (photon) {
+        const uint32_t k = ctx->k_nearest;
+        if (ctx->wf_res_slots != slots || ctx->wf_res_k != k) {
+            HIP_TRY(ctx, ctx->wf_requests.alloc((size_t)slots * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->wf_res_n.alloc((size_t)2 * slots * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->wf_res_r2.alloc((size_t)2 * slots * sizeof(double)));
+            HIP_TRY(ctx, ctx->wf_res_idx.alloc((size_t)2 * k * slots * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->wf_res_d2.alloc((size_t)2 * k * slots * sizeof(double)));
+            ctx->wf_res_slots = (uint32_t)slots;
+            ctx->wf_res_k = k;
+        }
+        ka.pool = pr[0].pool;
+        ka.requests = ctx->wf_requests.as<uint32_t>();
+        ka.pop = ctrl + 6;
+        ka.stats = ctx->stats.as<unsigned long long>();
+        ka.maps[0] = waveMapView(ctx, 0);
+        ka.maps[1] = waveMapView(ctx, 1);
+        ka.k = k;
+        ka.res_n = ctx->wf_res_n.as<uint32_t>();
+        ka.res_r2 = ctx->wf_res_r2.as<double>();
+        ka.res_idx = ctx->wf_res_idx.as<uint32_t>();
+        ka.res_d2 = ctx->wf_res_d2.as<double>();
+        knn_grid = (uint32_t)ctx->num_cus * 8u;
+        WfShadeArgs& s0 = sa[0];
+        s0.requests = ctx->wf_requests.as<uint32_t>();
+        s0.rpop_reset = ctrl + 6;
+        s0.pm.photons[0] = ctx->maps[0].photons;
+        s0.pm.photons[1] = ctx->maps[1].photons;
+        s0.pm.res_n = ka.res_n;
+        s0.pm.res_r2 = ka.res_r2;
+        s0.pm.res_idx = ka.res_idx;
+        s0.pm.res_d2 = ka.res_d2;
+        s0.pm.k = k;
+        s0.pm.direct_visualization = ctx->direct_visualization != 0;
+    }
+
     const uint64_t check_every = (uint64_t)std::max<long>(2, envi("MCRT_WF_CHECK", 16));
     bool done[2] = {false, halves == 1};
     for (uint64_t it = 0; !(done[0] && done[1]); it++) {
@@ -1542,14 +1663,22 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             unsigned long long* c = ctrl + 4 * h;
             sa[h].count_out = c + (it & 1);
             sa[h].count_reset = c + ((it + 1) & 1);
-            hipLaunchKernelGGL(wfShadeKernel, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
+            if (photon) {
+                sa[h].rcount_out = ctrl + 4 + (it & 1);
+                sa[h].rcount_reset = ctrl + 4 + ((it + 1) & 1);
+                hipLaunchKernelGGL(wfShadeKernel<true>, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
+            } else {
+                hipLaunchKernelGGL(wfShadeKernel<false>, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
+            }
             ctx->launches++;
             // the two halves look at their queue length at different iterations, so that one stream always has work queued
             if (it % check_every == (h == 0 ? check_every - 1 : check_every / 2 - 1) || it < 2) {
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + h, c + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
+                if (photon)  // (one half only) requests count as work too
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + 1, ctrl + 4 + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
                 HIP_TRY(ctx, hipStreamSynchronize(hs[h]));
-                if (ctx->wf_host[h] == 0ull) {  // nothing queued: every slot of this half is done
+                if (ctx->wf_host[h] == 0ull && (!photon || ctx->wf_host[1] == 0ull)) {  // nothing queued: every slot of this half is done
                     done[h] = true;
                     continue;
                 }
@@ -1557,6 +1686,11 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             ta[h].count = c + (it & 1);
             hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h]);
             ctx->launches++;
+            if (photon) {
+                ka.count = ctrl + 4 + (it & 1);
+                hipLaunchKernelGGL(wfKnnKernel, dim3(knn_grid), dim3(256), 0, hs[h], ka);
+                ctx->launches++;
+            }
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1604,15 +1738,18 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
     const bool filtered = cam->film_filter != MCRT_FILM_BOX;  // per-sample splats: the wavefront pipeline's shade kernel has them
-    if (filtered && (photon || ctx->scene.num_nodes == 0))
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for path-traced scenes with a BVH");
+    if (filtered && ctx->scene.num_nodes == 0)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for scenes with a BVH");
     const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
     const char* mn = getenv("MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
     if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
-        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests);
+        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false);
+    // photon-mapped frames: the same switch (deep tree -> trace / kNN / shade launches); k must fit the per-wave candidate buffer
+    if (photon && ctx->scene.num_nodes > 0 && ctx->k_nearest <= 128 && (want_wf || (!all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
+        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true);
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
                                                {renderKernelSM<true, false>, renderKernelSM<true, true>}};

@@ -286,24 +286,15 @@ MCRT_HD void smNeeFinish(PathState& st, const ShadeViewT<L>& sh, const NeePendin
     st.radiance = st.radiance + direct * nee.throughput;
 }
 
-// The shade block: everything PathTracer::sampleRay does between two Scene::intersect calls of the
-// path (path-tracer.cpp:27-49), with sampleDirect cut at its shadow-ray trace. Returns true when the
-// path continues with st.ray; nee.pending says whether a shadow ray (returned in shadow_ray / shadow_q)
-// must be traced first.
+// The tail of a bounce once the Interaction exists: next-event estimate set-up (cut at its shadow-ray trace), BSDF
+// sampling, throughput update, russian roulette, refraction history. Shared by the path tracer's shade block and the
+// photon mapper's (photon-mapper.cpp:308-311,319-325,334-339), which skips the next-event estimate on dirac hits.
 template <bool L>
-MCRT_HD bool smShade(PathState& st, RefractionHistory& rh, const ShadeViewT<L>& sh, const Hit& isect, NeePending& nee,
-                     Ray& shadow_ray, ShadowQuery& shadow_q, SobolTab tab) {
+MCRT_HD bool smContinue(PathState& st, RefractionHistory& rh, const ShadeViewT<L>& sh, const InteractionT<L>& ia, bool do_nee, NeePending& nee,
+                        Ray& shadow_ray, ShadowQuery& shadow_q, SobolTab tab) {
     nee.pending = false;
-    if (isect.surface == kNoSurface) {  // :27-30
-        st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
-        return false;
-    }
-    InteractionT<L> ia;
-    interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);  // :32
-    st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;   // :34
-
-    DirectQuery dq;  // :35, integrator.cpp:31-66
-    if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
+    DirectQuery dq;  // path-tracer.cpp:35 / photon-mapper.cpp:319-323, integrator.cpp:31-66
+    if (do_nee && sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
         // integrator.cpp:75-81 evaluated ahead of the trace: it does not depend on the shadow hit
         d3 bsdf_absIdotN;
         double bsdf_pdf;
@@ -325,6 +316,25 @@ MCRT_HD bool smShade(PathState& st, RefractionHistory& rh, const ShadeViewT<L>& 
     if (absorb(st.ray, st.throughput, st.smp, tab)) return false;                                               // :44-47
     rh.update(st.ray);                                                                                          // :49
     return true;
+}
+
+// The shade block: everything PathTracer::sampleRay does between two Scene::intersect calls of the
+// path (path-tracer.cpp:27-49), with sampleDirect cut at its shadow-ray trace. Returns true when the
+// path continues with st.ray; nee.pending says whether a shadow ray (returned in shadow_ray / shadow_q)
+// must be traced first.
+template <bool L>
+MCRT_HD bool smShade(PathState& st, RefractionHistory& rh, const ShadeViewT<L>& sh, const Hit& isect, NeePending& nee,
+                     Ray& shadow_ray, ShadowQuery& shadow_q, SobolTab tab) {
+    nee.pending = false;
+    if (isect.surface == kNoSurface) {  // :27-30
+        st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
+        return false;
+    }
+    InteractionT<L> ia;
+    interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);  // :32
+    st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;   // :34
+
+    return smContinue(st, rh, sh, ia, true, nee, shadow_ray, shadow_q, tab);
 }
 
 }  // namespace mcrt

@@ -78,7 +78,9 @@ enum : uint32_t {
     kWfDone = 8u,         // no pixels left for this slot
     kWfDirac = 16u,
     kWfRefraction = 32u,
-    kWfRhShift = 8        // RefractionHistory::size in bits 8..11
+    kWfRhShift = 8,       // RefractionHistory::size in bits 8..11
+    kWfEstWait = 1u << 12,  // photon mapper: the hit in the slot waits for its radiance estimates
+    kWfEstNeedG = 1u << 13  // ... the global estimate too (the path ends with it)
 };
 
 struct WfPool {
@@ -136,15 +138,58 @@ MCRT_HD void wfStoreHit(const WfPool& P, uint32_t item, const Hit& h) {
     }
 }
 
+// ---- photon mapper (PhotonMapper::sampleRay, photon-mapper.cpp:279-341) in wavefront form. A non-specular hit needs
+// the caustic estimate (and, when it is the path's last hit, the global one) before the bounce can go on: the shade
+// launch files an estimate request and leaves the slot waiting; a kNN launch (one query per wave, mcrt_waveknn.hpp, at
+// 6 waves per SIMD instead of the megakernel's 2) writes the k photons of every requested search; the next shade launch
+// rebuilds the Interaction from the untouched ray / hit / sampler words, sums the photons' contributions per lane
+// (estimateCausticRadiance / estimateGlobalRadiance, photon-mapper.cpp:343-391) and finishes the bounce.
+struct WfPmView {
+    const float* photons[2];     // [n][8] global map, caustic map
+    const uint32_t* res_n;       // [2][slots] photons found by the search of (map, slot)
+    const double* res_r2;        // [2][slots] largest squared distance among them (photons.top().distance2)
+    const uint32_t* res_idx;     // [2][k][slots]
+    const double* res_d2;        // [2][k][slots]
+    uint32_t k;
+    bool direct_visualization;
+};
+
+template <bool L>
+MCRT_HD d3 wfPhotonEstimate(const WfPmView& pm, uint32_t n_slots, uint32_t slot, int map, const InteractionT<L>& ia) {
+    const uint32_t n = pm.res_n[(size_t)map * n_slots + slot];
+    if (n == 0) return splat(0.0);
+    const double r2 = pm.res_r2[(size_t)map * n_slots + slot];
+    const double inv_max_squared_radius = 1.0 / r2;
+    const float* photons = pm.photons[map];
+    d3 radiance = splat(0.0);
+    for (uint32_t i = 0; i < n; i++) {
+        const size_t at = ((size_t)map * pm.k + i) * n_slots + slot;
+        const float* ph = photons + (size_t)pm.res_idx[at] * 8;
+        d3 bsdf_absIdotN;
+        double bsdf_pdf;
+        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
+            const d3 flux = d3{(double)ph[0], (double)ph[1], (double)ph[2]};
+            if (map == 1) {  // caustic: cone filter, photon-mapper.cpp:380-388
+                const double wp = gmax(0.0, 1.0 - sqrt(pm.res_d2[at] * inv_max_squared_radius));
+                radiance = radiance + (flux * bsdf_absIdotN * wp) / bsdf_pdf;
+            } else {
+                radiance = radiance + flux * bsdf_absIdotN / bsdf_pdf;
+            }
+        }
+    }
+    return map == 1 ? 3.0 * radiance * inv_max_squared_radius * kInvPi : radiance / (r2 * kPi);
+}
+
 // ---- shade side. Env supplies the three places where lanes cooperate:
 //   bool any(bool)                      true if the predicate holds for any lane of the wave (host: identity)
 //   unsigned long long pop(bool need)   next index of the frame's pixel work counter for the lanes that need one
 //   void push(slot, bool p0, bool p1)   queue the slot's bounce ray / shadow ray for the next trace launch
 //   void filmAdd(double*, double)       accumulate into a film splat (any lane, any time; atomic on the GPU)
-// The first three are called by every lane of the wave, at the same place.
-template <bool L, class Env>
+//   void request(slot, want, global)    photon mapper: queue the slot's caustic (and global) search for the next kNN launch
+// All but filmAdd are called by every lane of the wave, at the same place.
+template <bool L, bool kPhoton, class Env>
 MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, const WfFrame& fr, const ShadeViewT<L>& sh,
-                         RefractionHistory& rh, SobolTab tab, uint32_t& paths) {
+                         RefractionHistory& rh, SobolTab tab, uint32_t& paths, const WfPmView* pm = nullptr) {
     const unsigned long long fw = valid ? P.getu(kWfFlags, slot) : (unsigned long long)kWfDone;
     const uint32_t flags = (uint32_t)fw;
     const bool was_done = (flags & kWfDone) != 0u;
@@ -158,6 +203,17 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
     uint32_t px = 0, ly = 0, sample = 0;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     bool need_pixel = false;
+    bool want_estimate = false, need_g = false;  // photon mapper: this hit needs its radiance estimates first
+    auto loadHit0 = [&]() {
+        Hit h;
+        h.t = P.getd(kWfHit0T, slot);
+        h.u = P.getd(kWfHit0U, slot);
+        h.v = P.getd(kWfHit0V, slot);
+        const unsigned long long hs = P.getu(kWfHit0S, slot);
+        h.surface = (uint32_t)hs;
+        h.interpolate = (hs >> 32) != 0ull;
+        return h;
+    };
 
     if (!was_done) {
         // ---- load the slot
@@ -209,35 +265,70 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             smNeeFinish(st, sh, nee, sh_hit);
         }
 
-        // ---- this bounce (path-tracer.cpp:27-49)
+        // ---- this bounce (path-tracer.cpp:27-49 / photon-mapper.cpp:288-340)
         bool ended;
-        if (alive) {
-            Hit h;
-            h.t = P.getd(kWfHit0T, slot);
-            h.u = P.getd(kWfHit0U, slot);
-            h.v = P.getd(kWfHit0V, slot);
-            const unsigned long long hs = P.getu(kWfHit0S, slot);
-            h.surface = (uint32_t)hs;
-            h.interpolate = (hs >> 32) != 0ull;
-            Ray shadow_ray;
-            ShadowQuery shadow_q;
-            alive = smShade(st, rh, sh, h, nee, shadow_ray, shadow_q, tab);
-            if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
-            if (nee.pending) {
-                P.set3(kWfShO, slot, shadow_ray.start);
-                P.set3(kWfShD, slot, shadow_ray.direction);
-                P.setd(kWfShNear, slot, shadow_q.t_near);
-                P.setd(kWfShFar, slot, shadow_q.t_far);
-                P.setu(kWfNeeLight, slot, nee.light);
-                P.set3(kWfNeeBsdf, slot, nee.bsdf_absIdotN);
-                P.setd(kWfNeePdf, slot, nee.bsdf_pdf);
-                P.setd(kWfNeeAreaCos, slot, nee.area_cos);
-                P.set3(kWfNeeThroughput, slot, nee.throughput);
+        Ray shadow_ray;
+        ShadowQuery shadow_q;
+        if constexpr (!kPhoton) {
+            if (alive) {
+                const Hit h = loadHit0();
+                alive = smShade(st, rh, sh, h, nee, shadow_ray, shadow_q, tab);
+                if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
+                ended = !alive && !nee.pending;
+            } else {
+                nee.pending = false;
+                ended = have_pixel;  // the path died at its previous bounce; its last NEE has just been added
             }
-            ended = !alive && !nee.pending;
         } else {
-            nee.pending = false;
-            ended = have_pixel;  // the path died at its previous bounce; its last NEE has just been added
+            const bool waiting = (flags & kWfEstWait) != 0u;
+            if (alive) {
+                const Hit h = loadHit0();
+                bool go_on = false;  // finish the bounce with `ia` (sampling, russian roulette)
+                InteractionT<L> ia;
+                if (h.surface == kNoSurface) {
+                    alive = false;  // no sky in photon mode (photon-mapper.cpp:292-295)
+                } else {
+                    // (after a wait: the same Interaction again — ray, hit and sampler have not moved)
+                    interactionInit(ia, sh, h, st.ray, rh.externalIOR(st.ray), st.smp, tab);
+                    if (!waiting) {
+                        st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;  // :299
+                        if (ia.dirac_delta) {                                                        // :301-306
+                            if (!st.ray.dirac_delta && st.ray.depth != 0) alive = false;
+                            else go_on = true;
+                        } else {
+                            want_estimate = true;                                                    // :315 (+ :327-330)
+                            need_g = !(!pm->direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0));
+                        }
+                    } else {
+                        st.radiance = st.radiance + wfPhotonEstimate(*pm, P.n, slot, 1, ia) * st.throughput;  // :315
+                        if (flags & kWfEstNeedG) {
+                            st.radiance = st.radiance + wfPhotonEstimate(*pm, P.n, slot, 0, ia) * st.throughput;  // :330: the path ends here
+                            alive = false;
+                        } else {
+                            go_on = true;
+                        }
+                    }
+                }
+                if (go_on) {
+                    alive = smContinue(st, rh, sh, ia, !ia.dirac_delta, nee, shadow_ray, shadow_q, tab);
+                    if (alive) st.smp.shuffle();  // photon-mapper.cpp:290, next bounce
+                }
+                ended = !alive && !nee.pending && !want_estimate;
+            } else {
+                nee.pending = false;
+                ended = have_pixel;
+            }
+        }
+        if (nee.pending) {
+            P.set3(kWfShO, slot, shadow_ray.start);
+            P.set3(kWfShD, slot, shadow_ray.direction);
+            P.setd(kWfShNear, slot, shadow_q.t_near);
+            P.setd(kWfShFar, slot, shadow_q.t_far);
+            P.setu(kWfNeeLight, slot, nee.light);
+            P.set3(kWfNeeBsdf, slot, nee.bsdf_absIdotN);
+            P.setd(kWfNeePdf, slot, nee.bsdf_pdf);
+            P.setd(kWfNeeAreaCos, slot, nee.area_cos);
+            P.set3(kWfNeeThroughput, slot, nee.throughput);
         }
         if (ended && fr.film.type != MCRT_FILM_BOX) {  // Film::deposit with a reconstruction filter: a splat per sample
             Sampler at_start = st.smp;  // the sample's pixel position: the two draws of camera.cpp:79-80, sampler as it was then
@@ -297,7 +388,8 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
     // ---- store the slot
     if (!was_done) {
         uint32_t nf = (alive ? kWfAlive : 0u) | (have_pixel ? kWfHavePixel : 0u) | (nee.pending ? kWfNeePending : 0u) | (done ? kWfDone : 0u) |
-                      (st.ray.dirac_delta ? kWfDirac : 0u) | (st.ray.refraction ? kWfRefraction : 0u) | ((uint32_t)rh.size << kWfRhShift);
+                      (st.ray.dirac_delta ? kWfDirac : 0u) | (st.ray.refraction ? kWfRefraction : 0u) | ((uint32_t)rh.size << kWfRhShift) |
+                      (want_estimate ? kWfEstWait : 0u) | (want_estimate && need_g ? kWfEstNeedG : 0u);
         P.setu(kWfFlags, slot, (unsigned long long)nf | ((unsigned long long)st.ls.light << 32));
         if (!done) {
             P.set3(kWfRayO, slot, st.ray.start);
@@ -321,7 +413,8 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
                 if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.iors[(uint32_t)i * rh.stride]);
         }
     }
-    env.push(slot, !was_done && !done && alive, !was_done && nee.pending);
+    env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending);
+    if constexpr (kPhoton) env.request(slot, want_estimate, need_g);
 }
 
 }  // namespace mcrt

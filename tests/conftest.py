@@ -75,6 +75,7 @@ def emu():
     L.emu_intersect.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, vp, vp, vp]
     L.emu_render_sm.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
     L.emu_render_wf.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.emu_render_wf_pm.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.emu_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]
     L.emu_octree_build.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(vp)]
     L.emu_octree_desc.argtypes = [vp]

@@ -323,6 +323,10 @@ struct HostWfEnv {
     bool any(bool b) const { return b; }
     unsigned long long pop(bool need) const { return need ? (*work)++ : 0ull; }
     void filmAdd(double* a, double v) const { *a += v; }
+    std::vector<uint32_t>* requests;
+    void request(uint32_t slot, bool want, bool global) const {
+        if (want) requests->push_back(slot | (global ? 0x80000000u : 0u));
+    }
     void push(uint32_t slot, bool p0, bool p1) const {
         if (p0) queue->push_back(slot * 2u);
         if (p1) queue->push_back(slot * 2u + 1u);
@@ -330,10 +334,45 @@ struct HostWfEnv {
 };
 }  // namespace
 
+int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                     int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                     double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations,searches */);
+
 int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
                   double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations */) {
+    return emu_render_wf_pm(scene, nullptr, nullptr, 0, 0, cam, global_seed, slots, owned_rows, out_rgb, counters);
+}
+
+// photon = (k_nearest > 0): the photon mapper's wavefront form; the kNN launch is stood in for by the per-lane search of
+// mcrt_integrator.hpp (same k photons; the wave-cooperative search itself is device-only code, checked on the GPU)
+int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                     int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                     double* out_rgb, uint64_t* counters) {
+    const bool photon = k_nearest > 0;
     Emu E;
     if (int rc = setup(E, scene, 0)) return rc;
+    PhotonMapView maps[2];
+    std::vector<uint32_t> res_n, res_idx;
+    std::vector<double> res_r2, res_d2;
+    WfPmView pm;
+    memset(&pm, 0, sizeof(pm));
+    if (photon) {
+        setupMap(E, 0, gmap, maps[0]);
+        setupMap(E, 1, cmap, maps[1]);
+        setupKnn(E, k_nearest);
+        res_n.assign((size_t)2 * slots, 0);
+        res_r2.assign((size_t)2 * slots, 0.0);
+        res_idx.assign((size_t)2 * k_nearest * slots, 0);
+        res_d2.assign((size_t)2 * k_nearest * slots, 0.0);
+        pm.photons[0] = maps[0].photons;
+        pm.photons[1] = maps[1].photons;
+        pm.res_n = res_n.data();
+        pm.res_r2 = res_r2.data();
+        pm.res_idx = res_idx.data();
+        pm.res_d2 = res_d2.data();
+        pm.k = k_nearest;
+        pm.direct_visualization = direct_visualization != 0;
+    }
     if (scene->num_nodes == 0 || slots == 0) return -200;
     QTrace qt;
     qt.init(E, scene);
@@ -372,16 +411,36 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
         f.blob = blob.data();
     }
     unsigned long long work = 0;
-    std::vector<uint32_t> queue;
-    HostWfEnv env{&work, &queue};
+    std::vector<uint32_t> queue, requests;
+    HostWfEnv env{&work, &queue, &requests};
     TraceCounters cnt = {0, 0, 0, 0};
     uint32_t paths = 0;
-    uint64_t iterations = 0;
+    uint64_t iterations = 0, searches = 0;
     for (;;) {
         queue.clear();
-        for (uint32_t s = 0; s < slots; s++) wfShadeSlot(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths);
+        requests.clear();
+        for (uint32_t s = 0; s < slots; s++) {
+            if (photon) wfShadeSlot<false, true>(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths, &pm);
+            else wfShadeSlot<false, false>(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths);
+        }
         iterations++;
-        if (queue.empty()) break;
+        if (queue.empty() && requests.empty()) break;
+        for (uint32_t req : requests) {  // the kNN launch
+            const uint32_t slot = req & 0x7FFFFFFFu;
+            const d3 p = P.get3(kWfRayO, slot) + P.get3(kWfRayD, slot) * P.getd(kWfHit0T, slot);
+            for (int map = 1; map >= ((req >> 31) ? 0 : 1); map--) {
+                uint32_t visits = 0;
+                const uint32_t c = knnSearch(maps[map], p, k_nearest, E.ks, visits);
+                searches++;
+                res_n[(size_t)map * slots + slot] = c;
+                res_r2[(size_t)map * slots + slot] = c ? E.ks.res(0).distance2 : 0.0;  // heap top = the farthest of the k
+                for (uint32_t j = 0; j < c; j++) {
+                    const size_t at = ((size_t)map * k_nearest + j) * slots + slot;
+                    res_idx[at] = E.ks.res(j).index;
+                    res_d2[at] = E.ks.res(j).distance2;
+                }
+            }
+        }
         for (uint32_t item : queue) {
             d3 o, d;
             bool shadow;
@@ -396,6 +455,7 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
     if (counters) {
         counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
         counters[5] = iterations;
+        if (photon) counters[6] = searches;
     }
     return 0;
 }

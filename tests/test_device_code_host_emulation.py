@@ -104,6 +104,23 @@ def test_wavefront_sharded_rows(pkg, emu, manifest):
         assert np.array_equal(out, ref[rows])
 
 
+@pytest.mark.parametrize("slots", [500, 100000])
+def test_wavefront_photon_mapper_device_code(pkg, emu, manifest, slots):
+    """The photon mapper in wavefront form (estimate requests, a kNN pass, per-lane estimate sums in the next shade pass)."""
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    out = np.zeros((cam.height, cam.width, 3))
+    cnt = (C.c_uint64 * 7)()
+    g, c = img.photons(0), img.photons(1)
+    rc = emu.emu_render_wf_pm(C.byref(img.scene), C.byref(g), C.byref(c), img.param("k_nearest_photons") or 50,
+                              int(img.param("direct_visualization")), C.byref(cam), manifest["seed"], slots, cam.height, out.ctypes.data, cnt)
+    assert rc == 0 and cnt[3] == 0 and cnt[6] > 0
+    # the k photons are summed in heap-array order, which differs from the reference's -> few ulp
+    assert rel_error(out, load_radiance(r)).max() < 1e-12
+
+
 def test_photon_mapper_device_code(pkg, emu, manifest):
     case = manifest["cases"]["hexagon_room_pm"]
     img = pkg.SceneImage(golden_path(case["image"]))

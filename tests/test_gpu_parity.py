@@ -97,6 +97,23 @@ def test_photon_mapper_matches_reference(pkg, ctx, manifest):
     assert st["knn_searches"] > 0
 
 
+def test_photon_mapper_wavefront_pipeline(pkg, ctx, manifest, kernel_env):
+    """The photon-mapped frame through the wavefront pipeline (trace / kNN / shade launches; the default when the BVH
+    has 65 536 nodes or more): the reference's radiance, and the megakernel's up to the order of the estimate sums."""
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    ctx.upload_image(img)
+    ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons") or 50, bool(img.param("direct_visualization")))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    base, st0 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    kernel_env("wf")
+    out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    _check(out, load_radiance(r), "hexagon_room_pm wavefront")
+    assert st["paths"] == st0["paths"] and st["knn_searches"] == st0["knn_searches"] and st["kernel_launches"] > 3
+    assert rel_error(out, base).max() < 1e-12
+
+
 def test_rays_equal_oracle_count(pkg, ctx, oracle, manifest):
     case = manifest["cases"]["hexagon_room_diffuse"]
     img = pkg.SceneImage(golden_path(case["image"]))
