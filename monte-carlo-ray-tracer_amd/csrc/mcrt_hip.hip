@@ -1747,8 +1747,11 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
     if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false);
-    // photon-mapped frames: the same switch (deep tree -> trace / kNN / shade launches); k must fit the per-wave candidate buffer
-    if (photon && ctx->scene.num_nodes > 0 && ctx->k_nearest <= 128 && (want_wf || (!all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
+    // photon-mapped frames go through the pipeline (trace / kNN / shade launches) on request only: measured slower than
+    // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
+    // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
+    // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
+    if (photon && ctx->scene.num_nodes > 0 && ctx->k_nearest <= 128 && want_wf)
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true);
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
