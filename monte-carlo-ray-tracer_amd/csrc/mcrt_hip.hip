@@ -1339,8 +1339,8 @@ struct mcrt_ctx {
     bool has_photons = false;
     PhotonMapView maps[2]{};
     DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2];
-    const ChildRec* map_children_ptr[2] = {nullptr, nullptr};
-    uint32_t map_root_contained[2] = {0, 0}, map_root_leaf[2] = {0, 0};
+    const WideRec* map_children_ptr[2] = {nullptr, nullptr};
+    uint32_t map_root_a[2] = {0, 0}, map_root_m[2] = {0, 0};
     uint32_t k_nearest = 50;
     int direct_visualization = 0;
 
@@ -1430,9 +1430,9 @@ int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
 PhotonMapViewW waveMapView(const mcrt_ctx* ctx, int which) {
     PhotonMapViewW v;
     v.base = ctx->maps[which];
-    v.octant_children = ctx->map_children_ptr[which];
-    v.root_contained = ctx->map_root_contained[which];
-    v.root_leaf = ctx->map_root_leaf[which];
+    v.wide = ctx->map_children_ptr[which];
+    v.root_a = ctx->map_root_a[which];
+    v.root_m = ctx->map_root_m[which];
     return v;
 }
 
@@ -1871,29 +1871,60 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     if (int rc = uploadArray(ctx, ctx->map_next[which], m->octant_next_sibling, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_leaf[which], m->octant_leaf, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_photons[which], m->photons, (size_t)m->num_photons * 8)) return rc;
-    {   // child lists for the wave-cooperative search: children of o are o+1 and its next_sibling chain
-        ChildRec none;
-        memset(&none, 0, sizeof(none));
-        none.octant = 0xFFFFFFFFu;
-        std::vector<ChildRec> children(n * 8, none);
-        for (size_t o = 0; o < n; o++) {
-            if (m->octant_leaf[o]) continue;
-            uint32_t c = (uint32_t)o + 1, slot = 0;
+    {   // record lists for the wave-cooperative search (mcrt_waveknn.hpp: WideRec); children of o are o+1 and its sibling chain
+        const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1u);
+        auto scannable = [&](size_t o) { return m->octant_leaf[o] != 0 || contained[o] <= k; };
+        auto forChildren = [&](size_t o, auto f) {
+            uint32_t c = (uint32_t)o + 1;
+            int count = 0;
             while (c != 0xFFFFFFFFu && c < n) {
-                if (slot >= 8) return fail(ctx, MCRT_ERR_INVALID, "photon octant with more than 8 children");
-                ChildRec& r = children[o * 8 + slot++];
-                memcpy(r.b, m->octant_bounds + (size_t)c * 6, 48);
-                r.octant = c;
-                r.contained = contained[c];
-                r.start = (uint32_t)m->octant_start_data[c];
-                r.leaf = m->octant_leaf[c] ? 1u : 0u;
+                if (++count > 8) return false;
+                f((size_t)c);
                 c = m->octant_next_sibling[c];
             }
+            return true;
+        };
+        std::vector<uint32_t> first(n, 0), count(n, 0);
+        uint64_t total = 0;
+        bool ok = true;
+        for (size_t o = 0; o < n && ok; o++) {
+            if (scannable(o)) continue;
+            uint32_t cnt = 0;
+            ok = forChildren(o, [&](size_t c) {
+                if (scannable(c)) cnt++;
+                else ok = forChildren(c, [&](size_t) { cnt++; }) && ok;
+            }) && ok;
+            first[o] = (uint32_t)total;
+            count[o] = cnt;
+            total += cnt;
         }
-        if (int rc = uploadArray(ctx, ctx->map_children[which], children.data(), children.size())) return rc;
-        ctx->map_children_ptr[which] = ctx->map_children[which].as<ChildRec>();
-        ctx->map_root_contained[which] = contained[0];
-        ctx->map_root_leaf[which] = m->octant_leaf[0] ? 1u : 0u;
+        if (!ok) return fail(ctx, MCRT_ERR_INVALID, "photon octant with more than 8 children");
+        if (total > 0xFFFFFFFFull) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon map too large for 32-bit record indices");
+        std::vector<WideRec> wide(total);
+        auto fill = [&](WideRec& r, size_t c) {
+            memset(&r, 0, sizeof(r));
+            memcpy(r.b, m->octant_bounds + c * 6, 48);
+            r.contained = contained[c];
+            if (scannable(c)) {
+                r.a = (uint32_t)m->octant_start_data[c];
+                r.m = 0x80000000u | contained[c];
+            } else {
+                r.a = first[c];
+                r.m = count[c];
+            }
+        };
+        for (size_t o = 0; o < n; o++) {
+            if (scannable(o)) continue;
+            size_t at = first[o];
+            forChildren(o, [&](size_t c) {
+                if (scannable(c)) fill(wide[at++], c);
+                else forChildren(c, [&](size_t g) { fill(wide[at++], g); });
+            });
+        }
+        if (int rc = uploadArray(ctx, ctx->map_children[which], wide.data(), wide.size())) return rc;
+        ctx->map_children_ptr[which] = ctx->map_children[which].as<WideRec>();
+        ctx->map_root_a[which] = scannable(0) ? 0u : first[0];
+        ctx->map_root_m[which] = scannable(0) ? (0x80000000u | contained[0]) : count[0];
     }
     v.num_octants = m->num_octants;
     v.num_photons = m->num_photons;
@@ -2085,9 +2116,9 @@ int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map, c
     if (k_nearest_photons == 0) return fail(ctx, MCRT_ERR_INVALID, "k_nearest_photons must be > 0");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->has_photons = false;
+    ctx->k_nearest = k_nearest_photons;  // before the maps: the search's record lists expand octants with more than k photons
     if (int rc = uploadMap(ctx, 0, global_map)) return rc;
     if (int rc = uploadMap(ctx, 1, caustic_map)) return rc;
-    ctx->k_nearest = k_nearest_photons;
     ctx->direct_visualization = direct_visualization ? 1 : 0;
     ctx->has_photons = true;
     return MCRT_OK;

@@ -36,20 +36,23 @@ struct WaveKnnLds {
     MCRT_LDS_AS uint32_t* idx;  // [kWaveCand] photon indices
 };
 
-// One child of an octant as the descent reads it: one 64-byte record per child, the 8 records of an
-// octant contiguous (a node visit is a single memory round trip for the 8 lanes that test the children).
-struct ChildRec {
+// What one step of the descent reads: for an inner octant, up to 64 records — its children that can be scanned right
+// away (leaves, or octants with <= k photons, linear-octree.cpp:51) and, for every other child, that child's children
+// instead (two octree levels per step: half as many dependent steps, and the box tests use the whole wave instead of 8
+// lanes). Skipping the boxes of the expanded children only loosens pruning (a grandchild's box lies inside its parent's).
+// One 64-byte record per entry, the records of an octant contiguous.
+struct WideRec {
     double b[6];
-    uint32_t octant;     // 0xFFFFFFFF: no child in this slot
     uint32_t contained;
-    uint32_t start;      // first photon of the child's subtree
-    uint32_t leaf;       // 1: the child is a leaf
+    uint32_t a;      // scannable entry: first photon; inner entry: first record of ITS list
+    uint32_t m;      // scannable entry: 0x80000000 | photon count; inner entry: number of records in its list (1..64)
+    uint32_t pad;
 };
 
 struct PhotonMapViewW {
     PhotonMapView base;
-    const ChildRec* octant_children;  // [n][8]
-    uint32_t root_contained, root_leaf;
+    const WideRec* wide;
+    uint32_t root_a, root_m;  // the root as an entry
 };
 
 // Broadcast from lane `src` (wave-uniform): v_readlane, no LDS round trip.
@@ -269,10 +272,10 @@ __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
 // [0, n) and r2_max the largest of its distances; returns n. All 64 lanes must call with the same arguments.
 //
 // A frontier entry carries everything the visit of its octant needs — {distance2, a, b}: scannable octant (leaf,
-// or <= k photons, linear-octree.cpp:51) a = first photon, b = 0x80000000 | count; inner octant a = octant index —
-// so that popping an octant costs no memory access and a visit is ONE round trip (its 8 child records, or its
-// photons). The 8 lanes that test the children rotate with the step number and drop the children they keep into
-// their own two frontier slots; only when a lane's slots are both taken does the wave look for a free slot elsewhere.
+// or <= k photons, linear-octree.cpp:51) a = first photon, b = 0x80000000 | count; inner octant a = first record of its
+// list, b = number of records — so that popping an octant costs no memory access and a visit is ONE round trip (its
+// record list, or its photons). Lane l tests record l and drops it, if kept, into its own two frontier slots; only when a
+// lane's slots are both taken does the wave look for a free slot elsewhere.
 __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
                                          uint32_t& overflow, uint32_t& octant_visits) {
     r2_max = 0.0;
@@ -290,10 +293,8 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     uint32_t count = 0;
     bool dirty = false;    // candidates appended since the buffer was last reduced
     bool bounded = false;  // max_distance2 has been tightened to a k-photon radius at least once
-    // root
-    uint32_t cur_a = (map.root_leaf || map.root_contained <= k) ? 0u : 0u;
-    uint32_t cur_b = (map.root_leaf || map.root_contained <= k) ? (kScan | map.root_contained) : 1u;
-    for (uint32_t step = 0;; step++) {
+    uint32_t cur_a = map.root_a, cur_b = map.root_m;  // root
+    for (;;) {
         octant_visits++;
         if (cur_b & kScan) {
             const uint32_t start = cur_a, contained = cur_b & ~kScan;
@@ -345,30 +346,28 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                 max_distance2 = gmin(max_distance2, bound);
             }
         } else {
-            // children: this step's 8 lanes take one child each
-            const uint32_t g = (step & 7u) * 8u;
-            const bool tester = lane >= g && lane < g + 8u;
+            // records of the octant (children / grandchildren): one per lane
             float cd2 = INFINITY, corner = INFINITY;
             uint32_t ca = kNone, cb = 0u;
             bool push = false;
-            if (tester) {
-                const ChildRec* cr = map.octant_children + (size_t)cur_a * 8 + (lane - g);
+            if (lane < cur_b) {
+                const WideRec* cr = map.wide + (size_t)cur_a + lane;
                 double bb[6];
                 for (int c = 0; c < 6; c++) bb[c] = cr->b[c];
-                const uint32_t child = cr->octant, child_contained = cr->contained, child_start = cr->start, child_leaf = cr->leaf;
-                if (child != kNone) {
-                    const double d2c = boxDistance2(bb, p);
-                    push = d2c <= max_distance2;
-                    cd2 = floatBelow(d2c);
-                    // linear-octree.cpp:96-100; rounded UP to float: still an upper bound of the k-th distance
-                    if (push && child_contained >= k) corner = floatAbove(boxMaxDistance2(bb, p));
-                    const bool scan = child_leaf != 0u || child_contained <= k;
-                    ca = scan ? child_start : child;
-                    cb = scan ? (kScan | child_contained) : 1u;
-                }
+                const uint32_t rec_contained = cr->contained;
+                ca = cr->a;
+                cb = cr->m;
+                const double d2c = boxDistance2(bb, p);
+                push = d2c <= max_distance2;
+                cd2 = floatBelow(d2c);
+                // linear-octree.cpp:96-100; rounded UP to float: still an upper bound of the k-th distance
+                if (push && rec_contained >= k) corner = floatAbove(boxMaxDistance2(bb, p));
             }
             const double best_corner = (double)waveMinPosF(corner);
             if (best_corner < max_distance2) max_distance2 = best_corner;
+            // the bound of THIS step already applies to its records (the reference tightens while it loops over the children,
+            // linear-octree.cpp:91-101); with up to 64 records per step it also keeps the frontier small
+            push = push && (double)cd2 <= max_distance2;
             // keep the pushed children: own slots first
             if (push && f_b[0] == 0u) {
                 f_d2[0] = cd2; f_a[0] = ca; f_b[0] = cb;
