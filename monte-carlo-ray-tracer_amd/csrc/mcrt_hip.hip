@@ -962,6 +962,28 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // photon-mapping eye pass with wave-cooperative radiance estimates (mcrt_waveknn.hpp)
 // ------------------------------------------------------------------------------------------------
+// Wave-synchronous walk over the quantised child blocks (mcrt_qbvh.hpp) with the step functions of the lane state
+// machine: inner steps while any lane has one, a leaf step when enough lanes wait at a leaf or nothing else is left.
+// Used by the photon-mapping eye pass for trees that stay in HBM.
+template <bool kCount>
+__device__ inline Hit traceWalkQ(const SmSceneView<false>& sv, const QView<true>& qv, const SmStack& stk, const Ray& ray, bool shadow,
+                                 const ShadowQuery* sq, TraceCounters& cnt) {
+    Trav T;
+    travBeginQ<false, true, kCount>(sv, qv, T, ray.start, ray.direction, ray.inv_direction, shadow, sq, cnt);
+    for (;;) {
+        const bool inner = T.active && (T.node_m & kSmInner);
+        if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
+        if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);
+        const bool leaf = T.active && !(T.node_m & kSmInner);
+        const unsigned long long m_leaf = __ballot(leaf), m_inner = __ballot(T.active && (T.node_m & kSmInner));
+        if (!(m_leaf | m_inner)) break;
+        if (m_leaf && (__popcll(m_leaf) >= 32 || __popcll(m_inner) < 8)) {
+            if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
+        }
+    }
+    return T.best;
+}
+
 struct PmExtra {
     PhotonMapViewW global_map, caustic_map;
 };
@@ -975,6 +997,41 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     LaneStack stk;
     RefractionHistory rh;
     setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    TraceCounters cnt = {0u, 0u, 0u, 0u};
+    // tree in HBM: walk it through the quantised child blocks; the top blocks take the place of the staged node records
+    SmSceneView<false> smv;
+    QView<true> qv;
+    SmStack smstk;
+    if constexpr (!kAll) {
+        const LdsPlan lp = planLds(scene, blockDim.x);
+        MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
+        const uint32_t room = scene.stage_nodes * 56u / 64u;
+        qv.blocks = scene.qblocks;
+        qv.lds_blocks = room < scene.num_qblocks ? room : scene.num_qblocks;
+        qv.lds_ptr = lq;
+        qv.root_a = scene.q_root_a;
+        qv.root_m = scene.q_root_m;
+        __syncthreads();  // setupViews' copies of the node records are not read by this kernel
+        for (uint32_t i = threadIdx.x; i < qv.lds_blocks * 16u; i += blockDim.x)
+            reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(scene.qblocks)[i];
+        __syncthreads();
+        smv.num_nodes = scene.num_nodes;
+        smv.nodes = scene.nodes64;
+        smv.prim = scene.prim;
+        smv.lds_nodes = 0;
+        smv.lds_node_ptr = nullptr;
+        smstk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(stk.lds);  // same 8-byte entries, same [16][lanes] region
+        smstk.lds_stride = stk.lds_stride;
+        smstk.spill = reinterpret_cast<SmStackEntry*>(stk.spill);
+        smstk.spill_stride = stk.spill_stride;
+    }
+    auto intersect = [&](const Ray& ray, bool shadow, const ShadowQuery* sq) {
+        if constexpr (kAll) {
+            return shadow ? sceneIntersect<kAll, kCount, true>(sv, ray, stk, cnt, sq) : sceneIntersect<kAll, kCount, false>(sv, ray, stk, cnt);
+        } else {
+            return traceWalkQ<kCount>(smv, qv, smstk, ray, shadow, sq, cnt);
+        }
+    };
     // per-wave candidate buffer behind the common LDS plan
     WaveKnnLds W;
     {
@@ -985,7 +1042,6 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     }
 
     PathState st;
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
     uint32_t paths = 0, searches = 0, octant_visits = 0, knn_overflow = 0;
     bool have_pixel = false, path_active = false, exhausted = false;
     uint32_t px = 0, py = 0, ly = 0, sample = 0;
@@ -1037,7 +1093,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
         bool ended = false, needC = false, needG = false;
         if (path_active) {
             st.smp.shuffle();
-            Hit isect = sceneIntersect<kAll, kCount, false>(sv, st.ray, stk, cnt);
+            Hit isect = intersect(st.ray, false, nullptr);
             if (isect.surface == kNoSurface) {
                 ended = true;  // no sky in photon mode (:292-295)
             } else {
@@ -1064,7 +1120,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
             if (!ia.dirac_delta) {
                 DirectQuery dq;
                 if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
-                    Hit shadow = sceneIntersect<kAll, kCount, true>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
+                    Hit shadow = intersect(dq.shadow_ray, true, &dq.sq);
                     st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
                 }
             }
