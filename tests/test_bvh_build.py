@@ -135,3 +135,47 @@ def test_gpu_path_large_scene_and_render(pkg):
     t_host = time.perf_counter() - t
     print("octree BVH of 6 898 815 triangles: GPU-assisted %.2f s, host %.2f s (incl. the comparison with the reference's arrays)" % (t_gpu, t_host))
     ctx.close()
+
+
+def test_builder_argument_errors(pkg, manifest):
+    L = pkg.lib()
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room"]["image"]))
+    h = C.c_void_p()
+    assert L.mcrt_bvh_build_sah(C.byref(img.scene), 3, 0, 0, C.byref(h)) == -1          # arity must be 2 or 4
+    assert L.mcrt_bvh_build_sah(C.byref(img.scene), 4, 1, 0, C.byref(h)) == -1          # one bin cannot split
+    assert L.mcrt_bvh_build_sah(None, 4, 0, 0, C.byref(h)) == -1
+    assert L.mcrt_bvh_build_octree(None, None, C.byref(h)) == -1
+    bad = pkg.SceneDesc()
+    C.memmove(C.byref(bad), C.byref(img.scene), C.sizeof(pkg.SceneDesc))
+    bad.abi_version = 1
+    assert L.mcrt_bvh_build_octree(None, C.byref(bad), C.byref(h)) == -1                # descriptor of another ABI
+    bvh = pkg.Bvh(img.scene)
+    other = pkg.SceneImage(golden_path(manifest["cases"]["metals"]["image"]))
+    s = C.c_void_p()
+    assert L.mcrt_scene_with_bvh(C.byref(other.scene), C.byref(bvh.desc), C.byref(s)) == -1  # surface counts differ
+    bvh.close()
+
+
+def test_rebuilt_scene_renders_like_the_original(pkg, oracle, manifest):
+    """mcrt_scene_with_bvh + the rebuilt tree through a whole render (oracle): the frame of the original image."""
+    case = manifest["cases"]["metals"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    from conftest import camera_for, load_radiance
+    cam = camera_for(img, r)
+    bvh = pkg.Bvh(img.scene, kind="quaternary_sah")  # another hierarchy over the same surfaces: same closest hits
+    rebuilt = bvh.apply(img.scene)
+
+    class _Img:
+        scene = rebuilt.desc
+        path = img.path
+
+        @staticmethod
+        def photons(which):
+            return None
+
+        @staticmethod
+        def param(key):
+            return 0
+    out, _ = oracle.render(_Img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
+    np.testing.assert_array_equal(out, load_radiance(r))
