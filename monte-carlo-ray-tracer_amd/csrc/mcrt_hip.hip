@@ -984,6 +984,37 @@ __device__ inline Hit traceWalkQ(const SmSceneView<false>& sv, const QView<true>
     return T.best;
 }
 
+// What traceWalkQ needs, carved out of the LDS plan of the wave-synchronous kernels (planLds): the top child blocks take
+// the place of the staged node records, the traversal stack region is used with the state machine's 8-byte entries.
+struct QWalk {
+    SmSceneView<false> sv;
+    QView<true> qv;
+    SmStack stk;
+};
+__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q) {  // every thread calls
+    const LdsPlan lp = planLds(scene, blockDim.x);
+    MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
+    const uint32_t room = scene.stage_nodes * 56u / 64u;
+    q.qv.blocks = scene.qblocks;
+    q.qv.lds_blocks = room < scene.num_qblocks ? room : scene.num_qblocks;
+    q.qv.lds_ptr = lq;
+    q.qv.root_a = scene.q_root_a;
+    q.qv.root_m = scene.q_root_m;
+    __syncthreads();  // setupViews' copies of the node records are not read by these kernels
+    for (uint32_t i = threadIdx.x; i < q.qv.lds_blocks * 16u; i += blockDim.x)
+        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(scene.qblocks)[i];
+    __syncthreads();
+    q.sv.num_nodes = scene.num_nodes;
+    q.sv.nodes = scene.nodes64;
+    q.sv.prim = scene.prim;
+    q.sv.lds_nodes = 0;
+    q.sv.lds_node_ptr = nullptr;
+    q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [16][lanes] region
+    q.stk.lds_stride = lstk.lds_stride;
+    q.stk.spill = reinterpret_cast<SmStackEntry*>(lstk.spill);
+    q.stk.spill_stride = lstk.spill_stride;
+}
+
 struct PmExtra {
     PhotonMapViewW global_map, caustic_map;
 };
@@ -998,38 +1029,14 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     RefractionHistory rh;
     setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
     TraceCounters cnt = {0u, 0u, 0u, 0u};
-    // tree in HBM: walk it through the quantised child blocks; the top blocks take the place of the staged node records
-    SmSceneView<false> smv;
-    QView<true> qv;
-    SmStack smstk;
-    if constexpr (!kAll) {
-        const LdsPlan lp = planLds(scene, blockDim.x);
-        MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
-        const uint32_t room = scene.stage_nodes * 56u / 64u;
-        qv.blocks = scene.qblocks;
-        qv.lds_blocks = room < scene.num_qblocks ? room : scene.num_qblocks;
-        qv.lds_ptr = lq;
-        qv.root_a = scene.q_root_a;
-        qv.root_m = scene.q_root_m;
-        __syncthreads();  // setupViews' copies of the node records are not read by this kernel
-        for (uint32_t i = threadIdx.x; i < qv.lds_blocks * 16u; i += blockDim.x)
-            reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(scene.qblocks)[i];
-        __syncthreads();
-        smv.num_nodes = scene.num_nodes;
-        smv.nodes = scene.nodes64;
-        smv.prim = scene.prim;
-        smv.lds_nodes = 0;
-        smv.lds_node_ptr = nullptr;
-        smstk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(stk.lds);  // same 8-byte entries, same [16][lanes] region
-        smstk.lds_stride = stk.lds_stride;
-        smstk.spill = reinterpret_cast<SmStackEntry*>(stk.spill);
-        smstk.spill_stride = stk.spill_stride;
-    }
+    // tree in HBM: walk it through the quantised child blocks
+    QWalk qw;
+    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
     auto intersect = [&](const Ray& ray, bool shadow, const ShadowQuery* sq) {
         if constexpr (kAll) {
             return shadow ? sceneIntersect<kAll, kCount, true>(sv, ray, stk, cnt, sq) : sceneIntersect<kAll, kCount, false>(sv, ray, stk, cnt);
         } else {
-            return traceWalkQ<kCount>(smv, qv, smstk, ray, shadow, sq, cnt);
+            return traceWalkQ<kCount>(qw.sv, qw.qv, qw.stk, ray, shadow, sq, cnt);
         }
     };
     // per-wave candidate buffer behind the common LDS plan
@@ -1215,6 +1222,8 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     LaneStack stk;
     RefractionHistory rh;
     setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    QWalk qw;  // tree in HBM: quantised child blocks
+    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
 
     EmitState es;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
@@ -1250,7 +1259,14 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
         out.store = false;
         out.caustic = false;
         if (active) {
-            const bool done = emitBounce<false, kAll>(es, rh, sv, sh, stk, cnt, tab, prm.non_caustic_reject, out);
+            bool done;
+            if constexpr (kAll) {
+                done = emitBounce<false, kAll>(es, rh, sv, sh, stk, cnt, tab, prm.non_caustic_reject, out);
+            } else {
+                es.smp.shuffle();  // photon-mapper.cpp:233 (emitBounce's first line)
+                const Hit isect = traceWalkQ<false>(qw.sv, qw.qv, qw.stk, es.ray, false, nullptr, cnt);
+                done = emitAfterHit(es, rh, sh, isect, tab, prm.non_caustic_reject, out);
+            }
             if (done) active = false;
         }
         for (int which = 0; which < 2; which++) {

@@ -154,15 +154,26 @@ MCRT_HD void emitBegin(EmitState& es, RefractionHistory& rh, const ShadeViewT<L>
     rh.init(es.ray);
 }
 
+template <bool kAll>
+MCRT_HD bool emitAfterHit(EmitState& es, RefractionHistory& rh, const ShadeViewT<kAll>& sh, const Hit& isect, SobolTab tab,
+                          double non_caustic_reject, PhotonOut& out);
+
 // One iteration of the while(true) in PhotonMapper::emitPhoton. Returns true when the photon path has
 // ended; out.store says whether this bounce deposited a photon (out.caustic: into which map).
 template <bool kCount, bool kAll>
 MCRT_HD bool emitBounce(EmitState& es, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh,
                         const LaneStack& stk, TraceCounters& cnt, SobolTab tab, double non_caustic_reject, PhotonOut& out) {
-    out.store = false;
-    out.caustic = false;
     es.smp.shuffle();                                                            // :233
     Hit isect = sceneIntersect<kAll, kCount, false>(sv, es.ray, stk, cnt);       // :235
+    return emitAfterHit(es, rh, sh, isect, tab, non_caustic_reject, out);
+}
+
+// ... the part after Scene::intersect (callers that walk the tree differently trace the ray themselves).
+template <bool kAll>
+MCRT_HD bool emitAfterHit(EmitState& es, RefractionHistory& rh, const ShadeViewT<kAll>& sh, const Hit& isect, SobolTab tab,
+                          double non_caustic_reject, PhotonOut& out) {
+    out.store = false;
+    out.caustic = false;
     if (isect.surface == kNoSurface) return true;                                // :237-240
     InteractionT<kAll> ia;
     interactionInit(ia, sh, isect, es.ray, rh.externalIOR(es.ray), es.smp, tab);  // :242

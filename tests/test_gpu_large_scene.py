@@ -125,3 +125,27 @@ def test_full_size_traversal_equals_oracle(pkg, oracle, name):
     assert (~same).sum() <= 5  # exact-t ties and the z-fight above only
     np.testing.assert_array_equal(uv[same], uv0[same])
     ctx.close()
+
+
+def test_c5_emission_matches_oracle(pkg, oracle):
+    """Photon emission through the 6.9 M-triangle octree BVH (emitKernel walking the quantised child blocks) against the
+    oracle's emission pass: photons matched by (light, emission, bounce) key, fields within 2e-6 (ocml vs glibc trig)."""
+    from conftest import sort_by_key
+    img, _, _ = _config(pkg, "c5")
+    want = oracle.emit_photons(img, 2000, 10.0, 0x12345678)
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    got = ctx.emit_photons(2000, 10.0, 0x12345678)
+    assert got["paths"] == want["paths"] == 20000
+    assert abs(got["rays"] - want["rays"]) <= 0.002 * want["rays"] + 2
+    for name in ("global_", "caustic"):
+        a, ak = sort_by_key(*got[name])
+        b, bk = want[name]
+        common, ia, ib = np.intersect1d(ak, bk, return_indices=True)
+        unmatched = (len(ak) - len(common)) + (len(bk) - len(common))
+        assert unmatched <= 0.002 * len(bk) + 2
+        x, y = a[ia].astype(np.float64), b[ib].astype(np.float64)
+        err = np.abs(x - y) / np.maximum(np.abs(y), 1e-3)
+        assert int((err.max(axis=1) > 2e-6).sum()) <= 0.002 * len(common) + 2
+        print("c5 %s: %d photons, %d unmatched keys, max field error %.2e" % (name, len(bk), unmatched, err.max() if len(common) else 0.0))
+    ctx.close()
