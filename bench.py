@@ -155,10 +155,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # MCRT_BENCH_SHARE_GPU=1 (rehearsal of the N > 1 path on a one-GPU box, not a measurement): every rank uses cuda:0 and the
+    # collectives run over gloo, which moves CUDA tensors through the host
+    share_gpu = world > 1 and os.environ.get("MCRT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
     tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
