@@ -72,14 +72,26 @@ MCRT_HD void travBeginQ(const SmSceneView<kAll>& sv, const QView<kLds>& qv, Trav
     }
 }
 
-// Visit one INNER node through its block(s): decode and test the children (bvh.cpp:108-119), continue
-// with the nearest hit child, push the rest.
+// Visit one INNER node through its block(s): decode and test the children (bvh.cpp:108-119), continue with the nearest
+// hit child, push the rest — farthest first, so that the stack hands them back nearest first (the closer a subtree is
+// visited, the sooner T.best.t cuts the others off). The four children of a block are tested and ordered without
+// branches (a 5-exchange sorting network on {entry distance, link}); only the pushes are conditional.
 template <bool kLds, bool kCount>
 MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const Ray r = travRay(T);
-    double near_t = 0.0;
+    constexpr double kMiss = INFINITY;  // entry distance of a child that is absent, missed or culled
+    double near_t = kMiss;
     uint32_t near_a = 0, near_m = 0;
-    bool have_near = false;
+    auto push = [&](double t, uint32_t a, uint32_t m) {
+        if (T.sp < kMaxStackDepth) {
+            SmStackEntry e;
+            e.key = (floatBits(floatBelow(t)) & ~0x1FFu) | m;
+            e.a = a;
+            stk.put(T.sp++, e);
+        } else {
+            cnt.overflow = 1;
+        }
+    };
     uint32_t bi = T.node_a;
     bool more = true;
     while (more) {
@@ -88,52 +100,54 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
         more = (b.w[3] >> 31) != 0u;
         const float ox = bitsFloat(b.w[0]), oy = bitsFloat(b.w[1]), oz = bitsFloat(b.w[2]);
         const double cx = qCell(b.w[3] & 0xFFu), cy = qCell((b.w[3] >> 8) & 0xFFu), cz = qCell((b.w[3] >> 16) & 0xFFu);
+        double t[4];
+        uint32_t a[4], m[4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int c = 0; c < 4; c++) {
-            if ((uint32_t)c < n) {
-                Box cb;
-                cb.v[0] = qDecode(ox, qByte(b, c * 6 + 0), cx);
-                cb.v[1] = qDecode(oy, qByte(b, c * 6 + 1), cy);
-                cb.v[2] = qDecode(oz, qByte(b, c * 6 + 2), cz);
-                cb.v[3] = qDecode(ox, qByte(b, c * 6 + 3), cx);
-                cb.v[4] = qDecode(oy, qByte(b, c * 6 + 4), cy);
-                cb.v[5] = qDecode(oz, qByte(b, c * 6 + 5), cz);
-                const uint32_t a = b.w[10 + c];
-                const uint32_t m = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0xFFFFu;
-                if (kCount) cnt.node_tests++;
-                double t;
-                const bool hit = boxIntersect<true>(cb, r, t);
-                if (hit && t <= T.best.t) {
-                    uint32_t push_a = a, push_m = m;
-                    double push_t = t;
-                    bool push = true;
-                    if (!have_near || t < near_t) {
-                        push = have_near;
-                        push_a = near_a;
-                        push_m = near_m;
-                        push_t = near_t;
-                        near_a = a;
-                        near_m = m;
-                        near_t = t;
-                        have_near = true;
-                    }
-                    if (push) {
-                        if (T.sp < kMaxStackDepth) {
-                            SmStackEntry e;
-                            e.key = (floatBits(floatBelow(push_t)) & ~0x1FFu) | push_m;
-                            e.a = push_a;
-                            stk.put(T.sp++, e);
-                        } else {
-                            cnt.overflow = 1;
-                        }
-                    }
-                }
-            }
+            Box cb;
+            cb.v[0] = qDecode(ox, qByte(b, c * 6 + 0), cx);
+            cb.v[1] = qDecode(oy, qByte(b, c * 6 + 1), cy);
+            cb.v[2] = qDecode(oz, qByte(b, c * 6 + 2), cz);
+            cb.v[3] = qDecode(ox, qByte(b, c * 6 + 3), cx);
+            cb.v[4] = qDecode(oy, qByte(b, c * 6 + 4), cy);
+            cb.v[5] = qDecode(oz, qByte(b, c * 6 + 5), cz);
+            a[c] = b.w[10 + c];
+            m[c] = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0xFFFFu;
+            double tt;
+            const bool hit = boxIntersect<true>(cb, r, tt);
+            const bool keep = (uint32_t)c < n && hit && tt <= T.best.t;
+            if (kCount) cnt.node_tests += (uint32_t)c < n ? 1u : 0u;
+            t[c] = keep ? tt : kMiss;
         }
+        auto exchange = [&](int i, int j) {  // afterwards t[i] <= t[j]
+            const bool sw = t[j] < t[i];
+            const double ti = sw ? t[j] : t[i], tj = sw ? t[i] : t[j];
+            const uint32_t ai = sw ? a[j] : a[i], aj = sw ? a[i] : a[j];
+            const uint32_t mi = sw ? m[j] : m[i], mj = sw ? m[i] : m[j];
+            t[i] = ti; t[j] = tj; a[i] = ai; a[j] = aj; m[i] = mi; m[j] = mj;
+        };
+        exchange(0, 1);
+        exchange(2, 3);
+        exchange(0, 2);
+        exchange(1, 3);
+        exchange(1, 2);
+        if (t[3] < kMiss) push(t[3], a[3], m[3]);
+        if (t[2] < kMiss) push(t[2], a[2], m[2]);
+        if (t[1] < kMiss) push(t[1], a[1], m[1]);
+        // the block's nearest against the nearest of the node's earlier blocks (nodes with more than 4 children)
+        const bool better = t[0] < near_t;
+        const double lose_t = better ? near_t : t[0];
+        const uint32_t lose_a = better ? near_a : a[0], lose_m = better ? near_m : m[0];
+        if (better) {
+            near_t = t[0];
+            near_a = a[0];
+            near_m = m[0];
+        }
+        if (lose_t < kMiss) push(lose_t, lose_a, lose_m);
     }
-    if (have_near) {
+    if (near_t < kMiss) {
         T.node_a = near_a;
         T.node_m = near_m;
     } else {
