@@ -67,11 +67,14 @@ def _config(pkg, name):
     return pkg.SceneImage(p), make_large.CONFIGS[name], make_large.golden_path(name)
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
-def test_full_size_rows_match_reference(pkg, name):
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm"])
+def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
     @ 1024 spp; C5: 6 898 815 triangles, photon-mapped — against the reference's radiance for the same rows
     (committed goldens made by tests/large/make_large.py)."""
+    if ":" in name:  # the same rows through the other kernel (default for these trees: the wavefront pipeline)
+        name, kernel = name.split(":")
+        monkeypatch.setenv("MCRT_KERNEL", kernel)
     img, c, golden = _config(pkg, name)
     assert (img.scene.num_surfaces, img.scene.num_nodes) == (c["surfaces"], c["nodes"])
     ctx = pkg.Context(0)
