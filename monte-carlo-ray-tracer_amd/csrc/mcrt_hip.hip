@@ -693,7 +693,7 @@ struct WfTraceArgs {
     const double* prim;
     SmStackEntry* spill;
     uint32_t total_lanes;
-    int refill_lanes, leaf_lanes, min_inner;
+    int refill_lanes, leaf_lanes, min_inner, lds_stack;
 };
 
 // Where the rays of a trace launch come from and where their hits go.
@@ -741,6 +741,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     stk.lds_stride = blockDim.x;
     stk.spill = a.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = a.total_lanes;
+    stk.lds_depth = a.lds_stack;
     SmSceneView<false> sv;
     sv.num_nodes = a.num_nodes;
     sv.nodes = a.nodes;
@@ -1419,7 +1420,8 @@ struct mcrt_ctx {
     int direct_visualization = 0;
 
     DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
-    uint32_t spill_lanes = 0, knn_lanes = 0, knn_k = 0;
+    size_t spill_bytes = 0;
+    uint32_t knn_lanes = 0, knn_k = 0;
 
     // photon emission pass
     std::vector<double> host_light_flux;  // [num_lights][3] emittance * area (photon-mapper.cpp:64)
@@ -1482,13 +1484,18 @@ int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g,
     return MCRT_OK;
 }
 
+int ensureSpill(mcrt_ctx* ctx, size_t bytes) {  // traversal-stack spill area, shared by every kernel (one render at a time)
+    if (ctx->spill_bytes < bytes) {
+        HIP_TRY(ctx, ctx->spill.alloc(bytes));
+        ctx->spill_bytes = bytes;
+    }
+    return MCRT_OK;
+}
+
 int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-    if (ctx->spill_lanes < total_lanes) {
-        HIP_TRY(ctx, ctx->spill.alloc((size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
-        ctx->spill_lanes = total_lanes;
-    }
+    if (int rc = ensureSpill(ctx, (size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry))) return rc;
     if (photon && (ctx->knn_lanes < total_lanes || ctx->knn_k < ctx->k_nearest)) {
         const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1);
         HIP_TRY(ctx, ctx->knn_res_d2.alloc((size_t)total_lanes * k * sizeof(double)));
@@ -1532,7 +1539,8 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
     const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
-    const uint32_t stack_bytes = kLdsStackDepth * tp.block * (uint32_t)sizeof(SmStackEntry);
+    const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
+    const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
     if ((long)stack_bytes > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
     const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes) / 64u);
@@ -1545,10 +1553,9 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     if (tp.grid < 1) tp.grid = 1;
     const uint32_t total_lanes = tp.grid * tp.block;
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-    if (ctx->spill_lanes < 2 * total_lanes) {  // two trace launches (the two halves of the wavefront pool) can be resident at once
-        HIP_TRY(ctx, ctx->spill.alloc((size_t)2 * total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry)));
-        ctx->spill_lanes = 2 * total_lanes;
-    }
+    // two trace launches (the two halves of the wavefront pool) can be resident at once; a region holds kMaxStackDepth entries
+    // per lane whatever part of them lives in LDS
+    if (int rc = ensureSpill(ctx, (size_t)2 * total_lanes * kMaxStackDepth * sizeof(StackEntry))) return rc;
     WfTraceArgs& ta = tp.args;
     memset(&ta, 0, sizeof(ta));
     ta.stats = ctx->stats.as<unsigned long long>();
@@ -1564,6 +1571,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 32);
     ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 32);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
+    ta.lds_stack = (int)lds_stack;
     return MCRT_OK;
 }
 
@@ -1673,7 +1681,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         unsigned long long* c = ctrl + 4 * h;  // {count[2], pop} of this half
         ta[h] = tp.args;
         ta[h].pop = c + 2;
-        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * (kMaxStackDepth - kLdsStackDepth);
+        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * kMaxStackDepth;
         pr[h].pool.w = ctx->wf_pool.as<unsigned long long>();
         pr[h].pool.n = (uint32_t)slots;
         pr[h].queue = ctx->wf_queue.as<uint32_t>() + (size_t)h * 2 * half_slots;

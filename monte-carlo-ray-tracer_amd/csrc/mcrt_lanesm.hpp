@@ -46,13 +46,14 @@ struct SmStack {
     uint32_t lds_stride;
     SmStackEntry* spill;
     uint32_t spill_stride;
+    int lds_depth = kLdsStackDepth;  // entries per lane kept in LDS (the trace kernel trades some of them for more tree blocks)
     MCRT_HD void put(int sp, SmStackEntry e) const {
-        if (sp < kLdsStackDepth) lds[(uint32_t)sp * lds_stride] = e;
-        else spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride] = e;
+        if (sp < lds_depth) lds[(uint32_t)sp * lds_stride] = e;
+        else spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride] = e;
     }
     MCRT_HD SmStackEntry get(int sp) const {
-        if (sp < kLdsStackDepth) return lds[(uint32_t)sp * lds_stride];
-        return spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
+        if (sp < lds_depth) return lds[(uint32_t)sp * lds_stride];
+        return spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride];
     }
 };
 
