@@ -1,17 +1,5 @@
-// libmcrt_hip.so — gfx950 kernels and the C ABI of include/mcrt.h.
-//
-// Kernel structure (one launch per render):
-//   persistent workgroups; every LANE owns one pixel at a time and runs that pixel's spp samples in
-//   the reference's order (so the per-pixel FP64 sum is the reference's, film.cpp:99-113). The loop
-//   body is ONE BOUNCE (mcrt_integrator.hpp); a lane whose path ended is re-armed with the next
-//   sample in the same iteration, and a lane whose pixel is complete takes the next pixel from a
-//   global work counter through a wave-aggregated pop: __ballot of the lanes that need work, one
-//   atomicAdd of popcount by the first such lane, prefix-popcount as each lane's offset. The wave
-//   therefore stays compacted (all 64 lanes tracing) until the frame runs out of pixels.
-//   Pixels are enumerated in 8x8 tiles so that a wave's rays are coherent.
-//   LDS per workgroup: Sobol byte tables (24 KiB), per-lane traversal stack [depth][lane], and a
-//   staged copy of the scene: the whole scene when it is small (hexagon_room: 16 nodes, 44 prims),
-//   else the top of the BVH (breadth-first prefix of the node array).
+// libmcrt_hip.so — host side of the gfx950 library: context, scene / photon-map upload, kernel selection and launches
+// (megakernels and the wavefront frame loop), and the C ABI of include/mcrt.h. The kernels are in mcrt_kernels.hpp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -33,1342 +21,7 @@
 using namespace mcrt;
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// kernel parameter blocks
-// ------------------------------------------------------------------------------------------------
-struct DeviceScene {
-    // global memory
-    uint32_t num_nodes, num_surfaces, num_materials, num_lights;
-    const double* node_bounds;
-    const NodeMeta* node_meta;
-    const Node64* nodes64;
-    const QBlock* qblocks;        // quantised child blocks of the trace kernel (mcrt_qbvh.hpp)
-    uint32_t num_qblocks, q_root_a, q_root_m;
-    const double* prim;
-    const double* flat_prim;      // kind-sorted copy (flat mode)
-    const uint32_t* flat_index;
-    uint32_t flat_tris;
-    const double* surf_v;
-    const double* surf_normal;
-    const double* surf_vn;  // may be null
-    const double* surf_area;
-    const uint32_t* surf_material;
-    const uint8_t* surf_kind;
-    const mcrt_material* materials;
-    const uint32_t* light_surface;
-    const double* light_cdf;
-    const uint32_t* sobol_tab;
-    double scene_ior;
-    // staging plan
-    uint32_t stage_all;    // 1: whole scene in LDS
-    uint32_t stage_nodes;  // number of leading nodes staged
-    uint32_t flat;         // 1: tiny scene, test every primitive in a wave-uniform loop (no BVH walk)
-};
-
-struct DevicePhotonMap {
-    PhotonMapView view;
-};
-
-struct RenderParams {
-    mcrt_camera_desc cam;
-    uint32_t global_seed, spp;
-    uint32_t owned_rows;
-    uint32_t tiles_x, tiles_y;
-    uint64_t work_items;  // tiles_x * tiles_y * 64
-    double* out;          // [owned_rows][width][3]
-    unsigned long long* work_counter;
-    unsigned long long* stats;  // paths, rays, node_tests, prim_tests, knn_searches, overflow, knn_octants
-    StackEntry* spill;
-    uint32_t total_lanes;
-    // photon mapping
-    PhotonMapView global_map, caustic_map;
-    uint32_t k_nearest, direct_visualization;
-    double* knn_res_d2;
-    uint32_t* knn_res_idx;
-    double* knn_visit_d2;
-    uint32_t* knn_visit_oct;
-    // lane-state-machine gating (renderKernelSM)
-    int sm_shade_lanes, sm_regen_lanes, sm_min_trav, sm_leaf_lanes, sm_min_inner;
-};
-
-// ------------------------------------------------------------------------------------------------
-// LDS carving
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
-constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
-
-struct LdsPlan {
-    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material,
-        surf_kind, materials, light_surface, light_cdf, total;
-};
-
-__host__ __device__ inline uint32_t alignUp(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
-
-__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block) {
-    LdsPlan p;
-    uint32_t off = 0;
-    p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(StackEntry);
-    p.iors = off; off += kMaxIors * block * 8u;
-    off = alignUp(off, 16);
-    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
-    p.node_bounds = off; off += nn * 48;
-    p.node_meta = off; off = alignUp(off + nn * 8, 16);
-    if (s.stage_all) {
-        const uint32_t ns = s.num_surfaces;
-        p.prim = off; off += ns * kPrimStride * 8;
-        p.flat_prim = off; off += s.flat ? ns * kPrimStride * 8 : 0;
-        p.flat_index = off; off = alignUp(off + (s.flat ? ns * 4 : 0), 16);
-        p.surf_v = off; off += ns * 72;
-        p.surf_normal = off; off += ns * 24;
-        p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
-        p.surf_area = off; off += ns * 8;
-        p.surf_material = off; off = alignUp(off + ns * 4, 16);
-        p.surf_kind = off; off = alignUp(off + ns, 16);
-        p.materials = off; off = alignUp(off + s.num_materials * (uint32_t)sizeof(mcrt_material), 16);
-        p.light_cdf = off; off += s.num_lights * 8;
-        p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
-    } else {
-        p.prim = p.flat_prim = p.flat_index = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
-            p.light_cdf = p.light_surface = off;
-    }
-    p.total = off;
-    return p;
-}
-
-template <class T>
-__device__ inline MCRT_LDS_AS T* ldsAt(unsigned char* base, uint32_t off) {
-    return (MCRT_LDS_AS T*)(base + off);
-}
-
-template <class T>
-__device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t count) {
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
-}
-
-// Builds the per-lane views; stages the scene into LDS (ends with __syncthreads()).
-// kAll: whole scene LDS-resident (the views carry address-space-3 pointers, so every scene access in
-// the hot loops is a ds_read); otherwise only the top of the BVH is staged.
-template <bool kAll>
-__device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
-                                  SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes) {
-    const LdsPlan p = planLds(s, blockDim.x);
-    rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
-    rh.stride = blockDim.x;
-    rh.size = 0;
-    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
-    stageCopy(ltab, s.sobol_tab, (uint32_t)kSobolTableWords);
-    tab = ltab;
-
-    stk.lds = ldsAt<StackEntry>(lds, p.stack) + threadIdx.x;
-    stk.lds_stride = blockDim.x;
-    stk.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    stk.spill_stride = total_lanes;
-
-    sv.num_nodes = s.flat ? 0u : s.num_nodes;
-    sv.num_surfaces = s.num_surfaces;
-    const uint32_t nn = kAll ? s.num_nodes : s.stage_nodes;
-    MCRT_LDS_AS double* lnb = ldsAt<double>(lds, p.node_bounds);
-    MCRT_LDS_AS NodeMeta* lnm = ldsAt<NodeMeta>(lds, p.node_meta);
-    stageCopy(lnb, s.node_bounds, nn * 6);
-    stageCopy(lnm, s.node_meta, nn);
-    sv.lds_nodes = nn;
-    sv.lds_node_bounds = lnb;
-    sv.lds_node_meta = lnm;
-    sh.num_lights = s.num_lights;
-    sh.scene_ior = s.scene_ior;
-
-    if constexpr (kAll) {
-        const uint32_t ns = s.num_surfaces;
-        sv.node_bounds = lnb;
-        sv.node_meta = lnm;
-        MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
-        stageCopy(lp, s.prim, ns * kPrimStride);
-        sv.prim = lp;
-        sv.flat_tris = s.flat_tris;
-        sv.flat_prim = nullptr;
-        sv.flat_index = nullptr;
-        if (s.flat) {
-            MCRT_LDS_AS double* lfp = ldsAt<double>(lds, p.flat_prim);
-            stageCopy(lfp, s.flat_prim, ns * kPrimStride);
-            sv.flat_prim = lfp;
-            MCRT_LDS_AS uint32_t* lfi = ldsAt<uint32_t>(lds, p.flat_index);
-            stageCopy(lfi, s.flat_index, ns);
-            sv.flat_index = lfi;
-        }
-        MCRT_LDS_AS double* lv = ldsAt<double>(lds, p.surf_v);
-        stageCopy(lv, s.surf_v, ns * 9);
-        sh.surf_v = lv;
-        MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
-        stageCopy(ln, s.surf_normal, ns * 3);
-        sh.surf_normal = ln;
-        MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
-        if (s.surf_vn) stageCopy(lvn, s.surf_vn, ns * 9);
-        sh.surf_vn = lvn;
-        MCRT_LDS_AS double* la = ldsAt<double>(lds, p.surf_area);
-        stageCopy(la, s.surf_area, ns);
-        sh.surf_area = la;
-        MCRT_LDS_AS uint32_t* lm = ldsAt<uint32_t>(lds, p.surf_material);
-        stageCopy(lm, s.surf_material, ns);
-        sh.surf_material = lm;
-        MCRT_LDS_AS uint8_t* lk = ldsAt<uint8_t>(lds, p.surf_kind);
-        stageCopy(lk, s.surf_kind, ns);
-        sh.surf_kind = lk;
-        MCRT_LDS_AS uint64_t* lmat = ldsAt<uint64_t>(lds, p.materials);
-        stageCopy(lmat, reinterpret_cast<const uint64_t*>(s.materials), s.num_materials * (uint32_t)(sizeof(mcrt_material) / 8));
-        sh.materials = (MCRT_LDS_AS const mcrt_material*)lmat;
-        MCRT_LDS_AS double* lc = ldsAt<double>(lds, p.light_cdf);
-        stageCopy(lc, s.light_cdf, s.num_lights);
-        sh.light_cdf = lc;
-        MCRT_LDS_AS uint32_t* ll = ldsAt<uint32_t>(lds, p.light_surface);
-        stageCopy(ll, s.light_surface, s.num_lights);
-        sh.light_surface = ll;
-    } else {
-        sv.node_bounds = s.node_bounds;
-        sv.node_meta = s.node_meta;
-        sv.prim = s.prim;
-        sv.flat_tris = 0;
-        sv.flat_prim = nullptr;
-        sv.flat_index = nullptr;
-        sh.surf_v = s.surf_v;
-        sh.surf_normal = s.surf_normal;
-        sh.surf_vn = s.surf_vn;
-        sh.surf_area = s.surf_area;
-        sh.surf_material = s.surf_material;
-        sh.surf_kind = s.surf_kind;
-        sh.materials = s.materials;
-        sh.light_surface = s.light_surface;
-        sh.light_cdf = s.light_cdf;
-    }
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------
-// wave helpers (wavefront = 64 lanes on gfx950)
-// ------------------------------------------------------------------------------------------------
-__device__ inline uint32_t laneId() { return __lane_id(); }
-
-__device__ inline unsigned long long waveBroadcast64(unsigned long long v, int src) {  // src wave-uniform
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Wave-aggregated pop from a global counter: lanes with need == true each receive a distinct index.
-__device__ inline unsigned long long wavePop(bool need, unsigned long long* counter) {
-    const unsigned long long mask = __ballot(need);
-    if (mask == 0ull) return 0ull;
-    const int leader = __ffsll((long long)mask) - 1;
-    const uint32_t lane = laneId();
-    unsigned long long base = 0ull;
-    if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-    base = waveBroadcast64(base, leader);
-    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-    return base + rank;
-}
-
-__device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
-    unsigned long long x = v;
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t lo = __shfl_down((uint32_t)x, off, 64), hi = __shfl_down((uint32_t)(x >> 32), off, 64);
-        x += ((unsigned long long)hi << 32) | lo;
-    }
-    if (laneId() == 0 && x) atomicAdd(dst, x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// the integrator kernel
-// ------------------------------------------------------------------------------------------------
-template <int kIntegrator, bool kCount, bool kAll, bool kProf = false>
-__global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    SceneViewT<kAll> sv;
-    ShadeViewT<kAll> sh;
-    SobolTab tab;
-    LaneStack stk;
-    RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
-
-    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
-    KnnScratch ks;
-    PhotonViews pv;
-    if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER) {
-        ks.res_d2 = prm.knn_res_d2 + gl;
-        ks.res_idx = prm.knn_res_idx + gl;
-        ks.visit_d2 = prm.knn_visit_d2 + gl;
-        ks.visit_oct = prm.knn_visit_oct + gl;
-        ks.stride = prm.total_lanes;
-        pv.global_map = prm.global_map;
-        pv.caustic_map = prm.caustic_map;
-        pv.k_nearest = prm.k_nearest;
-        pv.direct_visualization = prm.direct_visualization != 0;
-    }
-
-    PathState st;
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    PhaseProf<kProf> prof;
-    if constexpr (kProf) prof.begin();
-    uint32_t paths = 0, searches = 0, octant_visits = 0;
-    bool have_pixel = false, path_active = false, exhausted = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    const uint32_t W = prm.cam.width;
-
-    for (;;) {
-        if (kProf) prof.mark(kPhLoop);
-        const bool need = !have_pixel && !exhausted;
-        if (__ballot(need)) {
-            const unsigned long long w = wavePop(need, prm.work_counter);
-            if (need) {
-                if (w >= prm.work_items) {
-                    exhausted = true;
-                } else {
-                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                    if (lx < W && ly < prm.owned_rows) {
-                        px = lx;
-                        py = localToGlobalRow(prm.cam, ly);
-                        have_pixel = true;
-                        sample = 0;
-                        acc0 = acc1 = acc2 = 0.0;
-                        st.smp.initiate(prm.global_seed, py * W + px);  // camera.cpp:73
-                    }
-                }
-            }
-        }
-        if (!__ballot(have_pixel)) {
-            if (!__ballot(!exhausted)) break;
-            continue;
-        }
-        if (have_pixel) {
-            if (!path_active) {
-                if (kProf) prof.mark(kPhRegen);
-                st.smp.setIndex(sample);  // camera.cpp:77
-                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
-                path_active = true;
-                paths++;
-            }
-            bool done;
-            if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
-                done = photonMapperBounce<kCount, kAll>(st, rh, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
-            else
-                done = pathTracerBounce<kCount, kAll, kProf>(st, rh, sv, sh, stk, cnt, tab, &prof);
-            if (kProf) prof.mark(kPhLoop);
-            if (done) {
-                // Film::deposit, default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105)
-                acc0 += st.radiance.x * 1.0;
-                acc1 += st.radiance.y * 1.0;
-                acc2 += st.radiance.z * 1.0;
-                path_active = false;
-                if (++sample == prm.spp) {
-                    // Film::Splat::get (film.cpp:107-113): max(sum / weight_sum, 0)
-                    const double wsum = (double)prm.spp;
-                    double* o = prm.out + ((size_t)ly * W + px) * 3;
-                    o[0] = gmax(acc0 / wsum, 0.0);
-                    o[1] = gmax(acc1 / wsum, 0.0);
-                    o[2] = gmax(acc2 / wsum, 0.0);
-                    have_pixel = false;
-                }
-            }
-        }
-    }
-
-    waveAccumulate(prm.stats + 0, paths);
-    waveAccumulate(prm.stats + 1, cnt.rays);
-    if (kCount) {
-        waveAccumulate(prm.stats + 2, cnt.node_tests);
-        waveAccumulate(prm.stats + 3, cnt.prim_tests);
-    }
-    waveAccumulate(prm.stats + 4, searches);
-    waveAccumulate(prm.stats + 5, cnt.overflow);
-    waveAccumulate(prm.stats + 6, octant_visits);
-    if constexpr (kProf) {
-        prof.mark(kPhLoop);
-        for (int i = 0; i < kNumPhases; i++) {
-            atomicAdd(prm.stats + 8 + i, prof.wave_cycles[i]);
-            atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// the lane-state-machine integrator (scenes whose BVH is walked; see mcrt_lanesm.hpp)
-// ------------------------------------------------------------------------------------------------
-struct SmLdsPlan {
-    uint32_t sobol, stack, iors, nodes, prim, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
-        light_surface, light_cdf, total;
-};
-
-__host__ __device__ inline SmLdsPlan planSmLds(const DeviceScene& s, uint32_t block) {
-    SmLdsPlan p;
-    uint32_t off = 0;
-    p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(SmStackEntry);
-    p.iors = off; off += kMaxIors * block * 8u;
-    off = alignUp(off, 64);
-    const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
-    p.nodes = off; off += nn * 64u;
-    if (s.stage_all) {
-        const uint32_t ns = s.num_surfaces;
-        p.prim = off; off += ns * kPrimStride * 8;
-        p.surf_v = off; off += ns * 72;
-        p.surf_normal = off; off += ns * 24;
-        p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
-        p.surf_area = off; off += ns * 8;
-        p.surf_material = off; off = alignUp(off + ns * 4, 16);
-        p.surf_kind = off; off = alignUp(off + ns, 16);
-        p.materials = off; off = alignUp(off + s.num_materials * (uint32_t)sizeof(mcrt_material), 16);
-        p.light_cdf = off; off += s.num_lights * 8;
-        p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
-    } else {
-        p.prim = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
-            p.light_cdf = p.light_surface = off;
-    }
-    p.total = off;
-    return p;
-}
-
-enum : int { kStRegen = 0, kStTrav = 1, kStShade = 2, kStDone = 3 };
-
-template <bool kCount, bool kAll, bool kProf = false>
-__global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene, const RenderParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    const SmLdsPlan p = planSmLds(scene, blockDim.x);
-
-    // ---- staging
-    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
-    stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
-    const SobolTab tab = ltab;
-    SmStack stk;
-    stk.lds = ldsAt<SmStackEntry>(lds, p.stack) + threadIdx.x;
-    stk.lds_stride = blockDim.x;
-    stk.spill = reinterpret_cast<SmStackEntry*>(prm.spill) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    stk.spill_stride = prm.total_lanes;
-    RefractionHistory rh;
-    rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
-    rh.stride = blockDim.x;
-    rh.size = 0;
-
-    SmSceneView<kAll> sv;
-    ShadeViewT<kAll> sh;
-    sv.num_nodes = scene.num_nodes;
-    const uint32_t nn = kAll ? scene.num_nodes : scene.stage_nodes;
-    MCRT_LDS_AS uint64_t* lnodes = ldsAt<uint64_t>(lds, p.nodes);
-    // whole scene resident: the exact 64-byte records; tree in HBM: quantised child blocks (mcrt_qbvh.hpp), the
-    // first nn of them (the top of the tree) here in LDS
-    QView<true> qv;
-    qv.blocks = scene.qblocks;
-    qv.lds_blocks = 0;
-    qv.lds_ptr = (MCRT_LDS_AS const QBlock*)lnodes;
-    qv.root_a = scene.q_root_a;
-    qv.root_m = scene.q_root_m;
-    if constexpr (kAll) {
-        stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.nodes64), nn * 8u);
-        sv.lds_nodes = nn;
-    } else {
-        qv.lds_blocks = nn < scene.num_qblocks ? nn : scene.num_qblocks;
-        stageCopy(lnodes, reinterpret_cast<const uint64_t*>(scene.qblocks), qv.lds_blocks * 8u);
-        sv.lds_nodes = 0;
-    }
-    sv.lds_node_ptr = (MCRT_LDS_AS const Node64*)lnodes;
-    sh.num_lights = scene.num_lights;
-    sh.scene_ior = scene.scene_ior;
-    if constexpr (kAll) {
-        const uint32_t ns = scene.num_surfaces;
-        sv.nodes = (MCRT_LDS_AS const Node64*)lnodes;
-        MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
-        stageCopy(lp, scene.prim, ns * kPrimStride);
-        sv.prim = lp;
-        MCRT_LDS_AS double* lv = ldsAt<double>(lds, p.surf_v);
-        stageCopy(lv, scene.surf_v, ns * 9);
-        sh.surf_v = lv;
-        MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
-        stageCopy(ln, scene.surf_normal, ns * 3);
-        sh.surf_normal = ln;
-        MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
-        if (scene.surf_vn) stageCopy(lvn, scene.surf_vn, ns * 9);
-        sh.surf_vn = lvn;
-        MCRT_LDS_AS double* la = ldsAt<double>(lds, p.surf_area);
-        stageCopy(la, scene.surf_area, ns);
-        sh.surf_area = la;
-        MCRT_LDS_AS uint32_t* lm = ldsAt<uint32_t>(lds, p.surf_material);
-        stageCopy(lm, scene.surf_material, ns);
-        sh.surf_material = lm;
-        MCRT_LDS_AS uint8_t* lk = ldsAt<uint8_t>(lds, p.surf_kind);
-        stageCopy(lk, scene.surf_kind, ns);
-        sh.surf_kind = lk;
-        MCRT_LDS_AS uint64_t* lmat = ldsAt<uint64_t>(lds, p.materials);
-        stageCopy(lmat, reinterpret_cast<const uint64_t*>(scene.materials), scene.num_materials * (uint32_t)(sizeof(mcrt_material) / 8));
-        sh.materials = (MCRT_LDS_AS const mcrt_material*)lmat;
-        MCRT_LDS_AS double* lc = ldsAt<double>(lds, p.light_cdf);
-        stageCopy(lc, scene.light_cdf, scene.num_lights);
-        sh.light_cdf = lc;
-        MCRT_LDS_AS uint32_t* ll = ldsAt<uint32_t>(lds, p.light_surface);
-        stageCopy(ll, scene.light_surface, scene.num_lights);
-        sh.light_surface = ll;
-    } else {
-        sv.nodes = scene.nodes64;
-        sv.prim = scene.prim;
-        sh.surf_v = scene.surf_v;
-        sh.surf_normal = scene.surf_normal;
-        sh.surf_vn = scene.surf_vn;
-        sh.surf_area = scene.surf_area;
-        sh.surf_material = scene.surf_material;
-        sh.surf_kind = scene.surf_kind;
-        sh.materials = scene.materials;
-        sh.light_surface = scene.light_surface;
-        sh.light_cdf = scene.light_cdf;
-    }
-    __syncthreads();
-
-    // ---- per-lane state
-    PathState st;
-    NeePending nee;
-    nee.pending = false;
-    Trav T;
-    T.active = false;
-    T.shadow = false;
-    T.sp = 0;
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    uint32_t paths = 0;
-    int state = kStRegen;
-    bool have_pixel = false, alive = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    const uint32_t W = prm.cam.width;
-
-    // thresholds: the expensive blocks run when this many lanes wait for them, or when fewer than
-    // kMinTrav lanes are still traversing (so that nothing starves)
-    const int kShadeLanes = prm.sm_shade_lanes, kRegenLanes = prm.sm_regen_lanes, kMinTrav = prm.sm_min_trav;
-    const int kLeafLanes = prm.sm_leaf_lanes, kMinInner = prm.sm_min_inner;
-    PhaseProf<kProf> prof;  // phases here: regen, traverse = inner steps, shade, shadow = leaf steps, loop = transitions
-    if constexpr (kProf) prof.begin();
-
-    auto smBegin = [&](d3 o, d3 d, d3 inv, bool shadow, const ShadowQuery* sq, TraceCounters& c) {
-        if constexpr (kAll) travBegin<kAll, kCount>(sv, T, o, d, inv, shadow, sq, c);
-        else travBeginQ<kAll, true, kCount>(sv, qv, T, o, d, inv, shadow, sq, c);
-    };
-    // path end: Film::deposit (box filter) + next sample / pixel bookkeeping
-    auto endPath = [&]() {
-        acc0 += st.radiance.x * 1.0;
-        acc1 += st.radiance.y * 1.0;
-        acc2 += st.radiance.z * 1.0;
-        if (++sample == prm.spp) {
-            const double wsum = (double)prm.spp;
-            double* o = prm.out + ((size_t)ly * W + px) * 3;
-            o[0] = gmax(acc0 / wsum, 0.0);
-            o[1] = gmax(acc1 / wsum, 0.0);
-            o[2] = gmax(acc2 / wsum, 0.0);
-            have_pixel = false;
-        }
-        state = kStRegen;
-    };
-
-    for (;;) {
-        unsigned long long tp = prof.now();
-        // ---- cheap transitions of lanes whose traversal has just finished
-        if (state == kStTrav && !T.active) {
-            if (T.shadow) {
-                smNeeFinish(st, sh, nee, T.best);
-                nee.pending = false;
-                if (alive) smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
-                else endPath();
-            } else {
-                state = kStShade;
-            }
-        }
-
-        if (kProf) { prof.span(kPhLoop, tp, true); tp = prof.now(); }
-        const unsigned long long m_trav = __ballot(state == kStTrav && T.active);
-        const int n_trav = __popcll(m_trav);
-        const unsigned long long m_shade = __ballot(state == kStShade);
-        const unsigned long long m_regen = __ballot(state == kStRegen);
-        if (!(m_trav | m_shade | m_regen)) break;  // every lane is done
-
-        // ---- regenerate: next sample of the lane's pixel, or a new pixel from the global counter
-        if (m_regen && (__popcll(m_regen) >= kRegenLanes || n_trav < kMinTrav)) {
-            const bool need = state == kStRegen && !have_pixel;
-            if (__ballot(need)) {
-                const unsigned long long w = wavePop(need, prm.work_counter);
-                if (need) {
-                    if (w >= prm.work_items) {
-                        state = kStDone;
-                    } else {
-                        const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                        const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                        ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                        if (lx < W && ly < prm.owned_rows) {
-                            px = lx;
-                            py = localToGlobalRow(prm.cam, ly);
-                            have_pixel = true;
-                            sample = 0;
-                            acc0 = acc1 = acc2 = 0.0;
-                            st.smp.initiate(prm.global_seed, py * W + px);
-                        }
-                    }
-                }
-            }
-            if (state == kStRegen && have_pixel) {
-                st.smp.setIndex(sample);
-                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
-                paths++;
-                st.smp.shuffle();  // path-tracer.cpp:23, first bounce
-                smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
-                state = kStTrav;
-            }
-        }
-
-        if (kProf) { prof.span(kPhRegen, tp, (m_regen >> __lane_id()) & 1ull); tp = prof.now(); }
-        // ---- shade
-        if (m_shade && (__popcll(m_shade) >= kShadeLanes || n_trav < kMinTrav)) {
-            if (state == kStShade) {
-                Ray shadow_ray;
-                ShadowQuery shadow_q;
-                alive = smShade(st, rh, sh, T.best, nee, shadow_ray, shadow_q, tab);
-                if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
-                if (nee.pending) {
-                    smBegin( shadow_ray.start, shadow_ray.direction, shadow_ray.inv_direction, true, &shadow_q, cnt);
-                    state = kStTrav;
-                } else if (alive) {
-                    smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
-                    state = kStTrav;
-                } else {
-                    endPath();
-                }
-            }
-        }
-
-        if (kProf) { prof.span(kPhShade, tp, (m_shade >> __lane_id()) & 1ull); tp = prof.now(); }
-        // ---- traversal steps: inner nodes first (all such lanes together), then leaves
-        {
-            const bool trav = state == kStTrav && T.active;
-            const bool inner = trav && (T.node_m & kSmInner);
-            if constexpr (kAll) {
-                if (inner) travInnerStep<kAll, kCount>(sv, T, stk, cnt);
-            } else {
-                if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
-                if (inner && !T.fast) travInnerStep<kAll, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
-            }
-            if (kProf) { prof.span(kPhTraverse, tp, inner); tp = prof.now(); }
-            const bool leaf = state == kStTrav && T.active && !(T.node_m & kSmInner);
-            const unsigned long long m_leaf = __ballot(leaf);
-            const unsigned long long m_inner = __ballot(state == kStTrav && T.active && (T.node_m & kSmInner));
-            if (m_leaf && (__popcll(m_leaf) >= kLeafLanes || __popcll(m_inner) < kMinInner)) {
-                if (leaf) travLeafStep<kAll, kCount>(sv, T, stk, cnt);
-            }
-            if (kProf) prof.span(kPhShadow, tp, leaf);
-        }
-    }
-
-    waveAccumulate(prm.stats + 0, paths);
-    waveAccumulate(prm.stats + 1, cnt.rays);
-    if (kCount) {
-        waveAccumulate(prm.stats + 2, cnt.node_tests);
-        waveAccumulate(prm.stats + 3, cnt.prim_tests);
-    }
-    waveAccumulate(prm.stats + 5, cnt.overflow);
-    if constexpr (kProf) {
-        for (int i = 0; i < kNumPhases; i++) {
-            atomicAdd(prm.stats + 8 + i, prof.wave_cycles[i]);
-            atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// wavefront path tracer (mcrt_wavefront.hpp): trace kernel + shade kernel, path state pooled in HBM
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kWfBlock = 256;      // shade kernel
-constexpr uint32_t kTraceMaxBlock = 1024;  // trace kernel: up to 16 waves per workgroup, 128 VGPRs
-
-struct WfTraceArgs {
-    const unsigned long long* count;    // number of queued rays
-    unsigned long long* pop;            // next queue index to hand out (zeroed by the shade launch)
-    unsigned long long* stats;
-    const Node64* nodes;                // exact records: root test, rays with a zero direction component
-    const QBlock* qblocks;
-    uint32_t num_nodes, lds_blocks, q_root_a, q_root_m;
-    const double* prim;
-    SmStackEntry* spill;
-    uint32_t total_lanes;
-    int refill_lanes, leaf_lanes, min_inner, lds_stack;
-};
-
-// Where the rays of a trace launch come from and where their hits go.
-struct PoolRays {  // the wavefront pipeline: queue of (slot, port) items into the slot pool
-    WfPool pool;
-    const uint32_t* queue;
-    __device__ uint32_t item(unsigned long long w) const { return queue[w]; }
-    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const { wfLoadRay(pool, it, o, d, shadow, sq); }
-    __device__ void store(uint32_t it, const Hit& h) const { wfStoreHit(pool, it, h); }
-};
-struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
-    const double* start;
-    const double* direction;
-    double* out_t;
-    uint32_t* out_surface;
-    double* out_uv;
-    __device__ uint32_t item(unsigned long long w) const { return (uint32_t)w; }
-    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
-        o = ld3(start + 3 * (size_t)it);
-        d = ld3(direction + 3 * (size_t)it);
-        shadow = false;
-        sq.t_near = 0.0;
-        sq.t_far = kDblMax;
-        sq.light = kNoSurface;
-    }
-    __device__ void store(uint32_t it, const Hit& h) const {
-        out_t[it] = h.t;
-        out_surface[it] = h.surface;
-        out_uv[2 * (size_t)it] = h.u;
-        out_uv[2 * (size_t)it + 1] = h.v;
-    }
-};
-
-// Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
-// traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
-// are visited through quantised child blocks, the top of the tree from LDS.
-template <class Rays, bool kCount>
-__global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
-    extern __shared__ __align__(64) unsigned char lds[];
-    MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
-    for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
-        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
-    SmStack stk;
-    stk.lds = ldsAt<SmStackEntry>(lds, a.lds_blocks * 64u) + threadIdx.x;
-    stk.lds_stride = blockDim.x;
-    stk.spill = a.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    stk.spill_stride = a.total_lanes;
-    stk.lds_depth = a.lds_stack;
-    SmSceneView<false> sv;
-    sv.num_nodes = a.num_nodes;
-    sv.nodes = a.nodes;
-    sv.prim = a.prim;
-    sv.lds_nodes = 0;
-    sv.lds_node_ptr = nullptr;
-    QView<true> qv;
-    qv.blocks = a.qblocks;
-    qv.lds_blocks = a.lds_blocks;
-    qv.lds_ptr = lq;
-    qv.root_a = a.q_root_a;
-    qv.root_m = a.q_root_m;
-    __syncthreads();
-
-    const unsigned long long n = *a.count;
-    Trav T;
-    T.active = false;
-    T.shadow = false;
-    T.fast = true;
-    T.sp = 0;
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    bool have = false, exhausted = n == 0ull;
-    uint32_t item = 0;
-    for (;;) {
-        if (have && !T.active) {  // finished since the last look: hand the hit back
-            rays.store(item, T.best);
-            have = false;
-        }
-        const unsigned long long m_have = __ballot(have);
-        if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
-            const unsigned long long w = wavePop(!have, a.pop);
-            if (!have && w < n) {
-                item = rays.item(w);
-                d3 o, d;
-                bool shadow;
-                ShadowQuery sq;
-                rays.load(item, o, d, shadow, sq);
-                travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
-                have = true;
-            }
-            exhausted = __ballot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
-        }
-        if (!__ballot(have)) {
-            if (exhausted) break;
-            continue;
-        }
-        const bool inner = have && T.active && (T.node_m & kSmInner);
-        if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
-        if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
-        const bool leaf = have && T.active && !(T.node_m & kSmInner);
-        const unsigned long long m_leaf = __ballot(leaf);
-        const unsigned long long m_inner = __ballot(have && T.active && (T.node_m & kSmInner));
-        if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
-            if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
-        }
-    }
-    waveAccumulate(a.stats + 1, cnt.rays);
-    if (kCount) {
-        waveAccumulate(a.stats + 2, cnt.node_tests);
-        waveAccumulate(a.stats + 3, cnt.prim_tests);
-    }
-    waveAccumulate(a.stats + 5, cnt.overflow);
-}
-
-struct WfShadeArgs {
-    WfPool pool;
-    uint32_t slot_base, slot_count;   // the slots this launch serves (one half of the pool per stream)
-    WfFrame fr;
-    uint32_t* queue;
-    unsigned long long* count_out;    // rays queued by this launch
-    unsigned long long* count_reset;  // the other parity's counter, consumed by the trace launch before this one
-    unsigned long long* pop_reset;
-    unsigned long long* work;         // the frame's pixel work counter
-    unsigned long long* stats;
-    // photon mapper: estimate requests (slot | need_global << 31) for the next kNN launch, and the results of the last one
-    uint32_t* requests;
-    unsigned long long* rcount_out;
-    unsigned long long* rcount_reset;
-    unsigned long long* rpop_reset;
-    WfPmView pm;
-};
-
-struct DevWfEnv {
-    unsigned long long* work;
-    uint32_t* queue;
-    unsigned long long* count;
-    uint32_t* requests;
-    unsigned long long* rcount;
-    __device__ void request(uint32_t slot, bool want, bool global) const {
-        const unsigned long long m = __ballot(want);
-        if (!m) return;
-        const uint32_t lane = laneId();
-        const int leader = __ffsll((long long)__ballot(true)) - 1;
-        unsigned long long base = 0ull;
-        if ((int)lane == leader) base = atomicAdd(rcount, (unsigned long long)__popcll(m));
-        base = waveBroadcast64(base, leader);
-        if (want) requests[base + __popcll(m & ((1ull << lane) - 1ull))] = slot | (global ? 0x80000000u : 0u);
-    }
-    __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
-    __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
-    __device__ void filmAdd(double* a, double v) const { atomicAdd(a, v); }  // std::atomic<double> of Film::Splat
-    __device__ void push(uint32_t slot, bool p0, bool p1) const {
-        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-        const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
-        if (!total) return;
-        const uint32_t lane = laneId();
-        const int leader = __ffsll((long long)__ballot(true)) - 1;
-        unsigned long long base = 0ull;
-        if ((int)lane == leader) base = atomicAdd(count, (unsigned long long)total);
-        base = waveBroadcast64(base, leader);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        // the wave's bounce rays first, then its shadow rays (neighbouring queue entries = similar rays)
-        if (p0) queue[base + __popcll(m0 & below)] = slot * 2u;
-        if (p1) queue[base + n0 + __popcll(m1 & below)] = slot * 2u + 1u;
-    }
-};
-
-// 3 waves per SIMD (168 VGPRs, 148 B/lane of scratch): the launch is bound by the latency of its scattered scene reads;
-// measured C3 1122 -> 1158 Mray/s against the natural 221 VGPRs / 2 waves, 1017 at 4 waves (spills take over).
-template <bool kPhoton>
-__global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) wfShadeKernel(const DeviceScene scene, const WfShadeArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, 0);
-    stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
-    RefractionHistory rh;
-    rh.iors = ldsAt<double>(lds, kSobolTableWords * 4u) + threadIdx.x;
-    rh.stride = blockDim.x;
-    rh.size = 0;
-    ShadeViewT<false> sh;
-    sh.num_lights = scene.num_lights;
-    sh.scene_ior = scene.scene_ior;
-    sh.surf_v = scene.surf_v;
-    sh.surf_normal = scene.surf_normal;
-    sh.surf_vn = scene.surf_vn;
-    sh.surf_area = scene.surf_area;
-    sh.surf_material = scene.surf_material;
-    sh.surf_kind = scene.surf_kind;
-    sh.materials = scene.materials;
-    sh.light_surface = scene.light_surface;
-    sh.light_cdf = scene.light_cdf;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *a.count_reset = 0ull;
-        *a.pop_reset = 0ull;
-        if (kPhoton) {
-            *a.rcount_reset = 0ull;
-            *a.rpop_reset = 0ull;
-        }
-    }
-    __syncthreads();
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = local < a.slot_count;
-    DevWfEnv env{a.work, a.queue, a.count_out, a.requests, a.rcount_out};
-    uint32_t paths = 0;
-    wfShadeSlot<false, kPhoton>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
-    waveAccumulate(a.stats + 0, paths);
-}
-
-// Film::scan over the frame (film.cpp:81-84,107-113): the splats of a reconstruction-filter frame -> image.
-__global__ void filmResolveKernel(const double* blob, uint64_t pixels, double* out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pixels) filmResolve(blob + i * 4, out + i * 3);
-}
-
-// kNN launch of the wavefront photon mapper: one estimate request per wave at a time (mcrt_waveknn.hpp), the k photons
-// of every search written out for the next shade launch. 80 VGPRs: 6 waves per SIMD.
-struct WfKnnArgs {
-    WfPool pool;
-    const uint32_t* requests;
-    const unsigned long long* count;
-    unsigned long long* pop;
-    unsigned long long* stats;
-    PhotonMapViewW maps[2];  // global, caustic
-    uint32_t k;
-    uint32_t* res_n;
-    double* res_r2;
-    uint32_t* res_idx;
-    double* res_d2;
-};
-
-__global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
-    __shared__ double s_d2[4 * kWaveCand];
-    __shared__ uint32_t s_idx[4 * kWaveCand];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    WaveKnnLds W;
-    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
-    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
-    const unsigned long long n = *a.count;
-    const uint32_t slots = a.pool.n;
-    uint32_t overflow = 0, visits = 0, searches = 0;
-    for (;;) {
-        unsigned long long w = 0ull;
-        if (lane == 0) w = atomicAdd(a.pop, 1ull);
-        w = waveBroadcast64(w, 0);
-        if (w >= n) break;
-        const uint32_t req = a.requests[w];
-        const uint32_t slot = req & 0x7FFFFFFFu;
-        // Interaction::position = ray(t) (interaction.cpp:15)
-        const d3 p = a.pool.get3(kWfRayO, slot) + a.pool.get3(kWfRayD, slot) * a.pool.getd(kWfHit0T, slot);
-        for (int map = 1; map >= ((req >> 31) ? 0 : 1); map--) {  // caustic map always, global map on request
-            double r2;
-            const uint32_t c = waveKnnSearch(a.maps[map], p, a.k, W, r2, overflow, visits);
-            searches++;
-            if (lane == 0) {
-                a.res_n[(size_t)map * slots + slot] = c;
-                a.res_r2[(size_t)map * slots + slot] = r2;
-            }
-            for (uint32_t j = lane; j < c; j += 64) {
-                const size_t at = ((size_t)map * a.k + j) * slots + slot;
-                a.res_idx[at] = W.idx[j];
-                a.res_d2[at] = W.d2[j];
-            }
-        }
-    }
-    if (lane == 0) {
-        if (searches) atomicAdd(a.stats + 4, (unsigned long long)searches);
-        if (visits) atomicAdd(a.stats + 6, (unsigned long long)visits);
-        if (overflow) atomicAdd(a.stats + 5, 1ull);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// photon-mapping eye pass with wave-cooperative radiance estimates (mcrt_waveknn.hpp)
-// ------------------------------------------------------------------------------------------------
-// Wave-synchronous walk over the quantised child blocks (mcrt_qbvh.hpp) with the step functions of the lane state
-// machine: inner steps while any lane has one, a leaf step when enough lanes wait at a leaf or nothing else is left.
-// Used by the photon-mapping eye pass for trees that stay in HBM.
-template <bool kCount>
-__device__ inline Hit traceWalkQ(const SmSceneView<false>& sv, const QView<true>& qv, const SmStack& stk, const Ray& ray, bool shadow,
-                                 const ShadowQuery* sq, TraceCounters& cnt) {
-    Trav T;
-    travBeginQ<false, true, kCount>(sv, qv, T, ray.start, ray.direction, ray.inv_direction, shadow, sq, cnt);
-    for (;;) {
-        const bool inner = T.active && (T.node_m & kSmInner);
-        if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
-        if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);
-        const bool leaf = T.active && !(T.node_m & kSmInner);
-        const unsigned long long m_leaf = __ballot(leaf), m_inner = __ballot(T.active && (T.node_m & kSmInner));
-        if (!(m_leaf | m_inner)) break;
-        if (m_leaf && (__popcll(m_leaf) >= 32 || __popcll(m_inner) < 8)) {
-            if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
-        }
-    }
-    return T.best;
-}
-
-// What traceWalkQ needs, carved out of the LDS plan of the wave-synchronous kernels (planLds): the top child blocks take
-// the place of the staged node records, the traversal stack region is used with the state machine's 8-byte entries.
-struct QWalk {
-    SmSceneView<false> sv;
-    QView<true> qv;
-    SmStack stk;
-};
-__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q) {  // every thread calls
-    const LdsPlan lp = planLds(scene, blockDim.x);
-    MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
-    const uint32_t room = scene.stage_nodes * 56u / 64u;
-    q.qv.blocks = scene.qblocks;
-    q.qv.lds_blocks = room < scene.num_qblocks ? room : scene.num_qblocks;
-    q.qv.lds_ptr = lq;
-    q.qv.root_a = scene.q_root_a;
-    q.qv.root_m = scene.q_root_m;
-    __syncthreads();  // setupViews' copies of the node records are not read by these kernels
-    for (uint32_t i = threadIdx.x; i < q.qv.lds_blocks * 16u; i += blockDim.x)
-        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(scene.qblocks)[i];
-    __syncthreads();
-    q.sv.num_nodes = scene.num_nodes;
-    q.sv.nodes = scene.nodes64;
-    q.sv.prim = scene.prim;
-    q.sv.lds_nodes = 0;
-    q.sv.lds_node_ptr = nullptr;
-    q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [16][lanes] region
-    q.stk.lds_stride = lstk.lds_stride;
-    q.stk.spill = reinterpret_cast<SmStackEntry*>(lstk.spill);
-    q.stk.spill_stride = lstk.spill_stride;
-}
-
-struct PmExtra {
-    PhotonMapViewW global_map, caustic_map;
-};
-
-template <bool kCount, bool kAll>
-__global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    SceneViewT<kAll> sv;
-    ShadeViewT<kAll> sh;
-    SobolTab tab;
-    LaneStack stk;
-    RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    // tree in HBM: walk it through the quantised child blocks
-    QWalk qw;
-    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
-    auto intersect = [&](const Ray& ray, bool shadow, const ShadowQuery* sq) {
-        if constexpr (kAll) {
-            return shadow ? sceneIntersect<kAll, kCount, true>(sv, ray, stk, cnt, sq) : sceneIntersect<kAll, kCount, false>(sv, ray, stk, cnt);
-        } else {
-            return traceWalkQ<kCount>(qw.sv, qw.qv, qw.stk, ray, shadow, sq, cnt);
-        }
-    };
-    // per-wave candidate buffer behind the common LDS plan
-    WaveKnnLds W;
-    {
-        const uint32_t base = alignUp(planLds(scene, blockDim.x).total, 16);
-        const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-        W.d2 = ldsAt<double>(lds, base) + wave * kWaveCand;
-        W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
-    }
-
-    PathState st;
-    uint32_t paths = 0, searches = 0, octant_visits = 0, knn_overflow = 0;
-    bool have_pixel = false, path_active = false, exhausted = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    const uint32_t W_img = prm.cam.width;
-    const bool direct_visualization = prm.direct_visualization != 0;
-
-    for (;;) {
-        const bool need = !have_pixel && !exhausted;
-        if (__ballot(need)) {
-            const unsigned long long w = wavePop(need, prm.work_counter);
-            if (need) {
-                if (w >= prm.work_items) {
-                    exhausted = true;
-                } else {
-                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                    if (lx < W_img && ly < prm.owned_rows) {
-                        px = lx;
-                        py = localToGlobalRow(prm.cam, ly);
-                        have_pixel = true;
-                        sample = 0;
-                        acc0 = acc1 = acc2 = 0.0;
-                        st.smp.initiate(prm.global_seed, py * W_img + px);
-                    }
-                }
-            }
-        }
-        if (!__ballot(have_pixel)) {
-            if (!__ballot(!exhausted)) break;
-            continue;
-        }
-        if (have_pixel && !path_active) {
-            st.smp.setIndex(sample);
-            pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
-            path_active = true;
-            paths++;
-        }
-
-        // ---- part 1 (per lane): PhotonMapper::sampleRay up to the radiance estimates (photon-mapper.cpp:288-313)
-        InteractionT<kAll> ia;
-        ia.material = sh.materials;
-        ia.position = ia.out = ia.shading_cs.c0 = ia.shading_cs.c1 = ia.shading_cs.c2 = splat(0.0);
-        ia.n1 = ia.n2 = ia.R = ia.T = 0.0;
-        ia.type = kDiffuse;
-        ia.inside = false;
-        ia.dirac_delta = false;
-        bool ended = false, needC = false, needG = false;
-        if (path_active) {
-            st.smp.shuffle();
-            Hit isect = intersect(st.ray, false, nullptr);
-            if (isect.surface == kNoSurface) {
-                ended = true;  // no sky in photon mode (:292-295)
-            } else {
-                interactionInit(ia, sh, isect, st.ray, rh.externalIOR(st.ray), st.smp, tab);
-                st.radiance = st.radiance + sampleEmissive(sh, ia, st.ls) * st.throughput;
-                if (ia.dirac_delta) {
-                    if (!st.ray.dirac_delta && st.ray.depth != 0) ended = true;  // :303-306
-                } else {
-                    needC = true;                                                                       // :315
-                    needG = !(!direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0));     // :317 / :327
-                }
-            }
-        }
-        // ---- part 2 (whole wave): caustic estimates, then global estimates
-        const d3 C = waveEstimate(needC, ia, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
-        if (needC) st.radiance = st.radiance + C * st.throughput;
-        const d3 G = waveEstimate(needG, ia, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
-        if (needG) {
-            st.radiance = st.radiance + G * st.throughput;  // :330, the path ends here
-            ended = true;
-        }
-        // ---- part 3 (per lane): next-event estimate, BSDF sampling, russian roulette (:308-311, :319-325, :334-339)
-        if (path_active && !ended) {
-            if (!ia.dirac_delta) {
-                DirectQuery dq;
-                if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
-                    Hit shadow = intersect(dq.shadow_ray, true, &dq.sq);
-                    st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
-                }
-            }
-            d3 bsdf_absIdotN;
-            if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) {
-                ended = true;
-            } else {
-                st.throughput = st.throughput * (bsdf_absIdotN / st.ls.bsdf_pdf);
-                if (absorb(st.ray, st.throughput, st.smp, tab)) ended = true;
-                else rh.update(st.ray);
-            }
-        }
-        if (path_active && ended) {
-            acc0 += st.radiance.x * 1.0;
-            acc1 += st.radiance.y * 1.0;
-            acc2 += st.radiance.z * 1.0;
-            path_active = false;
-            if (++sample == prm.spp) {
-                const double wsum = (double)prm.spp;
-                double* o = prm.out + ((size_t)ly * W_img + px) * 3;
-                o[0] = gmax(acc0 / wsum, 0.0);
-                o[1] = gmax(acc1 / wsum, 0.0);
-                o[2] = gmax(acc2 / wsum, 0.0);
-                have_pixel = false;
-            }
-        }
-    }
-    waveAccumulate(prm.stats + 0, paths);
-    waveAccumulate(prm.stats + 1, cnt.rays);
-    if (kCount) {
-        waveAccumulate(prm.stats + 2, cnt.node_tests);
-        waveAccumulate(prm.stats + 3, cnt.prim_tests);
-    }
-    waveAccumulate(prm.stats + 4, searches);
-    waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
-    waveAccumulate(prm.stats + 6, octant_visits);
-}
-
-// LinearOctree::knnSearch operator: one query at a time per wave
-__global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
-                                                     uint32_t* out_index, double* out_d2, unsigned long long* flags) {
-    __shared__ double s_d2[4 * kWaveCand];
-    __shared__ uint32_t s_idx[4 * kWaveCand];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    WaveKnnLds W;
-    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
-    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
-    const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    uint32_t overflow = 0, visits = 0;
-    for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {
-        const d3 pt = ld3(p + 3 * q);
-        double r2;
-        const uint32_t c = waveKnnSearch(map, pt, k, W, r2, overflow, visits);
-        waveSortResult(W, c);
-        if (lane == 0) out_count[q] = c;
-        for (uint32_t j = lane; j < k; j += 64) {
-            out_index[q * k + j] = j < c ? W.idx[j] : 0xFFFFFFFFu;
-            out_d2[q * k + j] = j < c ? W.d2[j] : INFINITY;
-        }
-    }
-    if (overflow && lane == 0) atomicAdd(flags, 1ull);
-}
-
-// ------------------------------------------------------------------------------------------------
-// photon emission pass (§8(f) rank 1): one photon path per lane at a time, regenerated like the eye paths
-// ------------------------------------------------------------------------------------------------
-struct EmitParams {
-    uint32_t num_lights;
-    const unsigned long long* light_first;  // [num_lights + 1] prefix sums of the per-light emission counts
-    const double* light_photon_flux;        // [num_lights][3]
-    unsigned long long total_emissions;     // this launch handles paths [first_emission, total_emissions)
-    unsigned long long first_emission;
-    uint32_t global_seed;
-    double non_caustic_reject;
-    float* photons[2];                      // 0 global, 1 caustic: [capacity][8]
-    unsigned long long* keys[2];
-    unsigned long long capacity[2];
-    unsigned long long* counters;           // [0] work, [1] global count, [2] caustic count, [3] paths, [4] rays, [5] overflow
-    StackEntry* spill;
-    uint32_t total_lanes;
-};
-
-// wave-aggregated append: lanes with store == true get consecutive slots of the list
-__device__ inline unsigned long long waveAppend(bool store, unsigned long long* counter) { return wavePop(store, counter); }
-
-template <bool kAll>
-__global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, const EmitParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    SceneViewT<kAll> sv;
-    ShadeViewT<kAll> sh;
-    SobolTab tab;
-    LaneStack stk;
-    RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
-    QWalk qw;  // tree in HBM: quantised child blocks
-    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
-
-    EmitState es;
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    uint32_t paths = 0;
-    bool active = false, exhausted = false;
-    for (;;) {
-        const bool need = !active && !exhausted;
-        if (__ballot(need)) {
-            const unsigned long long e = prm.first_emission + wavePop(need, prm.counters + 0);
-            if (need) {
-                if (e >= prm.total_emissions) {
-                    exhausted = true;
-                } else {
-                    // which light: largest i with light_first[i] <= e
-                    uint32_t lo = 0, hi = prm.num_lights - 1;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi + 1) / 2;
-                        if (prm.light_first[mid] <= e) lo = mid;
-                        else hi = mid - 1;
-                    }
-                    const d3 pf = ld3(prm.light_photon_flux + 3 * (size_t)lo);
-                    emitBegin(es, rh, sh, lo, (uint32_t)(e - prm.light_first[lo]), pf, prm.global_seed, tab);
-                    active = true;
-                    paths++;
-                }
-            }
-        }
-        if (!__ballot(active)) {
-            if (!__ballot(!exhausted)) break;
-            continue;
-        }
-        PhotonOut out;
-        out.store = false;
-        out.caustic = false;
-        if (active) {
-            bool done;
-            if constexpr (kAll) {
-                done = emitBounce<false, kAll>(es, rh, sv, sh, stk, cnt, tab, prm.non_caustic_reject, out);
-            } else {
-                es.smp.shuffle();  // photon-mapper.cpp:233 (emitBounce's first line)
-                const Hit isect = traceWalkQ<false>(qw.sv, qw.qv, qw.stk, es.ray, false, nullptr, cnt);
-                done = emitAfterHit(es, rh, sh, isect, tab, prm.non_caustic_reject, out);
-            }
-            if (done) active = false;
-        }
-        for (int which = 0; which < 2; which++) {
-            const bool mine = out.store && (out.caustic == (which == 1));
-            if (__ballot(mine)) {
-                const unsigned long long slot = waveAppend(mine, prm.counters + 1 + which);
-                if (mine && slot < prm.capacity[which]) {
-                    float* o = prm.photons[which] + slot * 8ull;
-                    for (int k = 0; k < 8; k++) o[k] = out.rec[k];
-                    prm.keys[which][slot] = out.key;
-                }
-            }
-        }
-    }
-    waveAccumulate(prm.counters + 3, paths);
-    waveAccumulate(prm.counters + 4, cnt.rays);
-    waveAccumulate(prm.counters + 5, cnt.overflow);
-}
-
-// ------------------------------------------------------------------------------------------------
-// operator-level kernels
-// ------------------------------------------------------------------------------------------------
-template <bool kAll>
-__global__ void __launch_bounds__(kBlock) intersectKernel(const DeviceScene scene, uint64_t n, const double* start,
-                                                       const double* direction, double* out_t, uint32_t* out_surface,
-                                                       double* out_uv, StackEntry* spill, uint32_t total_lanes) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    SceneViewT<kAll> sv;
-    ShadeViewT<kAll> sh;
-    SobolTab tab;
-    LaneStack stk;
-    RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, spill, total_lanes);
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
-        Hit h = sceneIntersect<kAll, false, false>(sv, ray, stk, cnt);
-        out_t[i] = h.t;
-        out_surface[i] = h.surface;
-        out_uv[2 * i] = h.u;
-        out_uv[2 * i + 1] = h.v;
-    }
-}
-
-__global__ void samplerKernel(const uint32_t* tab, uint64_t n, const uint32_t* pixel, const uint32_t* index,
-                              uint32_t shuffles, uint32_t global_seed, double* out) {
-    __shared__ uint32_t ltab[kSobolTableWords];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kSobolTableWords; i += blockDim.x) ltab[i] = tab[i];
-    __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        Sampler s;
-        s.initiate(global_seed, pixel[i]);
-        s.setIndex(index[i]);
-        for (uint32_t k = 0; k < shuffles; k++) s.shuffle();
-        for (int d = 0; d < 7; d++) out[i * 7 + d] = s.get(d, (SobolTab)ltab);
-    }
-}
-
-__global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
-                          uint32_t* out_index, double* out_d2, double* res_d2, uint32_t* res_idx, double* visit_d2,
-                          uint32_t* visit_oct, uint32_t total_lanes) {
-    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
-    KnnScratch ks;
-    ks.res_d2 = res_d2 + gl;
-    ks.res_idx = res_idx + gl;
-    ks.visit_d2 = visit_d2 + gl;
-    ks.visit_oct = visit_oct + gl;
-    ks.stride = total_lanes;
-    for (uint64_t i = gl; i < n; i += total_lanes) {
-        uint32_t visits = 0;
-        uint32_t c = knnSearch(map, ld3(p + 3 * i), k, ks, visits);
-        out_count[i] = c;
-        // heap-sort the result in place (ascending distance, ties by index) into the output row
-        for (uint32_t q = 0; q < k; q++) {
-            out_index[i * k + q] = 0xFFFFFFFFu;
-            out_d2[i * k + q] = INFINITY;
-        }
-        // selection by repeated extraction of the max-heap root
-        uint32_t size = c;
-        while (size > 0) {
-            KnnEntry top = ks.res(0);
-            out_index[i * k + (size - 1)] = top.index;
-            out_d2[i * k + (size - 1)] = top.distance2;
-            KnnEntry last = ks.res(size - 1);
-            size--;
-            if (size > 0) knnSiftDown(ks, size, last, 0);
-        }
-        // fix tie order (equal distance2: ascending index) with a local insertion pass
-        for (uint32_t a = 1; a < c; a++) {
-            uint32_t b = a;
-            while (b > 0 && out_d2[i * k + b - 1] == out_d2[i * k + b] && out_index[i * k + b - 1] > out_index[i * k + b]) {
-                uint32_t t = out_index[i * k + b - 1];
-                out_index[i * k + b - 1] = out_index[i * k + b];
-                out_index[i * k + b] = t;
-                b--;
-            }
-        }
-    }
-}
+#include "mcrt_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side

@@ -20,7 +20,7 @@
 // counter. The arithmetic of a path is the same functions in the same order as mcrt_lanesm.hpp:
 // smShade / smNeeFinish / travBegin / travInnerStep / travLeafStep.
 //
-// Everything in this header is plain per-slot / per-ray code shared by the gfx950 kernels (mcrt_hip.hip)
+// Everything in this header is plain per-slot / per-ray code shared by the gfx950 kernels (mcrt_kernels.hpp)
 // and the host emulation used by the CPU tests (tests/emu).
 #pragma once
 
