@@ -328,6 +328,32 @@ int  mcrt_scene_with_bvh(const mcrt_scene_desc* scene, const mcrt_bvh_desc* bvh,
 const mcrt_scene_desc* mcrt_scene_get(const mcrt_scene* scene);
 void mcrt_scene_free(mcrt_scene* scene);
 
+/* ------------------------------------------------------------------------------------------
+ * Image::save on the GPU (camera/image.cpp:37-88; SURVEY.md §8(f) rank 4, "tonemap/exposure"): what the reference does with
+ * the frame after Camera::sampleImage — auto exposure from the median of a 65 536-bin brightness histogram (getExposure
+ * :62-72, common/histogram.cpp:6-41), auto gain from the 99th percentile of the tone-mapped brightness (getGain :77-87),
+ * the tone map (camera/pixel-operators.cpp:7-44), sRGB gamma (color/srgb.hpp:55-63) and truncation to bytes in B,G,R
+ * order (pixel-operators.cpp:51-55) — as five kernels on the frame where mcrt_render_device left it, so that 3 bytes per
+ * pixel cross PCIe instead of 24. Every step but pow() is IEEE-exact and in the reference's order; a byte can differ from
+ * the reference's only where pow's last bit moves a value across an integer (tests allow 1 step on < 1e-4 of the bytes).
+ * The fields are the scene file's camera "image" object (image.cpp:10-35). */
+enum { MCRT_TONEMAP_HABLE = 0, MCRT_TONEMAP_ACES = 1 };
+typedef struct mcrt_image_desc {
+    uint32_t width, height;          /* of the buffer handed in (the full frame: exposure is a whole-image statistic) */
+    uint32_t tonemapper;             /* MCRT_TONEMAP_*; "tonemapper" (default Hable)                                  */
+    uint32_t plain;                  /* "plain": no tone map, exposure and gain 1                                      */
+    double exposure_compensation;    /* EV: exposure = 0.5 / median * 2^EV                                             */
+    double gain_compensation;        /* EV                                                                             */
+} mcrt_image_desc;
+/* d_rgb: width*height*3 doubles in device memory; d_bgr: width*height*3 bytes in device memory (rows top to bottom, the
+ * TGA payload). factors (host, may be NULL) receives {exposure_factor, gain_factor}. Synchronous on `stream`. */
+int mcrt_tonemap_device(mcrt_ctx* ctx, const double* d_rgb, const mcrt_image_desc* image, uint8_t* d_bgr, double* factors,
+                        void* stream);
+/* Same from/to host memory (copies in, runs the kernels, copies the bytes out). */
+int mcrt_tonemap(mcrt_ctx* ctx, const double* rgb, const mcrt_image_desc* image, uint8_t* bgr, double* factors);
+/* HeaderTGA + payload (camera/image.hpp:39-50, image.cpp:42-51): uncompressed 24 bpp, top-left origin. Host only. */
+int mcrt_tga_save(const char* path, uint32_t width, uint32_t height, const uint8_t* bgr);
+
 uint32_t mcrt_abi_version(void);
 
 #ifdef __cplusplus

@@ -109,6 +109,24 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+TONEMAP_HABLE, TONEMAP_ACES = 0, 1
+TONEMAPPERS = {"HABLE": TONEMAP_HABLE, "ACES": TONEMAP_ACES}
+
+
+class ImageDesc(C.Structure):
+    """mcrt_image_desc — the camera's "image" object (camera/image.cpp:10-35)."""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("tonemapper", C.c_uint32), ("plain", C.c_uint32),
+        ("exposure_compensation", C.c_double), ("gain_compensation", C.c_double),
+    ]
+
+    @classmethod
+    def make(cls, width, height, tonemapper="HABLE", plain=False, exposure_compensation=0.0, gain_compensation=0.0):
+        # image.cpp:25-34: the name is upper-cased; "ACES" selects filmicACES, anything else filmicHable
+        tm = tonemapper if isinstance(tonemapper, int) else TONEMAPPERS.get(str(tonemapper).upper(), TONEMAP_HABLE)
+        return cls(int(width), int(height), tm, int(bool(plain)), float(exposure_compensation), float(gain_compensation))
+
+
 class PhotonEmission(C.Structure):
     """mcrt_photon_emission."""
     _fields_ = [
@@ -117,6 +135,14 @@ class PhotonEmission(C.Structure):
         ("global_keys", _u64p), ("caustic_keys", _u64p),
         ("emission_paths", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double),
     ]
+
+
+def tga_save(path, bgr):
+    """mcrt_tga_save: the reference's .tga (HeaderTGA + B,G,R bytes) for a [H,W,3] uint8 array."""
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    rc = lib().mcrt_tga_save(os.fsencode(path), bgr.shape[1], bgr.shape[0], bgr.ctypes.data)
+    if rc != 0:
+        raise McrtError("mcrt_tga_save(%s) failed: %d" % (path, rc))
 
 
 class McrtError(RuntimeError):
@@ -171,6 +197,9 @@ def lib():
     L.mcrt_photon_map_get.restype = C.POINTER(PhotonMapDesc)
     L.mcrt_photon_map_free.argtypes = [vp]
     L.mcrt_photon_map_free.restype = None
+    L.mcrt_tonemap_device.argtypes = [vp, vp, C.POINTER(ImageDesc), vp, _dp, vp]
+    L.mcrt_tonemap.argtypes = [vp, _dp, C.POINTER(ImageDesc), vp, _dp]
+    L.mcrt_tga_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
     L.mcrt_image_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.mcrt_image_free.argtypes = [vp]
     L.mcrt_image_free.restype = None
@@ -402,6 +431,22 @@ class Context:
         st = Stats()
         self._check(self._lib.mcrt_render_finish(self._h, C.byref(st)), "mcrt_render_finish")
         return st.as_dict()
+
+    def tonemap(self, rgb, image):
+        """mcrt_tonemap: Image::save of a host frame [H,W,3] FP64 -> ([H,W,3] uint8 in B,G,R order, (exposure, gain))."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+        assert rgb.shape == (image.height, image.width, 3)
+        bgr = np.empty((image.height, image.width, 3), dtype=np.uint8)
+        factors = (C.c_double * 2)()
+        self._check(self._lib.mcrt_tonemap(self._h, rgb.ctypes.data_as(_dp), C.byref(image), bgr.ctypes.data, factors), "mcrt_tonemap")
+        return bgr, (factors[0], factors[1])
+
+    def tonemap_device(self, rgb_ptr, image, bgr_ptr, stream=None):
+        """mcrt_tonemap_device on device pointers (e.g. torch tensors' data_ptr()); returns (exposure, gain)."""
+        factors = (C.c_double * 2)()
+        self._check(self._lib.mcrt_tonemap_device(self._h, C.c_void_p(int(rgb_ptr)), C.byref(image), C.c_void_p(int(bgr_ptr)), factors,
+                                                  C.c_void_p(int(stream)) if stream else None), "mcrt_tonemap_device")
+        return factors[0], factors[1]
 
     def emit_photons(self, emissions, caustic_factor, global_seed, shard_index=0, shard_count=1):
         """mcrt_emit_photons[_shard] -> dict(global_=(photons[n,8] f32, keys[n] u64), caustic=(...), paths, rays, kernel_ms)."""

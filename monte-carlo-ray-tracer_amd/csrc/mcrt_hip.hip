@@ -1185,5 +1185,6 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
 
 namespace mcrt {
 int ctxDevice(const mcrt_ctx* ctx) { return ctx->device; }
+void* ctxStream(const mcrt_ctx* ctx) { return (void*)ctx->stream; }
 int ctxFail(mcrt_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
 }  // namespace mcrt

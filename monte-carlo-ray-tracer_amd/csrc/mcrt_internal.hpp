@@ -9,6 +9,7 @@ struct mcrt_bvh;
 
 namespace mcrt {
 int ctxDevice(const mcrt_ctx* ctx);
+void* ctxStream(const mcrt_ctx* ctx);  // the context's hipStream_t
 int ctxFail(mcrt_ctx* ctx, int code, const std::string& msg);  // records the message for mcrt_last_error, returns code
 // mcrt_octree_gpu.hip: the octree BVH of `scene` with the per-surface work on the GPU of ctx (mcrt_bvh_shared.hpp)
 int bvhOctreeGpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, struct ::mcrt_bvh* out);

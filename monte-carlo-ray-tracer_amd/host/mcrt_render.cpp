@@ -3,9 +3,11 @@
 // (*.mcrt) written by the flattener inside the reference host.
 //
 //   mcrt_render scene.mcrt out.f64 [--width W --height H --sqrtspp S] [--seed N] [--photon] [--device D]
+//               [--tga out.tga [--tonemapper hable|aces] [--exposure EV] [--gain EV] [--plain]]
 //
 // Writes the frame as raw FP64 RGB, row-major (what Image::operator() holds, camera/image.cpp:53-56),
-// and prints the statistics. Tonemapping and the TGA writer stay with the reference (Image::save).
+// and prints the statistics. --tga also develops it the way Image::save does (auto exposure / gain, tone map, sRGB bytes:
+// mcrt_tonemap) and writes the reference's .tga; the "image" options default to the ones stored in the scene image.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +29,13 @@ int main(int argc, char** argv) {
     mcrt_camera_desc cam = *mcrt_image_camera(img);
     uint32_t seed = (uint32_t)mcrt_image_param(img, "global_seed");
     int photon = (int)mcrt_image_param(img, "photon_mapping"), device = 0;
+    auto from_bits = [](uint64_t u) { double d; std::memcpy(&d, &u, 8); return d; };
+    mcrt_image_desc image{};
+    image.tonemapper = (uint32_t)mcrt_image_param(img, "image_tonemapper");
+    image.plain = (uint32_t)mcrt_image_param(img, "image_plain");
+    image.exposure_compensation = from_bits(mcrt_image_param(img, "image_exposure_ev_bits"));
+    image.gain_compensation = from_bits(mcrt_image_param(img, "image_gain_ev_bits"));
+    std::string tga;
     for (int i = 3; i < argc; i++) {
         std::string k = argv[i];
         auto val = [&]() { return i + 1 < argc ? std::strtoul(argv[++i], nullptr, 0) : 0ul; };
@@ -36,6 +45,11 @@ int main(int argc, char** argv) {
         else if (k == "--seed") seed = (uint32_t)val();
         else if (k == "--device") device = (int)val();
         else if (k == "--photon") photon = 1;
+        else if (k == "--tga" && i + 1 < argc) tga = argv[++i];
+        else if (k == "--tonemapper" && i + 1 < argc) image.tonemapper = (argv[++i][0] | 0x20) == 'a' ? MCRT_TONEMAP_ACES : MCRT_TONEMAP_HABLE;
+        else if (k == "--exposure" && i + 1 < argc) image.exposure_compensation = std::strtod(argv[++i], nullptr);
+        else if (k == "--gain" && i + 1 < argc) image.gain_compensation = std::strtod(argv[++i], nullptr);
+        else if (k == "--plain") image.plain = 1;
     }
     cam.shard_index = 0;
     cam.shard_count = 1;
@@ -61,6 +75,19 @@ int main(int argc, char** argv) {
         return 1;
     }
     std::fclose(f);
+    if (!tga.empty()) {
+        image.width = cam.width;
+        image.height = cam.height;
+        std::vector<uint8_t> bgr((size_t)cam.width * cam.height * 3);
+        double factors[2];
+        rc = mcrt_tonemap(ctx, rgb.data(), &image, bgr.data(), factors);
+        if (rc == MCRT_OK) rc = mcrt_tga_save(tga.c_str(), cam.width, cam.height, bgr.data());
+        if (rc != MCRT_OK) {
+            std::fprintf(stderr, "mcrt error %d writing %s: %s\n", rc, tga.c_str(), mcrt_last_error(ctx));
+            return 1;
+        }
+        std::printf("{\"tga\":\"%s\",\"exposure_factor\":%.17g,\"gain_factor\":%.17g}\n", tga.c_str(), factors[0], factors[1]);
+    }
     std::printf("{\"width\":%u,\"height\":%u,\"spp\":%u,\"paths\":%llu,\"rays\":%llu,\"kernel_ms\":%.3f,\"total_ms\":%.3f,\"Mray_s\":%.1f}\n",
                 cam.width, cam.height, cam.sqrtspp * cam.sqrtspp, (unsigned long long)st.paths, (unsigned long long)st.rays,
                 st.kernel_ms, st.total_ms, st.rays / st.kernel_ms / 1e3);

@@ -1296,3 +1296,106 @@ void oracle_bsdf_kat(uint64_t n, const double* in, const double* consts, double*
         O[13] = d.x; O[14] = d.y; O[15] = d.z; O[16] = pdf; O[17] = 0.0;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Image::save (camera/image.cpp:37-88): exposure and gain from histograms, tone map, gamma, bytes.
+ * ------------------------------------------------------------------------------------------- */
+/* pixel-operators.cpp:7-18 */
+static v3 imgHableF(v3 x) {
+    const double A = 0.15, B = 0.50, C = 0.10, D = 0.20, E = 0.02, F = 0.30;
+    v3 num = vadds(vmul(x, vadds(vscale(x, A), C * B)), D * E);
+    v3 den = vadds(vmul(x, vadds(vscale(x, A), B)), D * F);
+    return vadds(vdiv(num, den), -(E / F));
+}
+static v3 imgFilmicHable(v3 in) { return vdiv(imgHableF(in), imgHableF(V(11.2, 11.2, 11.2))); }
+
+/* pixel-operators.cpp:20-39; glm mat3 * vec3 (type_mat3x3.inl:468-474): column 0 * x + column 1 * y + column 2 * z */
+static v3 imgMat(const double c0[3], const double c1[3], const double c2[3], v3 v) {
+    v3 r;
+    r.x = c0[0] * v.x + c1[0] * v.y + c2[0] * v.z;
+    r.y = c0[1] * v.x + c1[1] * v.y + c2[1] * v.z;
+    r.z = c0[2] * v.x + c1[2] * v.y + c2[2] * v.z;
+    return r;
+}
+static double imgClamp(double x, double lo, double hi) { double m = x < lo ? lo : x; return hi < m ? hi : m; } /* glm::clamp */
+static v3 imgFilmicACES(v3 in) {
+    static const double i0[3] = {0.59719, 0.07600, 0.02840}, i1[3] = {0.35458, 0.90834, 0.13383}, i2[3] = {0.04823, 0.01566, 0.83777};
+    static const double o0[3] = {1.60475, -0.10208, -0.00327}, o1[3] = {-0.53108, 1.10813, -0.07276}, o2[3] = {-0.07367, -0.00605, 1.07602};
+    v3 v = imgMat(i0, i1, i2, in);
+    v3 a = vadds(vmul(v, vadds(v, 0.0245786)), -0.000090537);
+    v3 b = vadds(vmul(v, vadds(vscale(v, 0.983729), 0.4329510)), 0.238081);
+    v3 c = imgMat(o0, o1, o2, vdiv(a, b));
+    c.x = imgClamp(c.x, 0.0, 1.0); c.y = imgClamp(c.y, 0.0, 1.0); c.z = imgClamp(c.z, 0.0, 1.0);
+    return c;
+}
+static v3 imgTonemap(uint32_t tonemapper, int plain, v3 in) { /* image.cpp:27-34 */
+    if (plain) return in;
+    return tonemapper == MCRT_TONEMAP_ACES ? imgFilmicACES(in) : imgFilmicHable(in);
+}
+
+/* common/histogram.cpp:6-41 */
+typedef struct { uint64_t* counts; uint64_t num_counts; double bin_size; uint64_t data_size; } ImgHistogram;
+static void imgHistogram(ImgHistogram* h, const double* data, uint64_t n, uint64_t num_bins) {
+    h->counts = NULL; h->num_counts = 0; h->bin_size = 1.0; h->data_size = n;
+    double max = -DBL_MAX;
+    for (uint64_t i = 0; i < n; i++) {
+        if (data[i] < 0.0) return;
+        if (max < data[i]) max = data[i];
+    }
+    h->counts = (uint64_t*)calloc(num_bins, sizeof(uint64_t));
+    h->num_counts = num_bins;
+    h->bin_size = max / (double)num_bins;
+    for (uint64_t i = 0; i < n; i++) {
+        double q = data[i] / h->bin_size;
+        uint64_t b = !(q < 9.2233720368547758e18) ? (uint64_t)1 << 63 : (uint64_t)q; /* what x86-64 makes of inf / NaN */
+        h->counts[b < num_bins - 1 ? b : num_bins - 1]++;
+    }
+}
+static double imgLevel(const ImgHistogram* h, double count_percentage) {
+    uint64_t num = (uint64_t)((double)h->data_size * count_percentage), count = 0;
+    double level = 0.0;
+    for (uint64_t i = 0; i < h->num_counts; i++) {
+        count += h->counts[i];
+        if (count >= num) { level = (double)(i + 1) * h->bin_size; break; }
+    }
+    return level;
+}
+
+int oracle_image_save(const double* rgb, uint32_t width, uint32_t height, uint32_t tonemapper, int plain,
+                      double exposure_compensation, double gain_compensation, uint8_t* bgr, double* factors) {
+    const uint64_t n = (uint64_t)width * height;
+    double exposure_factor = 1.0, gain_factor = 1.0;
+    if (!plain) {
+        double* brightness = (double*)malloc(n * sizeof(double));
+        if (!brightness) return -1;
+        ImgHistogram h;
+        /* getExposure, image.cpp:62-72 (glm::compAdd: T(0) + x + y + z) */
+        for (uint64_t i = 0; i < n; i++) brightness[i] = (((0.0 + rgb[3 * i]) + rgb[3 * i + 1]) + rgb[3 * i + 2]) / 3.0;
+        imgHistogram(&h, brightness, n, 65536);
+        double L = imgLevel(&h, 0.5);
+        free(h.counts);
+        exposure_factor = (L > 0.0 ? 0.5 / L : 1.0) * pow(2, exposure_compensation); /* :39, :19-22 */
+        /* getGain, image.cpp:77-87 */
+        for (uint64_t i = 0; i < n; i++) {
+            v3 t = imgTonemap(tonemapper, 0, vscale(ld3(rgb + 3 * i), exposure_factor));
+            brightness[i] = (((0.0 + t.x) + t.y) + t.z) / 3.0;
+        }
+        imgHistogram(&h, brightness, n, 65536);
+        L = imgLevel(&h, 0.99);
+        free(h.counts);
+        gain_factor = (L > 0.0 ? 0.99 / L : 1.0) * pow(2, gain_compensation); /* :40 */
+        free(brightness);
+    }
+    const double top = nextafter(256.0, 0.0); /* truncate, pixel-operators.cpp:51-55 */
+    for (uint64_t i = 0; i < n; i++) {
+        v3 t = vscale(imgTonemap(tonemapper, plain, vscale(ld3(rgb + 3 * i), exposure_factor)), gain_factor);
+        double c[3] = {t.x, t.y, t.z};
+        for (int k = 0; k < 3; k++) { /* sRGB::gammaCompress, color/srgb.hpp:55-63 */
+            double g = c[k] <= 0.0031308 ? 12.92 * c[k] : 1.055 * pow(c[k], 1.0 / 2.4) - 0.055;
+            c[k] = imgClamp(g, 0.0, 1.0) * top;
+        }
+        bgr[3 * i] = (uint8_t)c[2]; bgr[3 * i + 1] = (uint8_t)c[1]; bgr[3 * i + 2] = (uint8_t)c[0];
+    }
+    if (factors) { factors[0] = exposure_factor; factors[1] = gain_factor; }
+    return 0;
+}

@@ -64,6 +64,13 @@ int oracle_emit_photons(const mcrt_scene_desc* scene, double emissions, double c
  * reflectance(3), complex ior real(3), imag(3); out[18] as written by oracle/ref_main.cpp doKat. */
 void oracle_bsdf_kat(uint64_t n, const double* in, const double* consts, double* out);
 
+/* Image::save (camera/image.cpp:37-88) of a width x height FP64 RGB frame: exposure and gain factors from the two
+ * 65 536-bin histograms (image.cpp:62-87, common/histogram.cpp), the tone map (camera/pixel-operators.cpp), sRGB gamma
+ * (color/srgb.hpp:55-63) and truncation to B,G,R bytes — the payload of the reference's .tga. tonemapper: MCRT_TONEMAP_*.
+ * factors (may be NULL) receives {exposure_factor, gain_factor}. */
+int oracle_image_save(const double* rgb, uint32_t width, uint32_t height, uint32_t tonemapper, int plain,
+                      double exposure_compensation, double gain_compensation, uint8_t* bgr, double* factors);
+
 int oracle_hardware_threads(void);
 
 #ifdef __cplusplus

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <thread>
 #include <unordered_map>
 
@@ -63,6 +64,10 @@ struct Args {
     long bins = -1;
     long n = 100000;
     std::vector<std::pair<std::string, double>> rough;  // material specular_roughness overrides
+    // Image::save (camera/image.cpp:37-52) of the rendered frame: base name (".tga" is appended) and overrides of the
+    // camera's "image" object as key=value[,key=value...] ("" = the scene file's values)
+    std::vector<std::pair<std::string, std::string>> saves;
+    nlohmann::json image_json;  // the camera's "image" object after --width/--height (filled by loadScene)
 };
 
 [[noreturn]] void usage() {
@@ -72,6 +77,7 @@ struct Args {
         "   [--threads T] [--rows y0 y1] [--emissions E] [--caustic-factor F] [--k K] [--f-stop X] [--focus-distance D]\n"
         "   [--film-filter mitchell-netravali|catmull-rom|b-spline|hermite|gaussian|lanczos] [--film-radius R] [--film-cache N]\n"
         "   [--specular-roughness material value]... [--n N]\n"
+        "   [--save base key=value,...]... (render of the full frame: Image::save to base.tga; keys of the \"image\" object, \"-\" = none)\n"
         "   --out image.mcrt (flatten) --out-radiance file.f64 [--out-samples file.f64] (render) --out-kat dir (kat)\n"
         "   several modes in one run share ONE Camera/Scene/photon map (photon order is thread-dependent)\n");
     std::exit(2);
@@ -107,6 +113,7 @@ Args parse(int argc, char** argv) {
         else if (k == "--bvh") a.bvh = next();
         else if (k == "--bins") a.bins = std::stol(next());
         else if (k == "--n") a.n = std::stol(next());
+        else if (k == "--save") { std::string b = next(); a.saves.push_back({b, next()}); }
         else if (k == "--specular-roughness") { std::string m = next(); a.rough.push_back({m, std::stod(next())}); }
         else usage();
     }
@@ -117,7 +124,7 @@ Args parse(int argc, char** argv) {
     return a;
 }
 
-nlohmann::json loadScene(const Args& a) {
+nlohmann::json loadScene(Args& a) {
     std::ifstream f(a.scene);
     if (!f) { std::fprintf(stderr, "cannot open %s\n", a.scene.c_str()); std::exit(1); }
     nlohmann::json j;
@@ -144,6 +151,7 @@ nlohmann::json loadScene(const Args& a) {
     if (a.knn_k > 0) j["photon_map"]["k_nearest_photons"] = a.knn_k;
     for (const auto& r : a.rough) j["materials"][r.first]["specular_roughness"] = r.second;
     Scene::path = std::filesystem::absolute(std::filesystem::path(a.scene)).parent_path();
+    a.image_json = cam.at("image");
     return j;
 }
 
@@ -369,6 +377,16 @@ int doFlatten(const Args& a, Camera& camera) {
         keys.push_back("k_nearest_photons"); vals.push_back(pm->k_nearest_photons);
         keys.push_back("direct_visualization"); vals.push_back(pm->direct_visualization ? 1 : 0);
     }
+    {   // the camera's "image" object (image.cpp:17-34) for hosts that develop the frame with mcrt_tonemap; doubles as bit patterns
+        const Image& im = camera.image;
+        std::string tm = getOptional<std::string>(a.image_json, "tonemapper", "HABLE");
+        std::transform(tm.begin(), tm.end(), tm.begin(), toupper);
+        auto bits = [](double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; };
+        keys.push_back("image_tonemapper"); vals.push_back(tm == "ACES" ? MCRT_TONEMAP_ACES : MCRT_TONEMAP_HABLE);
+        keys.push_back("image_plain"); vals.push_back(im.plain ? 1 : 0);
+        keys.push_back("image_exposure_ev_bits"); vals.push_back(bits(getOptional(a.image_json, "exposure_compensation", 0.0)));
+        keys.push_back("image_gain_ev_bits"); vals.push_back(bits(getOptional(a.image_json, "gain_compensation", 0.0)));
+    }
     int rc = mcrt_image_save(a.out.c_str(), &F.desc, &cd, gp, cp, keys.data(), vals.data(), (uint32_t)keys.size());
     std::printf("flatten: %u nodes, %u surfaces, %u materials, %u lights, photons g=%llu c=%llu -> %s (rc=%d)\n",
                 F.desc.num_nodes, F.desc.num_surfaces, F.desc.num_materials, F.desc.num_lights,
@@ -444,8 +462,37 @@ int doRender(const Args& a, Camera& camera) {
         }
     writeRaw(a.out_radiance, out.data(), out.size() * sizeof(double));
     if (per_sample) writeRaw(a.out_samples, samples.data(), samples.size() * sizeof(double));
+    // Camera::saveImage's copy (camera.cpp:138-143) + Image::save, once per --save with that "image" object
+    std::string saves = "[";
+    for (const auto& sv : a.saves) {
+        if (y0 != 0 || y1 != H) { std::fprintf(stderr, "--save needs the full frame\n"); return 3; }
+        nlohmann::json ij = a.image_json;
+        std::stringstream ss(sv.second == "-" ? std::string() : sv.second);
+        for (std::string kv; std::getline(ss, kv, ',');) {
+            auto eq = kv.find('=');
+            std::string key = kv.substr(0, eq), val = kv.substr(eq + 1);
+            if (key == "tonemapper") ij[key] = val;
+            else if (key == "plain") ij[key] = (val == "true" || val == "1");
+            else ij[key] = std::stod(val);
+        }
+        Image im(ij);
+        for (long y = 0; y < H; y++)
+            for (long x = 0; x < W; x++) im((size_t)x, (size_t)y) = camera.film.scan((size_t)x, (size_t)y);
+        im.save(sv.first);
+        double ef = im.plain ? 1.0 : im.getExposure() * im.exposure_scale;
+        double gf = im.plain ? 1.0 : im.getGain(ef) * im.gain_scale;
+        std::string tm = getOptional<std::string>(ij, "tonemapper", "HABLE");
+        std::transform(tm.begin(), tm.end(), tm.begin(), toupper);
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s{\"tonemapper\":\"%s\",\"plain\":%s,\"exposure_compensation\":%.17g,\"gain_compensation\":%.17g,"
+                      "\"exposure_factor\":%.17g,\"gain_factor\":%.17g}", saves.size() > 1 ? "," : "", tm == "ACES" ? "ACES" : "HABLE",
+                      im.plain ? "true" : "false", getOptional(ij, "exposure_compensation", 0.0), getOptional(ij, "gain_compensation", 0.0), ef, gf);
+        saves += buf;
+    }
+    saves += "]";
     double paths = (double)W * (y1 - y0) * spp;
-    std::printf("{\"mode\":\"render\",\"width\":%ld,\"rows\":[%ld,%ld],\"spp\":%zu,\"threads\":%zu,"
+    std::printf("{\"mode\":\"render\",\"saves\":%s,", saves.c_str());
+    std::printf("\"width\":%ld,\"rows\":[%ld,%ld],\"spp\":%zu,\"threads\":%zu,"
                 "\"paths\":%.0f,\"seconds\":%.6f,\"paths_per_s\":%.1f,\"seed\":%u}\n",
                 W, y0, y1, spp, nthreads, paths, sec, paths / sec, Sampler::global_seed);
     return 0;

@@ -82,6 +82,7 @@ def emu():
     L.emu_octree_desc.restype = vp
     L.emu_octree_free.argtypes = [vp]
     L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_tonemap.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L
 

@@ -15,6 +15,7 @@
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_octree_shared.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_output.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_qbvh.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 
@@ -614,6 +615,53 @@ int emu_knn(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32
             out_d2[i * k + q] = q < c ? r[q].first : INFINITY;
         }
     }
+    return 0;
+}
+
+// mcrt_output.hip's kernels as loops: statKernel / histKernel / levelKernel per pass, then developKernel — the per-pixel
+// functions are the product's (mcrt_output.hpp).
+int emu_tonemap(const double* rgb, uint32_t width, uint32_t height, uint32_t tonemapper, int plain, double exposure_ev, double gain_ev,
+                uint8_t* bgr, double* factors) {
+    const uint64_t n = (uint64_t)width * height;
+    double factor[2] = {1.0, 1.0};
+    if (!plain) {
+        const double scale[2] = {std::pow(2.0, exposure_ev), std::pow(2.0, gain_ev)}, pct[2] = {0.5, 0.99};
+        for (int pass = 0; pass < 2; pass++) {
+            auto brightness = [&](uint64_t i) {
+                const d3 p{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+                if (pass == 0) return brightnessOf(p);
+                return brightnessOf(tonemapApply(tonemapper, false, d3{p.x * factor[0], p.y * factor[0], p.z * factor[0]}));
+            };
+            unsigned long long mx = 0;
+            bool neg = false;
+            for (uint64_t i = 0; i < n; i++) {
+                const double v = brightness(i);
+                if (v < 0.0) neg = true;
+                if (v > 0.0) mx = std::max(mx, dBits(v));
+            }
+            double level = 0.0;
+            const double m = bitsD(mx);
+            if (!neg && m > 0.0) {
+                std::vector<uint32_t> hist(kHistogramBins, 0);
+                const double bin_size = m / (double)kHistogramBins;
+                for (uint64_t i = 0; i < n; i++) hist[histogramBin(brightness(i), bin_size)]++;
+                const unsigned long long num = (unsigned long long)((double)n * pct[pass]);
+                unsigned long long count = 0;
+                for (uint32_t b = 0; b < kHistogramBins; b++) {
+                    count += hist[b];
+                    if (count >= num) {
+                        level = (double)(b + 1) * bin_size;
+                        break;
+                    }
+                }
+            }
+            factor[pass] = (level > 0.0 ? pct[pass] / level : 1.0) * scale[pass];
+        }
+    }
+    for (uint64_t i = 0; i < n; i++)
+        developPixel(tonemapper, plain != 0, d3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]}, factor[0], factor[1], bgr + 3 * i);
+    factors[0] = factor[0];
+    factors[1] = factor[1];
     return 0;
 }
 

@@ -7,6 +7,7 @@ For every case it writes
   <name>.mcrt            scene image (flattened Scene/BVH/Camera[/photon maps]) — input of both the
                          oracle and the HIP library
   <name>.<tag>.f64       FP64 radiance camera.film.scan(x,y) of the reference for the listed rows
+  <name>.<tag>.<save>.tga  Image::save of that frame (auto exposure/gain, tone map, sRGB bytes) per "saves" entry
   kat_<name>/            known-answer vectors of individual reference functions
 and records everything in manifest.json. Seed: MCRT_REF_SEED (default 0x12345678).
 """
@@ -28,7 +29,10 @@ CASES = [
          renders=[dict(tag="c1_256x256_s2", width=256, height=256, sqrtspp=2)], kat=2000),
     dict(name="hexagon_room", scene="hexagon_room.json", args=[],
          image=dict(width=1920, height=1080, sqrtspp=16),
-         renders=[dict(tag="c2_192x108_s4", width=192, height=108, sqrtspp=4),
+         renders=[dict(tag="c2_192x108_s4", width=192, height=108, sqrtspp=4,
+                       # Image::save with the scene's own "image" object (Hable, -0.25 EV) and with overrides of it
+                       saves=[dict(tag="scene", opts="-"), dict(tag="aces_gain", opts="tonemapper=ACES,gain_compensation=-0.5"),
+                              dict(tag="plain", opts="plain=true")]),
                   dict(tag="c2_1920x1080_s16_rows536_540", width=1920, height=1080, sqrtspp=16, rows=[536, 540])],
          kat=4000),
     dict(name="hexagon_room_ggx", scene="hexagon_room.json",
@@ -55,14 +59,15 @@ CASES = [
          renders=[dict(tag="veach_96x54_s3", width=96, height=54, sqrtspp=3)]),
     dict(name="metals", scene="metals.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
-         renders=[dict(tag="metals_96x54_s3", width=96, height=54, sqrtspp=3)]),
+         renders=[dict(tag="metals_96x54_s3", width=96, height=54, sqrtspp=3, saves=[dict(tag="scene", opts="-")])]),
     dict(name="oren_nayar_test", scene="oren_nayar_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="on_96x54_s3", width=96, height=54, sqrtspp=3)]),
     # Surface::Quadric (no BASELINE config uses it): 13 sliced quadrics, octree BVH, thin lens, sky light
     dict(name="quadric", scene="quadric.json", args=[],
          image=dict(width=96, height=72, sqrtspp=3),
-         renders=[dict(tag="quadric_96x72_s3", width=96, height=72, sqrtspp=3)], kat=3000),
+         renders=[dict(tag="quadric_96x72_s3", width=96, height=72, sqrtspp=3,
+                       saves=[dict(tag="scene", opts="-"), dict(tag="bright", opts="exposure_compensation=2.5,gain_compensation=1")])], kat=3000),
     # Film reconstruction filters (no shipped scene has a "film" key): splats instead of per-pixel sums
     dict(name="film_mitchell", scene="hexagon_room.json", args=["--film-filter", "mitchell-netravali"],
          image=dict(width=96, height=54, sqrtspp=3),
@@ -104,6 +109,10 @@ def main():
             mode = "render"
             cmd = base + [mode] + common + ["--width", str(r["width"]), "--height", str(r["height"]), "--sqrtspp", str(r["sqrtspp"]),
                                             "--out-radiance", os.path.join(HERE, rad)]
+            save_files = []
+            for sv in r.get("saves", []):
+                save_files.append("%s.%s.%s" % (case["name"], r["tag"], sv["tag"]))
+                cmd += ["--save", os.path.join(HERE, save_files[-1]), sv["opts"]]
             rows = r.get("rows")
             if rows:
                 cmd += ["--rows", str(rows[0]), str(rows[1])]
@@ -121,6 +130,8 @@ def main():
             info = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             entry["renders"].append(dict(file=rad, width=r["width"], height=r["height"], sqrtspp=r["sqrtspp"],
                                          rows=rows or [0, r["height"]], ref_seconds=info["seconds"], ref_threads=info["threads"]))
+            if save_files:
+                entry["renders"][-1]["saves"] = [dict(file=f + ".tga", **d) for f, d in zip(save_files, info["saves"])]
         if first:  # no render matched the image camera: flatten separately (path tracing only)
             assert not case.get("photon")
             cmd = base + ["flatten" + (",kat" if case.get("kat") else "")] + common + [

@@ -41,6 +41,7 @@ def lib():
         L.oracle_bsdf_kat.argtypes = [C.c_uint64, vp, vp, vp]
         L.oracle_hardware_threads.restype = C.c_int
         L.oracle_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, vp]
+        L.oracle_image_save.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
         _lib = L
     return _lib
 
@@ -109,6 +110,18 @@ def bsdf_kat(inputs, consts):
     out = np.empty((inputs.shape[0], 18))
     L.oracle_bsdf_kat(inputs.shape[0], inputs.ctypes.data, consts.ctypes.data, out.ctypes.data)
     return out
+
+
+def image_save(rgb, tonemapper, plain, exposure_compensation, gain_compensation):
+    """Image::save: ([H,W,3] FP64) -> ([H,W,3] uint8 in B,G,R order, (exposure_factor, gain_factor))."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w, _ = rgb.shape
+    bgr = np.empty((h, w, 3), dtype=np.uint8)
+    factors = np.empty(2)
+    rc = lib().oracle_image_save(rgb.ctypes.data, w, h, tonemapper, int(plain), exposure_compensation, gain_compensation,
+                                 bgr.ctypes.data, factors.ctypes.data)
+    assert rc == 0
+    return bgr, (float(factors[0]), float(factors[1]))
 
 
 def hardware_threads():

@@ -1,0 +1,187 @@
+"""Image::save (camera/image.cpp:37-88) — auto exposure / gain from histograms, tone map, sRGB gamma, B,G,R bytes, TGA.
+
+The golden .tga files were written by the reference's own Image::save (oracle/_ref/mcrt_ref --save, see
+tests/golden/make_golden.py) from the golden FP64 frames next to them. CPU tests pin the oracle restatement and the product's
+per-pixel code (host build, tests/emu) against those bytes; the GPU tests run the kernels through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+
+def _saves(manifest):
+    out = []
+    for name, case in sorted(manifest["cases"].items()):
+        for r in case["renders"]:
+            for sv in r.get("saves", []):
+                out.append((name, r, sv))
+    return out
+
+
+def _load(r, sv):
+    rgb = np.fromfile(golden_path(r["file"])).reshape(r["height"], r["width"], 3)
+    tga = np.fromfile(golden_path(sv["file"]), dtype=np.uint8)
+    return rgb, tga[:18], tga[18:].reshape(r["height"], r["width"], 3)
+
+
+def _image_desc(pkg, r, sv):
+    return pkg.ImageDesc.make(r["width"], r["height"], sv["tonemapper"], sv["plain"], sv["exposure_compensation"], sv["gain_compensation"])
+
+
+def test_golden_set_covers_both_tonemappers_and_plain(manifest):
+    saves = _saves(manifest)
+    assert {sv["tonemapper"] for _, _, sv in saves} == {"HABLE", "ACES"}
+    assert any(sv["plain"] for _, _, sv in saves) and any(sv["gain_compensation"] != 0 for _, _, sv in saves)
+    assert len(saves) >= 6
+
+
+def test_oracle_image_save_equals_reference(oracle, manifest):
+    for name, r, sv in _saves(manifest):
+        rgb, _, want = _load(r, sv)
+        bgr, factors = oracle.image_save(rgb, 1 if sv["tonemapper"] == "ACES" else 0, sv["plain"], sv["exposure_compensation"],
+                                         sv["gain_compensation"])
+        assert factors == (sv["exposure_factor"], sv["gain_factor"]), sv["file"]   # same libm, same order: same bits
+        np.testing.assert_array_equal(bgr, want, err_msg=sv["file"])
+
+
+def test_device_code_image_save_equals_reference(pkg, emu, manifest):
+    """mcrt_output.hpp (what the kernels inline) built for the host: same bytes, same factors."""
+    for name, r, sv in _saves(manifest):
+        rgb, _, want = _load(r, sv)
+        d = _image_desc(pkg, r, sv)
+        bgr = np.empty_like(want)
+        factors = np.empty(2)
+        assert emu.emu_tonemap(rgb.ctypes.data, d.width, d.height, d.tonemapper, d.plain, d.exposure_compensation, d.gain_compensation,
+                               bgr.ctypes.data, factors.ctypes.data) == 0
+        assert tuple(factors) == (sv["exposure_factor"], sv["gain_factor"]), sv["file"]
+        np.testing.assert_array_equal(bgr, want, err_msg=sv["file"])
+
+
+def test_image_save_edge_cases_oracle_vs_device_code(pkg, emu, oracle):
+    """Frames the reference's histogram treats specially: all black (bin size 0), one pixel (count threshold 0), a negative
+    brightness (no histogram at all -> factor 1), values far above the median (everything in bin 0 but one pixel)."""
+    rng = np.random.default_rng(5)
+    frames = {
+        "black": np.zeros((4, 5, 3)),
+        "one_pixel": np.array([[[0.3, 0.2, 0.9]]]),
+        "negative": np.concatenate([rng.random((3, 7, 3)), -0.01 * np.ones((1, 7, 3))]),
+        "spike": np.concatenate([1e-3 * rng.random((6, 9, 3)), 1e6 * np.ones((1, 9, 3))]),
+        "random": rng.random((33, 47, 3)) ** 4 * 20.0,
+    }
+    for tag, rgb in frames.items():
+        for tm in (0, 1):
+            rgb = np.ascontiguousarray(rgb)
+            want, wf = oracle.image_save(rgb, tm, False, 0.5, -0.25)
+            bgr = np.empty_like(want)
+            factors = np.empty(2)
+            h, w, _ = rgb.shape
+            assert emu.emu_tonemap(rgb.ctypes.data, w, h, tm, 0, 0.5, -0.25, bgr.ctypes.data, factors.ctypes.data) == 0
+            assert tuple(factors) == wf, (tag, tm)
+            np.testing.assert_array_equal(bgr, want, err_msg="%s/%d" % (tag, tm))
+
+
+def test_tga_save_writes_the_reference_file(pkg, manifest, tmp_path):
+    name, r, sv = _saves(manifest)[0]
+    _, header, payload = _load(r, sv)
+    out = str(tmp_path / "frame.tga")
+    pkg.tga_save(out, payload)
+    assert open(out, "rb").read() == open(golden_path(sv["file"]), "rb").read()
+    with pytest.raises(pkg.McrtError):
+        pkg.tga_save(str(tmp_path / "no_such_dir" / "x.tga"), payload)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: the kernels of mcrt_output.hip through the C ABI
+# ---------------------------------------------------------------------------------------------------------------------
+def _assert_bytes_close(bgr, want, what):
+    """Every step but pow() is exact; ocml's pow may differ from glibc's in the last bit, which moves a byte only when
+    the value sits within an ulp of an integer."""
+    diff = bgr.astype(np.int16) - want.astype(np.int16)
+    assert np.abs(diff).max() <= 1, what
+    assert np.count_nonzero(diff) <= max(1, diff.size // 10000), "%s: %d bytes differ" % (what, np.count_nonzero(diff))
+
+
+@pytest.mark.gpu
+def test_gpu_tonemap_equals_reference_tga(pkg, manifest):
+    ctx = pkg.Context(0)
+    for name, r, sv in _saves(manifest):
+        rgb, _, want = _load(r, sv)
+        bgr, factors = ctx.tonemap(rgb, _image_desc(pkg, r, sv))
+        # the factors involve no pow on the device (2^EV is computed on the host): exact
+        assert factors == (sv["exposure_factor"], sv["gain_factor"]), sv["file"]
+        _assert_bytes_close(bgr, want, sv["file"])
+
+
+@pytest.mark.gpu
+def test_gpu_tonemap_edge_cases(pkg, oracle):
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(5)
+    frames = {
+        "black": np.zeros((4, 5, 3)),
+        "one_pixel": np.array([[[0.3, 0.2, 0.9]]]),
+        "negative": np.concatenate([rng.random((3, 7, 3)), -0.01 * np.ones((1, 7, 3))]),
+        "spike": np.concatenate([1e-3 * rng.random((6, 9, 3)), 1e6 * np.ones((1, 9, 3))]),
+        "random": rng.random((33, 47, 3)) ** 4 * 20.0,
+    }
+    for tag, rgb in frames.items():
+        for tm in ("HABLE", "ACES"):
+            h, w, _ = rgb.shape
+            want, wf = oracle.image_save(rgb, pkg.TONEMAPPERS[tm], False, 0.5, -0.25)
+            bgr, factors = ctx.tonemap(rgb, pkg.ImageDesc.make(w, h, tm, False, 0.5, -0.25))
+            assert factors == wf, (tag, tm)
+            _assert_bytes_close(bgr, want, "%s/%s" % (tag, tm))
+
+
+@pytest.mark.gpu
+def test_gpu_render_then_tonemap_on_device_full_hd(pkg, oracle, manifest):
+    """The whole output path at the headline frame size with the frame staying in HBM: render (few samples) ->
+    mcrt_tonemap_device -> bytes; checked against the oracle's Image::save of the same frame."""
+    import torch
+    case = manifest["cases"]["hexagon_room"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = img.camera.copy()
+    cam.sqrtspp = 2
+    ctx = pkg.Context(0)
+    ctx.upload_scene(img.scene)
+    frame = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda:0")
+    ctx.render_device(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, frame.data_ptr())
+    ctx.render_finish()
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.uint8, device="cuda:0")
+    d = pkg.ImageDesc.make(cam.width, cam.height, "HABLE", False, -0.25, 0.0)   # hexagon_room.json's "image" object
+    factors = ctx.tonemap_device(frame.data_ptr(), d, out.data_ptr())
+    want, wf = oracle.image_save(frame.cpu().numpy(), 0, False, -0.25, 0.0)
+    assert factors == wf
+    _assert_bytes_close(out.cpu().numpy(), want, "1920x1080")
+    with pytest.raises(pkg.McrtError):
+        ctx.tonemap_device(0, d, out.data_ptr())
+
+
+def test_scene_image_carries_the_image_object(pkg):
+    """The flattener stores the camera's "image" object so that a host can develop the frame without the JSON."""
+    import struct
+    img = pkg.SceneImage(golden_path("quadric.mcrt"))   # quadric.json: "tonemapper": "Hable", "exposure_compensation": -1
+    assert img.param("image_tonemapper") == pkg.TONEMAP_HABLE and img.param("image_plain") == 0
+    assert struct.unpack("<d", struct.pack("<Q", img.param("image_exposure_ev_bits")))[0] == -1.0
+    assert pkg.SceneImage(golden_path("metals.mcrt")).param("image_tonemapper") == pkg.TONEMAP_ACES
+
+
+@pytest.mark.gpu
+def test_gpu_host_driver_writes_the_reference_tga(pkg, manifest, tmp_path):
+    """host/mcrt_render (C++ on the C ABI only): scene image in, FP64 frame and .tga out — against the reference's files."""
+    import subprocess
+    from conftest import load_radiance, rel_error
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "..", "host", "mcrt_render")
+    case = manifest["cases"]["quadric"]
+    r = case["renders"][0]
+    sv = [s for s in r["saves"] if s["file"].endswith(".scene.tga")][0]
+    f64, tga = str(tmp_path / "frame.f64"), str(tmp_path / "frame.tga")
+    subprocess.check_call([exe, golden_path(case["image"]), f64, "--tga", tga], timeout=600)
+    out = np.fromfile(f64).reshape(r["height"], r["width"], 3)
+    assert rel_error(out, load_radiance(r)).max() <= 1e-4
+    got = np.fromfile(tga, dtype=np.uint8)
+    want = np.fromfile(golden_path(sv["file"]), dtype=np.uint8)
+    assert got.shape == want.shape and np.array_equal(got[:18], want[:18])
+    _assert_bytes_close(got[18:], want[18:], "host driver tga")
