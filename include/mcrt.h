@@ -206,6 +206,19 @@ int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t glob
                        int integrator, double* d_out_rgb, void* stream);
 int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);
 
+/* Reconstruction-filter frames across GPUs. With a filter other than the box a sample is a splat over
+ * the pixels within the filter radius (Film::deposit, camera/film.cpp:61-79), so the samples of one shard's rows also
+ * land in its neighbours' rows: every shard accumulates into a FULL-frame copy of Film's blob — width*height records of
+ * {rgb_sum[3], weight_sum} (camera/film.hpp:22-37), 4 doubles each, overwritten by this call — the host sums the shards'
+ * buffers (one RCCL all-reduce / reduce; with shard_count 1 there is nothing to sum) and mcrt_film_resolve_device applies
+ * Splat::get (film.hpp:31-35, Film::scan film.cpp:81-84) to the sum: width*height*3 doubles, full frame. The reference
+ * adds the same splats with std::atomic<double> in thread-timing order, so sums agree to rounding (1e-12), not bits.
+ * cam->film_filter must not be MCRT_FILM_BOX; path tracer only. Returns when the shard's samples are complete
+ * (mcrt_render_finish() then collects the statistics). */
+int mcrt_render_film_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_rgbw,
+                            void* stream);
+int mcrt_film_resolve_device(mcrt_ctx* ctx, uint32_t width, uint32_t height, const double* d_rgbw, double* d_out_rgb, void* stream);
+
 /* Number of rows owned by (shard_index, shard_count, shard_rows) of `cam`, and their indices. */
 uint32_t mcrt_shard_rows(const mcrt_camera_desc* cam, uint32_t* rows /* may be NULL */);
 

@@ -197,6 +197,8 @@ def lib():
     L.mcrt_photon_map_get.restype = C.POINTER(PhotonMapDesc)
     L.mcrt_photon_map_free.argtypes = [vp]
     L.mcrt_photon_map_free.restype = None
+    L.mcrt_render_film_device.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, vp, vp]
+    L.mcrt_film_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mcrt_tonemap_device.argtypes = [vp, vp, C.POINTER(ImageDesc), vp, _dp, vp]
     L.mcrt_tonemap.argtypes = [vp, _dp, C.POINTER(ImageDesc), vp, _dp]
     L.mcrt_tga_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
@@ -426,6 +428,16 @@ class Context:
                                                  int(integrator), C.c_void_p(int(device_ptr)),
                                                  C.c_void_p(int(stream)) if stream else None),
                     "mcrt_render_device")
+
+    def render_film_device(self, cam, global_seed, integrator, rgbw_ptr, stream=None):
+        """mcrt_render_film_device: this shard's splats into a full-frame RGBW device buffer (width*height*4 doubles)."""
+        self._check(self._lib.mcrt_render_film_device(self._h, C.byref(cam), int(global_seed), int(integrator), C.c_void_p(int(rgbw_ptr)),
+                                                      C.c_void_p(int(stream)) if stream else None), "mcrt_render_film_device")
+
+    def film_resolve_device(self, width, height, rgbw_ptr, out_ptr, stream=None):
+        """mcrt_film_resolve_device: Splat::get over the (summed) RGBW buffer -> width*height*3 doubles."""
+        self._check(self._lib.mcrt_film_resolve_device(self._h, int(width), int(height), C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(out_ptr)),
+                                                       C.c_void_p(int(stream)) if stream else None), "mcrt_film_resolve_device")
 
     def render_finish(self):
         st = Stats()

@@ -231,8 +231,10 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
 // The wavefront frame loop: shade(0), then trace(i), shade(i+1) until a shade launch queues no ray. The host
 // looks at the queue length every few iterations (a launch with nothing to do costs microseconds), so the
 // call returns when the frame is complete; mcrt_render_finish() then only collects the statistics.
+// film_out != NULL (mcrt_render_film_device): the splats of this shard's samples stay in the caller's full-frame RGBW buffer
+// and the resolve is left to mcrt_film_resolve_device, after the caller has summed the shards' buffers.
 int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, double* d_out, hipStream_t stream,
-                    bool count_tests, bool photon) {
+                    bool count_tests, bool photon, double* film_out = nullptr) {
     auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
     WfFrame fr;
     memset(&fr, 0, sizeof(fr));
@@ -246,8 +248,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     fr.film.type = MCRT_FILM_BOX;
     if (cam->film_filter != MCRT_FILM_BOX) {  // Film::Film(width, height, json), film.cpp:19-58
         if (cam->film_filter > MCRT_FILM_LANCZOS) return fail(ctx, MCRT_ERR_INVALID, "camera: unknown film filter");
-        if (cam->shard_count > 1)
-            return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters splat across row groups: render them unsharded (shard_count <= 1)");
+        if (cam->shard_count > 1 && !film_out)
+            return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters splat across row groups: render them unsharded (shard_count <= 1) "
+                                                   "or with mcrt_render_film_device + mcrt_film_resolve_device");
         FilmView& f = fr.film;
         f.type = cam->film_filter;
         f.width = cam->width;
@@ -266,9 +269,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             f.inv_dx = (double)(f.cache_size - 1) / f.radius;
         }
         const size_t blob_bytes = (size_t)cam->width * cam->height * 4 * sizeof(double);
-        if (ctx->wf_film.bytes < blob_bytes) HIP_TRY(ctx, ctx->wf_film.alloc(blob_bytes));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_film.p, 0, blob_bytes, stream));
-        f.blob = ctx->wf_film.as<double>();
+        if (!film_out && ctx->wf_film.bytes < blob_bytes) HIP_TRY(ctx, ctx->wf_film.alloc(blob_bytes));
+        f.blob = film_out ? film_out : ctx->wf_film.as<double>();
+        HIP_TRY(ctx, hipMemsetAsync(f.blob, 0, blob_bytes, stream));
     }
 
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
@@ -434,7 +437,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[i], hs[i]));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev[i], 0));
         }
-    if (fr.film.type != MCRT_FILM_BOX) {
+    if (fr.film.type != MCRT_FILM_BOX && !film_out) {
         const uint64_t pixels = (uint64_t)cam->width * cam->height;
         hipLaunchKernelGGL(filmResolveKernel, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream, fr.film.blob, pixels, d_out);
         HIP_TRY(ctx, hipGetLastError());
@@ -446,7 +449,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
 }
 
 int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out,
-                 hipStream_t stream) {
+                 hipStream_t stream, double* film_out = nullptr) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_render before mcrt_upload_scene");
     if (int rc = validateCamera(ctx, cam)) return rc;
@@ -473,6 +476,8 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
     const bool filtered = cam->film_filter != MCRT_FILM_BOX;  // per-sample splats: the wavefront pipeline's shade kernel has them
+    if (film_out && (!filtered || photon))
+        return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for path-traced frames with a reconstruction filter (film_filter != box)");
     if (filtered && ctx->scene.num_nodes == 0)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for scenes with a BVH");
     const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
@@ -481,7 +486,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     const char* mn = getenv("MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
     if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
-        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false);
+        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false, film_out);
     // photon-mapped frames go through the pipeline (trace / kNN / shade launches) on request only: measured slower than
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
     // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
@@ -881,6 +886,24 @@ int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t glob
     if (!ctx) return MCRT_ERR_INVALID;
     if (!d_out_rgb) return fail(ctx, MCRT_ERR_INVALID, "d_out_rgb is NULL");
     return launchRender(ctx, cam, global_seed, integrator, d_out_rgb, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int mcrt_render_film_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_rgbw,
+                            void* stream) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!d_rgbw) return fail(ctx, MCRT_ERR_INVALID, "d_rgbw is NULL");
+    return launchRender(ctx, cam, global_seed, integrator, nullptr, stream ? (hipStream_t)stream : ctx->stream, d_rgbw);
+}
+
+int mcrt_film_resolve_device(mcrt_ctx* ctx, uint32_t width, uint32_t height, const double* d_rgbw, double* d_out_rgb, void* stream) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!d_rgbw || !d_out_rgb || width == 0 || height == 0) return fail(ctx, MCRT_ERR_INVALID, "mcrt_film_resolve_device: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t pixels = (uint64_t)width * height;
+    hipLaunchKernelGGL(filmResolveKernel, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                       d_rgbw, pixels, d_out_rgb);
+    HIP_TRY(ctx, hipGetLastError());
+    return MCRT_OK;
 }
 
 int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {

@@ -333,7 +333,8 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         if (ended && fr.film.type != MCRT_FILM_BOX) {  // Film::deposit with a reconstruction filter: a splat per sample
             Sampler at_start = st.smp;  // the sample's pixel position: the two draws of camera.cpp:79-80, sampler as it was then
             at_start.setIndex(sample);
-            const double fx = (double)px + at_start.get(kDimPixel, tab), fy = (double)ly + at_start.get(kDimPixel + 1, tab);
+            const double fx = (double)px + at_start.get(kDimPixel, tab);
+            const double fy = (double)localToGlobalRow(fr.cam, ly) + at_start.get(kDimPixel + 1, tab);  // splats land in any shard's rows
             filmDeposit(fr.film, fx, fy, st.radiance, [&](double* a, double v) { env.filmAdd(a, v); });
             if (++sample == fr.spp) have_pixel = false;
         } else if (ended) {  // Film::deposit with the box filter + next sample / pixel bookkeeping

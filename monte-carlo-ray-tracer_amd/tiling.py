@@ -5,6 +5,11 @@ read-only and with the default box film every sample lands in its own pixel (cam
 so rows are dealt round-robin in groups of `SHARD_ROWS` (interleaving balances cheap and expensive
 image regions) and the only collective of the data path is ONE gather of the packed rows to rank 0.
 Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in CPU tests.
+
+Frames with a reconstruction filter (camera/film.cpp:61-79) are the one case with a real exchange step: a sample splats
+into the pixels within the filter radius, i.e. into neighbouring shards' rows too, so every rank accumulates a full-frame
+{rgb_sum, weight_sum} buffer (mcrt_render_film_device), the buffers are summed onto rank 0 with ONE reduce
+(`reduce_film`) and rank 0 resolves the sum (mcrt_film_resolve_device).
 """
 import numpy as np
 
@@ -48,3 +53,11 @@ def gather_frame(tile, cam, rank, world, dist=None, gather_list=None, shard_rows
         rows = torch.from_numpy(rows_of(cam, r, world, shard_rows)).to(tile.device)
         frame[rows] = parts[r][: len(rows)]
     return frame
+
+
+def reduce_film(rgbw, rank, world, dist=None):
+    """rgbw: torch tensor [H, W, 4] float64 — this rank's splat sums over the FULL frame. After the call rank 0's tensor
+    holds the sum over all ranks (other ranks' tensors are unspecified). Returns rgbw on rank 0, None elsewhere."""
+    if world > 1:
+        dist.reduce(rgbw, dst=0, op=dist.ReduceOp.SUM)
+    return rgbw if rank == 0 else None

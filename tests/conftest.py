@@ -61,6 +61,10 @@ def manifest():
 
 @pytest.fixture(scope="session")
 def emu():
+    return load_emu()
+
+
+def load_emu():
     """Host build of the product's per-lane device code (tests/emu/mcrt_emu.cpp) — test harness only."""
     src = os.path.join(TESTS, "emu", "mcrt_emu.cpp")
     out = os.path.join(TESTS, "emu", "_build", "libmcrt_emu.so")
@@ -82,6 +86,9 @@ def emu():
     L.emu_octree_desc.restype = vp
     L.emu_octree_free.argtypes = [vp]
     L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_render_wf_film.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_film_resolve.argtypes = [vp, C.c_uint64, vp]
+    L.emu_film_resolve.restype = None
     L.emu_tonemap.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L

@@ -335,9 +335,26 @@ struct HostWfEnv {
 };
 }  // namespace
 
+static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                    int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                    double* out_rgb, uint64_t* counters, double* film_out);
+
 int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
                      int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
-                     double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations,searches */);
+                     double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations,searches */) {
+    return renderWf(scene, gmap, cmap, k_nearest, direct_visualization, cam, global_seed, slots, owned_rows, out_rgb, counters, nullptr);
+}
+
+// mcrt_render_film_device / mcrt_film_resolve_device: one shard's splats into a full-frame RGBW buffer; Splat::get over a buffer
+int emu_render_wf_film(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                       double* rgbw) {
+    if (cam->film_filter == MCRT_FILM_BOX) return -201;
+    return renderWf(scene, nullptr, nullptr, 0, 0, cam, global_seed, slots, owned_rows, nullptr, nullptr, rgbw);
+}
+
+void emu_film_resolve(const double* rgbw, uint64_t pixels, double* out_rgb) {
+    for (uint64_t i = 0; i < pixels; i++) filmResolve(rgbw + i * 4, out_rgb + i * 3);
+}
 
 int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
                   double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths,iterations */) {
@@ -346,9 +363,9 @@ int emu_render_wf(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
 
 // photon = (k_nearest > 0): the photon mapper's wavefront form; the kNN launch is stood in for by the per-lane search of
 // mcrt_integrator.hpp (same k photons; the wave-cooperative search itself is device-only code, checked on the GPU)
-int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
-                     int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
-                     double* out_rgb, uint64_t* counters) {
+static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                    int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
+                    double* out_rgb, uint64_t* counters, double* film_out) {
     const bool photon = k_nearest > 0;
     Emu E;
     if (int rc = setup(E, scene, 0)) return rc;
@@ -408,8 +425,9 @@ int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* g
             f.cache = cache.data();
             f.inv_dx = (double)(f.cache_size - 1) / f.radius;
         }
-        blob.assign((size_t)cam->width * cam->height * 4, 0.0);
-        f.blob = blob.data();
+        if (film_out) std::fill(film_out, film_out + (size_t)cam->width * cam->height * 4, 0.0);
+        else blob.assign((size_t)cam->width * cam->height * 4, 0.0);
+        f.blob = film_out ? film_out : blob.data();
     }
     unsigned long long work = 0;
     std::vector<uint32_t> queue, requests;
@@ -451,7 +469,7 @@ int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* g
             wfStoreHit(P, item, h);
         }
     }
-    if (fr.film.type != MCRT_FILM_BOX)
+    if (fr.film.type != MCRT_FILM_BOX && !film_out)
         for (size_t i = 0; i < (size_t)cam->width * cam->height; i++) filmResolve(&blob[i * 4], out_rgb + i * 3);
     if (counters) {
         counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;

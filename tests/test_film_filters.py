@@ -60,6 +60,106 @@ def test_gpu_film_matches_reference(pkg, manifest, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,world,shard_rows", [("film_mitchell", 2, 8), ("film_lanczos", 3, 4), ("film_gaussian_cached", 5, 1)])
+def test_film_shards_sum_to_the_frame_device_code(pkg, emu, manifest, name, world, shard_rows):
+    """mcrt_render_film_device per shard (host build of the device code): full-frame {rgb_sum, weight_sum} buffers whose SUM,
+    resolved, is the reference's frame — splats of one shard's samples land in the other shards' rows."""
+    img, cam, r = _case(pkg, manifest, name)
+    total = np.zeros((cam.height, cam.width, 4))
+    foreign = 0
+    for index in range(world):
+        shard = cam.copy()
+        shard.shard_index, shard.shard_count, shard.shard_rows = index, world, shard_rows
+        rows = pkg.shard_rows(shard)
+        rgbw = np.full((cam.height, cam.width, 4), np.nan)   # the call overwrites the whole buffer
+        assert emu.emu_render_wf_film(C.byref(img.scene), C.byref(shard), manifest["seed"], 500, len(rows), rgbw.ctypes.data) == 0
+        others = np.setdiff1d(np.arange(cam.height), rows)
+        foreign += np.count_nonzero(rgbw[others, :, 3])
+        total += rgbw
+    assert foreign > 0
+    out = np.empty((cam.height, cam.width, 3))
+    emu.emu_film_resolve(total.ctypes.data, cam.width * cam.height, out.ctypes.data)
+    assert rel_error(out, load_radiance(r)).max() < TOL
+
+
+def _film_worker(rank, world, port, out_path):
+    import importlib
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import ROOT, TESTS
+    for p in (ROOT, TESTS):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import conftest
+    import json
+    m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
+    emu = conftest.load_emu()
+    manifest = json.load(open(os.path.join(conftest.GOLDEN, "manifest.json")))
+    img, cam, r = _case(m, manifest, "film_mitchell")
+    shard = tiling.shard_camera(cam, rank, world)
+    rgbw = torch.zeros((cam.height, cam.width, 4), dtype=torch.float64)
+    # stand-in for mcrt_render_film_device: the same device code built for the host
+    assert emu.emu_render_wf_film(C.byref(img.scene), C.byref(shard), manifest["seed"], 4096, len(m.shard_rows(shard)), rgbw.data_ptr()) == 0
+    summed = tiling.reduce_film(rgbw, rank, world, dist)
+    if rank == 0:
+        out = np.empty((cam.height, cam.width, 3))
+        emu.emu_film_resolve(summed.data_ptr(), cam.width * cam.height, out.ctypes.data)   # stand-in for mcrt_film_resolve_device
+        np.save(out_path, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_film_frame_over_two_ranks_gloo(pkg, emu, manifest, tmp_path):
+    """The N > 1 host path of a reconstruction-filter frame: per-rank full-frame splat buffers, ONE reduce to rank 0, resolve."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "film.npy")
+    mp.spawn(_film_worker, args=(2, port, out_path), nprocs=2, join=True)
+    _, _, r = _case(pkg, manifest, "film_mitchell")
+    assert rel_error(np.load(out_path), load_radiance(r)).max() < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("film_mitchell", 2), ("film_lanczos", 3)])
+def test_gpu_film_shards_sum_to_the_frame(pkg, manifest, name, world):
+    """mcrt_render_film_device for every shard (one GPU standing in for `world` GPUs), torch sum in place of the RCCL
+    reduce, mcrt_film_resolve_device."""
+    import torch
+    img, cam, r = _case(pkg, manifest, name)
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    total = torch.zeros((cam.height, cam.width, 4), dtype=torch.float64, device="cuda:0")
+    paths = 0
+    for index in range(world):
+        shard = cam.copy()
+        shard.shard_index, shard.shard_count, shard.shard_rows = index, world, 8
+        rgbw = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+        ctx.render_film_device(shard, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rgbw.data_ptr())
+        paths += ctx.render_finish()["paths"]
+        total += rgbw
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda:0")
+    ctx.film_resolve_device(cam.width, cam.height, total.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert paths == cam.width * cam.height * cam.sqrtspp ** 2
+    rel = rel_error(out.cpu().numpy(), load_radiance(r)).max(axis=2)
+    assert (rel > 1e-4).sum() <= max(2, int(0.002 * rel.size)) and np.quantile(rel, 0.99) < 1e-9
+    box = cam.copy()
+    box.film_filter = 0
+    with pytest.raises(pkg.McrtError):
+        ctx.render_film_device(box, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, total.data_ptr())
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_film_unsupported_combinations(pkg, manifest):
     img, cam, _ = _case(pkg, manifest, "film_mitchell")
