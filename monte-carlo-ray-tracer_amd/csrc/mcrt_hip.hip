@@ -72,6 +72,7 @@ struct mcrt_ctx {
     uint32_t k_nearest = 50;
     int direct_visualization = 0;
 
+    DevBuf samples;  // per-sample radiance of a pass of the chunked integrator kernels (RenderParams::samples)
     DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
     size_t spill_bytes = 0;
     uint32_t knn_lanes = 0, knn_k = 0;
@@ -566,26 +567,57 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
         return MCRT_OK;
     }
-    // never launch more lanes than there is work
-    const uint64_t needed_blocks = (prm.work_items + kBlock - 1) / kBlock;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, needed_blocks);
-
     ctx->t_begin = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
+    ctx->launches = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     if (use_pm_wave) {
+        // never launch more lanes than there is work
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + kBlock - 1) / kBlock);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
         PmExtra pmx;
         pmx.global_map = waveMapView(ctx, 0);
         pmx.caustic_map = waveMapView(ctx, 1);
         hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
+        ctx->launches = 1;
     } else {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+        // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
+        // store holds (MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB), each pass = one
+        // integrator launch + the in-order resolve.
+        const char* sgb = getenv("MCRT_SAMPLE_STORE_GB");
+        const double store_gb = sgb ? atof(sgb) : 16.0;
+        const uint64_t row_bytes = (uint64_t)cam->width * prm.spp * 24ull;
+        uint64_t pass_rows = (uint64_t)(store_gb * 1e9) / row_bytes / 8 * 8;
+        pass_rows = std::max<uint64_t>(8, std::min<uint64_t>(pass_rows, ((uint64_t)prm.owned_rows + 7) / 8 * 8));
+        const uint64_t store_bytes = std::min<uint64_t>(pass_rows, prm.owned_rows) * row_bytes;
+        if (ctx->samples.bytes < store_bytes) HIP_TRY(ctx, ctx->samples.alloc(store_bytes));
+        prm.samples = ctx->samples.as<double>();
+        for (uint32_t row = 0; row < prm.owned_rows; row += (uint32_t)pass_rows) {
+            prm.row_base = row;
+            prm.row_end = (uint32_t)std::min<uint64_t>(prm.owned_rows, row + pass_rows);
+            prm.pass_pixels = (uint64_t)(prm.row_end - prm.row_base) * cam->width;
+            // units per pixel: a power of two that gives every resident lane >= 128 units, chunks of at least 4 samples
+            // (measured on the 1080p @ 256 spp frame, ms per shard for 1 / 8 shards: whole pixels 887 / 162, 2 chunks
+            // 864 / 133, 8 chunks 848 / 111, 64 chunks 844 / 107)
+            const char* ce = getenv("MCRT_CHUNKS");
+            uint64_t want = ce ? strtoull(ce, nullptr, 0) : (128ull * g.total_lanes + prm.pass_pixels - 1) / prm.pass_pixels;
+            uint32_t shift = 0;
+            while ((1ull << shift) < want && (prm.spp >> (shift + 1)) >= 4u) shift++;
+            prm.chunk_shift = shift;
+            prm.chunk = (prm.spp + (1u << shift) - 1u) >> shift;
+            const uint64_t tiles = (uint64_t)prm.tiles_x * ((prm.row_end - prm.row_base + 7) / 8);
+            prm.work_items = (tiles * 64ull) << shift;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + kBlock - 1) / kBlock);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+            hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
+                               prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
+            ctx->launches += 2;
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->pending = true;
-    ctx->launches = 1;
     return MCRT_OK;
 }
 

@@ -72,7 +72,38 @@ struct RenderParams {
     uint32_t* knn_visit_oct;
     // lane-state-machine gating (renderKernelSM)
     int sm_shade_lanes, sm_regen_lanes, sm_min_trav, sm_leaf_lanes, sm_min_inner;
+    // Sample-chunked work units (renderKernel, renderKernelSM). A unit is one pixel's samples [c*chunk, (c+1)*chunk): with
+    // whole pixels as units a frame ends with most lanes idle while the last pixels run their spp samples (1080p over 8
+    // GPUs leaves 2 pixels per resident lane: 70 % efficiency), with chunks the tail is one chunk. Every sample's radiance is
+    // stored and sampleResolveKernel adds a pixel's samples in the reference's order, so the FP64 sum is still
+    // Film::deposit's. A launch covers the local rows [row_base, row_end) — one pass of the frame, sized to the store.
+    uint32_t chunk, chunk_shift;  // samples per unit; units per pixel = 1 << chunk_shift
+    uint32_t row_base, row_end;
+    uint64_t pass_pixels;         // (row_end - row_base) * width
+    double* samples;              // [spp][pass_pixels][3]
 };
+
+struct WorkUnit {
+    uint32_t lx, ly, first, end;  // pixel (column, local row; edge tiles hold positions outside the image), samples [first, end)
+};
+__device__ inline WorkUnit decodeUnit(const RenderParams& prm, unsigned long long w) {
+    const unsigned long long item = w >> prm.chunk_shift;  // pixels in 8x8 tiles
+    const uint32_t c = (uint32_t)(w - (item << prm.chunk_shift));
+    const uint32_t tile = (uint32_t)(item >> 6), in = (uint32_t)(item & 63u);
+    WorkUnit u;
+    u.lx = (tile % prm.tiles_x) * 8u + (in & 7u);
+    u.ly = prm.row_base + (tile / prm.tiles_x) * 8u + (in >> 3);
+    u.first = c * prm.chunk;
+    u.end = u.first + prm.chunk < prm.spp ? u.first + prm.chunk : prm.spp;
+    return u;
+}
+// Film::deposit with the default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105) — the addend, kept per sample
+__device__ inline void storeSample(const RenderParams& prm, uint32_t sample, uint32_t px, uint32_t ly, d3 radiance) {
+    double* o = prm.samples + ((size_t)sample * prm.pass_pixels + ((size_t)(ly - prm.row_base) * prm.cam.width + px)) * 3;
+    o[0] = radiance.x * 1.0;
+    o[1] = radiance.y * 1.0;
+    o[2] = radiance.z * 1.0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // LDS carving
@@ -293,8 +324,7 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
     if constexpr (kProf) prof.begin();
     uint32_t paths = 0, searches = 0, octant_visits = 0;
     bool have_pixel = false, path_active = false, exhausted = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0, sample_end = 0;
     const uint32_t W = prm.cam.width;
 
     for (;;) {
@@ -306,15 +336,14 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
                 if (w >= prm.work_items) {
                     exhausted = true;
                 } else {
-                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                    if (lx < W && ly < prm.owned_rows) {
-                        px = lx;
+                    const WorkUnit u = decodeUnit(prm, w);
+                    if (u.lx < W && u.ly < prm.row_end && u.first < u.end) {
+                        px = u.lx;
+                        ly = u.ly;
                         py = localToGlobalRow(prm.cam, ly);
                         have_pixel = true;
-                        sample = 0;
-                        acc0 = acc1 = acc2 = 0.0;
+                        sample = u.first;
+                        sample_end = u.end;
                         st.smp.initiate(prm.global_seed, py * W + px);  // camera.cpp:73
                     }
                 }
@@ -339,20 +368,9 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
                 done = pathTracerBounce<kCount, kAll, kProf>(st, rh, sv, sh, stk, cnt, tab, &prof);
             if (kProf) prof.mark(kPhLoop);
             if (done) {
-                // Film::deposit, default box filter: own pixel, weight 1 (film.cpp:13-17,61-79,99-105)
-                acc0 += st.radiance.x * 1.0;
-                acc1 += st.radiance.y * 1.0;
-                acc2 += st.radiance.z * 1.0;
+                storeSample(prm, sample, px, ly, st.radiance);
                 path_active = false;
-                if (++sample == prm.spp) {
-                    // Film::Splat::get (film.cpp:107-113): max(sum / weight_sum, 0)
-                    const double wsum = (double)prm.spp;
-                    double* o = prm.out + ((size_t)ly * W + px) * 3;
-                    o[0] = gmax(acc0 / wsum, 0.0);
-                    o[1] = gmax(acc1 / wsum, 0.0);
-                    o[2] = gmax(acc2 / wsum, 0.0);
-                    have_pixel = false;
-                }
+                if (++sample == sample_end) have_pixel = false;
             }
         }
     }
@@ -517,8 +535,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
     uint32_t paths = 0;
     int state = kStRegen;
     bool have_pixel = false, alive = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0, sample_end = 0;
     const uint32_t W = prm.cam.width;
 
     // thresholds: the expensive blocks run when this many lanes wait for them, or when fewer than
@@ -532,19 +549,10 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
         if constexpr (kAll) travBegin<kAll, kCount>(sv, T, o, d, inv, shadow, sq, c);
         else travBeginQ<kAll, true, kCount>(sv, qv, T, o, d, inv, shadow, sq, c);
     };
-    // path end: Film::deposit (box filter) + next sample / pixel bookkeeping
+    // path end: Film::deposit (box filter) + next sample / work unit bookkeeping
     auto endPath = [&]() {
-        acc0 += st.radiance.x * 1.0;
-        acc1 += st.radiance.y * 1.0;
-        acc2 += st.radiance.z * 1.0;
-        if (++sample == prm.spp) {
-            const double wsum = (double)prm.spp;
-            double* o = prm.out + ((size_t)ly * W + px) * 3;
-            o[0] = gmax(acc0 / wsum, 0.0);
-            o[1] = gmax(acc1 / wsum, 0.0);
-            o[2] = gmax(acc2 / wsum, 0.0);
-            have_pixel = false;
-        }
+        storeSample(prm, sample, px, ly, st.radiance);
+        if (++sample == sample_end) have_pixel = false;
         state = kStRegen;
     };
 
@@ -578,15 +586,14 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
                     if (w >= prm.work_items) {
                         state = kStDone;
                     } else {
-                        const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                        const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                        ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                        if (lx < W && ly < prm.owned_rows) {
-                            px = lx;
+                        const WorkUnit u = decodeUnit(prm, w);
+                        if (u.lx < W && u.ly < prm.row_end && u.first < u.end) {
+                            px = u.lx;
+                            ly = u.ly;
                             py = localToGlobalRow(prm.cam, ly);
                             have_pixel = true;
-                            sample = 0;
-                            acc0 = acc1 = acc2 = 0.0;
+                            sample = u.first;
+                            sample_end = u.end;
                             st.smp.initiate(prm.global_seed, py * W + px);
                         }
                     }
@@ -879,6 +886,25 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
     uint32_t paths = 0;
     wfShadeSlot<false, kPhoton>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
     waveAccumulate(a.stats + 0, paths);
+}
+
+// The per-sample store of renderKernel / renderKernelSM -> image: rgb_sum += radiance * 1 in sample order (Film::deposit /
+// Splat::update, film.cpp:61-79,99-105), then Splat::get = max(sum / weight_sum, 0) (film.cpp:107-113). One lane per pixel;
+// consecutive lanes read consecutive 24-byte records of a sample plane.
+__global__ void __launch_bounds__(256) sampleResolveKernel(const double* samples, uint64_t pass_pixels, uint32_t spp, double* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pass_pixels) return;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const double* p = samples + i * 3;
+    for (uint32_t s = 0; s < spp; s++, p += pass_pixels * 3) {
+        acc0 += p[0];
+        acc1 += p[1];
+        acc2 += p[2];
+    }
+    const double wsum = (double)spp;
+    out[i * 3] = gmax(acc0 / wsum, 0.0);
+    out[i * 3 + 1] = gmax(acc1 / wsum, 0.0);
+    out[i * 3 + 2] = gmax(acc2 / wsum, 0.0);
 }
 
 // Film::scan over the frame (film.cpp:81-84,107-113): the splats of a reconstruction-filter frame -> image.
