@@ -242,10 +242,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     fr.cam = *cam;
     fr.global_seed = global_seed;
     fr.spp = cam->sqrtspp * cam->sqrtspp;
-    fr.owned_rows = mcrt_shard_rows(cam, nullptr);
+    const uint32_t owned_rows = mcrt_shard_rows(cam, nullptr);
     fr.tiles_x = (cam->width + 7) / 8;
-    fr.work_items = (unsigned long long)fr.tiles_x * ((fr.owned_rows + 7) / 8) * 64ull;
-    fr.out = d_out;
     fr.film.type = MCRT_FILM_BOX;
     if (cam->film_filter != MCRT_FILM_BOX) {  // Film::Film(width, height, json), film.cpp:19-58
         if (cam->film_filter > MCRT_FILM_LANCZOS) return fail(ctx, MCRT_ERR_INVALID, "camera: unknown film filter");
@@ -282,19 +280,39 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (fr.owned_rows == 0) {
+    if (owned_rows == 0) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
         ctx->pending = true;
         return MCRT_OK;
     }
 
-    // pool size: one slot per pixel up to 4 M slots (1.8 GB). More slots = fewer, longer trace launches (their tails
-    // amortised); the chip only needs ~262 k rays in flight, so the late phase of a frame, when only the expensive
-    // pixels are still running, stays full as well
-    const uint64_t pixels = (uint64_t)cam->width * fr.owned_rows;
-    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 22);
-    slots = std::min<uint64_t>(slots, (pixels + kWfBlock - 1) / kWfBlock * kWfBlock);
+    // Passes: as many rows as the per-sample store holds (box filter; splat frames keep no samples and are one pass).
+    const bool splats = fr.film.type != MCRT_FILM_BOX;
+    uint64_t pass_rows = owned_rows;
+    if (!splats) {
+        const char* sgb = getenv("MCRT_SAMPLE_STORE_GB");
+        const uint64_t row_bytes = (uint64_t)cam->width * fr.spp * 24ull;
+        pass_rows = (uint64_t)((sgb ? atof(sgb) : 16.0) * 1e9) / row_bytes / 8 * 8;
+        pass_rows = std::max<uint64_t>(8, std::min<uint64_t>(pass_rows, ((uint64_t)owned_rows + 7) / 8 * 8));
+        const uint64_t store_bytes = std::min<uint64_t>(pass_rows, owned_rows) * row_bytes;
+        if (ctx->samples.bytes < store_bytes) HIP_TRY(ctx, ctx->samples.alloc(store_bytes));
+        fr.samples = ctx->samples.as<double>();
+    }
+    // Pool size: up to 8 M slots (3.6 GB) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
+    // 1447 / 1492 / 1507 Mray/s with 4 / 8 / 16 M) — but no more
+    // than gives every slot 16 work units of at least 4 samples; units per pixel: the power of two that reaches 16 per slot.
+    const uint64_t pixels = (uint64_t)cam->width * std::min<uint64_t>(pass_rows, owned_rows);
+    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 23);
+    slots = std::min<uint64_t>(slots, (std::max<uint64_t>(pixels * fr.spp / 64, 1) + kWfBlock - 1) / kWfBlock * kWfBlock);
     slots = std::max<uint64_t>(slots, kWfBlock);
+    {
+        const char* ce = getenv("MCRT_CHUNKS");
+        const uint64_t want = ce ? strtoull(ce, nullptr, 0) : (16 * slots + pixels - 1) / pixels;
+        uint32_t shift = 0;
+        while ((1ull << shift) < want && (fr.spp >> (shift + 1)) >= 4u) shift++;
+        fr.chunk_shift = shift;
+        fr.chunk = (fr.spp + (1u << shift) - 1u) >> shift;
+    }
     if (ctx->wf_slots != slots) {
         HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
         HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * sizeof(uint32_t)));
@@ -302,6 +320,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     }
     if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(8 * sizeof(unsigned long long)));
     if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), 2 * sizeof(unsigned long long)));
+    auto runPass = [&]() -> int {  // the rows [fr.row_base, fr.row_end): shade / trace launches until nothing is queued
+    HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, 8 * sizeof(unsigned long long), stream));
     // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
@@ -417,6 +437,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
                 if (photon)  // (one half only) requests count as work too
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + 1, ctrl + 4 + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
                 HIP_TRY(ctx, hipStreamSynchronize(hs[h]));
+                static const bool wf_log = getenv("MCRT_WF_LOG") && atoi(getenv("MCRT_WF_LOG")) != 0;  // queue length over the frame
+                if (wf_log)
+                    fprintf(stderr, "[mcrt wf] iteration %llu queued %llu at %.2f ms\n", (unsigned long long)it, ctx->wf_host[h],
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
                 if (ctx->wf_host[h] == 0ull && (!photon || ctx->wf_host[1] == 0ull)) {  // nothing queued: every slot of this half is done
                     done[h] = true;
                     continue;
@@ -438,6 +462,21 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[i], hs[i]));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev[i], 0));
         }
+    return MCRT_OK;
+    };
+    for (uint32_t row = 0; row < owned_rows; row += (uint32_t)pass_rows) {
+        fr.row_base = row;
+        fr.row_end = (uint32_t)std::min<uint64_t>(owned_rows, row + pass_rows);
+        fr.pass_pixels = (unsigned long long)(fr.row_end - fr.row_base) * cam->width;
+        fr.work_items = ((unsigned long long)fr.tiles_x * ((fr.row_end - fr.row_base + 7) / 8) * 64ull) << fr.chunk_shift;
+        if (int rc = runPass()) return rc;
+        if (!splats) {  // the pass's samples, added up in sample order
+            hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((fr.pass_pixels + 255) / 256)), dim3(256), 0, stream, fr.samples,
+                               (uint64_t)fr.pass_pixels, fr.spp, d_out + (size_t)fr.row_base * cam->width * 3);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->launches++;
+        }
+    }
     if (fr.film.type != MCRT_FILM_BOX && !film_out) {
         const uint64_t pixels = (uint64_t)cam->width * cam->height;
         hipLaunchKernelGGL(filmResolveKernel, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, stream, fr.film.blob, pixels, d_out);
@@ -535,7 +574,6 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     prm.tiles_x = (cam->width + 7) / 8;
     prm.tiles_y = (prm.owned_rows + 7) / 8;
     prm.work_items = (uint64_t)prm.tiles_x * prm.tiles_y * 64ull;
-    prm.out = d_out;
     prm.work_counter = ctx->work_counter.as<unsigned long long>();
     prm.stats = ctx->stats.as<unsigned long long>();
     prm.spill = ctx->spill.as<StackEntry>();
@@ -571,16 +609,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     ctx->launches = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (use_pm_wave) {
-        // never launch more lanes than there is work
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + kBlock - 1) / kBlock);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-        PmExtra pmx;
-        pmx.global_map = waveMapView(ctx, 0);
-        pmx.caustic_map = waveMapView(ctx, 1);
-        hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
-        ctx->launches = 1;
-    } else {
+    {
         // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
         // store holds (MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB), each pass = one
         // integrator launch + the in-order resolve.
@@ -592,6 +621,11 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         const uint64_t store_bytes = std::min<uint64_t>(pass_rows, prm.owned_rows) * row_bytes;
         if (ctx->samples.bytes < store_bytes) HIP_TRY(ctx, ctx->samples.alloc(store_bytes));
         prm.samples = ctx->samples.as<double>();
+        PmExtra pmx;
+        if (use_pm_wave) {
+            pmx.global_map = waveMapView(ctx, 0);
+            pmx.caustic_map = waveMapView(ctx, 1);
+        }
         for (uint32_t row = 0; row < prm.owned_rows; row += (uint32_t)pass_rows) {
             prm.row_base = row;
             prm.row_end = (uint32_t)std::min<uint64_t>(prm.owned_rows, row + pass_rows);
@@ -607,9 +641,11 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             prm.chunk = (prm.spp + (1u << shift) - 1u) >> shift;
             const uint64_t tiles = (uint64_t)prm.tiles_x * ((prm.row_end - prm.row_base + 7) / 8);
             prm.work_items = (tiles * 64ull) << shift;
+            // never launch more lanes than there is work
             const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + kBlock - 1) / kBlock);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+            if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
+            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
             ctx->launches += 2;

@@ -58,7 +58,6 @@ struct RenderParams {
     uint32_t owned_rows;
     uint32_t tiles_x, tiles_y;
     uint64_t work_items;  // tiles_x * tiles_y * 64
-    double* out;          // [owned_rows][width][3]
     unsigned long long* work_counter;
     unsigned long long* stats;  // paths, rays, node_tests, prim_tests, knn_searches, overflow, knn_octants
     StackEntry* spill;
@@ -1062,8 +1061,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     PathState st;
     uint32_t paths = 0, searches = 0, octant_visits = 0, knn_overflow = 0;
     bool have_pixel = false, path_active = false, exhausted = false;
-    uint32_t px = 0, py = 0, ly = 0, sample = 0;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t px = 0, py = 0, ly = 0, sample = 0, sample_end = 0;
     const uint32_t W_img = prm.cam.width;
     const bool direct_visualization = prm.direct_visualization != 0;
 
@@ -1075,15 +1073,14 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
                 if (w >= prm.work_items) {
                     exhausted = true;
                 } else {
-                    const uint32_t tile = (uint32_t)(w >> 6), in = (uint32_t)(w & 63u);
-                    const uint32_t lx = (tile % prm.tiles_x) * 8u + (in & 7u);
-                    ly = (tile / prm.tiles_x) * 8u + (in >> 3);
-                    if (lx < W_img && ly < prm.owned_rows) {
-                        px = lx;
+                    const WorkUnit u = decodeUnit(prm, w);
+                    if (u.lx < W_img && u.ly < prm.row_end && u.first < u.end) {
+                        px = u.lx;
+                        ly = u.ly;
                         py = localToGlobalRow(prm.cam, ly);
                         have_pixel = true;
-                        sample = 0;
-                        acc0 = acc1 = acc2 = 0.0;
+                        sample = u.first;
+                        sample_end = u.end;
                         st.smp.initiate(prm.global_seed, py * W_img + px);
                     }
                 }
@@ -1152,18 +1149,9 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
             }
         }
         if (path_active && ended) {
-            acc0 += st.radiance.x * 1.0;
-            acc1 += st.radiance.y * 1.0;
-            acc2 += st.radiance.z * 1.0;
+            storeSample(prm, sample, px, ly, st.radiance);
             path_active = false;
-            if (++sample == prm.spp) {
-                const double wsum = (double)prm.spp;
-                double* o = prm.out + ((size_t)ly * W_img + px) * 3;
-                o[0] = gmax(acc0 / wsum, 0.0);
-                o[1] = gmax(acc1 / wsum, 0.0);
-                o[2] = gmax(acc2 / wsum, 0.0);
-                have_pixel = false;
-            }
+            if (++sample == sample_end) have_pixel = false;
         }
     }
     waveAccumulate(prm.stats + 0, paths);

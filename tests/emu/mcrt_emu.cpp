@@ -403,10 +403,16 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     fr.cam = *cam;
     fr.global_seed = global_seed;
     fr.spp = cam->sqrtspp * cam->sqrtspp;
-    fr.owned_rows = owned_rows;
     fr.tiles_x = (cam->width + 7) / 8;
-    fr.work_items = (unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull;
-    fr.out = out_rgb;
+    // one pass over the owned rows; units per pixel 1, 2 or 4 depending on the slot count, so that the tests cover whole-pixel
+    // units, chunks, and chunk counts that do not divide spp (empty last chunk)
+    fr.chunk_shift = slots % 3u;
+    fr.chunk = (fr.spp + (1u << fr.chunk_shift) - 1u) >> fr.chunk_shift;
+    fr.row_base = 0;
+    fr.row_end = owned_rows;
+    fr.pass_pixels = (unsigned long long)owned_rows * cam->width;
+    fr.work_items = ((unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull) << fr.chunk_shift;
+    std::vector<double> samples;
     fr.film.type = MCRT_FILM_BOX;
     std::vector<double> blob, cache;
     if (cam->film_filter != MCRT_FILM_BOX) {  // as launchWavefront sets the film up
@@ -428,6 +434,10 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
         if (film_out) std::fill(film_out, film_out + (size_t)cam->width * cam->height * 4, 0.0);
         else blob.assign((size_t)cam->width * cam->height * 4, 0.0);
         f.blob = film_out ? film_out : blob.data();
+    }
+    if (fr.film.type == MCRT_FILM_BOX) {
+        samples.assign((size_t)fr.spp * fr.pass_pixels * 3, 0.0);
+        fr.samples = samples.data();
     }
     unsigned long long work = 0;
     std::vector<uint32_t> queue, requests;
@@ -471,6 +481,13 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     }
     if (fr.film.type != MCRT_FILM_BOX && !film_out)
         for (size_t i = 0; i < (size_t)cam->width * cam->height; i++) filmResolve(&blob[i * 4], out_rgb + i * 3);
+    if (fr.film.type == MCRT_FILM_BOX)  // sampleResolveKernel: a pixel's samples added in sample order, Splat::get
+        for (size_t i = 0; i < (size_t)fr.pass_pixels; i++) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            for (uint32_t sidx = 0; sidx < fr.spp; sidx++)
+                for (int c = 0; c < 3; c++) acc[c] += samples[((size_t)sidx * fr.pass_pixels + i) * 3 + c];
+            for (int c = 0; c < 3; c++) out_rgb[i * 3 + c] = gmax(acc[c] / (double)fr.spp, 0.0);
+        }
     if (counters) {
         counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
         counters[5] = iterations;
