@@ -121,20 +121,21 @@ int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
 
 
 struct LaunchGeom {
-    uint32_t grid, lds_bytes, total_lanes;
+    uint32_t grid, lds_bytes, total_lanes, block = kBlock;
 };
 
 template <class K>
-int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g, int plan = 0) {
-    g.lds_bytes = plan == 1 ? planSmLds(s, kBlock).total : planLds(s, kBlock).total;
+int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g, int plan = 0) {  // plan 2: flat-scene instance
+    g.block = plan == 4 ? 1024u : plan == 3 ? 768u : kBlock;  // plan 2 / 3 / 4: the flat-scene instances (512 / 768 / 1024 lanes, no stack in LDS)
+    g.lds_bytes = plan == 1 ? planSmLds(s, kBlock).total : planLds(s, g.block, plan < 2).total;
     if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)g.lds_bytes));
     int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kBlock, g.lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)g.block, g.lds_bytes));
     if (per_cu < 1) per_cu = 1;
     g.grid = (uint32_t)(per_cu * ctx->num_cus);
-    g.total_lanes = g.grid * kBlock;
+    g.total_lanes = g.grid * g.block;
     return MCRT_OK;
 }
 
@@ -509,6 +510,16 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
     static const bool profile_phases = getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0;
     if (profile_phases && !photon) kernel = all ? renderKernel<PT, false, true, true> : renderKernel<PT, false, false, true>;
+    const bool flat_only = !photon && ctx->scene.flat && all && !count_tests && !profile_phases && !(getenv("MCRT_FLAT_GENERIC") && atoi(getenv("MCRT_FLAT_GENERIC")));
+    // Flat-mode scenes get their own instance of the kernel: without the BVH walk in the code it needs no traversal stack
+    // (64 KB of LDS at 512 lanes), so a CU can hold more waves; measured on the C2 frame (ms): generic instance 862,
+    // flat instance with 512 lanes (2 waves/SIMD, 256 VGPRs, no scratch) 795, 768 lanes (3, 168 VGPRs, 336 B/lane of
+    // scratch) 716, 1024 lanes (4, 128 VGPRs, 524 B/lane) 690 — the FP64 dependency chains of the primitive tests and the
+    // BSDF code want the extra waves more than they mind the spills.
+    const int flat_block = getenv("MCRT_FLAT_BLOCK") ? atoi(getenv("MCRT_FLAT_BLOCK")) : 1024;
+    if (flat_only)
+        kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
+                                    : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
     // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
     // wave-synchronous one for A/B runs)
     const char* kenv = getenv("MCRT_KERNEL");
@@ -560,7 +571,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         if (per_cu < 1) per_cu = 1;
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * kBlock;
-    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : 0)) {
+    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : (flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0))) {
         return rc;
     }
     if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
@@ -642,10 +653,10 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             const uint64_t tiles = (uint64_t)prm.tiles_x * ((prm.row_end - prm.row_base + 7) / 8);
             prm.work_items = (tiles * 64ull) << shift;
             // never launch more lanes than there is work
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + kBlock - 1) / kBlock);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + g.block - 1) / g.block);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
             if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
-            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, ctx->scene, prm);
+            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, ctx->scene, prm);
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
             ctx->launches += 2;

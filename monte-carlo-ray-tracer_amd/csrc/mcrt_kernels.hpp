@@ -117,11 +117,11 @@ struct LdsPlan {
 
 __host__ __device__ inline uint32_t alignUp(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block) {
+__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block, bool with_stack = true) {
     LdsPlan p;
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(StackEntry);
+    p.stack = off; off += with_stack ? kLdsStackDepth * block * (uint32_t)sizeof(StackEntry) : 0u;
     p.iors = off; off += kMaxIors * block * 8u;
     off = alignUp(off, 16);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
@@ -162,10 +162,10 @@ __device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t coun
 // Builds the per-lane views; stages the scene into LDS (ends with __syncthreads()).
 // kAll: whole scene LDS-resident (the views carry address-space-3 pointers, so every scene access in
 // the hot loops is a ds_read); otherwise only the top of the BVH is staged.
-template <bool kAll>
+template <bool kAll, bool kFlat = false>
 __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
                                   SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes) {
-    const LdsPlan p = planLds(s, blockDim.x);
+    const LdsPlan p = planLds(s, blockDim.x, !kFlat);
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
     rh.stride = blockDim.x;
     rh.size = 0;
@@ -292,15 +292,17 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // the integrator kernel
 // ------------------------------------------------------------------------------------------------
-template <int kIntegrator, bool kCount, bool kAll, bool kProf = false>
-__global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
+// kFlat != 0: instance for flat-mode scenes only (path tracer): no BVH walk in the code, no traversal stack in LDS;
+// kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs).
+template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
+__global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
     extern __shared__ __align__(16) unsigned char lds[];
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;
     LaneStack stk;
     RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    setupViews<kAll, kFlat != 0>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
 
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
     KnnScratch ks;
@@ -364,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const DeviceScene scene, 
             if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
                 done = photonMapperBounce<kCount, kAll>(st, rh, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
             else
-                done = pathTracerBounce<kCount, kAll, kProf>(st, rh, sv, sh, stk, cnt, tab, &prof);
+                done = pathTracerBounce<kCount, kAll, kProf, kFlat != 0>(st, rh, sv, sh, stk, cnt, tab, &prof);
             if (kProf) prof.mark(kPhLoop);
             if (done) {
                 storeSample(prm, sample, px, ly, st.radiance);

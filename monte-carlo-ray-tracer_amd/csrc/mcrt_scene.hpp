@@ -373,7 +373,8 @@ struct ShadowQuery {
     double t_far;    // d (1 + 1e-9): nothing farther can matter
 };
 
-template <bool kAll, bool kCount, bool kShadow>
+// kFlat: the caller knows the scene is in flat mode (a kernel instance for such scenes only): the BVH walk is not compiled in.
+template <bool kAll, bool kCount, bool kShadow, bool kFlat = false>
 MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const LaneStack& stk, TraceCounters& cnt,
                            const ShadowQuery* sq = nullptr) {
     Hit best;
@@ -384,8 +385,8 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
     best.interpolate = false;
     cnt.rays++;
 
-    if (sv.num_nodes == 0) {  // every primitive, as scene.cpp:161-173 does without a BVH
-        if (kAll && sv.flat_prim) {
+    if (kFlat || sv.num_nodes == 0) {  // every primitive, as scene.cpp:161-173 does without a BVH
+        if (kFlat || (kAll && sv.flat_prim)) {
             // wave-uniform loops over the kind-sorted copy: no per-lane control flow at all
             const uint32_t nt = sv.flat_tris, ns = sv.num_surfaces;
 #pragma unroll 2
