@@ -544,11 +544,21 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
     if (photon && ctx->scene.num_nodes > 0 && ctx->k_nearest <= 128 && want_wf)
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true);
+    // workgroup size of the state-machine kernel for trees that stay in HBM (MCRT_SM_BLOCK: 512 / 768 / 1024 lanes) and the
+    // stack entries per lane it keeps in LDS (MCRT_SM_STACK; the rest of a lane's stack is in the HBM spill area)
+    int sm_block = (int)kBlock, sm_depth = kLdsStackDepth;
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
                                                {renderKernelSM<true, false>, renderKernelSM<true, true>}};
         kernel = sm_table[count_tests ? 1 : 0][all ? 1 : 0];
         if (profile_phases) kernel = all ? renderKernelSM<false, true, true> : renderKernelSM<false, false, true>;
+        const int want = getenv("MCRT_SM_BLOCK") ? atoi(getenv("MCRT_SM_BLOCK")) : (int)kBlock;
+        if (!all && !count_tests && !profile_phases && (want == 768 || want == 1024)) {
+            sm_block = want;
+            sm_depth = want == 768 ? 8 : 6;
+            kernel = want == 768 ? renderKernelSM<false, false, false, 768> : renderKernelSM<false, false, false, 1024>;
+        }
+        if (getenv("MCRT_SM_STACK")) sm_depth = std::min(std::max(atoi(getenv("MCRT_SM_STACK")), 2), (int)kLdsStackDepth);
     }
 
     // photon mapping: wave-cooperative estimates unless k is too large for the per-wave buffer
@@ -571,10 +581,26 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         if (per_cu < 1) per_cu = 1;
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * kBlock;
-    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, use_sm ? 1 : (flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0))) {
+    } else if (use_sm) {
+        // the staged top of the tree shrinks to what the larger workgroup's stacks and refraction histories leave
+        g.block = (uint32_t)sm_block;
+        const uint32_t fixed = planSmLds(DeviceScene{}, g.block, (uint32_t)sm_depth).total;
+        if (!launch_scene.stage_all && fixed < ctx->max_lds)
+            launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, (ctx->max_lds - fixed) / 64u);
+        g.lds_bytes = planSmLds(launch_scene, g.block, (uint32_t)sm_depth).total;
+        if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)g.block, g.lds_bytes));
+        if (per_cu < 1) per_cu = 1;
+        g.grid = (uint32_t)(per_cu * ctx->num_cus);
+        g.total_lanes = g.grid * g.block;
+    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
         return rc;
     }
     if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
+    if (use_sm && sm_depth < kLdsStackDepth)
+        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (kMaxStackDepth - sm_depth) * sizeof(StackEntry))) return rc;
 
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
@@ -596,6 +622,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         prm.sm_min_trav = envi("MCRT_SM_MINTRAV", 20);
         prm.sm_leaf_lanes = envi("MCRT_SM_LEAF", 32);
         prm.sm_min_inner = envi("MCRT_SM_MININNER", 8);
+        prm.sm_lds_depth = sm_depth;
     }
     if (photon) {
         prm.global_map = ctx->maps[0];
@@ -656,7 +683,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + g.block - 1) / g.block);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
             if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
-            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, ctx->scene, prm);
+            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, use_sm ? launch_scene : ctx->scene, prm);
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
             ctx->launches += 2;

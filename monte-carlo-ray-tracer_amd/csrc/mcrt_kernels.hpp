@@ -70,7 +70,7 @@ struct RenderParams {
     double* knn_visit_d2;
     uint32_t* knn_visit_oct;
     // lane-state-machine gating (renderKernelSM)
-    int sm_shade_lanes, sm_regen_lanes, sm_min_trav, sm_leaf_lanes, sm_min_inner;
+    int sm_shade_lanes, sm_regen_lanes, sm_min_trav, sm_leaf_lanes, sm_min_inner, sm_lds_depth;
     // Sample-chunked work units (renderKernel, renderKernelSM). A unit is one pixel's samples [c*chunk, (c+1)*chunk): with
     // whole pixels as units a frame ends with most lanes idle while the last pixels run their spp samples (1080p over 8
     // GPUs leaves 2 pixels per resident lane: 70 % efficiency), with chunks the tail is one chunk. Every sample's radiance is
@@ -402,11 +402,11 @@ struct SmLdsPlan {
         light_surface, light_cdf, total;
 };
 
-__host__ __device__ inline SmLdsPlan planSmLds(const DeviceScene& s, uint32_t block) {
+__host__ __device__ inline SmLdsPlan planSmLds(const DeviceScene& s, uint32_t block, uint32_t stack_depth = kLdsStackDepth) {
     SmLdsPlan p;
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += kLdsStackDepth * block * (uint32_t)sizeof(SmStackEntry);
+    p.stack = off; off += stack_depth * block * (uint32_t)sizeof(SmStackEntry);
     p.iors = off; off += kMaxIors * block * 8u;
     off = alignUp(off, 64);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
@@ -433,10 +433,12 @@ __host__ __device__ inline SmLdsPlan planSmLds(const DeviceScene& s, uint32_t bl
 
 enum : int { kStRegen = 0, kStTrav = 1, kStShade = 2, kStDone = 3 };
 
-template <bool kCount, bool kAll, bool kProf = false>
-__global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene, const RenderParams prm) {
+// kLanes: workgroup size (512 / 768 / 1024 = 2 / 3 / 4 waves per SIMD at 256 / 168 / 128 VGPRs); the larger workgroups keep
+// fewer stack entries per lane in LDS (prm.sm_lds_depth).
+template <bool kCount, bool kAll, bool kProf = false, int kLanes = (int)kBlock>
+__global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene, const RenderParams prm) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const SmLdsPlan p = planSmLds(scene, blockDim.x);
+    const SmLdsPlan p = planSmLds(scene, blockDim.x, (uint32_t)prm.sm_lds_depth);
 
     // ---- staging
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
@@ -447,6 +449,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelSM(const DeviceScene scene
     stk.lds_stride = blockDim.x;
     stk.spill = reinterpret_cast<SmStackEntry*>(prm.spill) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = prm.total_lanes;
+    stk.lds_depth = prm.sm_lds_depth;
     RefractionHistory rh;
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
     rh.stride = blockDim.x;
