@@ -87,6 +87,43 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
         np.testing.assert_array_equal(out, base)
 
 
+@pytest.mark.parametrize("name,kernel,integrator", [("hexagon_room", None, "pt"), ("coffee_maker_qsah", None, "pt"), ("metals", "wf", "pt"),
+                                                    ("hexagon_room_pm", None, "pm"), ("veach_mis", "legacy", "pt")])
+def test_passes_and_chunks_do_not_change_the_frame(pkg, ctx, manifest, kernel_env, name, kernel, integrator):
+    """A per-sample store of 100 KB forces the frame through in passes of 8 rows (row offsets of the store, the work
+    counter and the resolve), and MCRT_CHUNKS 1 / 4 changes the work units from whole pixels to quarter pixels: the bits of
+    the frame must not depend on either (flat instance, state machine, wavefront pipeline, photon kernel, legacy kernel)."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    ctx.upload_image(img)
+    if integrator == "pm":
+        ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons") or 50, bool(img.param("direct_visualization")))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    mode = pkg.INTEGRATOR_PHOTON_MAPPER if integrator == "pm" else pkg.INTEGRATOR_PATH_TRACER
+    if kernel:
+        kernel_env(kernel)
+    base, st0 = ctx.sample_image(cam, manifest["seed"], mode)
+    _check(base, load_radiance(r), name)
+    for store, chunks in (("0.0001", None), (None, "1"), ("0.0001", "4")):
+        try:
+            if store:
+                os.environ["MCRT_SAMPLE_STORE_GB"] = store
+            if chunks:
+                os.environ["MCRT_CHUNKS"] = chunks
+            out, st = ctx.sample_image(cam, manifest["seed"], mode)
+        finally:
+            os.environ.pop("MCRT_SAMPLE_STORE_GB", None)
+            os.environ.pop("MCRT_CHUNKS", None)
+        assert st["paths"] == st0["paths"]
+        if store:
+            assert st["kernel_launches"] > st0["kernel_launches"]   # several passes
+        if integrator == "pm":   # the k photons of an estimate are summed in heap order, which depends on the search's timing
+            assert rel_error(out, base).max() < 1e-12
+        else:
+            np.testing.assert_array_equal(out, base)
+
+
 def test_photon_mapper_matches_reference(pkg, ctx, manifest):
     case = manifest["cases"]["hexagon_room_pm"]
     img = pkg.SceneImage(golden_path(case["image"]))
