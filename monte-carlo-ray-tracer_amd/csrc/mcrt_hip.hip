@@ -17,6 +17,7 @@
 #include "mcrt_waveknn.hpp"
 #include "mcrt_layout.hpp"
 #include "mcrt_internal.hpp"
+#include "mcrt_plan.hpp"
 
 using namespace mcrt;
 
@@ -291,12 +292,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool splats = fr.film.type != MCRT_FILM_BOX;
     uint64_t pass_rows = owned_rows;
     if (!splats) {
-        const char* sgb = getenv("MCRT_SAMPLE_STORE_GB");
-        const uint64_t row_bytes = (uint64_t)cam->width * fr.spp * 24ull;
-        pass_rows = (uint64_t)((sgb ? atof(sgb) : 16.0) * 1e9) / row_bytes / 8 * 8;
-        pass_rows = std::max<uint64_t>(8, std::min<uint64_t>(pass_rows, ((uint64_t)owned_rows + 7) / 8 * 8));
-        const uint64_t store_bytes = std::min<uint64_t>(pass_rows, owned_rows) * row_bytes;
-        if (ctx->samples.bytes < store_bytes) HIP_TRY(ctx, ctx->samples.alloc(store_bytes));
+        const PassPlan pp = planPasses(cam->width, owned_rows, fr.spp, sampleStoreGb());
+        pass_rows = pp.pass_rows;
+        if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         fr.samples = ctx->samples.as<double>();
     }
     // Pool size: up to 8 M slots (3.6 GB) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
@@ -307,12 +305,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     slots = std::min<uint64_t>(slots, (std::max<uint64_t>(pixels * fr.spp / 64, 1) + kWfBlock - 1) / kWfBlock * kWfBlock);
     slots = std::max<uint64_t>(slots, kWfBlock);
     {
-        const char* ce = getenv("MCRT_CHUNKS");
-        const uint64_t want = ce ? strtoull(ce, nullptr, 0) : (16 * slots + pixels - 1) / pixels;
-        uint32_t shift = 0;
-        while ((1ull << shift) < want && (fr.spp >> (shift + 1)) >= 4u) shift++;
-        fr.chunk_shift = shift;
-        fr.chunk = (fr.spp + (1u << shift) - 1u) >> shift;
+        const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels));
+        fr.chunk_shift = cp.shift;
+        fr.chunk = cp.chunk;
     }
     if (ctx->wf_slots != slots) {
         HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
@@ -651,13 +646,9 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
         // store holds (MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB), each pass = one
         // integrator launch + the in-order resolve.
-        const char* sgb = getenv("MCRT_SAMPLE_STORE_GB");
-        const double store_gb = sgb ? atof(sgb) : 16.0;
-        const uint64_t row_bytes = (uint64_t)cam->width * prm.spp * 24ull;
-        uint64_t pass_rows = (uint64_t)(store_gb * 1e9) / row_bytes / 8 * 8;
-        pass_rows = std::max<uint64_t>(8, std::min<uint64_t>(pass_rows, ((uint64_t)prm.owned_rows + 7) / 8 * 8));
-        const uint64_t store_bytes = std::min<uint64_t>(pass_rows, prm.owned_rows) * row_bytes;
-        if (ctx->samples.bytes < store_bytes) HIP_TRY(ctx, ctx->samples.alloc(store_bytes));
+        const PassPlan pp = planPasses(cam->width, prm.owned_rows, prm.spp, sampleStoreGb());
+        const uint64_t pass_rows = pp.pass_rows;
+        if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         prm.samples = ctx->samples.as<double>();
         PmExtra pmx;
         if (use_pm_wave) {
@@ -671,12 +662,10 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             // units per pixel: a power of two that gives every resident lane >= 128 units, chunks of at least 4 samples
             // (measured on the 1080p @ 256 spp frame, ms per shard for 1 / 8 shards: whole pixels 887 / 162, 2 chunks
             // 864 / 133, 8 chunks 848 / 111, 64 chunks 844 / 107)
-            const char* ce = getenv("MCRT_CHUNKS");
-            uint64_t want = ce ? strtoull(ce, nullptr, 0) : (128ull * g.total_lanes + prm.pass_pixels - 1) / prm.pass_pixels;
-            uint32_t shift = 0;
-            while ((1ull << shift) < want && (prm.spp >> (shift + 1)) >= 4u) shift++;
-            prm.chunk_shift = shift;
-            prm.chunk = (prm.spp + (1u << shift) - 1u) >> shift;
+            const ChunkPlan cp = planChunks(prm.spp, unitsWanted(g.total_lanes, 128, prm.pass_pixels));
+            const uint32_t shift = cp.shift;
+            prm.chunk_shift = cp.shift;
+            prm.chunk = cp.chunk;
             const uint64_t tiles = (uint64_t)prm.tiles_x * ((prm.row_end - prm.row_base + 7) / 8);
             prm.work_items = (tiles * 64ull) << shift;
             // never launch more lanes than there is work

@@ -1,0 +1,56 @@
+// Work-unit planning shared by the integrator launches (mcrt_hip.hip): how a frame is cut into passes of rows that fit
+// the per-sample store, and a pixel's samples into chunks (the work units of RenderParams / WfFrame). Plain host C++,
+// also built into tests/emu so that the rules are checked without a GPU.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+namespace mcrt {
+
+constexpr uint32_t kSampleBytes = 24;  // one sample's radiance in the store: 3 doubles
+constexpr uint32_t kMinChunk = 4;      // a work unit keeps at least this many samples (unless the pixel has fewer)
+
+struct PassPlan {
+    uint32_t pass_rows;    // local rows per pass: a multiple of 8 (pixels are handed out in 8x8 tiles), at least 8
+    uint64_t store_bytes;  // size of the store one pass needs
+};
+
+// As many rows per pass as a store of store_gb * 1e9 bytes holds.
+inline PassPlan planPasses(uint32_t width, uint32_t owned_rows, uint32_t spp, double store_gb) {
+    const uint64_t row_bytes = (uint64_t)width * spp * kSampleBytes;
+    uint64_t rows = (uint64_t)(store_gb * 1e9) / row_bytes / 8 * 8;
+    rows = std::max<uint64_t>(8, std::min<uint64_t>(rows, ((uint64_t)owned_rows + 7) / 8 * 8));
+    PassPlan p;
+    p.pass_rows = (uint32_t)rows;
+    p.store_bytes = std::min<uint64_t>(rows, owned_rows) * row_bytes;
+    return p;
+}
+
+struct ChunkPlan {
+    uint32_t shift;  // units per pixel = 1 << shift
+    uint32_t chunk;  // samples per unit = ceil(spp / units per pixel); the last unit(s) of a pixel may be short or empty
+};
+
+// The smallest power-of-two number of units per pixel that reaches `want`, as long as chunks keep kMinChunk samples.
+inline ChunkPlan planChunks(uint32_t spp, uint64_t want) {
+    ChunkPlan c;
+    c.shift = 0;
+    while ((1ull << c.shift) < want && (spp >> (c.shift + 1)) >= kMinChunk) c.shift++;
+    c.chunk = (spp + (1u << c.shift) - 1u) >> c.shift;
+    return c;
+}
+
+// Units per pixel that give each of `consumers` (resident lanes, pool slots) `per_consumer` units; MCRT_CHUNKS overrides.
+inline uint64_t unitsWanted(uint64_t consumers, uint64_t per_consumer, uint64_t pass_pixels) {
+    if (const char* e = getenv("MCRT_CHUNKS")) return strtoull(e, nullptr, 0);
+    return (per_consumer * consumers + pass_pixels - 1) / pass_pixels;
+}
+
+inline double sampleStoreGb() {  // MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB
+    const char* e = getenv("MCRT_SAMPLE_STORE_GB");
+    return e ? atof(e) : 16.0;
+}
+
+}  // namespace mcrt

@@ -89,6 +89,8 @@ def load_emu():
     L.emu_render_wf_film.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.emu_film_resolve.argtypes = [vp, C.c_uint64, vp]
     L.emu_film_resolve.restype = None
+    L.emu_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint64, vp]
+    L.emu_plan.restype = None
     L.emu_tonemap.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L

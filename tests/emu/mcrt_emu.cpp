@@ -16,6 +16,7 @@
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_octree_shared.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_output.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_plan.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_qbvh.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 
@@ -698,6 +699,16 @@ int emu_tonemap(const double* rgb, uint32_t width, uint32_t height, uint32_t ton
     factors[0] = factor[0];
     factors[1] = factor[1];
     return 0;
+}
+
+// mcrt_plan.hpp: out = {pass_rows, store_bytes, chunk_shift, chunk}
+void emu_plan(uint32_t width, uint32_t owned_rows, uint32_t spp, double store_gb, uint64_t want_units, uint64_t* out) {
+    const PassPlan pp = planPasses(width, owned_rows, spp, store_gb);
+    const ChunkPlan cp = planChunks(spp, want_units);
+    out[0] = pp.pass_rows;
+    out[1] = pp.store_bytes;
+    out[2] = cp.shift;
+    out[3] = cp.chunk;
 }
 
 }  // extern "C"
