@@ -219,6 +219,16 @@ int mcrt_render_film_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t
                             void* stream);
 int mcrt_film_resolve_device(mcrt_ctx* ctx, uint32_t width, uint32_t height, const double* d_rgbw, double* d_out_rgb, void* stream);
 
+/* One host process driving several GPUs — the shape of the reference's host, whose Camera::sampleImage fans out to worker
+ * threads (camera/camera.cpp:120-136). ctxs[i] is a context on device i's GPU with the scene (and photon maps) already
+ * uploaded; the frame's rows are dealt over the contexts (cam->shard_rows per group, 0 = 8; cam->shard_index/count are
+ * ignored), every context is driven by its own host thread and copies its rows into out_rgb (full frame, host memory). No
+ * collective: shards are independent and Image::save wants the frame on the host anyway. Reconstruction-filter frames are
+ * summed and resolved on the host. stats: counters summed over the contexts, times = the slowest context's. The result does
+ * not depend on the number of contexts (box filter: bit for bit). */
+int mcrt_render_multi(mcrt_ctx* const* ctxs, uint32_t count, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator,
+                      double* out_rgb, mcrt_stats* stats /* may be NULL */);
+
 /* Number of rows owned by (shard_index, shard_count, shard_rows) of `cam`, and their indices. */
 uint32_t mcrt_shard_rows(const mcrt_camera_desc* cam, uint32_t* rows /* may be NULL */);
 

@@ -137,6 +137,17 @@ class PhotonEmission(C.Structure):
     ]
 
 
+def render_multi(contexts, cam, global_seed, integrator=INTEGRATOR_PATH_TRACER):
+    """mcrt_render_multi: one frame over several contexts (one per GPU, scene already uploaded), one host thread each ->
+    (image[H,W,3] float64, stats dict)."""
+    out = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
+    st = Stats()
+    handles = (C.c_void_p * len(contexts))(*[c._h.value for c in contexts])
+    rc = lib().mcrt_render_multi(handles, len(contexts), C.byref(cam), int(global_seed), int(integrator), _ptr(out, C.c_double), C.byref(st))
+    contexts[0]._check(rc, "mcrt_render_multi")
+    return out, st.as_dict()
+
+
 def tga_save(path, bgr):
     """mcrt_tga_save: the reference's .tga (HeaderTGA + B,G,R bytes) for a [H,W,3] uint8 array."""
     bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
@@ -197,6 +208,7 @@ def lib():
     L.mcrt_photon_map_get.restype = C.POINTER(PhotonMapDesc)
     L.mcrt_photon_map_free.argtypes = [vp]
     L.mcrt_photon_map_free.restype = None
+    L.mcrt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(CameraDesc), C.c_uint32, C.c_int, _dp, C.POINTER(Stats)]
     L.mcrt_render_film_device.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, vp, vp]
     L.mcrt_film_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mcrt_tonemap_device.argtypes = [vp, vp, C.POINTER(ImageDesc), vp, _dp, vp]

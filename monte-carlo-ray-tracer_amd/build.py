@@ -40,7 +40,7 @@ def build_lib(force=False, verbose=True):
     deps = sources()
     if not force and _newer(LIB, deps):
         return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "mcrt_hip.hip"), os.path.join(CSRC, "mcrt_octree_gpu.hip"), os.path.join(CSRC, "mcrt_output.hip"),
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "mcrt_hip.hip"), os.path.join(CSRC, "mcrt_octree_gpu.hip"), os.path.join(CSRC, "mcrt_output.hip"), os.path.join(CSRC, "mcrt_multi.hip"),
                                          os.path.join(CSRC, "mcrt_image.cpp"), os.path.join(CSRC, "mcrt_octree.cpp"), os.path.join(CSRC, "mcrt_bvh.cpp")]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

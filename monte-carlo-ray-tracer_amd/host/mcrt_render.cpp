@@ -2,12 +2,13 @@
 // Camera::sampleImage() runs, but the flattened scene comes from a scene image
 // (*.mcrt) written by the flattener inside the reference host.
 //
-//   mcrt_render scene.mcrt out.f64 [--width W --height H --sqrtspp S] [--seed N] [--photon] [--device D]
+//   mcrt_render scene.mcrt out.f64 [--width W --height H --sqrtspp S] [--seed N] [--photon] [--device D | --devices D0,D1,...]
 //               [--tga out.tga [--tonemapper hable|aces] [--exposure EV] [--gain EV] [--plain]]
 //
 // Writes the frame as raw FP64 RGB, row-major (what Image::operator() holds, camera/image.cpp:53-56),
 // and prints the statistics. --tga also develops it the way Image::save does (auto exposure / gain, tone map, sRGB bytes:
 // mcrt_tonemap) and writes the reference's .tga; the "image" options default to the ones stored in the scene image.
+// --devices renders the frame on several GPUs from this one process (mcrt_render_multi: one host thread per GPU).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,7 @@ int main(int argc, char** argv) {
     image.exposure_compensation = from_bits(mcrt_image_param(img, "image_exposure_ev_bits"));
     image.gain_compensation = from_bits(mcrt_image_param(img, "image_gain_ev_bits"));
     std::string tga;
+    std::vector<int> devices;
     for (int i = 3; i < argc; i++) {
         std::string k = argv[i];
         auto val = [&]() { return i + 1 < argc ? std::strtoul(argv[++i], nullptr, 0) : 0ul; };
@@ -44,6 +46,12 @@ int main(int argc, char** argv) {
         else if (k == "--sqrtspp") cam.sqrtspp = (uint32_t)val();
         else if (k == "--seed") seed = (uint32_t)val();
         else if (k == "--device") device = (int)val();
+        else if (k == "--devices" && i + 1 < argc) {
+            for (const char* p = argv[++i]; *p;) {
+                devices.push_back((int)std::strtol(p, const_cast<char**>(&p), 10));
+                if (*p == ',') p++;
+            }
+        }
         else if (k == "--photon") photon = 1;
         else if (k == "--tga" && i + 1 < argc) tga = argv[++i];
         else if (k == "--tonemapper" && i + 1 < argc) image.tonemapper = (argv[++i][0] | 0x20) == 'a' ? MCRT_TONEMAP_ACES : MCRT_TONEMAP_HABLE;
@@ -53,18 +61,27 @@ int main(int argc, char** argv) {
     }
     cam.shard_index = 0;
     cam.shard_count = 1;
-    mcrt_ctx* ctx = nullptr;
-    if (mcrt_create(&ctx, device) != MCRT_OK) {
-        std::fprintf(stderr, "mcrt_create: %s\n", mcrt_last_error(nullptr));
-        return 1;
+    if (devices.empty()) devices.push_back(device);
+    std::vector<mcrt_ctx*> ctxs(devices.size(), nullptr);
+    int rc = MCRT_OK;
+    for (size_t d = 0; d < devices.size() && rc == MCRT_OK; d++) {
+        if (mcrt_create(&ctxs[d], devices[d]) != MCRT_OK) {
+            std::fprintf(stderr, "mcrt_create(device %d): %s\n", devices[d], mcrt_last_error(nullptr));
+            return 1;
+        }
+        rc = mcrt_upload_scene(ctxs[d], mcrt_image_scene(img));
+        if (rc == MCRT_OK && photon)
+            rc = mcrt_upload_photons(ctxs[d], mcrt_image_photons(img, 0), mcrt_image_photons(img, 1),
+                                     (uint32_t)mcrt_image_param(img, "k_nearest_photons"), (int)mcrt_image_param(img, "direct_visualization"));
+        if (rc != MCRT_OK) std::fprintf(stderr, "device %d: %s\n", devices[d], mcrt_last_error(ctxs[d]));
     }
-    int rc = mcrt_upload_scene(ctx, mcrt_image_scene(img));
-    if (rc == MCRT_OK && photon)
-        rc = mcrt_upload_photons(ctx, mcrt_image_photons(img, 0), mcrt_image_photons(img, 1),
-                                 (uint32_t)mcrt_image_param(img, "k_nearest_photons"), (int)mcrt_image_param(img, "direct_visualization"));
+    mcrt_ctx* ctx = ctxs[0];
     std::vector<double> rgb((size_t)cam.width * cam.height * 3);
     mcrt_stats st;
-    if (rc == MCRT_OK) rc = mcrt_render(ctx, &cam, seed, photon ? MCRT_INTEGRATOR_PHOTON_MAPPER : MCRT_INTEGRATOR_PATH_TRACER, rgb.data(), &st);
+    const int mode = photon ? MCRT_INTEGRATOR_PHOTON_MAPPER : MCRT_INTEGRATOR_PATH_TRACER;
+    if (rc == MCRT_OK)
+        rc = ctxs.size() > 1 ? mcrt_render_multi(ctxs.data(), (uint32_t)ctxs.size(), &cam, seed, mode, rgb.data(), &st)
+                             : mcrt_render(ctx, &cam, seed, mode, rgb.data(), &st);
     if (rc != MCRT_OK) {
         std::fprintf(stderr, "mcrt error %d: %s\n", rc, mcrt_last_error(ctx));
         return 1;
@@ -91,7 +108,7 @@ int main(int argc, char** argv) {
     std::printf("{\"width\":%u,\"height\":%u,\"spp\":%u,\"paths\":%llu,\"rays\":%llu,\"kernel_ms\":%.3f,\"total_ms\":%.3f,\"Mray_s\":%.1f}\n",
                 cam.width, cam.height, cam.sqrtspp * cam.sqrtspp, (unsigned long long)st.paths, (unsigned long long)st.rays,
                 st.kernel_ms, st.total_ms, st.rays / st.kernel_ms / 1e3);
-    mcrt_destroy(ctx);
+    for (mcrt_ctx* c : ctxs) mcrt_destroy(c);
     mcrt_image_free(img);
     return 0;
 }

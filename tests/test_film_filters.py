@@ -171,3 +171,18 @@ def test_gpu_film_unsupported_combinations(pkg, manifest):
         ctx.sample_image(sharded, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     assert "unsharded" in str(e.value)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_render_multi_film(pkg, manifest):
+    """mcrt_render_multi with a reconstruction filter: per-context splat buffers, summed and resolved on the host."""
+    img, cam, r = _case(pkg, manifest, "film_mitchell")
+    ctxs = [pkg.Context(0) for _ in range(3)]
+    for c in ctxs:
+        c.upload_image(img)
+    out, st = pkg.render_multi(ctxs, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+    rel = rel_error(out, load_radiance(r)).max(axis=2)
+    assert st["paths"] == cam.width * cam.height * cam.sqrtspp ** 2
+    assert (rel > 1e-4).sum() <= max(2, int(0.002 * rel.size)) and np.quantile(rel, 0.99) < 1e-9
+    for c in ctxs:
+        c.close()

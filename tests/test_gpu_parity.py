@@ -303,3 +303,27 @@ def test_error_behaviour(pkg, manifest):
     with pytest.raises(pkg.McrtError):
         c.sample_image(cam, 1)
     c.close()
+
+
+@pytest.mark.parametrize("name,count,integrator", [("hexagon_room", 2, "pt"), ("coffee_maker_qsah", 3, "pt"), ("hexagon_room_pm", 2, "pm")])
+def test_render_multi_equals_one_context(pkg, manifest, name, count, integrator):
+    """mcrt_render_multi (one host thread per context, rows dealt over the contexts, frame assembled in host memory) with
+    `count` contexts on the one GPU of the box: the frame of a single context, bit for bit."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    mode = pkg.INTEGRATOR_PHOTON_MAPPER if integrator == "pm" else pkg.INTEGRATOR_PATH_TRACER
+    ctxs = [pkg.Context(0) for _ in range(count)]
+    for c in ctxs:
+        c.upload_image(img)
+    base, st0 = ctxs[0].sample_image(cam, manifest["seed"], mode)
+    out, st = pkg.render_multi(ctxs, cam, manifest["seed"], mode)
+    _check(out, load_radiance(r), name + " multi")
+    assert st["paths"] == st0["paths"] and st["rays"] == st0["rays"]
+    if integrator == "pm":
+        assert rel_error(out, base).max() < 1e-12
+    else:
+        np.testing.assert_array_equal(out, base)
+    for c in ctxs:
+        c.close()

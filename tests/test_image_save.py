@@ -185,3 +185,7 @@ def test_gpu_host_driver_writes_the_reference_tga(pkg, manifest, tmp_path):
     want = np.fromfile(golden_path(sv["file"]), dtype=np.uint8)
     assert got.shape == want.shape and np.array_equal(got[:18], want[:18])
     _assert_bytes_close(got[18:], want[18:], "host driver tga")
+    # the same frame from two contexts driven by this one process (mcrt_render_multi; both on the box's only GPU)
+    f64b = str(tmp_path / "frame2.f64")
+    subprocess.check_call([exe, golden_path(case["image"]), f64b, "--devices", "0,0"], timeout=600)
+    assert np.array_equal(np.fromfile(f64b), np.fromfile(f64))
