@@ -837,11 +837,18 @@ static double bbMaxDistance2(const double* b, v3 p) { /* common/bounding-box.cpp
 }
 static v3 photonPos(const mcrt_photon_map_desc* m, uint64_t i) { const float* p = m->photons + 8 * i; return V((double)p[3], (double)p[4], (double)p[5]); } /* photon.hpp:14-17 */
 
+/* Study hooks (tools/knn_hint_study.py; single-threaded use only): a recorder of the searches of a render, and an initial
+ * bound for a search (DBL_MAX = the reference's). Neither is used by any parity test's oracle path. */
+static double* g_knn_rec = NULL; static uint64_t g_knn_rec_cap = 0, g_knn_rec_n = 0; static double g_knn_rec_tag[2] = {0, 0};
+void oracle_knn_recorder(double* buf, uint64_t cap) { g_knn_rec = buf; g_knn_rec_cap = cap; g_knn_rec_n = 0; }
+uint64_t oracle_knn_recorded(void) { return g_knn_rec_n; }
+static double g_knn_initial_bound2 = DBL_MAX;
+
 static void knnSearch(const mcrt_photon_map_desc* m, v3 p, size_t k, KnnHeap* result, DQueue* to_visit, oracle_counters* cnt) { /* linear-octree.cpp:25-117 */
     result->size = 0;
     if (!m || m->num_octants == 0) return;
     if (k > m->num_photons) k = (size_t)m->num_photons;
-    double max_distance2 = DBL_MAX;
+    double max_distance2 = g_knn_initial_bound2;
     to_visit->size = 0;
     DNode current = {bbDistance2(m->octant_bounds, p), 0};
     for (;;) {
@@ -892,6 +899,22 @@ static int cmpKnn(const void* a, const void* b) {
     return x->index < y->index ? -1 : (x->index > y->index ? 1 : 0);
 }
 
+/* Study: searches with a caller-given initial bound (squared; DBL_MAX = none) and the octants / photons they touch. */
+void oracle_knn_hinted(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, const double* bound2,
+                       double* out_kth_distance2, uint32_t* out_count, uint64_t* octants, uint64_t* photons) {
+    KnnHeap res = {0, 0, 0}; DQueue dq = {0, 0, 0};
+    oracle_counters c; memset(&c, 0, sizeof c);
+    for (uint64_t i = 0; i < n; i++) {
+        g_knn_initial_bound2 = bound2 ? bound2[i] : DBL_MAX;
+        knnSearch(map, ld3(p + 3 * i), k, &res, &dq, &c);
+        out_count[i] = (uint32_t)res.size;
+        out_kth_distance2[i] = res.size ? res.H[0].distance2 : INFINITY; /* heap top = the farthest kept */
+    }
+    g_knn_initial_bound2 = DBL_MAX;
+    *octants = c.knn_octants; *photons = c.knn_photons;
+    free(res.H); free(dq.H);
+}
+
 void oracle_knn(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k,
                 uint32_t* out_count, uint32_t* out_index, double* out_distance2) {
     KnnHeap res = {0, 0, 0}; DQueue dq = {0, 0, 0};
@@ -919,6 +942,7 @@ static v3 estimateGlobalRadiance(Ctx* C, const Interaction* ia) { /* :343-363 */
     const mcrt_photon_map_desc* m = C->maps[0];
     KnnHeap* photons = (KnnHeap*)C->ts->knn_result[0];
     if (C->S.c) C->S.c->knn_searches++;
+    if (g_knn_rec && g_knn_rec_n < g_knn_rec_cap) { double* r = g_knn_rec + 6 * g_knn_rec_n++; r[0] = 0; r[1] = ia->position.x; r[2] = ia->position.y; r[3] = ia->position.z; r[4] = g_knn_rec_tag[0]; r[5] = g_knn_rec_tag[1]; }
     knnSearch(m, ia->position, C->k_nearest, photons, (DQueue*)C->ts->knn_visit, C->S.c);
     if (photons->size == 0) return V(0, 0, 0);
     double bsdf_pdf; v3 bsdf_absIdotN; v3 radiance = V(0, 0, 0);
@@ -934,6 +958,7 @@ static v3 estimateCausticRadiance(Ctx* C, const Interaction* ia) { /* :368-391 *
     const mcrt_photon_map_desc* m = C->maps[1];
     KnnHeap* photons = (KnnHeap*)C->ts->knn_result[1];
     if (C->S.c) C->S.c->knn_searches++;
+    if (g_knn_rec && g_knn_rec_n < g_knn_rec_cap) { double* r = g_knn_rec + 6 * g_knn_rec_n++; r[0] = 1; r[1] = ia->position.x; r[2] = ia->position.y; r[3] = ia->position.z; r[4] = g_knn_rec_tag[0]; r[5] = g_knn_rec_tag[1]; }
     knnSearch(m, ia->position, C->k_nearest, photons, (DQueue*)C->ts->knn_visit, C->S.c);
     if (photons->size == 0) return V(0, 0, 0);
     double inv_max_squared_radius = 1.0 / photons->H[0].distance2;
@@ -1071,6 +1096,7 @@ static void samplePixel(Job* job, Ctx* C, uint32_t x, uint32_t y) {
             ray = rayDir(start, vnormalize(vsub(focus_point, start)), job->scene->scene_ior);
         }
         if (C->S.c) C->S.c->paths++;
+        if (g_knn_rec) { g_knn_rec_tag[0] = (double)((size_t)y * cam->width + x); g_knn_rec_tag[1] = (double)i; }
         v3 L = job->integrator == MCRT_INTEGRATOR_PHOTON_MAPPER ? photonMapperSampleRay(C, ray, &smp)
                                                                 : pathTracerSampleRay(C, ray, &smp);
         /* Film::deposit with the default box filter, radius 0.5: the sample's own pixel, weight 1 (film.cpp:13-17,61-79) */

@@ -59,6 +59,13 @@ int oracle_emit_photons(const mcrt_scene_desc* scene, double emissions, double c
                         float* caustic_photons, uint64_t* caustic_keys, uint64_t caustic_capacity, uint64_t* caustic_count,
                         uint64_t* emission_paths, uint64_t* rays);
 
+/* Study hooks (tools/knn_hint_study.py): record the kNN searches of a SINGLE-THREADED oracle_render into buf ([cap][6]:
+ * map, x, y, z, pixel, sample); and run searches with a caller-given initial squared bound, counting octants / photons. */
+void oracle_knn_recorder(double* buf, uint64_t cap);
+uint64_t oracle_knn_recorded(void);
+void oracle_knn_hinted(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, const double* bound2,
+                       double* out_kth_distance2, uint32_t* out_count, uint64_t* octants, uint64_t* photons);
+
 /* Known-answer helpers for the BSDF building blocks (material/fresnel.cpp, material/ggx.cpp,
  * material/material.cpp). in[11] = wi(3) wo(3) n1 n2 alpha u v; consts[10] = roughness,
  * reflectance(3), complex ior real(3), imag(3); out[18] as written by oracle/ref_main.cpp doKat. */
