@@ -1,31 +1,46 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Mray/s of the path-tracing hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2_ggx|c1] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|...] [--no-cpu] [--no-secondary] [--no-counters]
 
-One "step" = one full frame of the workload: every owned pixel traced with spp samples by the HIP
-integrator kernel (ray generation, BVH traversal, shading, NEE shadow rays, film accumulation), the
-image rows left in HBM; with N > 1 the framebuffer rows are dealt to the ranks in groups of 8 and each
-step ends with ONE RCCL gather of the packed rows to rank 0 over xGMI.
+One "step" = one full frame of the workload: every owned pixel traced with spp samples by the HIP integrator kernel(s)
+(ray generation, BVH traversal, shading, NEE shadow rays, film accumulation), the image rows left in HBM; with N > 1 the
+framebuffer rows are dealt to the ranks in groups of 8 and each step ends with ONE RCCL gather of the packed rows to
+rank 0 over xGMI.
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on): hexagon_room.json camera 0,
-1920x1080 @ 256 spp, scene image tests/golden/hexagon_room.mcrt (flattened by the reference's own
-loader/BVH builder; synthetic = no external data needed). Inputs (scene arrays, Sobol tables) are
-resident in HBM before the timed region.
+Headline workload (BASELINE.json configs[1], the config the metric is quoted on): hexagon_room.json camera 0,
+1920x1080 @ 256 spp, scene image tests/golden/hexagon_room.mcrt (flattened by the reference's own loader/BVH builder).
+Inputs (scene arrays, Sobol tables, photon maps) are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     algorithmic bytes (B_ray = n_node*64 + n_tri*72 + n_sphere*32 + 300,
-               per-ray counts measured by the reference-equivalent oracle) per launch / kernel time
-               measured with HIP events on the kernel's stream, against the 8 TB/s HBM peak;
-  cpu_baseline the CPU integrator timed on this box's host cores on a bounded sample of the SAME
-               workload (rows of the same frame at the same spp).
+Rank 0 prints ONE JSON line (contract in the task statement). At N = 1 it also carries
+  roofline      of the headline kernel. hexagon_room lives in LDS, so its bound is the vector ALU, not HBM: `frac` =
+                FP64-rate lane-slots doing work / lane-slots the chip has (SQ_THREAD_CYCLES_VALU against 1024 SIMDs x 16
+                lanes x 2.4 GHz), read from rocprofv3 PMC passes of ONE frame of the same workload made inside this run
+                (child processes of this script under `rocprofv3 --pmc`); `traffic` = HBM bytes of that frame from the
+                FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+                `algorithmic_GBs` = reference-equivalent bytes (B_ray = n_node*64 + n_tri*72 +
+                n_sphere*32 + 300, per-ray counts of the reference's best-first traversal measured by the oracle) per
+                second of kernel time — a work rate, reported beside the bound, never as its fraction;
+  cpu_baseline  the reference's own integrator (oracle/_ref/mcrt_ref, kind "reference") on this box's host cores, on rows
+                of the SAME frame, at all hardware threads and at the thread count where it runs best (its shared_ptr
+                reference counts contend), and the C restatement ("port_value");
+  parity        the frame's rows 536-540 against the reference's radiance for those rows (tests/golden, made by the
+                reference itself): max relative error and the number of pixels beyond 1e-4;
+  secondary     driver-timed legs on the kernels that DO walk trees in HBM and search photon maps — spaceship cockpit
+                (renderKernelSM), photon-mapped hexagon_room (renderKernelPM, kNN) and metal_bunnies C3 (wavefront
+                pipeline) — each with its own HBM roofline (algorithmic bytes / kernel time / 8 TB/s; measured traffic
+                beside it) and cpu_baseline.
 """
 import argparse
+import glob
 import importlib
 import json
 import os
+import shutil
+import sqlite3
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -39,42 +54,73 @@ WORKLOADS = {
     "c2": ("hexagon_room.mcrt", 1920, 1080, 16, "hexagon_room.json cam0 1920x1080 @ 256 spp (BASELINE configs[1])"),
     "c2_ggx": ("hexagon_room_ggx.mcrt", 1920, 1080, 16, "hexagon_room.json + GGX roughness, 1920x1080 @ 256 spp"),
     "c1": ("hexagon_room_diffuse.mcrt", 256, 256, 2, "hexagon_room_diffuse.json 256x256 @ 4 spp (BASELINE configs[0])"),
-    # secondary: photon-mapped frame (BASELINE configs[4] class of work on the scene that is available):
-    # 1e7 photon paths emitted on the GPU, maps built on the host, then timed eye passes with kNN estimates
+    # photon-mapped frame (BASELINE configs[4] class of work on the scene that is available): photon paths emitted on the
+    # GPU, maps built GPU-assisted, then timed eye passes with kNN estimates
     "pm": ("hexagon_room_pm.mcrt", 1920, 1080, 2, "hexagon_room.json photon mapping: 1e6 emissions x caustic_factor 10, k=50, 1920x1080 @ 4 spp"),
-    # secondary (not the headline): a real BVH that does not fit in LDS; image made by tests/large/make_large.py
+    # a real BVH that does not fit in LDS; image made by tests/large/make_large.py
     "spaceship": ("../../oracle/_ref/images/spaceship.mcrt", 1920, 1080, 8,
                   "spaceship.json (68 760 of 457 200 triangles present), quaternary SAH, 1920x1080 @ 64 spp"),
     # BASELINE configs[2] at full size; the Stanford bunny is not in the reference tree (.MISSING_LARGE_BLOBS), a
     # synthetic 81 920-triangle stand-in is (tests/large/make_synthetic.py). The 120 MB image is flattened on this
-    # machine by the reference's loader + BVH builder (tests/large/make_large.py:ensure_c3_image)
+    # machine by the reference's loader + BVH builder (tests/large/make_large.py:ensure_image)
     "c3": ("../../oracle/_ref/images/metal_bunnies_c3.mcrt", 1920, 1080, 32,
            "metal_bunnies.json (stand-in bunny mesh, 491 592 triangles), quaternary SAH, 1920x1080 @ 1024 spp (BASELINE configs[2])"),
-    # BASELINE configs[3] on ONE GPU (the 8-GPU figure is the driver's scaling run): the two missing hull meshes replaced by
-    # stand-ins of the same triangle counts (tests/large/gen_mesh.c), 457 200 triangles in total
+    # BASELINE configs[3] on ONE GPU: the two missing hull meshes replaced by stand-ins of the same triangle counts
     "c4": ("../../oracle/_ref/images/spaceship_c4.mcrt", 3840, 2160, 32,
            "spaceship.json (stand-in hull meshes, 457 200 triangles), quaternary SAH, 3840x2160 @ 1024 spp (BASELINE configs[3])"),
     # BASELINE configs[4]: water.obj replaced by a 6 734 450-triangle heightfield; photons emitted on the GPU
-    # (--emissions x caustic_factor 10 paths), octrees built on the host, timed eye passes with k = 50 estimates
     "c5": ("../../oracle/_ref/images/water_caustics_c5.mcrt", 1000, 1000, 16,
            "water_caustics.json (stand-in water surface, 6 898 815 triangles), octree BVH, photon map, 1000x1000 @ 256 spp (BASELINE configs[4])"),
 }
-# reference-side scene + flags for the cpu_baseline "reference" leg
+# reference-side scene + flags for the cpu_baseline "reference" leg (scene copies under oracle/_ref/scenes, made by
+# tests/large/make_large.py in the build container; they travel to the GPU box with the snapshot)
 REF_SCENES = {
     "hexagon_room.mcrt": ("hexagon_room.json", []),
     "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
     "spaceship_c4.mcrt": ("spaceship.json", []),
+    "spaceship.mcrt": ("spaceship_cockpit.json", []),
 }
+SECONDARY = ("spaceship", "pm", "c3")
 SEED = 0x12345678
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# vector-ALU peak in FP64-rate lane slots: 256 CUs x 4 SIMDs, a wave64 FP64 instruction occupies its SIMD for 4 cycles
+# (16 lanes per cycle), 2.4 GHz max clock (MI355X_MICROARCH.md chip parameters) = 39.3e12 lane-ops/s (x2 = 78.6 TFLOP/s FMA)
+VALU_SIMDS = 1024
+VALU_PEAK_GLANEOPS = VALU_SIMDS * 16 * 2.4
 SHARD_ROWS = 8
+# stored per-ray counts of the reference-equivalent traversal (oracle, DESIGN.md "Measurement"): used when the CPU leg is skipped
+STORED_COUNTS = {"spaceship": dict(node_per_ray=33.44, tri_per_ray=6.96, sphere_per_ray=0.0),
+                 "c3": dict(node_per_ray=46.28, tri_per_ray=7.17, sphere_per_ray=0.02),
+                 "c4": dict(node_per_ray=71.99, tri_per_ray=14.22, sphere_per_ray=0.0),
+                 "c5": dict(node_per_ray=45.05, tri_per_ray=7.28, sphere_per_ray=0.0),
+                 "pm": dict(node_per_ray=14.34, tri_per_ray=9.30, sphere_per_ray=7.40)}
+DEFAULT_COUNTS = dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31)
 
 
-def cpu_baseline(m, img, cam, budget_s=15.0, integrator=0, pm_maps=None):
-    """Times the CPU integrator on rows of the same frame. Prefers the reference itself
-    (oracle/_ref/mcrt_ref + oracle/_ref/scenes, both produced by oracle/Makefile in the build
-    container); otherwise the C restatement (oracle/, kind "port"). Also returns the per-ray
-    node/primitive test counts of the reference-equivalent traversal (for the roofline)."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (checker code: oracle/ and oracle/_ref are used here and nowhere in the timed region)
+# ------------------------------------------------------------------------------------------------------------------
+def _run_reference(img_path, cam, r0, r1, threads):
+    """Rows [r0, r1) of the frame by the reference binary; returns its JSON record or None."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
+    ref_name, ref_flags = REF_SCENES.get(os.path.basename(img_path), (None, []))
+    ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", ref_name or "-")
+    if not (os.path.exists(ref_bin) and ref_name and os.path.exists(ref_scene)):
+        return None
+    cmd = [ref_bin, "render", "--scene", ref_scene] + ref_flags + ["--width", str(cam.width), "--height", str(cam.height), "--sqrtspp", str(cam.sqrtspp),
+                                                                   "--rows", str(r0), str(r1), "--out-radiance", "/dev/null"]
+    if threads:
+        cmd += ["--threads", str(threads)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_threads=True, ref_threads=None):
+    """Times the CPU integrator on rows of the same frame. Prefers the reference itself (oracle/_ref/mcrt_ref +
+    oracle/_ref/scenes, produced by oracle/Makefile in the build container); otherwise the C restatement (oracle/, kind
+    "port"). Also returns the per-ray node/primitive test counts of the reference-equivalent traversal (for the
+    algorithmic-bytes figure)."""
     import oracle_lib  # checker, cpu_baseline leg only
 
     threads = oracle_lib.hardware_threads()
@@ -92,11 +138,10 @@ def cpu_baseline(m, img, cam, budget_s=15.0, integrator=0, pm_maps=None):
                 return {"k_nearest_photons": 50, "direct_visualization": 0}.get(key, 0)
         img = _WithMaps
     mid = cam.height // 2
-    # calibration: 2 rows
-    t0 = time.time()
+    # the port, calibrated on 2 rows
     _, info = oracle_lib.render(img, cam, SEED, integrator, rows=(mid, mid + 2), threads=threads)
     per_row = max(info["seconds"] / 2.0, 1e-4)
-    rows = int(max(2, min(cam.height, budget_s / per_row)))
+    rows = int(max(2, min(cam.height, 0.5 * budget_s / per_row)))
     r0 = max(0, mid - rows // 2)
     _, info = oracle_lib.render(img, cam, SEED, integrator, rows=(r0, r0 + rows), threads=threads)
     rays = info["rays"]
@@ -107,29 +152,390 @@ def cpu_baseline(m, img, cam, budget_s=15.0, integrator=0, pm_maps=None):
         counts["knn_searches_per_s"] = info["knn_searches"] / info["seconds"]
         counts["knn_octants_per_search"] = info["knn_octants"] / info["knn_searches"]
         counts["knn_photons_per_search"] = info["knn_photons"] / info["knn_searches"]
+    spp = cam.sqrtspp ** 2
     port = dict(value=rays / info["seconds"] / 1e6, unit="Mray/s", cores=threads, kind="port",
-                sample="rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)" % (r0, r0 + rows, cam.width, cam.height, cam.sqrtspp ** 2,
-                                                                          info["paths"], info["seconds"]))
+                sample="rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)" % (r0, r0 + rows, cam.width, cam.height, spp, info["paths"], info["seconds"]))
     if "knn_searches_per_s" in counts:
         port["knn_searches_per_s"] = counts["knn_searches_per_s"]
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
-    ref_name, ref_flags = REF_SCENES.get(os.path.basename(img.path), (None, []))
-    ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", ref_name or "-")
     base = port
-    if os.path.exists(ref_bin) and ref_name and os.path.exists(ref_scene):
+    if integrator == 0:
         try:
-            out = subprocess.run([ref_bin, "render", "--scene", ref_scene] + ref_flags + ["--width", str(cam.width), "--height", str(cam.height),
-                                  "--sqrtspp", str(cam.sqrtspp), "--rows", str(r0), str(r0 + rows), "--out-radiance", "/dev/null"],
-                                 capture_output=True, text=True, timeout=600, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
-            line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-            r = json.loads(line)
-            base = dict(value=rays / r["seconds"] / 1e6, unit="Mray/s", cores=r["threads"], kind="reference",
-                        sample="reference Camera::samplePixel, rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)"
-                               % (r0, r0 + rows, cam.width, cam.height, cam.sqrtspp ** 2, r["paths"], r["seconds"]),
-                        port_value=port["value"])
+            rays_per_row = rays / rows  # rays of a row: the port traces the reference's paths (bit-identical frames)
+            # the reference at all hardware threads on ONE row, then (headline only) at fewer threads: its BVH::intersect
+            # copies shared_ptrs, whose reference counts contend, so all threads is rarely its best
+            cal = {}
+            for t in ([threads] + ([t for t in (64, 32, 16) if t < threads] if scan_threads else [])):
+                r = _run_reference(img.path, cam, mid, mid + 1, t)
+                if r is None:
+                    break
+                cal[t] = rays_per_row / r["seconds"]
+            if ref_threads and ref_threads not in cal and cal:
+                r = _run_reference(img.path, cam, mid, mid + 1, ref_threads)
+                if r:
+                    cal[ref_threads] = rays_per_row / r["seconds"]
+            if cal:
+                best_t = max(cal, key=cal.get) if (scan_threads or not ref_threads) else ref_threads
+                n_rows = int(max(1, min(rows, 0.5 * budget_s * cal[best_t] / rays_per_row)))
+                q0 = max(r0, mid - n_rows // 2)
+                r = _run_reference(img.path, cam, q0, q0 + n_rows, best_t)
+                sample_rays = rays_per_row * n_rows
+                base = dict(value=cal[threads] / 1e6, unit="Mray/s", cores=threads, kind="reference",
+                            sample="reference Camera::samplePixel, row %d of %dx%d @ %d spp at %d threads; best thread count: rows %d-%d (%d paths, %.1f s)"
+                                   % (mid, cam.width, cam.height, spp, threads, q0, q0 + n_rows, r["paths"], r["seconds"]),
+                            best_value=sample_rays / r["seconds"] / 1e6, best_cores=best_t,
+                            by_threads={str(k): v / 1e6 for k, v in sorted(cal.items())},
+                            port_value=port["value"], port_cores=threads)
         except Exception as ex:  # keep the port numbers
             base = dict(port, note="reference run failed: %r" % (ex,))
     return base, counts
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# in-run hardware counters: one frame of the workload in a child process under rocprofv3 --pmc (one pass per counter set)
+# ------------------------------------------------------------------------------------------------------------------
+SQ_SET = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
+          "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET))
+INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKernel")
+
+
+def collect_counters(workload, sqrtspp=None, emissions=None, passes=PMC_PASSES, timeout=300):
+    """Returns {"counters": {name: sum over the integrator dispatches of ONE frame}, "kernel_ms": ..., "per_kernel": ...}
+    or {"error": ...}. Separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit together)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    out = {"counters": {}, "per_kernel": {}, "frame": None}
+    for tag, names in passes:
+        tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--kernel-trace", "--pmc"] + names + ["-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--child-frame", "--workload", workload]
+            if sqrtspp:
+                cmd += ["--sqrtspp", str(sqrtspp)]
+            if emissions:
+                cmd += ["--emissions", str(emissions)]
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            frames = [l for l in p.stdout.splitlines() if l.startswith('{"child_frame"')]
+            if p.returncode != 0 or not frames:
+                out.setdefault("errors", []).append("%s pass: rc %d: %s" % (tag, p.returncode, (p.stderr or p.stdout)[-300:]))
+                continue
+            out["frame"] = json.loads(frames[-1])
+            for db in glob.glob(os.path.join(tmp, "**", "*_results.db"), recursive=True):
+                con = sqlite3.connect(db)
+                try:
+                    rows = list(con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"))
+                except sqlite3.Error as ex:
+                    out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
+                    rows = []
+                con.close()
+                for kname, cname, val, _n in rows:
+                    key = next((k for k in INTEGRATOR_KERNELS if k in kname), None)
+                    if key is None:
+                        continue  # sampleResolveKernel, memsets, torch kernels
+                    kk = "renderKernel" if key == "renderKernel" else key
+                    if "renderKernelSM" in kname:
+                        kk = "renderKernelSM"
+                    elif "renderKernelPM" in kname:
+                        kk = "renderKernelPM"
+                    out["per_kernel"].setdefault(kk, {})
+                    out["per_kernel"][kk][cname] = out["per_kernel"][kk].get(cname, 0.0) + float(val)
+                    out["counters"][cname] = out["counters"].get(cname, 0.0) + float(val)
+        except Exception as ex:
+            out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def counters_summary(pmc, scale=1.0):
+    """Derived figures from the raw sums (scale: frame of the timed configuration / frame the counters were taken on)."""
+    if not pmc or not pmc.get("counters"):
+        return None
+    c = pmc["counters"]
+    s = {"source": "rocprofv3 --pmc passes of one frame, child processes of this run", "frame_scale": scale}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # counters are in KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)
+        s["fetch_bytes"] = c["FETCH_SIZE"] * 1024.0 * 2.0 * scale
+        s["write_bytes"] = c["WRITE_SIZE"] * 1024.0 * scale
+        s["traffic_bytes"] = s["fetch_bytes"] + s["write_bytes"]
+    if "SQ_ACTIVE_INST_VALU" in c and pmc.get("frame"):
+        # SQ counters tick in quad-cycles (MI355X_MICROARCH.md, per-instruction constants). SIMD time is priced at the 2.4 GHz
+        # spec clock over the counted frame's own kernel time, so "busy" is a share of what the chip could issue at full clock.
+        frame_s = pmc["frame"]["kernel_ms"] * 1e-3
+        simd_cycles = VALU_SIMDS * frame_s * 2.4e9
+        s["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+        s["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0) if c.get("SQ_THREAD_CYCLES_VALU") else None
+        s["valu_lane_ops"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) * scale                # lane x quad-cycle = one FP64-rate lane slot
+        s["valu_insts"] = c.get("SQ_INSTS_VALU", 0.0) * scale
+        if c.get("SQ_WAVE_CYCLES"):
+            s["waves_waiting"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if c.get("GRBM_GUI_ACTIVE"):
+            clk = c["GRBM_GUI_ACTIVE"] / frame_s
+            if clk > 3.0e9:  # summed over the 8 XCDs
+                clk /= 8.0
+            s["measured_clock_GHz"] = clk / 1e9
+    if pmc.get("errors"):
+        s["errors"] = pmc["errors"]
+    if pmc.get("frame"):
+        s["frame"] = pmc["frame"]
+    return s
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    pass
+
+
+def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp=None):
+    """Scene (and photon maps) resident in HBM, output tile allocated: everything the timed region needs."""
+    import torch
+
+    wl = Workload()
+    wl.name = name
+    image_file, W, H, s, desc = WORKLOADS[name]
+    if sqrtspp:
+        s = int(sqrtspp)
+        desc += " [spp overridden to %d]" % (s * s)
+    wl.W, wl.H, wl.sqrtspp, wl.desc = W, H, s, desc
+    if name in ("c3", "c4", "c5"):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+        import make_large
+        if local_rank == 0 and make_large.ensure_image(name) is None:
+            raise RuntimeError("%s needs oracle/_ref (python __graft_entry__.py build in the build container)" % name)
+        if world > 1:
+            dist.barrier()
+    path = os.path.join(ROOT, "tests", "golden", image_file)
+    if not os.path.exists(path):
+        raise RuntimeError("scene image %s is not on this machine" % os.path.normpath(path))
+    img = m.SceneImage(path)
+    cam = img.camera
+    cam.width, cam.height, cam.sqrtspp = W, H, s
+    wl.img, wl.full = img, cam.copy()
+    wl.cam = tiling.shard_camera(wl.full, rank, world, SHARD_ROWS)
+    wl.ctx = m.Context(local_rank)
+    wl.ctx.upload_image(img)  # scene resident in HBM before the timed region
+    wl.integrator = m.INTEGRATOR_PATH_TRACER
+    wl.pm_maps, wl.emit_info = None, None
+    wl.photon = name in ("pm", "c5")
+    if wl.photon:
+        # emission pass on the GPU (sharded over the ranks and all-gathered), octrees GPU-assisted, upload
+        wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
+        em = wl.ctx.emit_photons(args.emissions, 10.0, SEED, rank, world)
+        wl.emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
+        lists = []
+        for key in ("global_", "caustic"):
+            ph = torch.from_numpy(em[key][0]).to(torch.device("cuda", local_rank))
+            if world > 1:
+                sizes = [torch.zeros(1, dtype=torch.int64, device=ph.device) for _ in range(world)]
+                dist.all_gather(sizes, torch.tensor([ph.shape[0]], dtype=torch.int64, device=ph.device))
+                cap = int(max(int(x.item()) for x in sizes))
+                pad = torch.zeros((cap, 8), dtype=torch.float32, device=ph.device)
+                pad[: ph.shape[0]] = ph
+                parts = [torch.empty_like(pad) for _ in range(world)]
+                dist.all_gather(parts, pad)
+                ph = torch.cat([parts[r][: int(sizes[r].item())] for r in range(world)])
+            lists.append(ph.cpu().numpy())
+        sc = img.scene
+        t_build = time.perf_counter()
+        bctx = None if args.host_octree else wl.ctx
+        wl.pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx))
+        wl.emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
+                            octree_build_s=time.perf_counter() - t_build, octree_builder="host" if args.host_octree else "gpu",
+                            emission_Mray_per_s=wl.emit_info["rays"] / max(wl.emit_info["kernel_ms"], 1e-9) / 1e3)
+        wl.ctx.upload_photons(wl.pm_maps[0].desc, wl.pm_maps[1].desc, 50, False)
+    wl.my_rows = m.shard_rows(wl.cam)
+    wl.dev = torch.device("cuda", local_rank)
+    wl.tile = torch.zeros((tiling.max_rows(wl.full, world, SHARD_ROWS), W, 3), dtype=torch.float64, device=wl.dev)  # packed owned rows (+ padding)
+    wl.gathered = [torch.empty_like(wl.tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    wl.stream = torch.cuda.current_stream(wl.dev).cuda_stream
+    return wl
+
+
+def run_steps(wl, steps, warmup, world, dist):
+    """W untimed steps, then exactly K timed steps between barrier + synchronize; returns (seconds, per-step stats)."""
+    import torch
+
+    def step():
+        wl.ctx.render_device(wl.cam, SEED, wl.integrator, wl.tile.data_ptr(), wl.stream)
+        st = wl.ctx.render_finish()
+        if world > 1:
+            dist.gather(wl.tile, wl.gathered, dst=0)  # the single collective of the data path
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(wl.dev)
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(steps)]
+    sync()
+    return time.perf_counter() - t0, stats
+
+
+def hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, knn_per_launch, pmc):
+    """Trees that stay in HBM: algorithmic bytes per launch / kernel time against the 8 TB/s peak; the
+    measured HBM traffic of a frame beside it."""
+    b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
+    achieved = rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": pmc.get("traffic_bytes") if pmc else None,
+         "kernel": m.KERNEL_NAMES.get(kernel_id, "?") + (" (all launches of the frame)" if kernel_id in (m.KERNEL_WAVEFRONT, m.KERNEL_WAVEFRONT_PM) else ""),
+         "kernel_id": kernel_id, "kernel_ms": kernel_ms, "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
+         "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")},
+         "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time (HIP events around the frame's launches); "
+                 "traffic = HBM bytes of one frame measured in this run (rocprofv3 PMC)"}
+    if counts.get("knn_photons_per_search") and knn_per_launch:
+        # SURVEY.md §8(d): B_knn = n_octant*128 + n_photon_scanned*32 + k*32 per search (reference-equivalent counts)
+        b_knn = counts["knn_octants_per_search"] * 128 + counts["knn_photons_per_search"] * 32 + 50 * 32
+        knn_rate = knn_per_launch / (kernel_ms * 1e-3)
+        r["knn"] = {"bytes_per_search": b_knn, "searches_per_s_in_kernel": knn_rate}
+        r["achieved"] = achieved + knn_rate * b_knn / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["achieved_rays_only"] = achieved
+    if pmc:
+        if pmc.get("traffic_bytes"):
+            r["traffic_GBs"] = pmc["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9
+            r["traffic_frac"] = r["traffic_GBs"] / HBM_PEAK_GBS
+        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "fetch_bytes", "write_bytes", "frame_scale", "errors") if k in pmc}
+    if r["frac"] > 1.0:  # more algorithmic bytes than HBM could move: the caches serve them; not an HBM fraction
+        r["note"] += "; algorithmic rate above the HBM peak (cache-served): frac withheld"
+        r["algorithmic_frac"] = r["frac"]
+        r["frac"] = None
+    return r
+
+
+def valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc):
+    """Scenes that live in LDS (flat kernel): the bound is the vector ALU. frac = FP64-rate lane slots that did work
+    (SQ_THREAD_CYCLES_VALU of one frame, measured in this run) per second of kernel time against the chip's 39.3e12/s."""
+    b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
+    r = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GLANEOPS, "unit": "G lane-op/s (FP64 rate: 1024 SIMDs x 16 lanes x 2.4 GHz)", "frac": None,
+         "traffic": pmc.get("traffic_bytes") if pmc else None,
+         "kernel": m.KERNEL_NAMES.get(kernel_id, "?"), "kernel_id": kernel_id, "kernel_ms": kernel_ms,
+         "algorithmic_GBs": rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9, "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
+         "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")},
+         "note": "scene resident in LDS: bound = vector ALU. achieved = lane-slots executing VALU work per second (SQ_THREAD_CYCLES_VALU of one frame, "
+                 "rocprofv3 PMC pass made in this run, / kernel time of the timed steps); frac = achieved / peak = VALU busy x lane utilisation (SIMD time priced at the 2.4 GHz spec clock). "
+                 "algorithmic_GBs = reference-equivalent bytes (SURVEY.md 8(d)) per second: a work rate, not HBM traffic; traffic = measured HBM bytes of one frame"}
+    if pmc and pmc.get("valu_lane_ops"):
+        r["achieved"] = pmc["valu_lane_ops"] / (kernel_ms * 1e-3) / 1e9
+        r["frac"] = r["achieved"] / VALU_PEAK_GLANEOPS
+        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "valu_insts", "measured_clock_GHz", "fetch_bytes", "write_bytes", "errors") if k in pmc}
+        r["counters"]["lane_ops_per_ray"] = pmc["valu_lane_ops"] / rays_per_launch
+        r["counters"]["valu_insts_per_ray"] = pmc["valu_insts"] * 64.0 / rays_per_launch  # wave instructions x 64 lanes
+        if pmc.get("traffic_bytes"):
+            r["traffic_GBs"] = pmc["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9
+    else:
+        r["note"] += "; counters unavailable in this run (%s)" % ((pmc or {}).get("errors") or "rocprofv3 pass skipped")
+    return r
+
+
+def c2_parity(wl, frame):
+    """Rows 536-540 of the full-size C2 frame against the reference's own radiance (tests/golden fixture)."""
+    g = os.path.join(ROOT, "tests", "golden", "hexagon_room.c2_1920x1080_s16_rows536_540.f64")
+    if wl.name != "c2" or wl.sqrtspp != 16 or not os.path.exists(g):
+        return None
+    ref = np.fromfile(g, dtype=np.float64).reshape(4, 1920, 3)
+    out = frame[536:540].cpu().numpy()
+    rel = (np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)).max(axis=2)
+    return {"rows": [536, 540], "pixels": int(rel.size), "max_rel": float(rel.max()), "p999_rel": float(np.quantile(rel, 0.999)),
+            "outliers_gt_1e-4": int((rel > 1e-4).sum()), "tolerance": 1e-4, "reference": "tests/golden/hexagon_room.c2_1920x1080_s16_rows536_540.f64 (rendered by the reference)"}
+
+
+def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup, want_cpu, want_counters, headline, ref_threads=None):
+    """One leg: set up, time, describe. Returns (result dict on rank 0 | None, best reference thread count)."""
+    import torch
+
+    wl = setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp=args.sqrtspp if headline else None)
+    elapsed, stats = run_steps(wl, steps, warmup, world, dist)
+    dev = wl.dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    acc = torch.tensor([float(sum(s["rays"] for s in stats)), float(sum(s["paths"] for s in stats)),
+                        float(sum(s["kernel_ms"] for s in stats)), float(sum(s["knn_searches"] for s in stats))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kmax = acc[2:3].clone()
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        acc[2] = kmax[0]
+    elapsed = float(t.item())
+    total_rays, total_paths, kernel_ms_sum, total_knn = (float(x) for x in acc)
+    result = None
+    if rank == 0:
+        if world > 1:  # sanity: the gathered frame is complete and finite
+            frame = torch.zeros((wl.H, wl.W, 3), dtype=torch.float64, device=dev)
+            for r in range(world):
+                rows = torch.from_numpy(tiling.rows_of(wl.full, r, world, SHARD_ROWS)).to(dev)
+                frame[rows] = wl.gathered[r][: len(rows)]
+        else:
+            frame = wl.tile[: len(wl.my_rows)]
+        kernel_id = stats[-1]["kernel_id"]
+        result = {
+            "metric": "Mray/s (whole node), 1920x1080 @ 256 spp path trace" if name.startswith("c2") else "Mray/s (whole node)",
+            "value": total_rays / elapsed / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl.desc, "width": wl.W, "height": wl.H, "spp": wl.sqrtspp ** 2, "integrator": "photon_mapper" if wl.photon else "path_tracer",
+                       "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
+                       "rays_per_step": total_rays / steps, "paths_per_step": total_paths / steps,
+                       "frame_mean_radiance": float(frame.mean().item()), "frame_finite": bool(torch.isfinite(frame).all().item()),
+                       "kernel": m.KERNEL_NAMES.get(kernel_id, "?"), "kernel_id": kernel_id, "kernel_launches_per_step": stats[-1]["kernel_launches"],
+                       "knn_searches_per_s": total_knn / elapsed if total_knn else None,
+                       "photon_pass": wl.emit_info if wl.photon else None},
+        }
+        par = c2_parity(wl, frame) if world == 1 else None
+        if par:
+            result["parity"] = par
+        counts = None
+        if world == 1 and want_cpu:
+            base, counts = cpu_baseline(m, wl.img, wl.full, args.cpu_seconds if headline else args.cpu_seconds * 0.6, wl.integrator, wl.pm_maps,
+                                        scan_threads=headline, ref_threads=ref_threads)
+            result["cpu_baseline"] = base
+            ref_threads = base.get("best_cores", ref_threads)
+        if counts is None:
+            counts = STORED_COUNTS.get(name, DEFAULT_COUNTS)
+    # the context's memory goes back before the counter passes (child processes) need the GPU
+    frame = None
+    wl.ctx.close()
+    del wl.tile, wl.gathered
+    torch.cuda.empty_cache()
+    if rank == 0:
+        pmc = None
+        if world == 1 and want_counters:
+            # counters of ONE frame; C3's frame takes 8 s under nothing and longer under counters: taken at 64 spp and scaled
+            # (per-sample work is the same; stated in frame_scale)
+            scale_spp = 8 if name == "c3" else None
+            raw = collect_counters(name, sqrtspp=scale_spp or (args.sqrtspp if headline else None), emissions=args.emissions if wl.photon else None)
+            scale = (wl.sqrtspp / scale_spp) ** 2 if scale_spp else 1.0
+            pmc = counters_summary(raw, scale) or {"errors": raw.get("errors") or [raw.get("error")]}
+        launches = steps
+        kernel_ms = kernel_ms_sum / launches
+        rays_per_launch = total_rays / steps / world
+        if kernel_id == m.KERNEL_FLAT:
+            result["roofline"] = valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc)
+        else:
+            result["roofline"] = hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, total_knn / steps / world, pmc)
+    return result, ref_threads
+
+
+def child_frame(args):
+    """One frame of a workload and nothing else: the process rocprofv3 wraps for the counter passes."""
+    import torch
+
+    m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
+    torch.cuda.set_device(0)
+    wl = setup_workload(args.workload, args, m, tiling, 0, 1, 0, None, sqrtspp=args.sqrtspp)
+    _, stats = run_steps(wl, 1, 0, 1, None)
+    st = stats[0]
+    print(json.dumps({"child_frame": args.workload, "spp": wl.sqrtspp ** 2, "rays": st["rays"], "paths": st["paths"], "kernel_ms": st["kernel_ms"],
+                      "kernel_id": st["kernel_id"], "knn_searches": st["knn_searches"]}), flush=True)
+    wl.ctx.close()
 
 
 def main():
@@ -138,23 +544,30 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (roofline then uses stored counts)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs (stored per-ray counts are used for the algorithmic bytes)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 PMC child passes")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sqrtspp", type=int, default=None, help="override the workload's samples per pixel (debugging; the line says so)")
     ap.add_argument("--host-octree", action="store_true", help="build the photon octrees with the host builder instead of the GPU-assisted one")
     ap.add_argument("--emissions", type=float, default=1e6, help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths)")
+    ap.add_argument("--child-frame", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.child_frame:
+        return child_frame(args)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     # MCRT_BENCH_SHARE_GPU=1 (rehearsal of the N > 1 path on a one-GPU box, not a measurement): every rank uses cuda:0 and the
     # collectives run over gloo, which moves CUDA tensors through the host
     share_gpu = world > 1 and os.environ.get("MCRT_BENCH_SHARE_GPU") == "1"
@@ -170,173 +583,28 @@ def main():
 
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
     tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
-    image_file, W, H, sqrtspp, desc = WORKLOADS[args.workload]
-    if args.workload in ("c3", "c4", "c5"):
-        sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
-        import make_large
-        if local_rank == 0 and make_large.ensure_image(args.workload) is None:
-            raise SystemExit("%s needs oracle/_ref (python __graft_entry__.py build in the build container)" % args.workload)
-        if world > 1:
-            dist.barrier()
-    img = m.SceneImage(os.path.join(ROOT, "tests", "golden", image_file))
-    cam = img.camera
-    cam.width, cam.height, cam.sqrtspp = W, H, sqrtspp
-    full = cam.copy()
-    cam = tiling.shard_camera(full, rank, world, SHARD_ROWS)
-    ctx = m.Context(local_rank)
-    ctx.upload_image(img)  # scene resident in HBM before the timed region
-    integrator = m.INTEGRATOR_PATH_TRACER
-    pm_maps = None
-    emit_info = None
-    photon_workload = args.workload in ("pm", "c5")
-    if photon_workload:
-        # emission pass on the GPU (sharded over the ranks and all-gathered), octrees on the host, upload
-        integrator = m.INTEGRATOR_PHOTON_MAPPER
-        em = ctx.emit_photons(args.emissions, 10.0, SEED, rank, world)
-        emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
-        lists = []
-        for name in ("global_", "caustic"):
-            ph = torch.from_numpy(em[name][0]).to(torch.device("cuda", local_rank))
-            if world > 1:
-                sizes = [torch.zeros(1, dtype=torch.int64, device=ph.device) for _ in range(world)]
-                dist.all_gather(sizes, torch.tensor([ph.shape[0]], dtype=torch.int64, device=ph.device))
-                cap = int(max(int(x.item()) for x in sizes))
-                pad = torch.zeros((cap, 8), dtype=torch.float32, device=ph.device)
-                pad[: ph.shape[0]] = ph
-                parts = [torch.empty_like(pad) for _ in range(world)]
-                dist.all_gather(parts, pad)
-                ph = torch.cat([parts[r][: int(sizes[r].item())] for r in range(world)])
-            lists.append(ph.cpu().numpy())
-        sc = img.scene
-        t_build = time.perf_counter()
-        # octrees: cell codes + radix sort + gather + leaf boxes on the GPU, octant assembly on the host (--host-octree: all on the host)
-        bctx = None if args.host_octree else ctx
-        pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx))
-        emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
-                         octree_build_s=time.perf_counter() - t_build, octree_builder="host" if args.host_octree else "gpu",
-                         emission_Mray_per_s=emit_info["rays"] / max(emit_info["kernel_ms"], 1e-9) / 1e3)
-        ctx.upload_photons(pm_maps[0].desc, pm_maps[1].desc, 50, False)
-
-    my_rows = m.shard_rows(cam)
-    max_rows = tiling.max_rows(full, world, SHARD_ROWS)
-    dev = torch.device("cuda", local_rank)
-    tile = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)  # packed owned rows (+ padding)
-    gathered = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    stats_acc = []
-
-    def step():
-        ctx.render_device(cam, SEED, integrator, tile.data_ptr(), stream)
-        st = ctx.render_finish()
-        if world > 1:
-            dist.gather(tile, gathered, dst=0)  # the single collective of the data path
-        return st
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats_acc.append(step())
-    sync()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(sum(s["rays"] for s in stats_acc)), float(sum(s["paths"] for s in stats_acc)),
-                         float(sum(s["kernel_ms"] for s in stats_acc)), float(sum(s["knn_searches"] for s in stats_acc))],
-                        dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kmax = rays[2:3].clone()
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        rays[2] = kmax[0]
-    elapsed = float(t.item())
-    total_rays, total_paths, kernel_ms_sum, total_knn = float(rays[0]), float(rays[1]), float(rays[2]), float(rays[3])
-
+    single = world == 1
+    result, ref_threads = measure(args.workload, args, m, tiling, rank, world, local_rank, dist, args.steps, args.warmup,
+                                  want_cpu=single and not args.no_cpu, want_counters=single and not args.no_counters, headline=True)
+    if single and args.workload == "c2" and not args.no_secondary:
+        # driver-timed legs on the kernels that walk trees in HBM / search photon maps (their own step counts: C3 is 8 s a frame)
+        result["secondary"] = {}
+        for name in SECONDARY:
+            t0 = time.perf_counter()
+            try:
+                leg, _ = measure(name, args, m, tiling, rank, world, local_rank, dist, args.secondary_steps, 1,
+                                 want_cpu=not args.no_cpu, want_counters=not args.no_counters, headline=False, ref_threads=ref_threads)
+                leg["leg_wall_s"] = time.perf_counter() - t0
+                for k in ("metric", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus"):
+                    leg.pop(k, None)
+            except Exception as ex:  # a leg that cannot run here (scene image absent) must not cost the headline
+                leg = {"error": repr(ex)}
+            result["secondary"][name] = leg
     if rank == 0:
-        # sanity: the gathered frame is complete and finite
-        if world > 1:
-            frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
-            for r in range(world):
-                rows = torch.from_numpy(tiling.rows_of(full, r, world, SHARD_ROWS)).to(dev)
-                frame[rows] = gathered[r][: len(rows)]
-        else:
-            frame = tile[: len(my_rows)]
-        finite = bool(torch.isfinite(frame).all().item())
-        mean = float(frame.mean().item())
-
-        result = {
-            "metric": "Mray/s (whole node), 1920x1080 @ 256 spp path trace" if args.workload.startswith("c2") else "Mray/s (whole node)",
-            "value": total_rays / elapsed / 1e6,
-            "unit": "Mray/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": desc, "width": W, "height": H, "spp": sqrtspp ** 2, "integrator": "photon_mapper" if photon_workload else "path_tracer",
-                       "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
-                       "rays_per_step": total_rays / args.steps, "paths_per_step": total_paths / args.steps,
-                       "frame_mean_radiance": mean, "frame_finite": finite,
-                       "knn_searches_per_s": total_knn / elapsed if total_knn else None,
-                       "photon_pass": emit_info if photon_workload else None},
-        }
-        counts = None
-        if world == 1 and not args.no_cpu:
-            base, counts = cpu_baseline(m, img, full, args.cpu_seconds, integrator, pm_maps)
-            result["cpu_baseline"] = base
-        if counts is None:
-            # per-ray counts of the reference-equivalent traversal measured on this workload by the oracle
-            # (DESIGN.md "Measurement"); used when the CPU leg is skipped (N > 1)
-            counts = {"spaceship": dict(node_per_ray=33.44, tri_per_ray=6.96, sphere_per_ray=0.0),
-                      "c3": dict(node_per_ray=46.28, tri_per_ray=7.17, sphere_per_ray=0.02),
-                      "c4": dict(node_per_ray=71.99, tri_per_ray=14.22, sphere_per_ray=0.0),
-                      "c5": dict(node_per_ray=45.05, tri_per_ray=7.28, sphere_per_ray=0.0),
-                      "pm": dict(node_per_ray=14.34, tri_per_ray=9.30, sphere_per_ray=7.40),
-                      }.get(args.workload, dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31))
-        b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
-        launches = args.steps * 1  # one integrator launch per step per GPU
-        kernel_ms = kernel_ms_sum / launches
-        rays_per_launch = total_rays / args.steps / world
-        achieved = rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if world == 1 and args.workload in tj:
-                traffic = tj[args.workload]["traffic_bytes"]
-        except Exception:
-            pass
-        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                              "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time; "
-                                      "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/). Scenes that fit in LDS "
-                                      "move almost nothing through HBM, so frac can exceed 1 for them.",
-                              "kernel": {"pm": "renderKernelPM", "c5": "renderKernelPM", "spaceship": "renderKernelSM", "c3": "wfTraceKernel + wfShadeKernel (all launches of the frame)",
-                                         "c4": "wfTraceKernel + wfShadeKernel (all launches of the frame)"}.get(args.workload, "renderKernel<path_tracer, flat>"),
-                              "kernel_ms": kernel_ms,
-                              "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
-                              "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")}}
-        if counts.get("knn_photons_per_search"):
-            # B_knn = n_octant*128 + n_photon_scanned*32 + k*32 per search (reference-equivalent counts)
-            b_knn = counts["knn_octants_per_search"] * 128 + counts["knn_photons_per_search"] * 32 + 50 * 32
-            knn_rate = total_knn / args.steps / world / (kernel_ms * 1e-3)
-            result["roofline"]["knn"] = {"bytes_per_search": b_knn, "searches_per_s_in_kernel": knn_rate,
-                                          "achieved_GBs_incl_knn": achieved + knn_rate * b_knn / 1e9}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -173,8 +173,21 @@ typedef struct mcrt_stats {
     double   kernel_ms;     /* HIP-event time of the integrator kernel(s) on their stream      */
     double   total_ms;      /* wall time of the call incl. copies                              */
     uint32_t kernel_launches;
-    uint32_t reserved;
+    uint32_t kernel_id;     /* MCRT_KERNEL_*: which kernel form traced the frame (tests pin it, so a silent
+                             * change of the selection rule in launchRender cannot pass unnoticed)            */
 } mcrt_stats;
+
+/* Kernel forms of the integrator; mcrt_stats.kernel_id of the last mcrt_render*. */
+enum {
+    MCRT_KERNEL_NONE = 0,          /* nothing launched (a shard that owns no rows)                                   */
+    MCRT_KERNEL_FLAT = 1,          /* renderKernel, flat-scene instance: wave-uniform loop over all primitives, scene in LDS */
+    MCRT_KERNEL_WAVESYNC = 2,      /* renderKernel<path tracer>, wave-synchronous bounce loop (MCRT_KERNEL=legacy, instrumented runs) */
+    MCRT_KERNEL_LANE_SM = 3,       /* renderKernelSM: per-lane state machine megakernel                               */
+    MCRT_KERNEL_WAVEFRONT = 4,     /* wfShadeKernel + wfTraceKernel over the slot pool                               */
+    MCRT_KERNEL_PM_WAVE = 5,       /* renderKernelPM: photon mapper, wave-cooperative kNN estimates                  */
+    MCRT_KERNEL_PM_LANE = 6,       /* renderKernel<photon mapper>: per-lane kNN (k > 128, MCRT_KERNEL=legacy)        */
+    MCRT_KERNEL_WAVEFRONT_PM = 7   /* wavefront pipeline with kNN launches (MCRT_KERNEL=wf, photon-mapped frames)    */
+};
 
 typedef struct mcrt_ctx mcrt_ctx; /* opaque; owns all device memory and one HIP stream */
 

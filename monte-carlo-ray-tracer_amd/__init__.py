@@ -22,6 +22,11 @@ ABI_VERSION = 2
 FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
+# mcrt_stats.kernel_id (include/mcrt.h MCRT_KERNEL_*)
+KERNEL_NONE, KERNEL_FLAT, KERNEL_WAVESYNC, KERNEL_LANE_SM, KERNEL_WAVEFRONT, KERNEL_PM_WAVE, KERNEL_PM_LANE, KERNEL_WAVEFRONT_PM = range(8)
+KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernel<path_tracer, flat>", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
+                KERNEL_LANE_SM: "renderKernelSM", KERNEL_WAVEFRONT: "wfTraceKernel + wfShadeKernel", KERNEL_PM_WAVE: "renderKernelPM",
+                KERNEL_PM_LANE: "renderKernel<photon_mapper>", KERNEL_WAVEFRONT_PM: "wfTraceKernel + wfKnnKernel + wfShadeKernel"}
 SURF_TRIANGLE, SURF_SPHERE = 0, 1
 NO_SURFACE = 0xFFFFFFFF
 
@@ -102,7 +107,7 @@ class Stats(C.Structure):
         ("paths", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
         ("prim_tests", C.c_uint64), ("knn_searches", C.c_uint64),
         ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-        ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32),
+        ("kernel_launches", C.c_uint32), ("kernel_id", C.c_uint32),
     ]
 
     def as_dict(self):

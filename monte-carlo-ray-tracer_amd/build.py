@@ -36,15 +36,54 @@ def sources():
     return src
 
 
+TUS = ["mcrt_hip.hip", "mcrt_octree_gpu.hip", "mcrt_output.hip", "mcrt_multi.hip", "mcrt_image.cpp", "mcrt_octree.cpp", "mcrt_bvh.cpp"]
+OBJ = os.path.join(CSRC, "_obj")
+
+
+def _deps_of(depfile):
+    """Prerequisites listed in a make-style dependency file written by `hipcc -MD -MF`."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    return [t for t in text.split(":", 1)[1].split() if t] if ":" in text else None
+
+
+def _stale(obj, depfile):
+    deps = _deps_of(depfile)
+    if deps is None or not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
 def build_lib(force=False, verbose=True):
-    deps = sources()
-    if not force and _newer(LIB, deps):
-        return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "mcrt_hip.hip"), os.path.join(CSRC, "mcrt_octree_gpu.hip"), os.path.join(CSRC, "mcrt_output.hip"), os.path.join(CSRC, "mcrt_multi.hip"),
-                                         os.path.join(CSRC, "mcrt_image.cpp"), os.path.join(CSRC, "mcrt_octree.cpp"), os.path.join(CSRC, "mcrt_bvh.cpp")]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    """One object per translation unit (compiled side by side, only the stale ones — hipcc's own -MD dependency files
+    decide), then one link. The objects stay under csrc/_obj/ (git-ignored)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = []
+    for tu in TUS:
+        obj = os.path.join(OBJ, tu + ".o")
+        dep = os.path.join(OBJ, tu + ".d")
+        if force or _stale(obj, dep):
+            jobs.append([hipcc] + flags + ["-MD", "-MF", dep, "-c", os.path.join(CSRC, tu), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, tu + ".o") for tu in TUS]
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

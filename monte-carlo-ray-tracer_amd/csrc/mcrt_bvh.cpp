@@ -12,10 +12,11 @@
 
 using namespace mcrt;
 
-struct mcrt_scene {
+struct mcrt_scene {  // owns every array its descriptor points into
     std::vector<uint8_t> kind, interp;
-    std::vector<uint32_t> material, light_surface;
-    std::vector<double> area, v, e, vn;
+    std::vector<uint32_t> material, light_surface, node_start, node_count, node_next;
+    std::vector<double> area, v, e, vn, node_bounds, light_cdf, quadrics;
+    std::vector<mcrt_material> materials;
     mcrt_scene_desc desc;
 };
 
@@ -370,42 +371,64 @@ const mcrt_bvh_desc* mcrt_bvh_get(const mcrt_bvh* bvh) { return bvh ? &bvh->desc
 void mcrt_bvh_free(mcrt_bvh* bvh) { delete bvh; }
 
 int mcrt_scene_with_bvh(const mcrt_scene_desc* s, const mcrt_bvh_desc* bvh, mcrt_scene** out) {
-    if (!out || !s || !bvh || bvh->num_surfaces != s->num_surfaces || !bvh->order || !s->surf_interpolate || !s->surf_material || !s->surf_area ||
-        !s->surf_e)
+    if (!out) return MCRT_ERR_INVALID;
+    *out = nullptr;
+    if (!s || !bvh || bvh->num_surfaces != s->num_surfaces || !bvh->order || !s->surf_kind || !s->surf_v || !s->surf_interpolate ||
+        !s->surf_material || !s->surf_area || !s->surf_e || !s->materials || s->num_materials == 0)
         return MCRT_ERR_INVALID;
+    if (bvh->num_nodes && (!bvh->node_bounds || !bvh->node_start_surface || !bvh->node_num_surfaces || !bvh->node_next_sibling)) return MCRT_ERR_INVALID;
+    if (s->num_lights && (!s->light_surface || !s->light_cdf)) return MCRT_ERR_INVALID;
+    if (s->num_quadrics && !s->quadrics) return MCRT_ERR_INVALID;
     const size_t n = s->num_surfaces;
-    mcrt_scene* S = new mcrt_scene();
-    S->kind.resize(n);
-    S->interp.resize(n);
-    S->material.resize(n);
-    S->area.resize(n);
-    S->v.resize(n * 9);
-    S->e.resize(n * 9);
-    if (s->surf_vn) S->vn.resize(n * 9);
-    std::vector<uint32_t> where(n);  // input index -> new position
-    for (size_t i = 0; i < n; i++) {
-        const size_t src = bvh->order[i];
-        if (src >= n) {
-            delete S;
-            return MCRT_ERR_INVALID;
+    for (uint32_t i = 0; i < s->num_lights; i++)
+        if (s->light_surface[i] >= n) return MCRT_ERR_INVALID;
+    mcrt_scene* S = nullptr;
+    try {
+        S = new mcrt_scene();
+        S->kind.resize(n);
+        S->interp.resize(n);
+        S->material.resize(n);
+        S->area.resize(n);
+        S->v.resize(n * 9);
+        S->e.resize(n * 9);
+        if (s->surf_vn) S->vn.resize(n * 9);
+        std::vector<uint32_t> where(n, 0xFFFFFFFFu);  // input index -> new position
+        for (size_t i = 0; i < n; i++) {
+            const size_t src = bvh->order[i];
+            if (src >= n || where[src] != 0xFFFFFFFFu) {  // order must be a permutation
+                delete S;
+                return MCRT_ERR_INVALID;
+            }
+            where[src] = (uint32_t)i;
+            S->kind[i] = s->surf_kind[src];
+            S->interp[i] = s->surf_interpolate[src];
+            S->material[i] = s->surf_material[src];
+            S->area[i] = s->surf_area[src];
+            memcpy(&S->v[i * 9], s->surf_v + src * 9, 72);
+            memcpy(&S->e[i * 9], s->surf_e + src * 9, 72);
+            if (s->surf_vn) memcpy(&S->vn[i * 9], s->surf_vn + src * 9, 72);
         }
-        where[src] = (uint32_t)i;
-        S->kind[i] = s->surf_kind[src];
-        S->interp[i] = s->surf_interpolate[src];
-        S->material[i] = s->surf_material[src];
-        S->area[i] = s->surf_area[src];
-        memcpy(&S->v[i * 9], s->surf_v + src * 9, 72);
-        memcpy(&S->e[i * 9], s->surf_e + src * 9, 72);
-        if (s->surf_vn) memcpy(&S->vn[i * 9], s->surf_vn + src * 9, 72);
+        S->light_surface.resize(s->num_lights);
+        for (uint32_t i = 0; i < s->num_lights; i++) S->light_surface[i] = where[s->light_surface[i]];
+        // the result owns everything: the caller may free `bvh` and the source descriptor's arrays afterwards
+        const size_t nn = bvh->num_nodes;
+        S->node_bounds.assign(bvh->node_bounds, bvh->node_bounds + nn * 6);
+        S->node_start.assign(bvh->node_start_surface, bvh->node_start_surface + nn);
+        S->node_count.assign(bvh->node_num_surfaces, bvh->node_num_surfaces + nn);
+        S->node_next.assign(bvh->node_next_sibling, bvh->node_next_sibling + nn);
+        S->materials.assign(s->materials, s->materials + s->num_materials);
+        if (s->num_lights) S->light_cdf.assign(s->light_cdf, s->light_cdf + s->num_lights);
+        if (s->num_quadrics) S->quadrics.assign(s->quadrics, s->quadrics + (size_t)s->num_quadrics * 22);
+    } catch (...) {
+        delete S;
+        return MCRT_ERR_INVALID;
     }
-    S->light_surface.resize(s->num_lights);
-    for (uint32_t i = 0; i < s->num_lights; i++) S->light_surface[i] = where[s->light_surface[i]];
-    S->desc = *s;  // materials, light_cdf, quadrics, scalars stay the caller's arrays
+    S->desc = *s;  // scalars and counts
     S->desc.num_nodes = bvh->num_nodes;
-    S->desc.node_bounds = bvh->node_bounds;
-    S->desc.node_start_surface = bvh->node_start_surface;
-    S->desc.node_num_surfaces = bvh->node_num_surfaces;
-    S->desc.node_next_sibling = bvh->node_next_sibling;
+    S->desc.node_bounds = S->node_bounds.data();
+    S->desc.node_start_surface = S->node_start.data();
+    S->desc.node_num_surfaces = S->node_count.data();
+    S->desc.node_next_sibling = S->node_next.data();
     S->desc.surf_kind = S->kind.data();
     S->desc.surf_interpolate = S->interp.data();
     S->desc.surf_material = S->material.data();
@@ -413,7 +436,10 @@ int mcrt_scene_with_bvh(const mcrt_scene_desc* s, const mcrt_bvh_desc* bvh, mcrt
     S->desc.surf_v = S->v.data();
     S->desc.surf_e = S->e.data();
     S->desc.surf_vn = s->surf_vn ? S->vn.data() : nullptr;
+    S->desc.materials = S->materials.data();
     S->desc.light_surface = S->light_surface.data();
+    S->desc.light_cdf = s->num_lights ? S->light_cdf.data() : nullptr;
+    S->desc.quadrics = s->num_quadrics ? S->quadrics.data() : nullptr;
     *out = S;
     return MCRT_OK;
 }

@@ -96,6 +96,7 @@ struct mcrt_ctx {
     bool pending = false;
     std::chrono::steady_clock::time_point t_begin;
     uint32_t launches = 0;
+    uint32_t kernel_id = MCRT_KERNEL_NONE;  // kernel form of the last render (mcrt_stats.kernel_id)
 };
 
 namespace {
@@ -120,6 +121,17 @@ int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
     return MCRT_OK;
 }
 
+
+// Control words of the wavefront pipeline, one allocation of this size wherever it is made: {count[2], pop, -} per half of
+// the pool (words 0..3 and 4..7; the photon mapper uses 4..6 as {rcount[2], rpop}). mcrt_intersect uses words 0..3.
+constexpr size_t kWfCtrlWords = 8;
+
+// Operator-level entry points and the emission pass share the context's stats buffer, events and scratch with a render:
+// they are refused while one is in flight.
+#define REJECT_IF_PENDING(ctx, what)                                                                                  \
+    do {                                                                                                              \
+        if ((ctx)->pending) return fail(ctx, MCRT_ERR_INVALID, what ": a render is in flight, call mcrt_render_finish first"); \
+    } while (0)
 
 struct LaunchGeom {
     uint32_t grid, lds_bytes, total_lanes, block = kBlock;
@@ -279,6 +291,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
     ctx->t_begin = std::chrono::steady_clock::now();
     ctx->launches = 0;
+    ctx->kernel_id = owned_rows == 0 ? MCRT_KERNEL_NONE : photon ? MCRT_KERNEL_WAVEFRONT_PM : MCRT_KERNEL_WAVEFRONT;
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -314,11 +327,11 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * sizeof(uint32_t)));
         ctx->wf_slots = (uint32_t)slots;
     }
-    if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(8 * sizeof(unsigned long long)));
+    if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
     if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), 2 * sizeof(unsigned long long)));
     auto runPass = [&]() -> int {  // the rows [fr.row_base, fr.row_end): shade / trace launches until nothing is queued
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, kWfCtrlWords * sizeof(unsigned long long), stream));
     // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
 
@@ -526,6 +539,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for path-traced frames with a reconstruction filter (film_filter != box)");
     if (filtered && ctx->scene.num_nodes == 0)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for scenes with a BVH");
+    // Film::Film(w, h, json) with "filter": "box" and a radius other than the default 0.5 splats too (film.cpp:27-30); that case
+    // is not built, so it is refused rather than rendered as the default box
+    if (!filtered && cam->film_radius != 0.0 && cam->film_radius != 0.5)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "box film filter with a radius other than 0.5 (film_radius 0 = default) is not supported");
+    if (filtered && photon && ctx->k_nearest > 128)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters on photon-mapped frames need k_nearest_photons <= 128 (wavefront pipeline)");
     const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
@@ -629,6 +648,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         prm.knn_visit_d2 = ctx->knn_visit_d2.as<double>();
         prm.knn_visit_oct = ctx->knn_visit_oct.as<uint32_t>();
     }
+    ctx->kernel_id = prm.owned_rows == 0 ? MCRT_KERNEL_NONE
+                     : use_pm_wave   ? MCRT_KERNEL_PM_WAVE
+                     : photon        ? MCRT_KERNEL_PM_LANE
+                     : use_sm        ? MCRT_KERNEL_LANE_SM
+                     : flat_only     ? MCRT_KERNEL_FLAT
+                                     : MCRT_KERNEL_WAVESYNC;
     if (prm.owned_rows == 0) {
         ctx->pending = true;
         ctx->launches = 0;
@@ -841,6 +866,7 @@ const char* mcrt_last_error(const mcrt_ctx* ctx) { return ctx ? ctx->error.c_str
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!s || s->abi_version != MCRT_ABI_VERSION) return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: wrong abi_version");
+    REJECT_IF_PENDING(ctx, "mcrt_upload_scene");
     if (s->num_surfaces == 0 || !s->surf_kind || !s->surf_interpolate || !s->surf_material || !s->surf_area || !s->surf_v || !s->surf_e ||
         !s->materials || s->num_materials == 0)
         return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: missing surface/material arrays");
@@ -949,6 +975,7 @@ int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map, c
                         uint32_t k_nearest_photons, int direct_visualization) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (k_nearest_photons == 0) return fail(ctx, MCRT_ERR_INVALID, "k_nearest_photons must be > 0");
+    REJECT_IF_PENDING(ctx, "mcrt_upload_photons");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->has_photons = false;
     ctx->k_nearest = k_nearest_photons;  // before the maps: the search's record lists expand octants with more than k photons
@@ -1029,6 +1056,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count();
         stats->kernel_launches = ctx->launches;
+        stats->kernel_id = ctx->kernel_id;
     }
     if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
     return MCRT_OK;
@@ -1069,6 +1097,7 @@ int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_fact
     if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
     if (shard_count == 0 || shard_index >= shard_count) return fail(ctx, MCRT_ERR_INVALID, "shard_index >= shard_count");
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_emit_photons before mcrt_upload_scene");
+    REJECT_IF_PENDING(ctx, "mcrt_emit_photons");
     if (!(emissions >= 0.0) || !(caustic_factor > 0.0)) return fail(ctx, MCRT_ERR_INVALID, "emissions must be >= 0 and caustic_factor > 0");
     memset(out, 0, sizeof(*out));
     const uint32_t nl = ctx->scene.num_lights;
@@ -1171,6 +1200,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
                    double* out_uv) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_intersect before mcrt_upload_scene");
+    REJECT_IF_PENDING(ctx, "mcrt_intersect");
     if (n == 0) return MCRT_OK;
     if (!start || !direction || !out_t || !out_surface) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1185,7 +1215,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         HIP_TRY(ctx, dt.alloc(n * 8));
         HIP_TRY(ctx, dsf.alloc(n * 4));
         HIP_TRY(ctx, duv.alloc(n * 16));
-        if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(4 * sizeof(unsigned long long)));
+        if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
         const unsigned long long ctrl_init[4] = {n, 0ull, 0ull, 0ull};
         HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_ctrl.p, ctrl_init, sizeof(ctrl_init), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->stats.p, 0, kStatsWords * sizeof(unsigned long long), ctx->stream));
@@ -1231,6 +1261,7 @@ int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_
     if (!ctx) return MCRT_ERR_INVALID;
     if (n == 0) return MCRT_OK;
     if (!pixel || !index || !out) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    REJECT_IF_PENDING(ctx, "mcrt_sampler");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dp, di, dout;
     if (int rc = uploadArray(ctx, dp, pixel, n)) return rc;
@@ -1249,6 +1280,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
              double* out_distance2) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "mcrt_knn before mcrt_upload_photons");
+    REJECT_IF_PENDING(ctx, "mcrt_knn");
     if (which < 0 || which > 1 || k == 0) return fail(ctx, MCRT_ERR_INVALID, "bad map selector or k");
     if (n == 0) return MCRT_OK;
     if (!p || !out_count || !out_index || !out_distance2) return fail(ctx, MCRT_ERR_INVALID, "null argument");

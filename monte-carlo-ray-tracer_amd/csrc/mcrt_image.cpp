@@ -6,6 +6,7 @@
 #include "../../include/mcrt.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -106,48 +107,63 @@ extern "C" {
 
 uint32_t mcrt_abi_version(void) { return MCRT_ABI_VERSION; }
 
-int mcrt_image_load(const char* path, mcrt_image** out) {
-    if (!path || !out) return MCRT_ERR_INVALID;
-    *out = nullptr;
+// The file is untrusted input: every chunk size is bounded by the file size, every array is checked against the element
+// count its sibling arrays derive (a truncated or mismatched image would otherwise make buildLayout / uploadArray read past
+// the host buffers), and nothing thrown by the containers crosses the C boundary.
+static int imageLoadImpl(const char* path, mcrt_image** out) {
     FILE* f = fopen(path, "rb");
     if (!f) return MCRT_ERR_IO;
+    struct Closer {
+        FILE* f;
+        ~Closer() { fclose(f); }
+    } closer{f};
+    if (fseek(f, 0, SEEK_END) != 0) return MCRT_ERR_IO;
+    const long file_size = ftell(f);
+    if (file_size < 16 || fseek(f, 0, SEEK_SET) != 0) return MCRT_ERR_IO;
     char magic[8];
     uint32_t abi = 0, num_chunks = 0;
     bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0;
     ok = ok && fread(&abi, 4, 1, f) == 1 && fread(&num_chunks, 4, 1, f) == 1;
-    if (!ok || abi != kImageVersion) {
-        fclose(f);
-        return MCRT_ERR_IO;
-    }
-    mcrt_image* img = new mcrt_image();
-    for (uint32_t c = 0; c < num_chunks && ok; c++) {
+    if (!ok || abi != kImageVersion) return MCRT_ERR_IO;
+    struct Holder {  // frees the image on every early return
+        mcrt_image* p;
+        ~Holder() { delete p; }
+    } hold{new mcrt_image()};
+    mcrt_image* img = hold.p;
+    for (uint32_t c = 0; c < num_chunks; c++) {
         char nm[25];
         uint64_t nb = 0;
         memset(nm, 0, sizeof(nm));
-        ok = fread(nm, 1, 24, f) == 24 && fread(&nb, 8, 1, f) == 1;
-        if (!ok) break;
+        if (fread(nm, 1, 24, f) != 24 || fread(&nb, 8, 1, f) != 1) return MCRT_ERR_IO;
+        const long at = ftell(f);
+        if (at < 0 || nb > (uint64_t)(file_size - at)) return MCRT_ERR_IO;  // a chunk cannot be larger than what is left of the file
         Chunk& ch = img->chunks[nm];
-        ch.bytes.resize(nb);
-        ok = nb == 0 || fread(ch.bytes.data(), 1, nb, f) == nb;
-        size_t pad = (8 - nb % 8) % 8;
-        if (ok && pad) ok = fseek(f, (long)pad, SEEK_CUR) == 0;
+        ch.bytes.resize((size_t)nb);
+        if (nb && fread(ch.bytes.data(), 1, (size_t)nb, f) != nb) return MCRT_ERR_IO;
+        const size_t pad = (8 - nb % 8) % 8;
+        if (pad && fseek(f, (long)pad, SEEK_CUR) != 0) return MCRT_ERR_IO;
     }
-    fclose(f);
-    if (!ok) {
-        delete img;
-        return MCRT_ERR_IO;
-    }
-
+    auto chunkBytes = [&](const char* name) -> uint64_t {
+        auto it = img->chunks.find(name);
+        return it == img->chunks.end() ? 0ull : (uint64_t)it->second.bytes.size();
+    };
+    // exact(name, count, elem): the chunk holds exactly count elements; optional chunks may also be absent
+    auto exact = [&](const char* name, uint64_t count, uint64_t elem, bool optional = false) {
+        const uint64_t b = chunkBytes(name);
+        return (optional && b == 0) || b == count * elem;
+    };
     mcrt_scene_desc& s = img->scene;
     memset(&s, 0, sizeof(s));
     s.abi_version = MCRT_ABI_VERSION;
     size_t n = 0;
     s.node_bounds = chunkPtr<double>(img, "node_bounds", &n);
+    if (n % 6 || n / 6 > 0xFFFFFFFFull) return MCRT_ERR_IO;
     s.num_nodes = (uint32_t)(n / 6);
     s.node_start_surface = chunkPtr<uint32_t>(img, "node_start");
     s.node_num_surfaces = chunkPtr<uint32_t>(img, "node_count");
     s.node_next_sibling = chunkPtr<uint32_t>(img, "node_next");
     s.surf_kind = chunkPtr<uint8_t>(img, "surf_kind", &n);
+    if (n == 0 || n > 0xFFFFFFFFull) return MCRT_ERR_IO;
     s.num_surfaces = (uint32_t)n;
     s.surf_interpolate = chunkPtr<uint8_t>(img, "surf_interp");
     s.surf_material = chunkPtr<uint32_t>(img, "surf_material");
@@ -156,10 +172,17 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
     s.surf_e = chunkPtr<double>(img, "surf_e");
     s.surf_vn = chunkPtr<double>(img, "surf_vn");
     s.materials = chunkPtr<mcrt_material>(img, "materials", &n);
+    if (n == 0 || chunkBytes("materials") % sizeof(mcrt_material) || n > 0xFFFFFFFFull) return MCRT_ERR_IO;
     s.num_materials = (uint32_t)n;
     s.light_surface = chunkPtr<uint32_t>(img, "light_surface", &n);
+    if (chunkBytes("light_surface") % 4 || n > 0xFFFFFFFFull) return MCRT_ERR_IO;
     s.num_lights = (uint32_t)n;
     s.light_cdf = chunkPtr<double>(img, "light_cdf");
+    const uint64_t nn = s.num_nodes, ns = s.num_surfaces;
+    if (!exact("node_start", nn, 4) || !exact("node_count", nn, 4) || !exact("node_next", nn, 4) || !exact("surf_interp", ns, 1) ||
+        !exact("surf_material", ns, 4) || !exact("surf_area", ns, 8) || !exact("surf_v", ns * 9, 8) || !exact("surf_e", ns * 9, 8) ||
+        !exact("surf_vn", ns * 9, 8, true) || !exact("light_cdf", s.num_lights, 8))
+        return MCRT_ERR_IO;
     const double* sc = chunkPtr<double>(img, "scene_scalars", &n);
     if (sc && n >= 7) {
         s.scene_ior = sc[0];
@@ -169,16 +192,31 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
         }
     }
     s.quadrics = chunkPtr<double>(img, "quadrics", &n);
+    if (chunkBytes("quadrics") % (22 * 8)) return MCRT_ERR_IO;
     s.num_quadrics = (uint32_t)(n / 22);
     // the camera record has grown over time (film filter fields): take what the file has, the rest stays zero (= box filter)
     memset(&img->camera, 0, sizeof(img->camera));
     {
         auto it = img->chunks.find("camera");
-        if (it != img->chunks.end())
+        if (it != img->chunks.end()) {
+            if (it->second.bytes.size() < offsetof(mcrt_camera_desc, film_filter)) return MCRT_ERR_IO;  // shorter than the first version of the record
             memcpy(&img->camera, it->second.bytes.data(), std::min(it->second.bytes.size(), sizeof(img->camera)));
+            const mcrt_camera_desc& cam = img->camera;
+            if (cam.width == 0 || cam.height == 0 || cam.sqrtspp == 0 || (uint64_t)cam.width * cam.height > 0xFFFFFFFFull ||
+                cam.sqrtspp > 65535u || cam.film_filter > MCRT_FILM_LANCZOS)
+                return MCRT_ERR_IO;
+        }
     }
-    img->has_map[0] = loadMap(img, "g_", &img->maps[0]);
-    img->has_map[1] = loadMap(img, "c_", &img->maps[1]);
+    for (int w = 0; w < 2; w++) {
+        const std::string p(w == 0 ? "g_" : "c_");
+        img->has_map[w] = loadMap(img, p.c_str(), &img->maps[w]);
+        if (chunkBytes((p + "oct_bounds").c_str()) == 0) continue;  // no such map in the file
+        const uint64_t no = chunkBytes((p + "oct_bounds").c_str()) / 48;
+        if (!img->has_map[w] || chunkBytes((p + "oct_bounds").c_str()) % 48 || no > 0xFFFFFFFFull || !exact((p + "oct_start").c_str(), no, 8) ||
+            !exact((p + "oct_contained").c_str(), no, 8) || !exact((p + "oct_next").c_str(), no, 4) || !exact((p + "oct_leaf").c_str(), no, 1) ||
+            chunkBytes((p + "photons").c_str()) % 32)
+            return MCRT_ERR_IO;
+    }
     const ParamKV* kv = chunkPtr<ParamKV>(img, "params", &n);
     for (size_t i = 0; kv && i < n; i++) {
         char key[25];
@@ -186,17 +224,24 @@ int mcrt_image_load(const char* path, mcrt_image** out) {
         memcpy(key, kv[i].key, 24);
         img->params[key] = kv[i].value;
     }
-    bool scene_ok = s.num_surfaces > 0 && s.surf_kind && s.surf_interpolate && s.surf_material &&
-                    s.surf_area && s.surf_v && s.surf_e && s.materials &&
-                    (s.num_nodes == 0 ||
-                     (s.node_start_surface && s.node_num_surfaces && s.node_next_sibling)) &&
-                    (s.num_lights == 0 || s.light_cdf);
-    if (!scene_ok) {
-        delete img;
-        return MCRT_ERR_IO;
-    }
+    const bool scene_ok = s.surf_kind && s.surf_interpolate && s.surf_material && s.surf_area && s.surf_v && s.surf_e && s.materials &&
+                          (s.num_nodes == 0 || (s.node_start_surface && s.node_num_surfaces && s.node_next_sibling)) &&
+                          (s.num_lights == 0 || s.light_cdf);
+    if (!scene_ok) return MCRT_ERR_IO;
+    hold.p = nullptr;
     *out = img;
     return MCRT_OK;
+}
+
+int mcrt_image_load(const char* path, mcrt_image** out) {
+    if (!path || !out) return MCRT_ERR_INVALID;
+    *out = nullptr;
+    try {
+        return imageLoadImpl(path, out);
+    } catch (...) {  // length_error / bad_alloc from the containers
+        *out = nullptr;
+        return MCRT_ERR_IO;
+    }
 }
 
 void mcrt_image_free(mcrt_image* img) { delete img; }

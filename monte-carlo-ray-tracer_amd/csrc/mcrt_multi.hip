@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,7 +31,7 @@ extern "C" int mcrt_render_multi(mcrt_ctx* const* ctxs, uint32_t count, const mc
     std::vector<int> rc(count, MCRT_OK);
     std::vector<mcrt_stats> st(count);
     std::vector<std::vector<double>> rgbw(splats ? count : 0);
-    auto work = [&](uint32_t i) {
+    auto workBody = [&](uint32_t i) {
         mcrt_camera_desc shard = *cam;
         shard.shard_index = i;
         shard.shard_count = count;
@@ -54,8 +55,23 @@ extern "C" int mcrt_render_multi(mcrt_ctx* const* ctxs, uint32_t count, const mc
         }
         (void)hipFree(d);
     };
+    auto work = [&](uint32_t i) {  // a worker thread must not let an exception (bad_alloc from resize) reach std::terminate
+        try {
+            workBody(i);
+        } catch (const std::exception& e) {
+            rc[i] = ctxFail(ctxs[i], MCRT_ERR_HIP, std::string("mcrt_render_multi: ") + e.what());
+        } catch (...) {
+            rc[i] = ctxFail(ctxs[i], MCRT_ERR_HIP, "mcrt_render_multi: unknown exception in a worker");
+        }
+    };
     std::vector<std::thread> pool;
-    for (uint32_t i = 1; i < count; i++) pool.emplace_back(work, i);
+    try {
+        pool.reserve(count);
+        for (uint32_t i = 1; i < count; i++) pool.emplace_back(work, i);
+    } catch (const std::exception& e) {  // std::system_error: no more threads
+        for (auto& t : pool) t.join();
+        return ctxFail(first, MCRT_ERR_HIP, std::string("mcrt_render_multi: cannot start a worker thread: ") + e.what());
+    }
     work(0);
     for (auto& t : pool) t.join();
     for (uint32_t i = 0; i < count; i++)
@@ -78,6 +94,7 @@ extern "C" int mcrt_render_multi(mcrt_ctx* const* ctxs, uint32_t count, const mc
             stats->prim_tests += st[i].prim_tests;
             stats->knn_searches += st[i].knn_searches;
             stats->kernel_launches += st[i].kernel_launches;
+            if (st[i].kernel_id != MCRT_KERNEL_NONE) stats->kernel_id = st[i].kernel_id;  // same scene, same rule: one form
             stats->kernel_ms = std::max(stats->kernel_ms, st[i].kernel_ms);  // the contexts run side by side
             stats->total_ms = std::max(stats->total_ms, st[i].total_ms);
         }

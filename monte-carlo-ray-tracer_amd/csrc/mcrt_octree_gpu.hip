@@ -81,7 +81,8 @@ extern "C" int mcrt_photon_map_build_gpu(mcrt_ctx* ctx, const float* photons, ui
     if (!ctx) return MCRT_ERR_INVALID;
     if (!out || (num_photons && !photons) || !bb_min || !bb_max || max_photons_per_leaf == 0)
         return ctxFail(ctx, MCRT_ERR_INVALID, "mcrt_photon_map_build_gpu: null argument or zero leaf capacity");
-    if (num_photons > 0xFFFFFFFEull) return ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "photon map larger than 2^32-2 photons per GPU");
+    // hipcub::DeviceRadixSort takes the item count as an int
+    if (num_photons > 0x7FFFFFFFull) return ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "photon map larger than 2^31-1 photons per GPU (radix sort item count)");
     mcrt_photon_map* M = new mcrt_photon_map();
     if (num_photons == 0) {
         finishMapDesc(M);
@@ -190,6 +191,7 @@ __global__ void gatherBoxKernel(const double* in, const uint32_t* index, uint64_
 int mcrt::bvhOctreeGpu(mcrt_ctx* ctx, const mcrt_scene_desc* s, mcrt_bvh* B) {
     BVH_TRY(hipSetDevice(ctxDevice(ctx)));
     const uint64_t n = s->num_surfaces;
+    if (n > 0x7FFFFFFFull) return ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "more than 2^31-1 surfaces (radix sort item count)");
     Dev d_kind, d_v, d_q, d_bb, d_bb2, d_keys, d_keys2, d_idx, d_idx2, d_tmp;
     BVH_TRY(d_kind.alloc(n));
     BVH_TRY(d_v.alloc(n * 72));

@@ -32,6 +32,7 @@ def test_spaceship_matches_reference(pkg, spaceship):
     print("spaceship: max rel %.3e, outliers %d / %d, %.1f Mray/s, %.2f rays/path" %
           (rel.max(), bad, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
     assert bad <= int(0.002 * rel.size)
+    assert st["kernel_id"] == pkg.KERNEL_LANE_SM  # 23 187 nodes: the state-machine megakernel walks the tree
     ctx.close()
 
 
@@ -72,6 +73,7 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
     @ 1024 spp; C5: 6 898 815 triangles, photon-mapped — against the reference's radiance for the same rows
     (committed goldens made by tests/large/make_large.py)."""
+    kernel = None
     if ":" in name:  # the same rows through the other kernel (default for these trees: the wavefront pipeline)
         name, kernel = name.split(":")
         monkeypatch.setenv("MCRT_KERNEL", kernel)
@@ -96,6 +98,8 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     print("%s rows %d-%d: max rel %.3e, outliers %d / %d, %.1f Mray/s, %.2f rays/path" %
           (name, r0, r1, rel.max(), bad, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
     assert bad <= max(4, int(0.002 * rel.size))
+    want = pkg.KERNEL_PM_WAVE if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" else pkg.KERNEL_WAVEFRONT
+    assert st["kernel_id"] == want, pkg.KERNEL_NAMES.get(st["kernel_id"])
     ctx.close()
 
 

@@ -26,6 +26,29 @@ def ctx(pkg):
     c.close()
 
 
+def expected_kernel(pkg, img, integrator, forced=None):
+    """Which kernel form launchRender must pick (include/mcrt.h MCRT_KERNEL_*): every parity test pins it, so a
+    frame that passes on another form than the one the test is about (a silent fallback) fails here."""
+    s = img.scene
+    photon = integrator == pkg.INTEGRATOR_PHOTON_MAPPER
+    kinds = np.ctypeslib.as_array(s.surf_kind, shape=(s.num_surfaces,))
+    quadrics = bool((kinds == 2).any())
+    flat = s.num_surfaces <= 64 and not quadrics
+    if forced == "wf":
+        return pkg.KERNEL_WAVEFRONT_PM if photon else pkg.KERNEL_WAVEFRONT
+    if photon:
+        return pkg.KERNEL_PM_LANE if forced == "legacy" else pkg.KERNEL_PM_WAVE
+    if flat and forced in (None, "sm", "legacy"):
+        return pkg.KERNEL_FLAT
+    if forced == "legacy":
+        return pkg.KERNEL_WAVESYNC
+    if s.num_nodes == 0:
+        return pkg.KERNEL_WAVESYNC  # brute-force Scene::intersect (no BVH) of a scene too large for the flat loop
+    if forced is None and s.num_nodes >= 65536:
+        return pkg.KERNEL_WAVEFRONT
+    return pkg.KERNEL_LANE_SM
+
+
 def _check(out, ref, what):
     rel = rel_error(out, ref).max(axis=2)
     bad = int((rel > TOL).sum())
@@ -50,6 +73,7 @@ def test_path_tracer_matches_reference(pkg, ctx, manifest, name):
         _check(out, load_radiance(r), "%s %s" % (name, r["file"]))
         assert st["paths"] == r["width"] * r["height"] * r["sqrtspp"] ** 2
         assert st["rays"] >= st["paths"] and st["kernel_launches"] >= 1
+        assert st["kernel_id"] == expected_kernel(pkg, img, pkg.INTEGRATOR_PATH_TRACER), pkg.KERNEL_NAMES.get(st["kernel_id"])
 
 
 @pytest.fixture
@@ -84,6 +108,7 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
             os.environ.pop("MCRT_WF_SLOTS", None)
         _check(out, load_radiance(r), "%s wavefront (%s slots)" % (name, slots))
         assert st["paths"] == st0["paths"] and st["kernel_launches"] > 2
+        assert st["kernel_id"] == pkg.KERNEL_WAVEFRONT and st0["kernel_id"] == expected_kernel(pkg, img, pkg.INTEGRATOR_PATH_TRACER)
         np.testing.assert_array_equal(out, base)
 
 
@@ -105,6 +130,7 @@ def test_passes_and_chunks_do_not_change_the_frame(pkg, ctx, manifest, kernel_en
         kernel_env(kernel)
     base, st0 = ctx.sample_image(cam, manifest["seed"], mode)
     _check(base, load_radiance(r), name)
+    assert st0["kernel_id"] == expected_kernel(pkg, img, mode, kernel), pkg.KERNEL_NAMES.get(st0["kernel_id"])
     for store, chunks in (("0.0001", None), (None, "1"), ("0.0001", "4")):
         try:
             if store:
@@ -115,7 +141,7 @@ def test_passes_and_chunks_do_not_change_the_frame(pkg, ctx, manifest, kernel_en
         finally:
             os.environ.pop("MCRT_SAMPLE_STORE_GB", None)
             os.environ.pop("MCRT_CHUNKS", None)
-        assert st["paths"] == st0["paths"]
+        assert st["paths"] == st0["paths"] and st["kernel_id"] == st0["kernel_id"]
         if store:
             assert st["kernel_launches"] > st0["kernel_launches"]   # several passes
         if integrator == "pm":   # the k photons of an estimate are summed in heap order, which depends on the search's timing
@@ -131,7 +157,7 @@ def test_photon_mapper_matches_reference(pkg, ctx, manifest):
     r = case["renders"][0]
     out, st = ctx.sample_image(camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
     _check(out, load_radiance(r), "hexagon_room_pm")
-    assert st["knn_searches"] > 0
+    assert st["knn_searches"] > 0 and st["kernel_id"] == pkg.KERNEL_PM_WAVE
 
 
 def test_photon_mapper_wavefront_pipeline(pkg, ctx, manifest, kernel_env):
@@ -148,6 +174,7 @@ def test_photon_mapper_wavefront_pipeline(pkg, ctx, manifest, kernel_env):
     out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
     _check(out, load_radiance(r), "hexagon_room_pm wavefront")
     assert st["paths"] == st0["paths"] and st["knn_searches"] == st0["knn_searches"] and st["kernel_launches"] > 3
+    assert st0["kernel_id"] == pkg.KERNEL_PM_WAVE and st["kernel_id"] == pkg.KERNEL_WAVEFRONT_PM
     assert rel_error(out, base).max() < 1e-12
 
 
@@ -203,6 +230,7 @@ def test_flat_and_bvh_modes_agree(pkg, oracle, manifest):
         hit = c.intersect(rays[:, :3].copy(), rays[:, 3:].copy())
         frame, st = c.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
         results.append((hit, frame, st["rays"]))
+        assert st["kernel_id"] == (pkg.KERNEL_FLAT if flat_max == "64" else pkg.KERNEL_LANE_SM)
         c.close()
     del os.environ["MCRT_FLAT_MAX"]
     (h0, f0, r0), (h1, f1, r1) = results
@@ -277,7 +305,7 @@ def test_c2_full_size_frame(pkg, ctx, manifest):
     out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     r0, r1 = r["rows"]
     _check(out[r0:r1], load_radiance(r), "C2 full-size rows %d-%d" % (r0, r1))
-    assert st["paths"] == 1920 * 1080 * 256
+    assert st["paths"] == 1920 * 1080 * 256 and st["kernel_id"] == pkg.KERNEL_FLAT
     assert np.isfinite(out).all() and (out >= 0).all()
     print("C2 full frame: %.1f Mray/s, %.2f rays/path, kernel %.1f ms" %
           (st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"], st["kernel_ms"]))
@@ -320,7 +348,7 @@ def test_render_multi_equals_one_context(pkg, manifest, name, count, integrator)
     base, st0 = ctxs[0].sample_image(cam, manifest["seed"], mode)
     out, st = pkg.render_multi(ctxs, cam, manifest["seed"], mode)
     _check(out, load_radiance(r), name + " multi")
-    assert st["paths"] == st0["paths"] and st["rays"] == st0["rays"]
+    assert st["paths"] == st0["paths"] and st["rays"] == st0["rays"] and st["kernel_id"] == st0["kernel_id"] == expected_kernel(pkg, img, mode)
     if integrator == "pm":
         assert rel_error(out, base).max() < 1e-12
     else:
