@@ -44,7 +44,7 @@ CASES = [
          renders=[dict(tag="dof_96x54_s3", width=96, height=54, sqrtspp=3)]),
     dict(name="hexagon_room_pm", scene="hexagon_room.json", photon=True, args=["--emissions", "4000"],
          image=dict(width=96, height=72, sqrtspp=2),
-         renders=[dict(tag="pm_96x72_s2", width=96, height=72, sqrtspp=2)], kat=1000),
+         renders=[dict(tag="pm_96x72_s2", width=96, height=72, sqrtspp=2, saves=[dict(tag="scene", opts="-")])], kat=1000),
     dict(name="coffee_maker_qsah", scene="coffe_maker.json", args=["--bvh", "quaternary_sah"],
          image=dict(width=160, height=120, sqrtspp=2),
          renders=[dict(tag="cm_160x120_s2", width=160, height=120, sqrtspp=2)], kat=3000),
