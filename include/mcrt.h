@@ -288,6 +288,15 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
 int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_t* index,
                  uint32_t shuffles, uint32_t global_seed, double* out);
 
+/* The lobe functions Interaction::BSDF is made of (ray/interaction.cpp:84-153), on n local-frame vectors (host arrays):
+ * in[n][11] = wi[3], wo[3], n1, n2, alpha, u, v (wi is folded into the upper hemisphere as |z| + 1e-3, renormalised, for the
+ * reflection lobes and negated for transmission); consts[10] = roughness, reflectance[3] of an Oren-Nayar material and a
+ * complex IOR real[3], imaginary[3]. out[n][18] = Fresnel::dielectric(n1, n2, wo.z) (material/fresnel.cpp:16-27) ·
+ * Fresnel::conductor rgb (:30-49) · GGX::reflection f, pdf (material/ggx.cpp:46-52) · GGX::transmission f, pdf (:54-65) ·
+ * GGX::visibleMicrofacet(u, v, wo) xyz (:67-88) · GGX::D(m) (:21-24) · GGX::Lambda(wo) (:31-34) ·
+ * Material::diffuseReflection rgb, pdf (material/material.cpp:17-27,82-95) · 0. No scene needed. */
+int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts, double* out);
+
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map
  * (which = 0 global, 1 caustic) for n query points p[n][3]. Outputs per query: count found
  * (≤ k), photon indices and squared distances sorted by ascending distance (ties by index),

@@ -198,6 +198,7 @@ def lib():
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
+    L.mcrt_bsdf.argtypes = [vp, C.c_uint64, _dp, _dp, _dp]
     L.mcrt_bvh_build_octree.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mcrt_bvh_build_sah.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.mcrt_bvh_get.argtypes = [vp]
@@ -513,6 +514,14 @@ class Context:
         self._check(self._lib.mcrt_sampler(self._h, pixel.shape[0], _ptr(pixel, C.c_uint32),
                                            _ptr(index, C.c_uint32), int(shuffles), int(global_seed),
                                            _ptr(out, C.c_double)), "mcrt_sampler")
+        return out
+
+    def bsdf(self, inputs, consts):
+        """mcrt_bsdf: inputs [n][11], consts [10] -> [n][18] (Fresnel / GGX / Oren-Nayar lobe values, include/mcrt.h)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
+        consts = np.ascontiguousarray(consts, dtype=np.float64)
+        out = np.zeros((inputs.shape[0], 18))
+        self._check(self._lib.mcrt_bsdf(self._h, inputs.shape[0], _ptr(inputs, C.c_double), _ptr(consts, C.c_double), _ptr(out, C.c_double)), "mcrt_bsdf")
         return out
 
     def knn(self, which, points, k):

@@ -1276,6 +1276,35 @@ int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_
     return MCRT_OK;
 }
 
+int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts, double* out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (n == 0) return MCRT_OK;
+    if (!in || !consts || !out) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    REJECT_IF_PENDING(ctx, "mcrt_bsdf");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    BsdfKatConsts c;
+    memset(&c, 0, sizeof(c));
+    c.rough.roughness = consts[0];
+    for (int k = 0; k < 3; k++) {
+        c.rough.reflectance[k] = consts[1 + k];
+        c.real[k] = consts[4 + k];
+        c.imag[k] = consts[7 + k];
+    }
+    const double variance = c.rough.roughness * c.rough.roughness;  // Material::computeProperties, material/material.cpp:106-108
+    c.rough.A = 1.0 - 0.5 * (variance / (variance + 0.33));
+    c.rough.B = 0.45 * (variance / (variance + 0.09));
+    c.rough.flags = MCRT_MAT_ROUGH;
+    DevBuf din, dout;
+    if (int rc = uploadArray(ctx, din, in, n * 11)) return rc;
+    HIP_TRY(ctx, dout.alloc(n * 18 * 8));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(bsdfKernel, dim3(grid), dim3(256), 0, ctx->stream, n, din.as<double>(), c, dout.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 18 * 8, hipMemcpyDeviceToHost));
+    return MCRT_OK;
+}
+
 int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, uint32_t* out_count, uint32_t* out_index,
              double* out_distance2) {
     if (!ctx) return MCRT_ERR_INVALID;

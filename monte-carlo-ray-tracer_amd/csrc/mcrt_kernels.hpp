@@ -1329,6 +1329,38 @@ __global__ void samplerKernel(const uint32_t* tab, uint64_t n, const uint32_t* p
     }
 }
 
+// mcrt_bsdf: the lobe functions behind Interaction::BSDF (ray/interaction.cpp:84-153) on caller-supplied local-frame
+// directions — Fresnel::dielectric / conductor, GGX::reflection / transmission / visibleMicrofacet / D / Lambda and
+// Material::diffuseReflection (Oren-Nayar) — one vector per lane, same device functions as the integrators.
+// in[n][11] = wi(3) wo(3) n1 n2 alpha u v; out[n][18] (layout in include/mcrt.h).
+struct BsdfKatConsts {
+    mcrt_material rough;   // roughness, reflectance, A, B, MCRT_MAT_ROUGH
+    double real[3], imag[3];
+};
+__global__ void __launch_bounds__(256) bsdfKernel(uint64_t n, const double* in, const BsdfKatConsts c, double* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double* I = in + 11 * i;
+        double* O = out + 18 * i;
+        const d3 wi = ld3(I), wo = ld3(I + 3);
+        const double n1 = I[6], n2 = I[7], al = I[8], u = I[9], v = I[10];
+        double pdf;
+        O[0] = fresnelDielectric(n1, n2, wo.z);
+        const d3 fc = fresnelConductor(n1, ld3(c.real), ld3(c.imag), wo.z);
+        O[1] = fc.x; O[2] = fc.y; O[3] = fc.z;
+        d3 wir = wi;
+        wir.z = fabs(wir.z) + 1e-3;
+        wir = normalize(wir);
+        O[4] = ggxReflection(wir, wo, al, al, pdf); O[5] = pdf;
+        O[6] = ggxTransmission(-wir, wo, n1, n2, al, al, pdf); O[7] = pdf;
+        const d3 m = ggxVisibleMicrofacet(u, v, wo, al, al);
+        O[8] = m.x; O[9] = m.y; O[10] = m.z;
+        O[11] = ggxD(m, al, al);
+        O[12] = ggxLambda(wo, al, al);
+        const d3 d = matDiffuseReflection(c.rough, wir, wo, pdf);
+        O[13] = d.x; O[14] = d.y; O[15] = d.z; O[16] = pdf; O[17] = 0.0;
+    }
+}
+
 __global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
                           uint32_t* out_index, double* out_d2, double* res_d2, uint32_t* res_idx, double* visit_d2,
                           uint32_t* visit_oct, uint32_t total_lanes) {

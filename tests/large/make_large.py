@@ -70,6 +70,11 @@ CONFIGS = {
                golden="water_caustics_c5.rows500_504.f64", image="water_caustics_c5.mcrt",
                surfaces=6898815, nodes=1925901),
 }
+# The same C5 scene and photon map at the spp the bench times (256 instead of the scene file's 16): one full-width row by the
+# reference (its photon pass is reproducible: same photon sets for the same seed, radiance equal to 1e-15). Rendered against the
+# c5 image with the camera's sqrtspp overridden (tests/test_gpu_large_scene.py).
+CONFIGS["c5_s16"] = dict(CONFIGS["c5"], flags=["--photon", "--emissions", "100000", "--width", "1000", "--height", "1000", "--sqrtspp", "16"],
+                         sqrtspp=16, rows=(500, 501), golden="water_caustics_c5.s16_rows500_501.f64", separate_render=True, base="c5")
 C3 = dict(CONFIGS["c3"], golden=os.path.join(GOLDEN, CONFIGS["c3"]["golden"]), image=os.path.join(OUT, CONFIGS["c3"]["image"]))
 
 
@@ -162,7 +167,9 @@ def make_golden(name, force=False):
     g = golden_path(name)
     if force or not os.path.exists(g):
         ensure_meshes(name)
-        if c["photon"]:
+        if c.get("separate_render"):  # rows only; the image is the base config's
+            _run([REF, "render"] + scene_flags(name) + ["--rows", str(c["rows"][0]), str(c["rows"][1]), "--out-radiance", g])
+        elif c["photon"]:
             # the rows and the image must come from the same process (one photon map): keep the image too
             os.makedirs(OUT, exist_ok=True)
             _run([REF, "flatten,render"] + scene_flags(name) + ["--rows", str(c["rows"][0]), str(c["rows"][1]), "--out", image_path(name),
@@ -175,6 +182,7 @@ def make_golden(name, force=False):
 def ensure_image(name):
     """Flatten the config's scene with the reference's loader and BVH builder (and, for c5, its photon pass).
     Returns the path, or None when the reference binary / scene copy is not on this machine."""
+    name = CONFIGS[name].get("base", name)  # variants share the base config's image
     p = image_path(name)
     if os.path.exists(p):
         return p
@@ -193,7 +201,8 @@ def main(force=False):
     build_generator()
     spaceship(force)
     for name in CONFIGS:
-        prepare_scene(name)
+        if "base" not in CONFIGS[name]:
+            prepare_scene(name)
         make_golden(name, force)
 
 

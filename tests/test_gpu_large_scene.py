@@ -58,6 +58,13 @@ def test_spaceship_traversal_equals_oracle(pkg, oracle, spaceship):
 
 # ---- BASELINE configs[2..4] at full size (stand-in meshes: tests/large/) ----
 
+def make_large_config(name):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    import make_large
+    return make_large.CONFIGS[name]
+
+
 def _config(pkg, name):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
@@ -68,7 +75,7 @@ def _config(pkg, name):
     return pkg.SceneImage(p), make_large.CONFIGS[name], make_large.golden_path(name)
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm", "c5_s16"])
 def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
     @ 1024 spp; C5: 6 898 815 triangles, photon-mapped — against the reference's radiance for the same rows
@@ -82,6 +89,9 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     ctx = pkg.Context(0)
     ctx.upload_image(img)
     cam = img.camera
+    if name == "c5_s16":  # the spp bench.py --workload c5 times (256), against a reference row at that spp
+        assert cam.sqrtspp == make_large_config("c5")["sqrtspp"]
+        cam.sqrtspp = 16
     assert (cam.width, cam.height, cam.sqrtspp) == (c["width"], c["height"], c["sqrtspp"])
     r0, r1 = c["rows"]
     cam.shard_rows, cam.shard_count = r1 - r0, (cam.height + r1 - r0 - 1) // (r1 - r0)

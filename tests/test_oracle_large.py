@@ -24,7 +24,7 @@ def test_synthetic_bunny_is_reproducible(tmp_path):
     assert hashlib.md5(open(p, "rb").read()).hexdigest() == make_large.BUNNY_MD5
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c5_s16"])
 def test_oracle_rows_equal_reference(pkg, oracle, name):
     import make_large
     p = make_large.ensure_image(name)  # also verifies the md5 of the generated meshes
@@ -34,6 +34,8 @@ def test_oracle_rows_equal_reference(pkg, oracle, name):
     img = pkg.SceneImage(p)
     assert (img.scene.num_surfaces, img.scene.num_nodes) == (c["surfaces"], c["nodes"])
     cam = img.camera
+    if "base" in c:  # variant of a config: the base image with another spp (c5_s16: the 256 spp the bench times)
+        cam.sqrtspp = c["sqrtspp"]
     assert (cam.width, cam.height, cam.sqrtspp) == (c["width"], c["height"], c["sqrtspp"])
     integ = pkg.INTEGRATOR_PHOTON_MAPPER if c["photon"] else pkg.INTEGRATOR_PATH_TRACER
     out, info = oracle.render(img, cam, make_large.SEED, integ, rows=c["rows"])
