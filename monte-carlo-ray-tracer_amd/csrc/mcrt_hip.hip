@@ -62,7 +62,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, qblocks, quadrics, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -518,13 +518,16 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
     static const bool profile_phases = getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0;
     if (profile_phases && !photon) kernel = all ? renderKernel<PT, false, true, true> : renderKernel<PT, false, false, true>;
-    const bool flat_only = !photon && ctx->scene.flat && all && !count_tests && !profile_phases && !(getenv("MCRT_FLAT_GENERIC") && atoi(getenv("MCRT_FLAT_GENERIC")));
+    const bool flat_only = !photon && ctx->scene.flat && ctx->scene.flat_pre && all && !count_tests && !profile_phases && !(getenv("MCRT_FLAT_GENERIC") && atoi(getenv("MCRT_FLAT_GENERIC")));
     // Flat-mode scenes get their own instance of the kernel: without the BVH walk in the code it needs no traversal stack
     // (64 KB of LDS at 512 lanes), so a CU can hold more waves; measured on the C2 frame (ms): generic instance 862,
     // flat instance with 512 lanes (2 waves/SIMD, 256 VGPRs, no scratch) 795, 768 lanes (3, 168 VGPRs, 336 B/lane of
     // scratch) 716, 1024 lanes (4, 128 VGPRs, 524 B/lane) 690 — the FP64 dependency chains of the primitive tests and the
     // BSDF code want the extra waves more than they mind the spills.
-    const int flat_block = getenv("MCRT_FLAT_BLOCK") ? atoi(getenv("MCRT_FLAT_BLOCK")) : 1024;
+    // With the FP32 cull in front of the FP64 tests (mcrt_scene.hpp) the order is reversed: 512 lanes 448.7 ms, 768 lanes 455.8,
+    // 1024 lanes 485.2 (split next-event estimate: 454 / 493 / 563) — fewer instructions per ray, and the spills of the
+    // narrow instances (107 / 169 VGPRs) now cost more than the extra waves hide.
+    const int flat_block = getenv("MCRT_FLAT_BLOCK") ? atoi(getenv("MCRT_FLAT_BLOCK")) : 512;
     if (flat_only)
         kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
@@ -580,6 +583,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
     PmKernelT pm_kernel = nullptr;
     DeviceScene launch_scene = ctx->scene;
+    if (getenv("MCRT_FLAT_CULL") && atoi(getenv("MCRT_FLAT_CULL")) == 0) launch_scene.flat_pre = nullptr;  // A/B: every primitive in FP64
     LaunchGeom g;
     if (use_pm_wave) {
         static const PmKernelT pm_table[2][2] = {{renderKernelPM<false, false>, renderKernelPM<false, true>},
@@ -609,7 +613,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         if (per_cu < 1) per_cu = 1;
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * g.block;
-    } else if (int rc = launchGeometry(ctx, kernel, ctx->scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
+    } else if (int rc = launchGeometry(ctx, kernel, launch_scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
         return rc;
     }
     if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
@@ -697,7 +701,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + g.block - 1) / g.block);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
             if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
-            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, use_sm ? launch_scene : ctx->scene, prm);
+            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
             ctx->launches += 2;
@@ -903,6 +907,8 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
+    if (L.flat_pre.empty()) ctx->flat_pre.release();
+    else if (int rc = uploadArray(ctx, ctx->flat_pre, L.flat_pre.data(), L.flat_pre.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_v, L.num_quadric_surfaces ? L.surf_v_patched.data() : s->surf_v, ns * 9)) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_normal, normal.data(), normal.size())) return rc;
     if (any_vn) {
@@ -934,6 +940,11 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.flat_prim = ctx->flat_prim.as<double>();
     d.flat_index = ctx->flat_index.as<uint32_t>();
     d.flat_tris = L.flat_tris;
+    d.flat_pre = L.flat_pre.empty() ? nullptr : ctx->flat_pre.as<float>();
+    d.pre_tri_pairs = L.pre_tri_pairs;
+    d.pre_sph_pairs = L.pre_sph_pairs;
+    for (int c = 0; c < 3; c++) d.pre_centre[c] = L.pre_centre[c];
+    d.pre_bound = L.pre_bound;
     d.surf_v = ctx->surf_v.as<double>();
     d.surf_normal = ctx->surf_normal.as<double>();
     d.surf_vn = any_vn ? ctx->surf_vn.as<double>() : nullptr;

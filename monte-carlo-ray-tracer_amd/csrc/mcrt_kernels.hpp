@@ -31,6 +31,9 @@ struct DeviceScene {
     const double* flat_prim;      // kind-sorted copy (flat mode)
     const uint32_t* flat_index;
     uint32_t flat_tris;
+    const float* flat_pre;        // FP32 cull records of the flat loop (mcrt_scene.hpp), null = none
+    uint32_t pre_tri_pairs, pre_sph_pairs;
+    double pre_centre[3], pre_bound;
     const double* surf_v;
     const double* surf_normal;
     const double* surf_vn;  // may be null
@@ -111,7 +114,7 @@ constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
 struct LdsPlan {
-    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, surf_v, surf_normal, surf_vn, surf_area, surf_material,
+    uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material,
         surf_kind, materials, light_surface, light_cdf, total;
 };
 
@@ -121,7 +124,7 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block,
     LdsPlan p;
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += with_stack ? kLdsStackDepth * block * (uint32_t)sizeof(StackEntry) : 0u;
+    p.stack = off; off += (with_stack && !s.flat) ? kLdsStackDepth * block * (uint32_t)sizeof(StackEntry) : 0u;  // the flat loop has no stack
     p.iors = off; off += kMaxIors * block * 8u;
     off = alignUp(off, 16);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
@@ -129,9 +132,10 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block,
     p.node_meta = off; off = alignUp(off + nn * 8, 16);
     if (s.stage_all) {
         const uint32_t ns = s.num_surfaces;
-        p.prim = off; off += ns * kPrimStride * 8;
+        p.prim = off; off += s.flat ? 0 : ns * kPrimStride * 8;  // flat scenes only read the kind-sorted copy
         p.flat_prim = off; off += s.flat ? ns * kPrimStride * 8 : 0;
         p.flat_index = off; off = alignUp(off + (s.flat ? ns * 4 : 0), 16);
+        p.flat_pre = off; off += (s.flat && s.flat_pre) ? (s.pre_tri_pairs * (uint32_t)kTriPairFloats + s.pre_sph_pairs * (uint32_t)kSphPairFloats) * 4u : 0u;
         p.surf_v = off; off += ns * 72;
         p.surf_normal = off; off += ns * 24;
         p.surf_vn = off; off += (s.surf_vn ? ns * 72 : 0);
@@ -142,7 +146,7 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block,
         p.light_cdf = off; off += s.num_lights * 8;
         p.light_surface = off; off = alignUp(off + s.num_lights * 4, 16);
     } else {
-        p.prim = p.flat_prim = p.flat_index = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
+        p.prim = p.flat_prim = p.flat_index = p.flat_pre = p.surf_v = p.surf_normal = p.surf_vn = p.surf_area = p.surf_material = p.surf_kind = p.materials =
             p.light_cdf = p.light_surface = off;
     }
     p.total = off;
@@ -151,7 +155,7 @@ __host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block,
 
 template <class T>
 __device__ inline MCRT_LDS_AS T* ldsAt(unsigned char* base, uint32_t off) {
-    return (MCRT_LDS_AS T*)(base + off);
+    return (MCRT_LDS_AS T*)((MCRT_LDS_AS unsigned char*)base + off);  // offset added in address space 3
 }
 
 template <class T>
@@ -196,11 +200,23 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         sv.node_bounds = lnb;
         sv.node_meta = lnm;
         MCRT_LDS_AS double* lp = ldsAt<double>(lds, p.prim);
-        stageCopy(lp, s.prim, ns * kPrimStride);
+        if (!s.flat) stageCopy(lp, s.prim, ns * kPrimStride);
         sv.prim = lp;
         sv.flat_tris = s.flat_tris;
         sv.flat_prim = nullptr;
         sv.flat_index = nullptr;
+        // (always a valid LDS address — the pair counts gate its use: hipcc 7.2 fails to select code for a read through a
+        // null address-space-3 pointer plus an offset)
+        MCRT_LDS_AS float* lpre = ldsAt<float>(lds, p.flat_pre);
+        const bool cull = s.flat && s.flat_pre;
+        sv.flat_pre = lpre;
+        sv.pre_tri_pairs = cull ? s.pre_tri_pairs : 0u;
+        sv.pre_sph_pairs = cull ? s.pre_sph_pairs : 0u;
+        sv.pre_cx = s.pre_centre[0];
+        sv.pre_cy = s.pre_centre[1];
+        sv.pre_cz = s.pre_centre[2];
+        sv.pre_bound = s.pre_bound;
+        if (cull) stageCopy(lpre, s.flat_pre, s.pre_tri_pairs * (uint32_t)kTriPairFloats + s.pre_sph_pairs * (uint32_t)kSphPairFloats);
         if (s.flat) {
             MCRT_LDS_AS double* lfp = ldsAt<double>(lds, p.flat_prim);
             stageCopy(lfp, s.flat_prim, ns * kPrimStride);
@@ -243,6 +259,9 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         sv.flat_tris = 0;
         sv.flat_prim = nullptr;
         sv.flat_index = nullptr;
+        sv.flat_pre = nullptr;
+        sv.pre_tri_pairs = sv.pre_sph_pairs = 0;
+        sv.pre_cx = sv.pre_cy = sv.pre_cz = sv.pre_bound = 0.0;
         sh.surf_v = s.surf_v;
         sh.surf_normal = s.surf_normal;
         sh.surf_vn = s.surf_vn;

@@ -57,23 +57,6 @@ struct SmStack {
     }
 };
 
-MCRT_HD uint32_t floatBits(float f) {
-    union {
-        float f;
-        uint32_t u;
-    } c;
-    c.f = f;
-    return c.u;
-}
-MCRT_HD float bitsFloat(uint32_t u) {
-    union {
-        float f;
-        uint32_t u;
-    } c;
-    c.u = u;
-    return c.f;
-}
-
 // One closest-hit query in progress.
 struct Trav {
     d3 o, d, inv;      // the ray being traversed

@@ -24,6 +24,10 @@ struct HostLayout {
     std::vector<double> flat_prim;     // [n][kPrimStride]
     std::vector<uint32_t> flat_index;  // [n] sorted slot -> surface index
     uint32_t flat_tris = 0;
+    // FP32 cull records of the flat loop (mcrt_scene.hpp "FP32 cull"); empty = no cull for this scene
+    std::vector<float> flat_pre;
+    uint32_t pre_tri_pairs = 0, pre_sph_pairs = 0;
+    double pre_centre[3] = {0.0, 0.0, 0.0}, pre_bound = 0.0;
     std::vector<Node64> nodes64;       // [n] box + meta records, same order as node_bounds
     std::vector<QBlock> qblocks;       // quantised child blocks (mcrt_qbvh.hpp), breadth-first over the inner nodes
     uint32_t q_root_a = 0, q_root_m = 0;
@@ -188,6 +192,110 @@ inline int convertNodes(const mcrt_scene_desc* s, std::vector<double>& bounds, s
     return MCRT_OK;
 }
 
+// FP32 cull records for the kind-sorted flat copy (L.flat_prim / L.flat_tris must be built). Error bounds: u = 2^-24,
+// every input (start - centre, direction, v0 - centre, E1, E2, sphere centre - centre) is rounded to float once, a ray
+// starts within `bound` (per axis) of the centre and has a unit direction; with Tmax >= |start - v0| for any such ray
+// the FP32 values differ from the exact ones by at most
+//   |d det| <= 14 u |E1||E2|     |d uN| <= 16 u |E2| Tmax     |d vN| <= 17 u |E1| Tmax     |d tN| <= 17 u |E1||E2| Tmax
+// and the products the cull compares by at most 31 u |E1||E2|^2 Tmax (A), 31 u |E1|^2|E2| Tmax (B), 31 u (|E1||E2|)^2 Tmax (C),
+// 40 u |E1||E2| ((|E1| + |E2|) Tmax + |E1||E2|) (W). The thresholds below are four times those. Spheres: with M = bound +
+// |centre offset|_inf, |d so_i| <= 2 u M and the discriminant / 4 = nb^2 - so2 + r^2 is off by at most
+// 2 u nb^2 + (12 u + 7 u M / r) so2 + (2 u r^2 + 7 u r M)  (using M |so| <= (r M + so2 M / r) / 2); again times four.
+inline void buildFlatCull(HostLayout& L, uint32_t ns) {
+    L.flat_pre.clear();
+    L.pre_tri_pairs = L.pre_sph_pairs = 0;
+    const uint32_t nt = L.flat_tris, nsph = ns - nt;
+    if (ns == 0) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](const double* p, double r) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], p[a] - r);
+            hi[a] = std::max(hi[a], p[a] + r);
+        }
+    };
+    for (uint32_t i = 0; i < ns; i++) {
+        const double* r = &L.flat_prim[(size_t)i * kPrimStride];
+        if (i < nt) {
+            const double v1[3] = {r[0] + r[3], r[1] + r[4], r[2] + r[5]}, v2[3] = {r[0] + r[6], r[1] + r[7], r[2] + r[8]};
+            grow(r, 0.0);
+            grow(v1, 0.0);
+            grow(v2, 0.0);
+        } else {
+            grow(r, fabs(r[3]));
+        }
+    }
+    double H = 0.0;
+    for (int a = 0; a < 3; a++) {
+        if (!(fabs(lo[a]) <= 1e7) || !(fabs(hi[a]) <= 1e7)) return;  // keeps every FP32 product far from overflow
+        L.pre_centre[a] = 0.5 * (lo[a] + hi[a]);
+        H = std::max(H, 0.5 * (hi[a] - lo[a]));
+    }
+    if (!(H > 0.0)) return;
+    L.pre_bound = 4.0 * H;  // rays may start up to four half-extents from the centre (a camera outside the room)
+    const double u = ldexp(1.0, -24), bound = L.pre_bound;
+    auto up = [](double x) {  // smallest float >= x (thresholds and additive constants round away from "reject")
+        float f = (float)x;
+        if ((double)f < x) f = nextafterf(f, INFINITY);
+        return f;
+    };
+    auto down = [](double x) {
+        float f = (float)x;
+        if ((double)f > x) f = nextafterf(f, -INFINITY);
+        return f;
+    };
+    auto len = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    L.pre_tri_pairs = (nt + 1) / 2;
+    L.pre_sph_pairs = (nsph + 1) / 2;
+    L.flat_pre.assign((size_t)L.pre_tri_pairs * kTriPairFloats + (size_t)L.pre_sph_pairs * kSphPairFloats, 0.0f);
+    for (uint32_t i = 0; i < 2 * L.pre_tri_pairs; i++) {
+        float* q = &L.flat_pre[(size_t)(i / 2) * kTriPairFloats + (i & 1)];  // component c at q[2 c]
+        if (i >= nt) {  // padding slot of an odd count: always rejected (and masked off anyway)
+            q[2 * 9] = -INFINITY;
+            continue;
+        }
+        const double* r = &L.flat_prim[(size_t)i * kPrimStride];
+        double a[3];
+        for (int c = 0; c < 3; c++) a[c] = r[c] - L.pre_centre[c];
+        for (int c = 0; c < 3; c++) q[2 * c] = (float)a[c];
+        for (int c = 0; c < 6; c++) q[2 * (3 + c)] = (float)r[3 + c];
+        const double e1 = len(r + 3), e2 = len(r + 6), tmax = sqrt(3.0) * bound + len(a);
+        const double k = 4.0 * u;
+        double eu = k * 31.0 * e1 * e2 * e2 * tmax, ev = k * 31.0 * e1 * e1 * e2 * tmax, et = k * 31.0 * e1 * e1 * e2 * e2 * tmax;
+        double ew = k * 40.0 * e1 * e2 * ((e1 + e2) * tmax + e1 * e2);
+        const bool degenerate = !(e1 > 1e-12) || !(e2 > 1e-12) || !(eu > 1e-30) || !(ev > 1e-30) || !(et > 1e-30) || !(ew > 1e-30);
+        if (degenerate) eu = ev = et = ew = INFINITY;  // always a survivor
+        q[2 * 9] = up(eu);
+        q[2 * 10] = up(ev);
+        q[2 * 11] = up(et);
+        q[2 * 12] = up(ew);
+    }
+    float* sph = L.flat_pre.data() + (size_t)L.pre_tri_pairs * kTriPairFloats;
+    for (uint32_t i = 0; i < 2 * L.pre_sph_pairs; i++) {
+        float* q = &sph[(size_t)(i / 2) * kSphPairFloats + (i & 1)];
+        if (i >= nsph) {  // padding: always rejected
+            q[2 * 3] = -INFINITY;
+            q[2 * 4] = 0.0f;
+            continue;
+        }
+        const double* r = &L.flat_prim[(size_t)(nt + i) * kPrimStride];
+        double c[3], cinf = 0.0;
+        for (int a = 0; a < 3; a++) {
+            c[a] = r[a] - L.pre_centre[a];
+            cinf = std::max(cinf, fabs(c[a]));
+            q[2 * a] = (float)c[a];
+        }
+        const double rad = fabs(r[3]), M = bound + cinf;
+        const double beta = 4.0 * (12.0 * u + 7.0 * u * M / rad), gamma = 4.0 * (2.0 * u * rad * rad + 7.0 * u * rad * M);
+        if (!(rad > 0.0) || !(beta < 0.25) || !(gamma > 1e-30)) {  // always a survivor
+            q[2 * 3] = INFINITY;
+            q[2 * 4] = 0.0f;
+        } else {
+            q[2 * 3] = up(rad * rad + gamma);
+            q[2 * 4] = down(1.0 - beta);
+        }
+    }
+}
+
 inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err) {
     const size_t ns = s->num_surfaces;
     L.prim.assign(ns * kPrimStride, 0.0);
@@ -247,6 +355,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             slot++;
             if (!sphere) L.flat_tris++;
         }
+    buildFlatCull(L, (uint32_t)ns);
     if (int rc = convertNodes(s, L.node_bounds, L.node_meta, err)) return rc;
     L.nodes64.assign(s->num_nodes, Node64{});
     for (uint32_t i = 0; i < s->num_nodes; i++) {

@@ -106,6 +106,23 @@ MCRT_HD double bitsD(unsigned long long u) {
     return c.d;
 }
 
+MCRT_HD uint32_t floatBits(float f) {
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.f = f;
+    return c.u;
+}
+MCRT_HD float bitsFloat(uint32_t u) {
+    union {
+        float f;
+        uint32_t u;
+    } c;
+    c.u = u;
+    return c.f;
+}
+
 MCRT_HD bool finite64(double x) { return fabs(x) <= kDblMax; }  // false for NaN and +-inf
 MCRT_HD double compMax(d3 v) { return gmax(gmax(v.x, v.y), v.z); }
 MCRT_HD double compMin(d3 v) { return gmin(gmin(v.x, v.y), v.z); }

@@ -104,6 +104,10 @@ struct SceneViewT {
     uint32_t flat_tris;
     cptr<double, kAll> flat_prim;
     cptr<uint32_t, kAll> flat_index;
+    // FP32 cull records of the flat loop ("FP32 cull" below); no pairs = test every primitive in FP64
+    cptr<float, kAll> flat_pre;
+    uint32_t pre_tri_pairs, pre_sph_pairs;
+    double pre_cx, pre_cy, pre_cz, pre_bound;
 };
 
 struct LaneStack {
@@ -116,8 +120,11 @@ struct LaneStack {
         else spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride] = e;
     }
     MCRT_HD StackEntry get(int sp) const {
-        if (sp < kLdsStackDepth) return lds[(uint32_t)sp * lds_stride];
-        return spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
+        // two typed reads instead of one read through a selected pointer: the select would be a generic (flat) pointer
+        // built from an address-space-3 one, which hipcc 7.2 cannot always select code for (intersectKernel<true>)
+        StackEntry e = lds[(uint32_t)(sp < kLdsStackDepth ? sp : kLdsStackDepth - 1) * lds_stride];
+        if (sp >= kLdsStackDepth) e = spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride];
+        return e;
     }
 };
 
@@ -359,6 +366,108 @@ MCRT_HD bool sphereTestFlat(P rec, d3 start, d3 direction, double& t_hit) {
     return !(d < 0.0) & (hi >= 0.0);
 }
 
+// ---- FP32 cull in front of the flat loop ------------------------------------------------------------------------
+// The flat loop runs the reference's FP64 Moller-Trumbore / quadratic on EVERY primitive for every ray (~75 / ~60
+// instructions each); all but one or two of those tests end in a reject. The cull evaluates the same determinants in
+// packed FP32 (two primitives per v_pk_* instruction) and rejects a primitive only when the FP64 test is CERTAIN to
+// reject it: every comparison carries an absolute error bound of the FP32 evaluation (inputs rounded to float around
+// the scene centre, rays starting within `pre_bound` of it; derivation in DESIGN.md "FP32 cull"), so the survivors are
+// a superset of the primitives the reference accepts. The survivors (a bit mask per lane) then go through the
+// unchanged FP64 tests, per lane; closest hit and tie rule are untouched, so the result is bit-identical by
+// construction. A ray outside the domain of the bounds (start farther than pre_bound from the centre, non-unit or
+// non-finite direction) keeps every primitive.
+//
+// Records (floats, host-built by buildFlatCull, mcrt_layout.hpp), two primitives interleaved per component:
+//   triangle pair [16][2]: a = v0 - centre (3), E1 (3), E2 (3), eu, ev, et, ew, pad (3)
+//   sphere pair   [4][2]:  c - centre (3), r^2 + gamma ; then [4][2]: 1 - beta, pad (3)       (kSphPairFloats = 16)
+// Rejected when (A = uN det, B = vN det, C = tN det, W = (uN + vN) det - det^2):
+//   A < -eu (u < 0) | B < -ev (v < 0) | C < -et (t < 0) | W > ew (u + v > 1)
+//   sphere: nb^2 (1 + 8u) - so2 (1 - beta) + (r^2 + gamma) < 0 (no real root) | (b > 0 and c > 0: both roots negative)
+typedef float f2 __attribute__((vector_size(8)));
+constexpr int kTriPairFloats = 32, kSphPairFloats = 16;
+constexpr float kCullB2 = 1.0f + 8.0f * 5.9604645e-8f * 1.0001f;
+
+template <class P>
+MCRT_HD f2 ldf2(P p) {
+    return f2{p[0], p[1]};
+}
+
+struct CullRay {
+    f2 sx, sy, sz, dx, dy, dz;  // start - centre and direction, each splat over the pair
+    bool in_domain;
+};
+template <bool kAll>
+MCRT_HD CullRay cullRay(const SceneViewT<kAll>& sv, d3 start, d3 direction) {
+    CullRay r;
+    const double x = start.x - sv.pre_cx, y = start.y - sv.pre_cy, z = start.z - sv.pre_cz;
+    r.in_domain = fabs(x) <= sv.pre_bound && fabs(y) <= sv.pre_bound && fabs(z) <= sv.pre_bound &&
+                  fabs(direction.x) <= 1.0000001 && fabs(direction.y) <= 1.0000001 && fabs(direction.z) <= 1.0000001;
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    const float gx = (float)direction.x, gy = (float)direction.y, gz = (float)direction.z;
+    r.sx = f2{fx, fx}; r.sy = f2{fy, fy}; r.sz = f2{fz, fz};
+    r.dx = f2{gx, gx}; r.dy = f2{gy, gy}; r.dz = f2{gz, gz};
+    return r;
+}
+
+// Bit i of the result is set when triangle i of the pairs given may be hit; pairs <= 16 (one mask word).
+template <class P>
+MCRT_HD uint32_t cullTriangles(P pre, uint32_t pairs, uint32_t count, const CullRay& r) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    uint32_t rej = 0;
+    for (uint32_t p = pairs; p-- > 0;) {
+        P q = pre + (size_t)p * kTriPairFloats;
+        const f2 ax = ldf2(q + 0), ay = ldf2(q + 2), az = ldf2(q + 4);
+        const f2 e1x = ldf2(q + 6), e1y = ldf2(q + 8), e1z = ldf2(q + 10);
+        const f2 e2x = ldf2(q + 12), e2y = ldf2(q + 14), e2z = ldf2(q + 16);
+        const f2 eu = ldf2(q + 18), ev = ldf2(q + 20), et = ldf2(q + 22), ew = ldf2(q + 24);
+        const f2 Px = r.dy * e2z - e2y * r.dz, Py = r.dz * e2x - e2z * r.dx, Pz = r.dx * e2y - e2x * r.dy;  // cross(direction, E2)
+        const f2 det = Px * e1x + Py * e1y + Pz * e1z;
+        const f2 Tx = r.sx - ax, Ty = r.sy - ay, Tz = r.sz - az;
+        const f2 uN = Px * Tx + Py * Ty + Pz * Tz;
+        const f2 Qx = Ty * e1z - e1y * Tz, Qy = Tz * e1x - e1z * Tx, Qz = Tx * e1y - e1x * Ty;              // cross(T, E1)
+        const f2 vN = Qx * r.dx + Qy * r.dy + Qz * r.dz;
+        const f2 tN = Qx * e2x + Qy * e2y + Qz * e2z;
+        const f2 A = uN * det + eu, B = vN * det + ev, C = tN * det + et;
+        const f2 W = (det * det + ew) - (uN + vN) * det;
+        // a set sign bit in any of the four = certain reject
+        const uint32_t x1 = floatBits(A[1]) | floatBits(B[1]) | floatBits(C[1]) | floatBits(W[1]);
+        const uint32_t x0 = floatBits(A[0]) | floatBits(B[0]) | floatBits(C[0]) | floatBits(W[0]);
+        rej = (rej << 1) | (x1 >> 31);
+        rej = (rej << 1) | (x0 >> 31);
+    }
+    const uint32_t all = count >= 32u ? 0xFFFFFFFFu : ((1u << count) - 1u);
+    return ((r.in_domain && pairs != 0u) ? ~rej : 0xFFFFFFFFu) & all;
+}
+
+// Bit i set: sphere i of the pairs given may be hit; pairs <= 16.
+template <class P>
+MCRT_HD uint32_t cullSpheres(P pre, uint32_t pairs, uint32_t count, const CullRay& r) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+    uint32_t rej = 0;
+    for (uint32_t p = pairs; p-- > 0;) {
+        P q = pre + (size_t)p * kSphPairFloats;
+        const f2 cx = ldf2(q + 0), cy = ldf2(q + 2), cz = ldf2(q + 4), cg = ldf2(q + 6), cb = ldf2(q + 8);
+        const f2 ox = cx - r.sx, oy = cy - r.sy, oz = cz - r.sz;     // centre - start = -so
+        const f2 nb = ox * r.dx + oy * r.dy + oz * r.dz;             // -dot(direction, so) = -b / 2
+        const f2 so2 = ox * ox + oy * oy + oz * oz;
+        const f2 inner = cg - so2 * cb;                              // < 0: the start is certainly outside the sphere (c > 0)
+        const f2 D = (nb * f2{kCullB2, kCullB2}) * nb + inner;       // < 0: the discriminant is certainly negative
+        // outside and heading away (b > 0, i.e. nb < 0): both roots negative
+        const uint32_t x1 = (floatBits(nb[1]) & floatBits(inner[1])) | floatBits(D[1]);
+        const uint32_t x0 = (floatBits(nb[0]) & floatBits(inner[0])) | floatBits(D[0]);
+        rej = (rej << 1) | (x1 >> 31);
+        rej = (rej << 1) | (x0 >> 31);
+    }
+    const uint32_t all = count >= 32u ? 0xFFFFFFFFu : ((1u << count) - 1u);
+    return ((r.in_domain && pairs != 0u) ? ~rej : 0xFFFFFFFFu) & all;
+}
+
+MCRT_HD uint32_t lowestBit(uint32_t m) { return (uint32_t)__builtin_ctz(m); }  // m != 0
+
 MCRT_HD void hitInit(Hit& h, double t_limit) {
     h.t = t_limit;
     h.u = 0.0;
@@ -387,8 +496,60 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
 
     if (kFlat || sv.num_nodes == 0) {  // every primitive, as scene.cpp:161-173 does without a BVH
         if (kFlat || (kAll && sv.flat_prim)) {
-            // wave-uniform loops over the kind-sorted copy: no per-lane control flow at all
             const uint32_t nt = sv.flat_tris, ns = sv.num_surfaces;
+            // kFlat instances only carry the culled form; without cull
+            // records (MCRT_FLAT_CULL=0) every primitive is a survivor
+            if (kFlat || sv.pre_tri_pairs + sv.pre_sph_pairs != 0u) {
+                // FP32 cull over all primitives (wave-uniform, packed), then the FP64 tests of each lane's survivors
+                const CullRay cr = cullRay(sv, ray.start, ray.direction);
+                // 32 primitives (16 pairs) per mask word
+                for (uint32_t base = 0; base < nt; base += 32u) {
+                    const uint32_t left = nt - base, pairs_left = sv.pre_tri_pairs - base / 2u;
+                    uint32_t mt = cullTriangles(sv.flat_pre + (size_t)(base / 2u) * kTriPairFloats, sv.pre_tri_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                                left < 32u ? left : 32u, cr);
+                    if (kCount) cnt.prim_tests += (uint32_t)__builtin_popcount(mt);
+                    while (mt) {
+                        const uint32_t i = base + lowestBit(mt);
+                        mt &= mt - 1u;
+                        double t, u, v;
+                        cptr<double, kAll> rec = sv.flat_prim + (size_t)i * kPrimStride;
+                        const bool ok = triangleTestFlat(rec, ray.start, ray.direction, t, u, v);
+                        const uint32_t idx = sv.flat_index[i];
+                        if (ok && closer(t, idx, best)) {
+                            const bool interp = rec[9] >= 2.0;
+                            best.t = t;
+                            best.u = interp ? u : 0.0;
+                            best.v = interp ? v : 0.0;
+                            best.interpolate = interp;
+                            best.surface = idx;
+                        }
+                    }
+                }
+                cptr<float, kAll> spre = sv.flat_pre + (size_t)sv.pre_tri_pairs * kTriPairFloats;
+                for (uint32_t base = 0; base < ns - nt; base += 32u) {
+                    const uint32_t left = ns - nt - base, pairs_left = sv.pre_sph_pairs - base / 2u;
+                    uint32_t ms = cullSpheres(spre + (size_t)(base / 2u) * kSphPairFloats, sv.pre_sph_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                              left < 32u ? left : 32u, cr);
+                    if (kCount) cnt.prim_tests += (uint32_t)__builtin_popcount(ms);
+                    while (ms) {
+                        const uint32_t i = nt + base + lowestBit(ms);
+                        ms &= ms - 1u;
+                        double t;
+                        const bool ok = sphereTestFlat(sv.flat_prim + (size_t)i * kPrimStride, ray.start, ray.direction, t);
+                        const uint32_t idx = sv.flat_index[i];
+                        if (ok && closer(t, idx, best)) {
+                            best.t = t;
+                            best.u = 0.0;
+                            best.v = 0.0;
+                            best.interpolate = false;
+                            best.surface = idx;
+                        }
+                    }
+                }
+                return best;
+            }
+            if constexpr (kFlat) return best;  // (not reached)
+            // wave-uniform loops over the kind-sorted copy: no per-lane control flow at all
 #pragma unroll 2
             for (uint32_t i = 0; i < nt; i++) {
                 double t, u, v;

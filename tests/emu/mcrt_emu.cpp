@@ -74,6 +74,9 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
         sv.flat_tris = E.L.flat_tris;
         sv.flat_prim = nullptr;
         sv.flat_index = nullptr;
+        sv.flat_pre = nullptr;
+        sv.pre_tri_pairs = sv.pre_sph_pairs = 0;
+        sv.pre_cx = sv.pre_cy = sv.pre_cz = sv.pre_bound = 0.0;
     };
     auto fillShade = [&](auto& sh) {
         sh.surf_v = E.L.num_quadric_surfaces ? E.L.surf_v_patched.data() : s->surf_v;
@@ -92,10 +95,20 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     fillScene(E.sv_top);
     fillShade(E.sh_all);
     fillShade(E.sh_top);
-    if (stage_mode == 2) {  // flat (tiny-scene) mode of the "all" flavour
+    if (stage_mode == 2 || stage_mode == 3) {  // flat (tiny-scene) mode of the "all" flavour; 3: with the FP32 cull in front
         E.sv_all.num_nodes = 0;
         E.sv_all.flat_prim = E.L.flat_prim.data();
         E.sv_all.flat_index = E.L.flat_index.data();
+        if (stage_mode == 3) {
+            if (E.L.flat_pre.empty()) return MCRT_ERR_UNSUPPORTED;
+            E.sv_all.flat_pre = E.L.flat_pre.data();
+            E.sv_all.pre_tri_pairs = E.L.pre_tri_pairs;
+            E.sv_all.pre_sph_pairs = E.L.pre_sph_pairs;
+            E.sv_all.pre_cx = E.L.pre_centre[0];
+            E.sv_all.pre_cy = E.L.pre_centre[1];
+            E.sv_all.pre_cz = E.L.pre_centre[2];
+            E.sv_all.pre_bound = E.L.pre_bound;
+        }
     }
     return 0;
 }
@@ -164,8 +177,9 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
                         done = E.stage_all ? photonMapperBounce<true, true>(st, E.rh, E.sv_all, E.sh_all, E.pv, E.stk, E.ks, cnt, searches, octant_visits, E.tab.data())
                                            : photonMapperBounce<true, false>(st, E.rh, E.sv_top, E.sh_top, E.pv, E.stk, E.ks, cnt, searches, octant_visits, E.tab.data());
                     else
-                        done = E.stage_all ? pathTracerBounce<true, true>(st, E.rh, E.sv_all, E.sh_all, E.stk, cnt, E.tab.data())
-                                           : pathTracerBounce<true, false>(st, E.rh, E.sv_top, E.sh_top, E.stk, cnt, E.tab.data());
+                        done = stage_lds == 3  ? pathTracerBounce<true, true, false, true>(st, E.rh, E.sv_all, E.sh_all, E.stk, cnt, E.tab.data())  // flat-scene instance
+                               : E.stage_all ? pathTracerBounce<true, true>(st, E.rh, E.sv_all, E.sh_all, E.stk, cnt, E.tab.data())
+                                             : pathTracerBounce<true, false>(st, E.rh, E.sv_top, E.sh_top, E.stk, cnt, E.tab.data());
                     if (done) break;
                 }
                 acc[0] += st.radiance.x * 1.0;
@@ -548,7 +562,7 @@ int emu_emit_photons(const mcrt_scene_desc* scene, double emissions, double caus
 int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int stage_lds,
                   double* out_t, uint32_t* out_surface, double* out_uv) {
     Emu E;
-    if (int rc = setup(E, scene, stage_lds == 3 ? 0 : stage_lds)) return rc;
+    if (int rc = setup(E, scene, stage_lds == 3 ? 0 : stage_lds == 4 ? 3 : stage_lds)) return rc;  // 4: flat loop behind the FP32 cull
     TraceCounters cnt = {0, 0, 0, 0};
     QTrace qt;
     if (stage_lds == 3) {
@@ -558,6 +572,7 @@ int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start,
     for (uint64_t i = 0; i < n; i++) {
         Ray ray = makeRay(ld3(start + 3 * i), ld3(direction + 3 * i), 1.0);
         Hit h = stage_lds == 3 ? qt.run(ray.start, ray.direction, false, nullptr, cnt)
+                : stage_lds == 4 ? sceneIntersect<true, true, false, true>(E.sv_all, ray, E.stk, cnt)
                 : E.stage_all ? sceneIntersect<true, true, false>(E.sv_all, ray, E.stk, cnt)
                             : sceneIntersect<false, true, false>(E.sv_top, ray, E.stk, cnt);
         out_t[i] = h.t;
@@ -566,6 +581,42 @@ int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start,
         out_uv[2 * i + 1] = h.v;
     }
     return cnt.overflow ? -100 : 0;
+}
+
+// FP32 cull of the flat loop (mcrt_scene.hpp): per ray, the survivor masks and the primitives the FP64 tests accept.
+// out[4 i + 0..3] = the numbers of {triangle survivors, sphere survivors, accepted triangles, accepted spheres};
+// the return value counts accepted primitives that the cull dropped (must be 0).
+int emu_flat_cull(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, uint32_t* out) {
+    Emu E;
+    if (int rc = setup(E, scene, 3)) return rc;
+    const SceneViewT<true>& sv = E.sv_all;
+    const uint32_t nt = sv.flat_tris, ns = sv.num_surfaces;
+    int missed = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const d3 o = ld3(start + 3 * i), d = ld3(direction + 3 * i);
+        const CullRay cr = cullRay(sv, o, d);
+        uint64_t mt = 0, ms = 0, at = 0, as = 0;  // (<= 64 primitives per kind: MCRT_FLAT_MAX)
+        for (uint32_t base = 0; base < nt; base += 32u)
+            mt |= (uint64_t)cullTriangles(sv.flat_pre + (size_t)(base / 2u) * kTriPairFloats, std::min(16u, sv.pre_tri_pairs - base / 2u),
+                                          std::min(32u, nt - base), cr) << base;
+        for (uint32_t base = 0; base < ns - nt; base += 32u)
+            ms |= (uint64_t)cullSpheres(sv.flat_pre + (size_t)sv.pre_tri_pairs * kTriPairFloats + (size_t)(base / 2u) * kSphPairFloats,
+                                        std::min(16u, sv.pre_sph_pairs - base / 2u), std::min(32u, ns - nt - base), cr) << base;
+        for (uint32_t j = 0; j < nt; j++) {
+            double t, u, v;
+            if (triangleTestFlat(sv.flat_prim + (size_t)j * kPrimStride, o, d, t, u, v)) at |= 1ull << j;
+        }
+        for (uint32_t j = nt; j < ns; j++) {
+            double t;
+            if (sphereTestFlat(sv.flat_prim + (size_t)j * kPrimStride, o, d, t)) as |= 1ull << (j - nt);
+        }
+        missed += __builtin_popcountll(at & ~mt) + __builtin_popcountll(as & ~ms);
+        out[4 * i + 0] = (uint32_t)__builtin_popcountll(mt);
+        out[4 * i + 1] = (uint32_t)__builtin_popcountll(ms);
+        out[4 * i + 2] = (uint32_t)__builtin_popcountll(at);
+        out[4 * i + 3] = (uint32_t)__builtin_popcountll(as);
+    }
+    return missed;
 }
 
 // mcrt_photon_map_build_gpu with its device steps done on the host: the same per-photon cell code

@@ -27,7 +27,10 @@ def _emu_render(emu, pkg, img, cam, seed, integ, rows, stage):
                                         ("hexagon_room", 2), ("ior_test", 2), ("veach_mis", 2), ("hexagon_room_dof", 2), ("hexagon_room_dof", 0),
                                         ("coffee_maker_qsah", 1), ("coffee_maker_bsah", 0), ("ior_test", 1),
                                         ("veach_mis", 1), ("metals", 0), ("oren_nayar_test", 1), ("ggx_test", 0),
-                                        ("quadric", 0), ("quadric", 1)])
+                                        ("quadric", 0), ("quadric", 1),
+                                        # 3: the flat-scene kernel instance — FP32 cull in front of the FP64 tests
+                                        ("hexagon_room", 3), ("hexagon_room_ggx", 3), ("ior_test", 3), ("hexagon_room_dof", 3), ("veach_mis", 3),
+                                        ("hexagon_room_diffuse", 3)])
 def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, name, stage):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
@@ -41,6 +44,8 @@ def test_path_tracer_device_code_equals_reference(pkg, emu, oracle, manifest, na
     # same rays as the reference-equivalent oracle (one Scene::intersect call per bounce/shadow ray)
     _, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
     assert cnt["rays"] == info["rays"] and cnt["paths"] == info["paths"]
+    if stage == 3:
+        assert cnt["prim_tests"] < (0.15 if img.scene.num_surfaces >= 20 else 0.6) * img.scene.num_surfaces * cnt["rays"]  # what the cull leaves for the FP64 tests
 
 
 @pytest.mark.parametrize("name,stage_all", [("hexagon_room", 1), ("hexagon_room_ggx", 0), ("coffee_maker_qsah", 0),
@@ -151,7 +156,10 @@ def test_traversal_device_code_kat(pkg, emu, oracle, manifest, name):
     start, direction = rays[:, :3].copy(), rays[:, 3:].copy()
     results = []
     # top-of-tree staged / whole scene staged / flat loop / quantised child blocks of the trace kernel
+    # (4: the flat loop behind its FP32 cull; scenes with at most 32 triangles and 32 spheres)
     stages = (0, 1, 2, 3) if img.scene.num_nodes else (0, 1, 2)
+    if name in ("hexagon_room", "ior_test"):
+        stages = stages + (4,)
     if img.scene.num_quadrics:
         stages = (0, 1, 3)  # the flat loop knows triangles and spheres only
     for stage in stages:
@@ -184,3 +192,57 @@ def test_knn_device_code_kat(pkg, emu, manifest):
         np.testing.assert_array_equal(cnt, np.fromfile(os.path.join(d, "knn_%s_count.u32" % tag), dtype=np.uint32))
         np.testing.assert_array_equal(d2, np.fromfile(os.path.join(d, "knn_%s_d2.f64" % tag)).reshape(-1, k))
         np.testing.assert_array_equal(idx, np.fromfile(os.path.join(d, "knn_%s_index.u32" % tag), dtype=np.uint32).reshape(-1, k))
+
+
+def _cull_rays(img, rng, n):
+    """Rays that stress the cull's error bounds: from points ON the primitives (where t, u, v sit at the edge of their
+    ranges) towards vertices, edge points and sphere tangent points, plus random rays in and around the scene."""
+    sc = img.scene
+    ns = sc.num_surfaces
+    kind = np.ctypeslib.as_array(sc.surf_kind, (ns,)).copy()
+    v = np.ctypeslib.as_array(sc.surf_v, (ns, 9)).copy()
+    tris = v[kind == 0].reshape(-1, 3, 3)
+    sph = v[kind == 1][:, :4]
+    targets = [tris.reshape(-1, 3)]                                                        # vertices
+    w = rng.random((4 * len(tris), 1))
+    i = rng.integers(0, len(tris), 4 * len(tris))
+    e = rng.integers(0, 3, 4 * len(tris))
+    targets.append(tris[i, e] * w + tris[i, (e + 1) % 3] * (1 - w))                         # points on edges
+    b = rng.dirichlet((1, 1, 1), 4 * len(tris))
+    targets.append((tris[i] * b[:, :, None]).sum(1))                                        # interior points
+    if len(sph):
+        d = rng.normal(size=(8 * len(sph), 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        j = rng.integers(0, len(sph), len(d))
+        targets.append(sph[j, :3] + d * sph[j, 3:4])                                         # points on the spheres
+        targets.append(sph[j, :3] + d * sph[j, 3:4] * (1 + rng.normal(scale=1e-6, size=(len(d), 1))))  # just off them
+    targets = np.concatenate(targets)
+    lo, hi = targets.min(0), targets.max(0)
+    starts = np.concatenate([targets, rng.uniform(lo - (hi - lo), hi + (hi - lo), (len(targets), 3))])  # incl. outside the scene box
+    a = starts[rng.integers(0, len(starts), n)]
+    t = targets[rng.integers(0, len(targets), n)]
+    t = t + rng.normal(scale=1.0, size=(n, 1)) * rng.choice([0.0, 1e-9, 1e-6, 1e-3], (n, 1)) * rng.normal(size=(n, 3))
+    d = t - a
+    keep = np.linalg.norm(d, axis=1) > 1e-12
+    a, d = a[keep], d[keep]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    axis = rng.random(len(d)) < 0.05  # some axis-parallel directions (zero components)
+    d[axis] = np.eye(3)[rng.integers(0, 3, axis.sum())] * rng.choice([-1.0, 1.0], (axis.sum(), 1))
+    return np.ascontiguousarray(a), np.ascontiguousarray(d)
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "ior_test", "hexagon_room_dof", "veach_mis"])
+def test_flat_cull_keeps_every_primitive_the_fp64_tests_accept(pkg, emu, manifest, name):
+    """The FP32 cull of the flat loop (mcrt_scene.hpp) may only drop primitives that Triangle::intersect /
+    Sphere::intersect reject: survivors must be a superset of the accepted primitives, also for rays that start on a
+    surface, graze edges and vertices, touch spheres, run parallel to an axis or start outside the scene box."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    rng = np.random.default_rng(7)
+    start, direction = _cull_rays(img, rng, 400000)
+    n = len(start)
+    out = np.zeros((n, 4), dtype=np.uint32)
+    missed = emu.emu_flat_cull(C.byref(img.scene), n, start.ctypes.data, direction.ctypes.data, out.ctypes.data)
+    assert missed == 0
+    accepted, survivors = out[:, 2:].sum() / n, out[:, :2].sum() / n
+    assert accepted > 0.5               # the rays do hit things
+    assert survivors < accepted + max(2.0, 0.2 * img.scene.num_surfaces)   # and the cull does cull, even on these rays
