@@ -585,20 +585,39 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     DeviceScene launch_scene = ctx->scene;
     if (getenv("MCRT_FLAT_CULL") && atoi(getenv("MCRT_FLAT_CULL")) == 0) launch_scene.flat_pre = nullptr;  // A/B: every primitive in FP64
     LaunchGeom g;
+    uint32_t pm_stack_depth = kLdsStackDepth;
     if (use_pm_wave) {
-        static const PmKernelT pm_table[2][2] = {{renderKernelPM<false, false>, renderKernelPM<false, true>},
-                                                 {renderKernelPM<true, false>, renderKernelPM<true, true>}};
-        pm_kernel = pm_table[count_tests ? 1 : 0][all ? 1 : 0];
+        static const PmKernelT pm_table[2][2][2] = {{{renderKernelPM<false, false>, renderKernelPM<false, true>},
+                                                     {renderKernelPM<true, false>, renderKernelPM<true, true>}},
+                                                    {{renderKernelPM<false, false, 1024>, renderKernelPM<false, true, 1024>},
+                                                     {renderKernelPM<true, false, 1024>, renderKernelPM<true, true, 1024>}}};
         if (!launch_scene.stage_all) launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, 128u);
-        const uint32_t extra = (kBlock / 64) * kWaveCand * 12u;
-        g.lds_bytes = alignUp(planLds(launch_scene, kBlock).total, 16) + extra;
+        // 1024 lanes per workgroup (4 waves per SIMD) when the LDS plan allows it: flat scenes have no traversal stack; a tree in
+        // HBM is walked with the state machine's stack, of which then only a few entries per lane stay in LDS (the rest
+        // spills to HBM); a staged BVH walked by the wave-synchronous code needs its 16 entries (512 lanes).
+        const int want = getenv("MCRT_PM_BLOCK") ? atoi(getenv("MCRT_PM_BLOCK")) : 1024;
+        g.block = kBlock;
+        auto ldsBytes = [&](uint32_t block, uint32_t depth) { return alignUp(planLds(launch_scene, block, true, depth).total, 16) + (block / 64) * kWaveCand * 12u; };
+        if (want == 1024) {
+            if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= ctx->max_lds) {
+                g.block = 1024;
+            } else if (!launch_scene.stage_all) {
+                for (uint32_t depth = 8; depth >= 2 && g.block == kBlock; depth -= 2)
+                    if (ldsBytes(1024, depth) <= ctx->max_lds) {
+                        g.block = 1024;
+                        pm_stack_depth = depth;
+                    }
+            }
+        }
+        pm_kernel = pm_table[g.block == 1024 ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
+        g.lds_bytes = ldsBytes(g.block, pm_stack_depth);
         if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
         int per_cu = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pm_kernel, (int)kBlock, g.lds_bytes));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pm_kernel, (int)g.block, g.lds_bytes));
         if (per_cu < 1) per_cu = 1;
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
-        g.total_lanes = g.grid * kBlock;
+        g.total_lanes = g.grid * g.block;
     } else if (use_sm) {
         // the staged top of the tree shrinks to what the larger workgroup's stacks and refraction histories leave
         g.block = (uint32_t)sm_block;
@@ -619,6 +638,8 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
     if (use_sm && sm_depth < kLdsStackDepth)
         if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (kMaxStackDepth - sm_depth) * sizeof(StackEntry))) return rc;
+    if (use_pm_wave && pm_stack_depth < (uint32_t)kLdsStackDepth)
+        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (kMaxStackDepth - pm_stack_depth) * sizeof(StackEntry))) return rc;
 
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
@@ -683,6 +704,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         if (use_pm_wave) {
             pmx.global_map = waveMapView(ctx, 0);
             pmx.caustic_map = waveMapView(ctx, 1);
+            pmx.stack_depth = pm_stack_depth;
         }
         for (uint32_t row = 0; row < prm.owned_rows; row += (uint32_t)pass_rows) {
             prm.row_base = row;
@@ -700,7 +722,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             // never launch more lanes than there is work
             const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + g.block - 1) / g.block);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-            if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(kBlock), g.lds_bytes, stream, launch_scene, prm, pmx);
+            if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pmx);
             else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
@@ -1055,6 +1077,9 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
             fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
                     h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
     }
+    if (ctx->kernel_id == MCRT_KERNEL_PM_WAVE && h[9] && getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0)
+        fprintf(stderr, "[mcrt pm] wave cycles inside the radiance estimates: %.1f%% of the kernel (%llu searches, %.1f octants per search)\n",
+                100.0 * (double)h[8] / (double)h[9], h[4], h[4] ? (double)h[6] / (double)h[4] : 0.0);
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (stats) {
@@ -1335,11 +1360,21 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         HIP_TRY(ctx, flags.alloc(8));
         HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
         const PhotonMapViewW mv = waveMapView(ctx, which);
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + 3) / 4);
+        // MCRT_KNN_BLOCKS: 256-lane workgroups per CU (occupancy experiments); MCRT_KNN_TIME=1: kernel time on stderr
+        const int per_cu = getenv("MCRT_KNN_BLOCKS") ? std::max(1, atoi(getenv("MCRT_KNN_BLOCKS"))) : 8;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu, (n + 3) / 4);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
                            di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (getenv("MCRT_KNN_TIME") && atoi(getenv("MCRT_KNN_TIME")) != 0) {
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            fprintf(stderr, "[mcrt knn] map %d: %llu searches, k = %u, %d workgroups per CU: %.3f ms = %.1f M searches/s\n", which,
+                    (unsigned long long)n, k, per_cu, ms, (double)n / ms / 1e3);
+        }
         unsigned long long f = 0;
         HIP_TRY(ctx, hipMemcpy(&f, flags.p, 8, hipMemcpyDeviceToHost));
         if (f) return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow (octree deeper than the 128-entry wave frontier)");

@@ -120,11 +120,11 @@ struct LdsPlan {
 
 __host__ __device__ inline uint32_t alignUp(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block, bool with_stack = true) {
+__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block, bool with_stack = true, uint32_t stack_depth = kLdsStackDepth) {
     LdsPlan p;
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
-    p.stack = off; off += (with_stack && !s.flat) ? kLdsStackDepth * block * (uint32_t)sizeof(StackEntry) : 0u;  // the flat loop has no stack
+    p.stack = off; off += (with_stack && !s.flat) ? stack_depth * block * (uint32_t)sizeof(StackEntry) : 0u;  // the flat loop has no stack
     p.iors = off; off += kMaxIors * block * 8u;
     off = alignUp(off, 16);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
@@ -168,8 +168,9 @@ __device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t coun
 // the hot loops is a ds_read); otherwise only the top of the BVH is staged.
 template <bool kAll, bool kFlat = false>
 __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
-                                  SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes) {
-    const LdsPlan p = planLds(s, blockDim.x, !kFlat);
+                                  SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes,
+                                  uint32_t stack_depth = kLdsStackDepth) {
+    const LdsPlan p = planLds(s, blockDim.x, !kFlat, stack_depth);
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
     rh.stride = blockDim.x;
     rh.size = 0;
@@ -1025,8 +1026,8 @@ struct QWalk {
     QView<true> qv;
     SmStack stk;
 };
-__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q) {  // every thread calls
-    const LdsPlan lp = planLds(scene, blockDim.x);
+__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q, uint32_t stack_depth) {  // every thread calls
+    const LdsPlan lp = planLds(scene, blockDim.x, true, stack_depth);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
     const uint32_t room = scene.stage_nodes * 56u / 64u;
     q.qv.blocks = scene.qblocks;
@@ -1043,7 +1044,8 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
     q.sv.prim = scene.prim;
     q.sv.lds_nodes = 0;
     q.sv.lds_node_ptr = nullptr;
-    q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [16][lanes] region
+    q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [depth][lanes] region
+    q.stk.lds_depth = (int)stack_depth;
     q.stk.lds_stride = lstk.lds_stride;
     q.stk.spill = reinterpret_cast<SmStackEntry*>(lstk.spill);
     q.stk.spill_stride = lstk.spill_stride;
@@ -1051,21 +1053,26 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
 
 struct PmExtra {
     PhotonMapViewW global_map, caustic_map;
+    uint32_t stack_depth;  // traversal-stack entries per lane kept in LDS (tree in HBM: the state machine's stack, any depth; else kLdsStackDepth)
 };
 
-template <bool kCount, bool kAll>
-__global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
+// kLanes: 512 (2 waves per SIMD, 256 VGPRs) or 1024 (4 waves per SIMD, 128 VGPRs). The kernel spends 97.6 % of its wave
+// cycles inside the radiance estimates (measured, hexagon_room maps), whose throughput follows the resident waves
+// (knnWaveKernel alone: 61 / 112 / 172 / 188 M searches/s at 1 / 2 / 4 / 5 waves per SIMD) — the spills the narrow
+// register budget causes in the per-lane path code do not matter next to that.
+template <bool kCount, bool kAll, int kLanes = (int)kBlock>
+__global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
     extern __shared__ __align__(16) unsigned char lds[];
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;
     LaneStack stk;
     RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes, pmx.stack_depth);
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     // tree in HBM: walk it through the quantised child blocks
     QWalk qw;
-    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
+    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw, pmx.stack_depth);
     auto intersect = [&](const Ray& ray, bool shadow, const ShadowQuery* sq) {
         if constexpr (kAll) {
             return shadow ? sceneIntersect<kAll, kCount, true>(sv, ray, stk, cnt, sq) : sceneIntersect<kAll, kCount, false>(sv, ray, stk, cnt);
@@ -1076,7 +1083,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     // per-wave candidate buffer behind the common LDS plan
     WaveKnnLds W;
     {
-        const uint32_t base = alignUp(planLds(scene, blockDim.x).total, 16);
+        const uint32_t base = alignUp(planLds(scene, blockDim.x, true, pmx.stack_depth).total, 16);
         const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
         W.d2 = ldsAt<double>(lds, base) + wave * kWaveCand;
         W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
@@ -1088,6 +1095,8 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     uint32_t px = 0, py = 0, ly = 0, sample = 0, sample_end = 0;
     const uint32_t W_img = prm.cam.width;
     const bool direct_visualization = prm.direct_visualization != 0;
+    unsigned long long cyc_est = 0ull;  // MCRT_COUNT_TESTS: wave cycles inside the radiance estimates / in the kernel
+    const unsigned long long cyc_begin = kCount ? clock64() : 0ull;
 
     for (;;) {
         const bool need = !have_pixel && !exhausted;
@@ -1147,6 +1156,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
             }
         }
         // ---- part 2 (whole wave): caustic estimates, then global estimates
+        const unsigned long long t_est = kCount ? clock64() : 0ull;
         const d3 C = waveEstimate(needC, ia, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
         if (needC) st.radiance = st.radiance + C * st.throughput;
         const d3 G = waveEstimate(needG, ia, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
@@ -1154,6 +1164,7 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
             st.radiance = st.radiance + G * st.throughput;  // :330, the path ends here
             ended = true;
         }
+        if (kCount) cyc_est += clock64() - t_est;
         // ---- part 3 (per lane): next-event estimate, BSDF sampling, russian roulette (:308-311, :319-325, :334-339)
         if (path_active && !ended) {
             if (!ia.dirac_delta) {
@@ -1187,6 +1198,10 @@ __global__ void __launch_bounds__(kBlock) renderKernelPM(const DeviceScene scene
     waveAccumulate(prm.stats + 4, searches);
     waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
     waveAccumulate(prm.stats + 6, octant_visits);
+    if (kCount && __lane_id() == 0) {
+        atomicAdd(prm.stats + 8, cyc_est);
+        atomicAdd(prm.stats + 9, (unsigned long long)(clock64() - cyc_begin));
+    }
 }
 
 // LinearOctree::knnSearch operator: one query at a time per wave
@@ -1246,7 +1261,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     RefractionHistory rh;
     setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
     QWalk qw;  // tree in HBM: quantised child blocks
-    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw);
+    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw, (uint32_t)kLdsStackDepth);
 
     EmitState es;
     TraceCounters cnt = {0u, 0u, 0u, 0u};

@@ -117,6 +117,22 @@ __device__ inline uint32_t waveMinU32(uint32_t v) {
     v = t < v ? t : v;
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ inline uint32_t waveMaxU32(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false);
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false);
+    v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // Non-negative floats order like their bit patterns.
 __device__ inline float waveMinPosF(float v) { return bitsFloat(waveMinU32(floatBits(v))); }
 __device__ inline float floatAbove(double t) {  // smallest float >= t (t >= 0)
@@ -201,7 +217,8 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
 // in distance2), the rest can never be among the k nearest. 19 wave-uniform steps instead of 63; the exact
 // selection runs once, at the end of the search. Returns the new count; all lanes must call.
 constexpr int kCoarseBits = 20;
-__device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2) {
+// `slack`: the search for the bits stops as soon as a prefix keeps between k and k + slack entries.
+__device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2, uint32_t slack = 0) {
     const uint32_t lane = __lane_id();
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
     unsigned long long key[4];
@@ -216,14 +233,21 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
         my_i[s] = valid[s] ? W.idx[j] : 0xFFFFFFFFu;
     }
     unsigned long long T = 0ull;
+    bool settled = false;
     for (int bit = 62; bit >= 64 - kCoarseBits; bit--) {  // bit 63 (sign) is clear in every key
         const unsigned long long trial = T | ((1ull << bit) - 1ull);
         uint32_t n_le = 0;
         for (int s = 0; s < 4; s++)
             if (s < rows) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
-        if (n_le < k) T |= (1ull << bit);
+        if (n_le < k) {
+            T |= (1ull << bit);
+        } else if (n_le <= k + slack) {  // k .. k + slack entries below this trial value: good enough a bound
+            T = trial;
+            settled = true;
+            break;
+        }
     }
-    T |= (1ull << (64 - kCoarseBits)) - 1ull;
+    if (!settled) T |= (1ull << (64 - kCoarseBits)) - 1ull;
     uint32_t out = 0;
     for (int s = 0; s < 4; s++) {
         const bool keep = valid[s] && key[s] <= T;
@@ -241,6 +265,46 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
     c.u = T;
     bound_d2 = c.d;
     return out;
+}
+
+// The k smallest of count <= 64 entries (count - k is small): the largest entry is dropped until k are left — among equal
+// keys the one latest in the buffer first, which keeps the entries equal to the k-th key "in buffer order until k are
+// reached" like waveSelectK. Result compacted into slots [0, n), kth_d2 = the largest distance kept. All lanes must call.
+__device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
+    const uint32_t lane = __lane_id();
+    bool valid = lane < count;
+    union { double d; uint32_t u[2]; } c;
+    c.d = valid ? W.d2[lane] : 0.0;
+    const uint32_t my_i = valid ? W.idx[lane] : 0xFFFFFFFFu;
+    const uint32_t hi = c.u[1], lo = c.u[0];
+    auto largest = [&](uint32_t& mh, uint32_t& ml) {  // the largest valid key (keys are non-negative doubles: they order like integers)
+        mh = waveMaxU32(valid ? hi : 0u);
+        ml = waveMaxU32((valid && hi == mh) ? lo : 0u);
+    };
+    uint32_t n = count;
+    while (n > k) {  // wave-uniform
+        uint32_t mh, ml;
+        largest(mh, ml);
+        const unsigned long long owners = __ballot(valid && hi == mh && lo == ml);
+        const int drop = 63 - __clzll((long long)owners);
+        if ((int)lane == drop) valid = false;
+        n--;
+    }
+    uint32_t mh = 0u, ml = 0u;
+    if (n > 0) largest(mh, ml);
+    union { double d; uint32_t u[2]; } r;
+    r.u[1] = mh;
+    r.u[0] = ml;
+    kth_d2 = r.d;
+    if (n != count) {  // close the gaps
+        const unsigned long long keep = __ballot(valid);
+        if (valid) {
+            const uint32_t slot = __popcll(keep & ((1ull << lane) - 1ull));
+            W.d2[slot] = c.d;
+            W.idx[slot] = my_i;
+        }
+    }
+    return n;
 }
 
 // Sort the first n (<= 64 per pass) result entries ascending by (distance2, index) in place (n <= 128).
@@ -326,7 +390,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         dirty = true;
                         if (count > kWaveCand - 64u) {  // make room: drop what cannot be among the k nearest
                             double bound;
-                            count = waveSelectBound(W, count, k, bound);
+                            count = waveSelectBound(W, count, k, bound, 4u);
                             if (count > kWaveCand - 64u) count = waveSelectK(W, count, k, bound);  // a crowd inside 0.4 %
                             dirty = false;
                             bounded = true;
@@ -340,7 +404,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
             // the buffer fills, since every later candidate already lies within that radius.
             if (dirty && count >= k && !bounded) {
                 double bound;
-                count = waveSelectBound(W, count, k, bound);
+                count = waveSelectBound(W, count, k, bound, 4u);
                 dirty = false;
                 bounded = true;
                 max_distance2 = gmin(max_distance2, bound);
@@ -414,12 +478,14 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
             else { f_d2[1] = INFINITY; f_b[1] = 0u; }
         }
     }
-    // exact selection, once: first shrink to the entries that can still matter, so that it runs on one buffer row
-    if (count > 64u) {
+    // exact selection, once: shrink to the entries that can still matter (k of them plus the few that share the k-th key's
+    // leading bits), then drop the largest until k are left — instead of a 63-step search for the exact k-th key
+    if (count > k) {
         double bound;
-        count = waveSelectBound(W, count, k, bound);
+        count = waveSelectBound(W, count, k, bound, 2u);
     }
-    return waveSelectK(W, count, k, r2_max);
+    if (count > 64u || count > k + 4u) return waveSelectK(W, count, k, r2_max);  // a crowd at the k-th distance: the general selection
+    return waveTrimToK(W, count, k, r2_max);
 }
 
 // estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) for every lane of the
@@ -435,34 +501,36 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         if ((int)lane == src) searches++;
-        // the asking lane's Interaction, as far as Interaction::BSDF reads it
-        InteractionT<L> q;
-        q.position = waveShfl3(ia.position, src);
-        q.out = waveShfl3(ia.out, src);
-        q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
-        q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
-        q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
-        q.n1 = waveShflD(ia.n1, src);
-        q.n2 = waveShflD(ia.n2, src);
-        q.R = waveShflD(ia.R, src);
-        q.T = waveShflD(ia.T, src);
-        q.type = __builtin_amdgcn_readlane(ia.type, src);
-        q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
-        {
-            // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
-            union { cptr<mcrt_material, L> p; unsigned long long u; } c;
-            c.u = 0ull;
-            c.p = ia.material;
-            unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
-            lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
-            hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
-            c.u = ((unsigned long long)hi << 32) | lo;
-            q.material = c.p;
-        }
+        // the asking lane's position now; the rest of its Interaction (as far as Interaction::BSDF reads it) only once the
+        // search is over — 32 fewer wave-uniform registers live across the search
+        const d3 qpos = waveShfl3(ia.position, src);
         double r2 = 0.0;
-        const uint32_t n = waveKnnSearch(map, q.position, k, W, r2, overflow, octant_visits);
+        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
         d3 sum = splat(0.0);
         if (n > 0) {  // r2 = photons.top().distance2: the farthest of the k
+            InteractionT<L> q;
+            q.position = qpos;
+            q.out = waveShfl3(ia.out, src);
+            q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
+            q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
+            q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
+            q.n1 = waveShflD(ia.n1, src);
+            q.n2 = waveShflD(ia.n2, src);
+            q.R = waveShflD(ia.R, src);
+            q.T = waveShflD(ia.T, src);
+            q.type = __builtin_amdgcn_readlane(ia.type, src);
+            q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
+            {
+                // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
+                union { cptr<mcrt_material, L> p; unsigned long long u; } c;
+                c.u = 0ull;
+                c.p = ia.material;
+                unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
+                lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+                hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
+                c.u = ((unsigned long long)hi << 32) | lo;
+                q.material = c.p;
+            }
             const double inv_max_squared_radius = 1.0 / r2;
             for (uint32_t base = 0; base < n; base += 64) {
                 const uint32_t j = base + lane;
