@@ -210,9 +210,9 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
-    if ((long)stack_bytes > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
-    const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes) / 64u);
-    tp.lds_bytes = lds_blocks * 64u + stack_bytes;
+    if ((long)stack_bytes + 64 > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
+    const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u) / 64u);
+    tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u;  // + the workgroup's queue cursor
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)tp.block, tp.lds_bytes));
@@ -236,8 +236,8 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.prim = ctx->scene.prim;
     ta.spill = ctx->spill.as<SmStackEntry>();
     ta.total_lanes = total_lanes;
-    ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 32);
-    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 32);
+    ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 24);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     return MCRT_OK;
@@ -324,7 +324,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     }
     if (ctx->wf_slots != slots) {
         HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
-        HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * sizeof(uint32_t)));
+        // ray queue, two entries per slot (bounce + shadow ray): item and light words, eight planes of doubles (WfRayQueue)
+        HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * (2 * sizeof(uint32_t) + 8 * sizeof(double))));
         ctx->wf_slots = (uint32_t)slots;
     }
     if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
@@ -370,13 +371,21 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * kMaxStackDepth;
         pr[h].pool.w = ctx->wf_pool.as<unsigned long long>();
         pr[h].pool.n = (uint32_t)slots;
-        pr[h].queue = ctx->wf_queue.as<uint32_t>() + (size_t)h * 2 * half_slots;
+        {
+            // each half owns the entries [h * 2 * half_slots, ...) of every plane
+            const size_t cap = ((size_t)slots + 2 * kWfBlock) * 2, off = (size_t)h * 2 * half_slots;
+            uint32_t* words = ctx->wf_queue.as<uint32_t>();
+            pr[h].q.item = words + off;
+            pr[h].q.light = words + cap + off;
+            pr[h].q.ray = reinterpret_cast<double*>(words + 2 * cap) + off;
+            pr[h].q.cap = cap;
+        }
         memset(&sa[h], 0, sizeof(WfShadeArgs));
         sa[h].pool = pr[h].pool;
         sa[h].slot_base = (uint32_t)h * half_slots;
         sa[h].slot_count = h == 0 ? std::min<uint32_t>(half_slots, (uint32_t)slots) : (uint32_t)slots - half_slots;
         sa[h].fr = fr;
-        sa[h].queue = ctx->wf_queue.as<uint32_t>() + (size_t)h * 2 * half_slots;
+        sa[h].queue = pr[h].q;
         sa[h].pop_reset = c + 2;
         sa[h].work = ctx->work_counter.as<unsigned long long>();
         sa[h].stats = ctx->stats.as<unsigned long long>();

@@ -52,7 +52,7 @@ struct PhaseProf<true> {
     __device__ void mark(int p) {
         const unsigned long long t = clock64();
         const unsigned long long dt = t - t0;
-        const unsigned long long mask = __ballot(1);
+        const unsigned long long mask = waveBallot(1);
         lane_cycles[cur] += dt;
         if ((int)__lane_id() == __ffsll((long long)mask) - 1) wave_cycles[cur] += dt;
         t0 = t;

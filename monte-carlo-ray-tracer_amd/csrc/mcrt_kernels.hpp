@@ -289,7 +289,7 @@ __device__ inline unsigned long long waveBroadcast64(unsigned long long v, int s
 
 // Wave-aggregated pop from a global counter: lanes with need == true each receive a distinct index.
 __device__ inline unsigned long long wavePop(bool need, unsigned long long* counter) {
-    const unsigned long long mask = __ballot(need);
+    const unsigned long long mask = waveBallot(need);
     if (mask == 0ull) return 0ull;
     const int leader = __ffsll((long long)mask) - 1;
     const uint32_t lane = laneId();
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
     for (;;) {
         if (kProf) prof.mark(kPhLoop);
         const bool need = !have_pixel && !exhausted;
-        if (__ballot(need)) {
+        if (waveBallot(need)) {
             const unsigned long long w = wavePop(need, prm.work_counter);
             if (need) {
                 if (w >= prm.work_items) {
@@ -370,8 +370,8 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
                 }
             }
         }
-        if (!__ballot(have_pixel)) {
-            if (!__ballot(!exhausted)) break;
+        if (!waveBallot(have_pixel)) {
+            if (!waveBallot(!exhausted)) break;
             continue;
         }
         if (have_pixel) {
@@ -595,16 +595,16 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
         }
 
         if (kProf) { prof.span(kPhLoop, tp, true); tp = prof.now(); }
-        const unsigned long long m_trav = __ballot(state == kStTrav && T.active);
+        const unsigned long long m_trav = waveBallot(state == kStTrav && T.active);
         const int n_trav = __popcll(m_trav);
-        const unsigned long long m_shade = __ballot(state == kStShade);
-        const unsigned long long m_regen = __ballot(state == kStRegen);
+        const unsigned long long m_shade = waveBallot(state == kStShade);
+        const unsigned long long m_regen = waveBallot(state == kStRegen);
         if (!(m_trav | m_shade | m_regen)) break;  // every lane is done
 
         // ---- regenerate: next sample of the lane's pixel, or a new pixel from the global counter
         if (m_regen && (__popcll(m_regen) >= kRegenLanes || n_trav < kMinTrav)) {
             const bool need = state == kStRegen && !have_pixel;
-            if (__ballot(need)) {
+            if (waveBallot(need)) {
                 const unsigned long long w = wavePop(need, prm.work_counter);
                 if (need) {
                     if (w >= prm.work_items) {
@@ -666,8 +666,8 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
             }
             if (kProf) { prof.span(kPhTraverse, tp, inner); tp = prof.now(); }
             const bool leaf = state == kStTrav && T.active && !(T.node_m & kSmInner);
-            const unsigned long long m_leaf = __ballot(leaf);
-            const unsigned long long m_inner = __ballot(state == kStTrav && T.active && (T.node_m & kSmInner));
+            const unsigned long long m_leaf = waveBallot(leaf);
+            const unsigned long long m_inner = waveBallot(state == kStTrav && T.active && (T.node_m & kSmInner));
             if (m_leaf && (__popcll(m_leaf) >= kLeafLanes || __popcll(m_inner) < kMinInner)) {
                 if (leaf) travLeafStep<kAll, kCount>(sv, T, stk, cnt);
             }
@@ -710,11 +710,10 @@ struct WfTraceArgs {
 };
 
 // Where the rays of a trace launch come from and where their hits go.
-struct PoolRays {  // the wavefront pipeline: queue of (slot, port) items into the slot pool
+struct PoolRays {  // the wavefront pipeline: rays in queue order (WfRayQueue), hits into the slot pool
     WfPool pool;
-    const uint32_t* queue;
-    __device__ uint32_t item(unsigned long long w) const { return queue[w]; }
-    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const { wfLoadRay(pool, it, o, d, shadow, sq); }
+    WfRayQueue q;
+    __device__ uint32_t load(unsigned long long w, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const { return q.get(w, o, d, shadow, sq); }
     __device__ void store(uint32_t it, const Hit& h) const { wfStoreHit(pool, it, h); }
 };
 struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
@@ -723,14 +722,14 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
     double* out_t;
     uint32_t* out_surface;
     double* out_uv;
-    __device__ uint32_t item(unsigned long long w) const { return (uint32_t)w; }
-    __device__ void load(uint32_t it, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
-        o = ld3(start + 3 * (size_t)it);
-        d = ld3(direction + 3 * (size_t)it);
+    __device__ uint32_t load(unsigned long long w, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
+        o = ld3(start + 3 * (size_t)w);
+        d = ld3(direction + 3 * (size_t)w);
         shadow = false;
         sq.t_near = 0.0;
         sq.t_far = kDblMax;
         sq.light = kNoSurface;
+        return (uint32_t)w;
     }
     __device__ void store(uint32_t it, const Hit& h) const {
         out_t[it] = h.t;
@@ -767,37 +766,53 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     qv.lds_ptr = lq;
     qv.root_a = a.q_root_a;
     qv.root_m = a.q_root_m;
+    // The queue is dealt to the workgroups in equal contiguous shares and a workgroup's waves take entries from its share
+    // through a cursor in LDS. (One global cursor for all waves was the kernel's bottleneck: a refill every 32 rays is
+    // ~45 M atomics per second on one address, about what an L2 channel serves — refilling at 16 idle lanes instead of
+    // 32 cost 37 % of the frame. Neighbouring entries are similar rays from the same part of the image, and a share holds
+    // thousands of them, so the shares finish within a per cent of each other.)
+    const unsigned long long n = *a.count;
+    MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
+    const uint32_t share_begin = (uint32_t)(n * blockIdx.x / gridDim.x), share_end = (uint32_t)(n * (blockIdx.x + 1ull) / gridDim.x);
+    if (threadIdx.x == 0) *cursor = share_begin;
     __syncthreads();
 
-    const unsigned long long n = *a.count;
     Trav T;
     T.active = false;
     T.shadow = false;
     T.fast = true;
     T.sp = 0;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
-    bool have = false, exhausted = n == 0ull;
+    bool have = false, exhausted = share_begin == share_end;
     uint32_t item = 0;
     for (;;) {
         if (have && !T.active) {  // finished since the last look: hand the hit back
             rays.store(item, T.best);
             have = false;
         }
-        const unsigned long long m_have = __ballot(have);
+        const unsigned long long m_have = waveBallot(have);
         if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
-            const unsigned long long w = wavePop(!have, a.pop);
-            if (!have && w < n) {
-                item = rays.item(w);
+            unsigned long long w = share_end;
+            {
+                const unsigned long long need = waveBallot(!have);  // (not empty here)
+                const int leader = __ffsll((long long)need) - 1;
+                uint32_t base = 0u;
+                if ((int)laneId() == leader) base = __atomic_fetch_add(cursor, (uint32_t)__popcll(need), __ATOMIC_RELAXED);  // ds_add_rtn_u32
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                const uint32_t mine = base + (uint32_t)__popcll(need & ((1ull << laneId()) - 1ull));
+                if (!have && base < share_end) w = mine;  // (base >= share_end: the cursor has run past the share; it cannot wrap: < 2^32 entries, < 2^20 lanes)
+            }
+            if (!have && w < share_end) {
                 d3 o, d;
                 bool shadow;
                 ShadowQuery sq;
-                rays.load(item, o, d, shadow, sq);
+                item = rays.load(w, o, d, shadow, sq);
                 travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
                 have = true;
             }
-            exhausted = __ballot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
+            exhausted = waveBallot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
         }
-        if (!__ballot(have)) {
+        if (!waveBallot(have)) {
             if (exhausted) break;
             continue;
         }
@@ -805,8 +820,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
         if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
         if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
         const bool leaf = have && T.active && !(T.node_m & kSmInner);
-        const unsigned long long m_leaf = __ballot(leaf);
-        const unsigned long long m_inner = __ballot(have && T.active && (T.node_m & kSmInner));
+        const unsigned long long m_leaf = waveBallot(leaf);
+        const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
         if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
             if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
         }
@@ -823,7 +838,7 @@ struct WfShadeArgs {
     WfPool pool;
     uint32_t slot_base, slot_count;   // the slots this launch serves (one half of the pool per stream)
     WfFrame fr;
-    uint32_t* queue;
+    WfRayQueue queue;
     unsigned long long* count_out;    // rays queued by this launch
     unsigned long long* count_reset;  // the other parity's counter, consumed by the trace launch before this one
     unsigned long long* pop_reset;
@@ -839,36 +854,36 @@ struct WfShadeArgs {
 
 struct DevWfEnv {
     unsigned long long* work;
-    uint32_t* queue;
+    WfRayQueue queue;
     unsigned long long* count;
     uint32_t* requests;
     unsigned long long* rcount;
     __device__ void request(uint32_t slot, bool want, bool global) const {
-        const unsigned long long m = __ballot(want);
+        const unsigned long long m = waveBallot(want);
         if (!m) return;
         const uint32_t lane = laneId();
-        const int leader = __ffsll((long long)__ballot(true)) - 1;
+        const int leader = __ffsll((long long)waveBallot(true)) - 1;
         unsigned long long base = 0ull;
         if ((int)lane == leader) base = atomicAdd(rcount, (unsigned long long)__popcll(m));
         base = waveBroadcast64(base, leader);
         if (want) requests[base + __popcll(m & ((1ull << lane) - 1ull))] = slot | (global ? 0x80000000u : 0u);
     }
-    __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
+    __device__ bool any(bool b) const { return waveBallot(b) != 0ull; }
     __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
     __device__ void filmAdd(double* a, double v) const { atomicAdd(a, v); }  // std::atomic<double> of Film::Splat
-    __device__ void push(uint32_t slot, bool p0, bool p1) const {
-        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+    __device__ void push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double near1, double far1, uint32_t light1) const {
+        const unsigned long long m0 = waveBallot(p0), m1 = waveBallot(p1);
         const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
         if (!total) return;
         const uint32_t lane = laneId();
-        const int leader = __ffsll((long long)__ballot(true)) - 1;
+        const int leader = __ffsll((long long)waveBallot(true)) - 1;
         unsigned long long base = 0ull;
         if ((int)lane == leader) base = atomicAdd(count, (unsigned long long)total);
         base = waveBroadcast64(base, leader);
         const unsigned long long below = (1ull << lane) - 1ull;
         // the wave's bounce rays first, then its shadow rays (neighbouring queue entries = similar rays)
-        if (p0) queue[base + __popcll(m0 & below)] = slot * 2u;
-        if (p1) queue[base + n0 + __popcll(m1 & below)] = slot * 2u + 1u;
+        if (p0) queue.put(base + __popcll(m0 & below), slot * 2u, o0, d0, 0.0, kDblMax, kNoSurface);
+        if (p1) queue.put(base + n0 + __popcll(m1 & below), slot * 2u + 1u, o1, d1, near1, far1, light1);
     }
 };
 
@@ -1010,7 +1025,7 @@ __device__ inline Hit traceWalkQ(const SmSceneView<false>& sv, const QView<true>
         if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
         if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);
         const bool leaf = T.active && !(T.node_m & kSmInner);
-        const unsigned long long m_leaf = __ballot(leaf), m_inner = __ballot(T.active && (T.node_m & kSmInner));
+        const unsigned long long m_leaf = waveBallot(leaf), m_inner = waveBallot(T.active && (T.node_m & kSmInner));
         if (!(m_leaf | m_inner)) break;
         if (m_leaf && (__popcll(m_leaf) >= 32 || __popcll(m_inner) < 8)) {
             if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
@@ -1100,7 +1115,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
 
     for (;;) {
         const bool need = !have_pixel && !exhausted;
-        if (__ballot(need)) {
+        if (waveBallot(need)) {
             const unsigned long long w = wavePop(need, prm.work_counter);
             if (need) {
                 if (w >= prm.work_items) {
@@ -1119,8 +1134,8 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
                 }
             }
         }
-        if (!__ballot(have_pixel)) {
-            if (!__ballot(!exhausted)) break;
+        if (!waveBallot(have_pixel)) {
+            if (!waveBallot(!exhausted)) break;
             continue;
         }
         if (have_pixel && !path_active) {
@@ -1269,7 +1284,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     bool active = false, exhausted = false;
     for (;;) {
         const bool need = !active && !exhausted;
-        if (__ballot(need)) {
+        if (waveBallot(need)) {
             const unsigned long long e = prm.first_emission + wavePop(need, prm.counters + 0);
             if (need) {
                 if (e >= prm.total_emissions) {
@@ -1289,8 +1304,8 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
                 }
             }
         }
-        if (!__ballot(active)) {
-            if (!__ballot(!exhausted)) break;
+        if (!waveBallot(active)) {
+            if (!waveBallot(!exhausted)) break;
             continue;
         }
         PhotonOut out;
@@ -1309,7 +1324,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
         }
         for (int which = 0; which < 2; which++) {
             const bool mine = out.store && (out.caustic == (which == 1));
-            if (__ballot(mine)) {
+            if (waveBallot(mine)) {
                 const unsigned long long slot = waveAppend(mine, prm.counters + 1 + which);
                 if (mine && slot < prm.capacity[which]) {
                     float* o = prm.photons[which] + slot * 8ull;

@@ -126,13 +126,11 @@ inline int buildQBlocks(HostLayout& L, std::string& err) {
                 memcpy(&q.w[ax], &o, 4);
             }
             q.w[3] = (uint32_t)exps[0] | ((uint32_t)exps[1] << 8) | ((uint32_t)exps[2] << 16) | ((nc | (b + 1 < nb ? 0x80u : 0u)) << 24);
-            uint8_t bytes[24] = {0};
-            for (uint32_t c = 0; c < nc; c++)
-                for (int ax = 0; ax < 3; ax++) {
-                    bytes[c * 6 + ax] = qlo[ax][c];
-                    bytes[c * 6 + 3 + ax] = qhi[ax][c];
+            for (int ax = 0; ax < 3; ax++)
+                for (uint32_t c = 0; c < nc; c++) {  // one word per (axis, side), child c in byte c
+                    q.w[4 + 2 * ax] |= (uint32_t)qlo[ax][c] << (8 * c);
+                    q.w[5 + 2 * ax] |= (uint32_t)qhi[ax][c] << (8 * c);
                 }
-            memcpy(&q.w[4], bytes, 24);
             for (uint32_t c = 0; c < nc; c++) {
                 uint32_t a, m;
                 link(c0 + c, a, m);

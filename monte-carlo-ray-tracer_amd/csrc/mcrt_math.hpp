@@ -15,6 +15,12 @@
 #define MCRT_HD inline
 #endif
 
+#if defined(__HIPCC__)
+// Lane mask of a predicate. (HIP's __ballot(int) materialises 0 / 1 per lane and compares it with zero again: two extra
+// vector instructions per ballot, and the wave-cooperative code lives on ballots.)
+__device__ __forceinline__ unsigned long long waveBallot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
+
 // LDS (address space 3) pointers: telling the compiler that staged scene data lives in LDS turns the
 // generic flat_load (which occupies the vector-memory path and both wait counters) into ds_read with
 // 32-bit addressing. On the host build (tests/emu) the qualifier is empty.
@@ -123,6 +129,11 @@ MCRT_HD float bitsFloat(uint32_t u) {
     return c.f;
 }
 
+MCRT_HD float floatAbove(double t) {  // smallest float >= t (t >= 0; +inf beyond the float range)
+    float f = (float)t;
+    if ((double)f < t) f = bitsFloat(floatBits(f) + 1u);
+    return f;
+}
 MCRT_HD bool finite64(double x) { return fabs(x) <= kDblMax; }  // false for NaN and +-inf
 MCRT_HD double compMax(d3 v) { return gmax(gmax(v.x, v.y), v.z); }
 MCRT_HD double compMin(d3 v) { return gmin(gmin(v.x, v.y), v.z); }

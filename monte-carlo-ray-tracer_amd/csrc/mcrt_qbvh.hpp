@@ -26,7 +26,9 @@ namespace mcrt {
 //   w[0..2]   float origin x,y,z            (<= every child's lower bound)
 //   w[3]      ex | ey << 8 | ez << 16 | n << 24     cell size per axis = 2^(e - 128); n = children in this
 //             block (1..4) | 0x80 when the node's next block follows (node with more than 4 children)
-//   w[4..9]   24 bytes: child c, byte c*6+k = lower x,y,z (k=0..2), upper x,y,z (k=3..5) in cells
+//   w[4..9]   24 bytes, one word per (axis, side): w[4 + 2 axis + side] = the four children's lower (side 0) / upper (side 1)
+//             cell coordinates on that axis, child c in byte c — so that the word of the planes a ray ENTERS through is
+//             picked with one select per axis
 //   w[10..13] child c: inner -> index of its first block, leaf -> first primitive
 //   w[14..15] child c (16 bits each): inner -> 0x100 | number of children, leaf -> number of primitives
 struct alignas(64) QBlock {
@@ -38,7 +40,7 @@ MCRT_HD double qCell(uint32_t e) { return bitsD((unsigned long long)((int)e - kQ
 // The one decode expression, used by the host builder's verification and by the kernels. q * cell is exact (8 bits
 // times a power of two), so the fused form rounds once, exactly like multiply-then-add would: one instruction.
 MCRT_HD double qDecode(float origin, uint32_t q, double cell) { return fma((double)q, cell, (double)origin); }
-MCRT_HD uint32_t qByte(const QBlock& b, int byte) { return (b.w[4 + byte / 4] >> (8 * (byte % 4))) & 0xFFu; }
+MCRT_HD uint32_t qByte(const QBlock& b, int child, int axis, int side) { return (b.w[4 + 2 * axis + side] >> (8 * child)) & 0xFFu; }
 
 template <bool kLds>
 struct QView {
@@ -76,8 +78,10 @@ MCRT_HD void travBeginQ(const SmSceneView<kAll>& sv, const QView<kLds>& qv, Trav
 // hit child, push the rest — farthest first, so that the stack hands them back nearest first (the closer a subtree is
 // visited, the sooner T.best.t cuts the others off). The four children of a block are tested and ordered without
 // branches (a 5-exchange sorting network on {entry distance, link}); only the pushes are conditional.
+// (FP64 form on the decoded boxes — what the superset argument above is stated for; kept as the yardstick of the FP32
+// form below in the host-emulation tests)
 template <bool kLds, bool kCount>
-MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+MCRT_HD void travInnerStepQ64(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const Ray r = travRay(T);
     constexpr double kMiss = INFINITY;  // entry distance of a child that is absent, missed or culled
     double near_t = kMiss;
@@ -107,12 +111,12 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
 #endif
         for (int c = 0; c < 4; c++) {
             Box cb;
-            cb.v[0] = qDecode(ox, qByte(b, c * 6 + 0), cx);
-            cb.v[1] = qDecode(oy, qByte(b, c * 6 + 1), cy);
-            cb.v[2] = qDecode(oz, qByte(b, c * 6 + 2), cz);
-            cb.v[3] = qDecode(ox, qByte(b, c * 6 + 3), cx);
-            cb.v[4] = qDecode(oy, qByte(b, c * 6 + 4), cy);
-            cb.v[5] = qDecode(oz, qByte(b, c * 6 + 5), cz);
+            cb.v[0] = qDecode(ox, qByte(b, c, 0, 0), cx);
+            cb.v[1] = qDecode(oy, qByte(b, c, 1, 0), cy);
+            cb.v[2] = qDecode(oz, qByte(b, c, 2, 0), cz);
+            cb.v[3] = qDecode(ox, qByte(b, c, 0, 1), cx);
+            cb.v[4] = qDecode(oy, qByte(b, c, 1, 1), cy);
+            cb.v[5] = qDecode(oz, qByte(b, c, 2, 1), cz);
             a[c] = b.w[10 + c];
             m[c] = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0xFFFFu;
             double tt;
@@ -150,6 +154,103 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
     if (near_t < kMiss) {
         T.node_a = near_a;
         T.node_m = near_m;
+    } else {
+        travPop(T, stk);
+    }
+}
+
+// The same visit with the slab tests in FP32 — the trace kernels' form. Per block and axis, with A = cell / d and
+// C = (origin - o) / d (both FP64, then rounded to float), the plane of cell coordinate q is crossed at t = q A + C; the
+// entry side uses C - m and the exit side C + m, where m = 2^-21 (255 |A| + |C|) + 2^-44 |o / d| covers the two
+// conversions, the FP32 multiply-add (each <= 2^-24 of 255 |A| + |C|) and the rounding of the FP64 form it replaces
+// (<= 2^-51 of |o / d| + |C|). So every FP32 entry distance is <= the FP64 one, every exit distance >=: a child the FP64
+// form keeps is kept here, with a key that is not larger — the walk visits a superset of the nodes again, and the
+// result (a minimum over exact FP64 primitive tests) is unchanged. A child's {entry distance, link meta} travel as one
+// word — the stack's key format (float bits, low 9 bits = m) — so the children are ordered with integer min / max and
+// pushed as they are. About half the instructions of the FP64 form (24 conversions + 24 multiply-adds + 28 min / max /
+// compare instead of 24 + 24 FP64 decodes, 48 FP64 slab operations and a 64-bit sorting network).
+constexpr uint32_t kQMissKey = 0xFFFFFFFFu;
+template <bool kLds, bool kCount>
+MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+    const float best_up = floatAbove(T.best.t);  // smallest float >= best.t
+    const double o[3] = {T.o.x, T.o.y, T.o.z}, inv[3] = {T.inv.x, T.inv.y, T.inv.z};
+    uint32_t near_key = kQMissKey, near_a = 0;
+    auto push = [&](uint32_t key, uint32_t a) {
+        if (T.sp < kMaxStackDepth) {
+            SmStackEntry e;
+            e.key = key;
+            e.a = a;
+            stk.put(T.sp++, e);
+        } else {
+            cnt.overflow = 1;
+        }
+    };
+    uint32_t bi = T.node_a;
+    bool more = true;
+    while (more) {
+        const QBlock b = qFetch(qv, bi++);
+        const uint32_t n = (b.w[3] >> 24) & 0x7Fu;
+        more = (b.w[3] >> 31) != 0u;
+        float A[3], Cn[3], Cf[3];
+        uint32_t wn[3], wf[3];  // cell coordinates of the planes the ray enters / leaves through, four children per word
+        for (int ax = 0; ax < 3; ax++) {
+            const double cell = qCell((b.w[3] >> (8 * ax)) & 0xFFu);
+            const double Ad = cell * inv[ax];
+            const double Cd = ((double)bitsFloat(b.w[ax]) - o[ax]) * inv[ax];
+            A[ax] = (float)Ad;
+            const float C = (float)Cd;
+            const float m = fmaf(fmaf(255.0f, fabsf(A[ax]), fabsf(C)), 4.76837158203125e-07f, fmaf(fabsf((float)(o[ax] * inv[ax])), 5.6843418860808015e-14f, 1e-30f));
+            Cn[ax] = C - m;
+            Cf[ax] = C + m;
+            const bool pos = inv[ax] >= 0.0;
+            wn[ax] = pos ? b.w[4 + 2 * ax] : b.w[5 + 2 * ax];
+            wf[ax] = pos ? b.w[5 + 2 * ax] : b.w[4 + 2 * ax];
+        }
+        uint32_t key[4], a[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int c = 0; c < 4; c++) {
+            const float tnx = fmaf((float)((wn[0] >> (8 * c)) & 0xFFu), A[0], Cn[0]);
+            const float tny = fmaf((float)((wn[1] >> (8 * c)) & 0xFFu), A[1], Cn[1]);
+            const float tnz = fmaf((float)((wn[2] >> (8 * c)) & 0xFFu), A[2], Cn[2]);
+            const float tfx = fmaf((float)((wf[0] >> (8 * c)) & 0xFFu), A[0], Cf[0]);
+            const float tfy = fmaf((float)((wf[1] >> (8 * c)) & 0xFFu), A[1], Cf[1]);
+            const float tfz = fmaf((float)((wf[2] >> (8 * c)) & 0xFFu), A[2], Cf[2]);
+            const float lo = fmaxf(fmaxf(tnx, tny), tnz), hi = fminf(fminf(tfx, tfy), tfz);
+            const float t = fmaxf(lo, 0.0f);
+            const bool keep = (uint32_t)c < n && hi >= t && t <= best_up;
+            if (kCount) cnt.node_tests += (uint32_t)c < n ? 1u : 0u;
+            const uint32_t m = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0x1FFu;
+            key[c] = keep ? ((floatBits(t) & ~0x1FFu) | m) : kQMissKey;
+            a[c] = b.w[10 + c];
+        }
+        auto exchange = [&](int i, int j) {  // afterwards key[i] <= key[j]
+            const bool sw = key[j] < key[i];
+            const uint32_t ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];
+            const uint32_t ai = sw ? a[j] : a[i], aj = sw ? a[i] : a[j];
+            key[i] = ki; key[j] = kj; a[i] = ai; a[j] = aj;
+        };
+        exchange(0, 1);
+        exchange(2, 3);
+        exchange(0, 2);
+        exchange(1, 3);
+        exchange(1, 2);
+        if (key[3] != kQMissKey) push(key[3], a[3]);
+        if (key[2] != kQMissKey) push(key[2], a[2]);
+        if (key[1] != kQMissKey) push(key[1], a[1]);
+        // the block's nearest against the nearest of the node's earlier blocks (nodes with more than 4 children)
+        const bool better = key[0] < near_key;
+        const uint32_t lose_key = better ? near_key : key[0], lose_a = better ? near_a : a[0];
+        if (better) {
+            near_key = key[0];
+            near_a = a[0];
+        }
+        if (lose_key != kQMissKey) push(lose_key, lose_a);
+    }
+    if (near_key != kQMissKey) {
+        T.node_a = near_a;
+        T.node_m = near_key & 0x1FFu;
     } else {
         travPop(T, stk);
     }

@@ -114,24 +114,33 @@ struct WfFrame {
     FilmView film;                  // type != MCRT_FILM_BOX: samples are splatted into film.blob instead (mcrt_film.hpp)
 };
 
-// ---- trace side: work item = slot * 2 + port (0 = bounce ray, closest hit; 1 = shadow ray, bounded any-hit)
-MCRT_HD void wfLoadRay(const WfPool& P, uint32_t item, d3& o, d3& d, bool& shadow, ShadowQuery& sq) {
-    const uint32_t slot = item >> 1;
-    shadow = (item & 1u) != 0u;
-    if (shadow) {
-        o = P.get3(kWfShO, slot);
-        d = P.get3(kWfShD, slot);
-        sq.t_near = P.getd(kWfShNear, slot);
-        sq.t_far = P.getd(kWfShFar, slot);
-        sq.light = (uint32_t)P.getu(kWfNeeLight, slot);
-    } else {
-        o = P.get3(kWfRayO, slot);
-        d = P.get3(kWfRayD, slot);
-        sq.t_near = 0.0;
-        sq.t_far = kDblMax;
-        sq.light = kNoSurface;
+// ---- trace side: work item = slot * 2 + port (0 = bounce ray, closest hit; 1 = shadow ray, bounded any-hit).
+// The rays themselves travel in QUEUE order (WfRayQueue: eight planes of doubles + the light of a shadow ray, entry w
+// next to entry w + 1), so a refill of the trace kernel — the idle lanes of a wave take consecutive entries — reads
+// consecutive words: one coalesced round trip after the pop, instead of the item, then scattered slot words.
+struct WfRayQueue {
+    uint32_t* item;    // [cap] slot * 2 + port
+    uint32_t* light;   // [cap] shadow ray: the surface aimed at
+    double* ray;       // [8][cap] o.xyz, d.xyz, t_near, t_far
+    uint64_t cap;
+    MCRT_HD void put(uint64_t w, uint32_t it, d3 o, d3 d, double t_near, double t_far, uint32_t l) const {
+        item[w] = it;
+        light[w] = l;
+        ray[0 * cap + w] = o.x; ray[1 * cap + w] = o.y; ray[2 * cap + w] = o.z;
+        ray[3 * cap + w] = d.x; ray[4 * cap + w] = d.y; ray[5 * cap + w] = d.z;
+        ray[6 * cap + w] = t_near; ray[7 * cap + w] = t_far;
     }
-}
+    MCRT_HD uint32_t get(uint64_t w, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
+        const uint32_t it = item[w];
+        o = d3{ray[0 * cap + w], ray[1 * cap + w], ray[2 * cap + w]};
+        d = d3{ray[3 * cap + w], ray[4 * cap + w], ray[5 * cap + w]};
+        sq.t_near = ray[6 * cap + w];
+        sq.t_far = ray[7 * cap + w];
+        sq.light = light[w];
+        shadow = (it & 1u) != 0u;
+        return it;
+    }
+};
 
 MCRT_HD void wfStoreHit(const WfPool& P, uint32_t item, const Hit& h) {
     const uint32_t slot = item >> 1;
@@ -191,7 +200,7 @@ MCRT_HD d3 wfPhotonEstimate(const WfPmView& pm, uint32_t n_slots, uint32_t slot,
 // ---- shade side. Env supplies the three places where lanes cooperate:
 //   bool any(bool)                      true if the predicate holds for any lane of the wave (host: identity)
 //   unsigned long long pop(bool need)   next index of the frame's pixel work counter for the lanes that need one
-//   void push(slot, bool p0, bool p1)   queue the slot's bounce ray / shadow ray for the next trace launch
+//   void push(slot, p0, p1, rays...)    queue the slot's bounce ray / shadow ray (given: origin, direction, shadow range, light) for the next trace launch
 //   void filmAdd(double*, double)       accumulate into a film splat (any lane, any time; atomic on the GPU)
 //   void request(slot, want, global)    photon mapper: queue the slot's caustic (and global) search for the next kNN launch
 // All but filmAdd are called by every lane of the wave, at the same place.
@@ -211,6 +220,9 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
     uint32_t px = 0, ly = 0, sample = 0, sample_end = 0;
     bool need_pixel = false;
     bool want_estimate = false, need_g = false;  // photon mapper: this hit needs its radiance estimates first
+    // the shadow ray this call may queue (written into the ray queue by env.push, in queue order)
+    d3 sh_o = splat(0.0), sh_d = splat(0.0);
+    double sh_near = 0.0, sh_far = 0.0;
     auto loadHit0 = [&]() {
         Hit h;
         h.t = P.getd(kWfHit0T, slot);
@@ -325,10 +337,10 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             }
         }
         if (nee.pending) {
-            P.set3(kWfShO, slot, shadow_ray.start);
-            P.set3(kWfShD, slot, shadow_ray.direction);
-            P.setd(kWfShNear, slot, shadow_q.t_near);
-            P.setd(kWfShFar, slot, shadow_q.t_far);
+            sh_o = shadow_ray.start;
+            sh_d = shadow_ray.direction;
+            sh_near = shadow_q.t_near;
+            sh_far = shadow_q.t_far;
             P.setu(kWfNeeLight, slot, nee.light);
             P.set3(kWfNeeBsdf, slot, nee.bsdf_absIdotN);
             P.setd(kWfNeePdf, slot, nee.bsdf_pdf);
@@ -414,7 +426,8 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
                 if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.iors[(uint32_t)i * rh.stride]);
         }
     }
-    env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending);
+    env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending, st.ray.start, st.ray.direction, sh_o, sh_d, sh_near, sh_far,
+             nee.pending ? nee.light : kNoSurface);
     if constexpr (kPhoton) env.request(slot, want_estimate, need_g);
 }
 

@@ -135,11 +135,6 @@ __device__ inline uint32_t waveMaxU32(uint32_t v) {
 }
 // Non-negative floats order like their bit patterns.
 __device__ inline float waveMinPosF(float v) { return bitsFloat(waveMinU32(floatBits(v))); }
-__device__ inline float floatAbove(double t) {  // smallest float >= t (t >= 0)
-    float f = (float)t;
-    if ((double)f < t) f = bitsFloat(floatBits(f) + 1u);
-    return f;
-}
 __device__ inline uint32_t waveRead(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }  // src wave-uniform
 
 // Keep the k smallest of the first `count` buffer entries, compacted (unordered) into slots [0, k);
@@ -179,20 +174,20 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
         const unsigned long long trial = T | ((1ull << bit) - 1ull);  // all candidates with this bit clear
         uint32_t n_le = 0;
         for (int s = 0; s < 4; s++)
-            if (s < rows) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
+            if (s < rows) n_le += __popcll(waveBallot(valid[s] && key[s] <= trial));
         if (n_le < k) T |= (1ull << bit);
     }
     uint32_t n_lt = 0;
-    for (int s = 0; s < 4; s++) n_lt += __popcll(__ballot(valid[s] && key[s] < T));
+    for (int s = 0; s < 4; s++) n_lt += __popcll(waveBallot(valid[s] && key[s] < T));
     // compaction: everything below T, then entries equal to T until k are kept
     uint32_t out = 0, eq_left = k - n_lt;
     for (int s = 0; s < 4; s++) {
         const bool lt = valid[s] && key[s] < T;
         const bool eq = valid[s] && key[s] == T;
-        const unsigned long long m_lt = __ballot(lt), m_eq = __ballot(eq);
+        const unsigned long long m_lt = waveBallot(lt), m_eq = waveBallot(eq);
         const uint32_t eq_rank = __popcll(m_eq & ((1ull << lane) - 1ull));
         const bool keep_eq = eq && eq_rank < eq_left;
-        const unsigned long long m_keep = m_lt | __ballot(keep_eq);
+        const unsigned long long m_keep = m_lt | waveBallot(keep_eq);
         const bool keep = lt || keep_eq;
         if (keep) {
             const uint32_t slot = out + __popcll(m_keep & ((1ull << lane) - 1ull));
@@ -202,7 +197,7 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
             W.idx[slot] = my_i[s];
         }
         out += __popcll(m_keep);
-        const uint32_t n_eq_kept = __popcll(__ballot(keep_eq));
+        const uint32_t n_eq_kept = __popcll(waveBallot(keep_eq));
         eq_left -= n_eq_kept;
     }
     union { double d; unsigned long long u; } c;
@@ -238,7 +233,7 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
         const unsigned long long trial = T | ((1ull << bit) - 1ull);
         uint32_t n_le = 0;
         for (int s = 0; s < 4; s++)
-            if (s < rows) n_le += __popcll(__ballot(valid[s] && key[s] <= trial));
+            if (s < rows) n_le += __popcll(waveBallot(valid[s] && key[s] <= trial));
         if (n_le < k) {
             T |= (1ull << bit);
         } else if (n_le <= k + slack) {  // k .. k + slack entries below this trial value: good enough a bound
@@ -251,7 +246,7 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
     uint32_t out = 0;
     for (int s = 0; s < 4; s++) {
         const bool keep = valid[s] && key[s] <= T;
-        const unsigned long long m_keep = __ballot(keep);
+        const unsigned long long m_keep = waveBallot(keep);
         if (keep) {
             const uint32_t slot = out + __popcll(m_keep & ((1ull << lane) - 1ull));
             union { double d; unsigned long long u; } c;
@@ -285,7 +280,7 @@ __device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint
     while (n > k) {  // wave-uniform
         uint32_t mh, ml;
         largest(mh, ml);
-        const unsigned long long owners = __ballot(valid && hi == mh && lo == ml);
+        const unsigned long long owners = waveBallot(valid && hi == mh && lo == ml);
         const int drop = 63 - __clzll((long long)owners);
         if ((int)lane == drop) valid = false;
         n--;
@@ -297,7 +292,7 @@ __device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint
     r.u[0] = ml;
     kth_d2 = r.d;
     if (n != count) {  // close the gaps
-        const unsigned long long keep = __ballot(valid);
+        const unsigned long long keep = waveBallot(valid);
         if (valid) {
             const uint32_t slot = __popcll(keep & ((1ull << lane) - 1ull));
             W.d2[slot] = c.d;
@@ -379,7 +374,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                     d3 d = p - d3{(double)px[c], (double)py[c], (double)pz[c]};  // glm::distance2(data.pos(), p)
                     const double d2v = dot(d, d);
                     const bool cand = i < contained && d2v <= max_distance2;
-                    const unsigned long long mask = __ballot(cand);
+                    const unsigned long long mask = waveBallot(cand);
                     if (mask) {
                         const uint32_t slot = count + __popcll(mask & ((1ull << lane) - 1ull));
                         if (cand) {
@@ -440,19 +435,19 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                 f_d2[1] = cd2; f_a[1] = ca; f_b[1] = cb;
                 push = false;
             }
-            unsigned long long pmask = __ballot(push);  // (rare) both slots of the tester taken: any free slot of the wave
+            unsigned long long pmask = waveBallot(push);  // (rare) both slots of the tester taken: any free slot of the wave
             while (pmask) {
                 const int src = __ffsll((long long)pmask) - 1;
                 pmask &= pmask - 1;
                 const float d = bitsFloat(waveRead(floatBits(cd2), src));
                 const uint32_t a = waveRead(ca, src), b = waveRead(cb, src);
-                const unsigned long long free0 = __ballot(f_b[0] == 0u);
+                const unsigned long long free0 = waveBallot(f_b[0] == 0u);
                 if (free0) {
                     if ((int)lane == __ffsll((long long)free0) - 1) {
                         f_d2[0] = d; f_a[0] = a; f_b[0] = b;
                     }
                 } else {
-                    const unsigned long long free1 = __ballot(f_b[1] == 0u);
+                    const unsigned long long free1 = waveBallot(f_b[1] == 0u);
                     if (free1) {
                         if ((int)lane == __ffsll((long long)free1) - 1) {
                             f_d2[1] = d; f_a[1] = a; f_b[1] = b;
@@ -468,7 +463,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
         const float best = waveMinPosF(mine);
         if (!(best < INFINITY)) break;                // frontier empty
         if ((double)best > max_distance2) break;      // linear-octree.cpp:113
-        const unsigned long long owner = __ballot(mine == best);
+        const unsigned long long owner = waveBallot(mine == best);
         const int ol = __ffsll((long long)owner) - 1;
         const int which = f_d2[0] <= f_d2[1] ? 0 : 1;
         cur_a = waveRead(which == 0 ? f_a[0] : f_a[1], ol);
@@ -496,7 +491,7 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
                                   const WaveKnnLds& W, uint32_t& searches, uint32_t& octant_visits, uint32_t& overflow) {
     d3 result = splat(0.0);
     const uint32_t lane = __lane_id();
-    unsigned long long mask = __ballot(want);
+    unsigned long long mask = waveBallot(want);
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;

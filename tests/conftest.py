@@ -93,6 +93,7 @@ def load_emu():
     L.emu_plan.restype = None
     L.emu_tonemap.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
     L.emu_flat_cull.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    L.emu_qstep_check.argtypes = [vp, C.c_uint64, vp, vp, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     return L
 

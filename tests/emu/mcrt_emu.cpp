@@ -7,6 +7,8 @@
 // the product links or loads it, and libmcrt_hip.so has no host execution path.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -237,6 +239,92 @@ struct QTrace {
 };
 }  // namespace
 
+// FP32 form of the block visit against its FP64 yardstick (mcrt_qbvh.hpp): walks n rays with the FP32 form and, at every
+// inner visit, runs the FP64 form on a copy of the state; every child the FP64 form keeps (pushes or continues with) must
+// be kept by the FP32 form with a key (entry distance, rounded down) that is not larger. Returns the number of violations;
+// out[0] = inner visits, out[1] = children kept by FP64, out[2] = children kept by FP32.
+extern "C" int emu_qstep_check(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, uint64_t* out) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return -1;
+    if (scene->num_nodes == 0) return -2;
+    QTrace qt;
+    qt.init(E, scene);
+    std::vector<SmStackEntry> a_lds(kMaxStackDepth), b_lds(kMaxStackDepth), dummy(1);
+    auto mk = [&](std::vector<SmStackEntry>& v) {
+        SmStack s;
+        s.lds = v.data();
+        s.lds_stride = 1;
+        s.spill = dummy.data();
+        s.spill_stride = 0;
+        s.lds_depth = kMaxStackDepth;
+        return s;
+    };
+    SmStack sa = mk(a_lds), sb = mk(b_lds);
+    TraceCounters cnt = {0, 0, 0, 0};
+    int bad = 0;
+    uint64_t visits = 0, kept64 = 0, kept32 = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const d3 o = ld3(start + 3 * i), d = ld3(direction + 3 * i);
+        Trav T;
+        travBeginQ<false, true, true>(qt.sv, qt.qv, T, o, d, rcp3(d), false, nullptr, cnt);
+        while (T.active) {
+            if (T.node_m & kSmInner) {
+                if (T.fast) {
+                    Trav A = T, B = T;
+                    A.sp = 0;
+                    B.sp = 0;
+                    travInnerStepQ64<true, true>(qt.qv, A, sa, cnt);
+                    travInnerStepQ<true, true>(qt.qv, B, sb, cnt);
+                    // kept sets: pushed entries + the child continued with (if the visit did not end in a pop: sp == 0 and active
+                    // after a visit that kept nothing means the state is unchanged/inactive)
+                    auto collect = [&](const Trav& X, const std::vector<SmStackEntry>& st, std::vector<std::pair<uint32_t, uint32_t>>& v, bool f32) {
+                        for (int k = 0; k < X.sp; k++) v.push_back({st[k].a, st[k].key});
+                        (void)f32;
+                    };
+                    std::vector<std::pair<uint32_t, uint32_t>> v64, v32;
+                    collect(A, a_lds, v64, false);
+                    collect(B, b_lds, v32, true);
+                    // the near child is not on the stack: recover it when the visit kept anything
+                    const bool near64 = A.active && (A.sp > 0 || A.node_a != T.node_a || A.node_m != T.node_m);
+                    const bool near32 = B.active && (B.sp > 0 || B.node_a != T.node_a || B.node_m != T.node_m);
+                    visits++;
+                    kept64 += v64.size() + (near64 ? 1 : 0);
+                    kept32 += v32.size() + (near32 ? 1 : 0);
+                    // a child is identified by its link AND its meta (a leaf's first primitive and an inner child's first block
+                    // may be the same number)
+                    auto has = [&](uint32_t a, uint32_t m, uint32_t key64) {
+                        if (near32 && B.node_a == a && B.node_m == m) return true;  // continued with: nearest, no key to compare
+                        for (auto& e : v32)
+                            if (e.first == a && (e.second & 0x1FFu) == m) return (e.second & ~0x1FFu) <= (key64 & ~0x1FFu);
+                        return false;
+                    };
+                    for (auto& e : v64)
+                        if (!has(e.first, e.second & 0x1FFu, e.second)) {
+                            bad++;
+                            if (getenv("QDBG")) {
+                                fprintf(stderr, "bad: a=%u key64=%08x (t=%g) near32=%d B.node_a=%u; v32:", e.first, e.second, (double)bitsFloat(e.second), (int)near32, B.node_a);
+                                for (auto& f : v32) fprintf(stderr, " [%u %08x t=%g]", f.first, f.second, (double)bitsFloat(f.second));
+                                fprintf(stderr, " | v64:");
+                                for (auto& f : v64) fprintf(stderr, " [%u %08x t=%g]", f.first, f.second, (double)bitsFloat(f.second));
+                                fprintf(stderr, " near64=%d A.node_a=%u best=%g\n", (int)near64, A.node_a, T.best.t);
+                            }
+                        }
+                    if (near64 && !has(A.node_a, A.node_m, 0xFFFFFFFFu)) bad++;
+                    travInnerStepQ<true, true>(qt.qv, T, qt.stk, cnt);
+                } else {
+                    travInnerStep<false, true>(qt.sv, T, qt.stk, cnt);
+                }
+            } else {
+                travLeafStep<false, true>(qt.sv, T, qt.stk, cnt);
+            }
+        }
+    }
+    out[0] = visits;
+    out[1] = kept64;
+    out[2] = kept32;
+    return bad;
+}
+
 // The lane-state-machine integrator (mcrt_lanesm.hpp) driven for one lane at a time: the same
 // regenerate / traverse-step / shade / NEE-finish functions the gfx950 kernel calls, without the
 // wave-level gating (which only changes how lanes interleave, not what a lane computes).
@@ -333,9 +421,14 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
 // wfStoreHit the gfx950 kernels run, with the wave-level cooperation (work pop, queue append) done serially.
 // The camera's shard fields select the rows, exactly as for mcrt_render.
 namespace {
+struct HostRayRec {  // one entry of the ray queue (the device keeps these as planes: WfRayQueue)
+    uint32_t item, light;
+    d3 o, d;
+    double t_near, t_far;
+};
 struct HostWfEnv {
     unsigned long long* work;
-    std::vector<uint32_t>* queue;
+    std::vector<HostRayRec>* queue;
     bool any(bool b) const { return b; }
     unsigned long long pop(bool need) const { return need ? (*work)++ : 0ull; }
     void filmAdd(double* a, double v) const { *a += v; }
@@ -343,9 +436,9 @@ struct HostWfEnv {
     void request(uint32_t slot, bool want, bool global) const {
         if (want) requests->push_back(slot | (global ? 0x80000000u : 0u));
     }
-    void push(uint32_t slot, bool p0, bool p1) const {
-        if (p0) queue->push_back(slot * 2u);
-        if (p1) queue->push_back(slot * 2u + 1u);
+    void push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double near1, double far1, uint32_t light1) const {
+        if (p0) queue->push_back(HostRayRec{slot * 2u, kNoSurface, o0, d0, 0.0, kDblMax});
+        if (p1) queue->push_back(HostRayRec{slot * 2u + 1u, light1, o1, d1, near1, far1});
     }
 };
 }  // namespace
@@ -455,7 +548,8 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
         fr.samples = samples.data();
     }
     unsigned long long work = 0;
-    std::vector<uint32_t> queue, requests;
+    std::vector<HostRayRec> queue;
+    std::vector<uint32_t> requests;
     HostWfEnv env{&work, &queue, &requests};
     TraceCounters cnt = {0, 0, 0, 0};
     uint32_t paths = 0;
@@ -485,13 +579,13 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
                 }
             }
         }
-        for (uint32_t item : queue) {
-            d3 o, d;
-            bool shadow;
+        for (const HostRayRec& r : queue) {
             ShadowQuery sq;
-            wfLoadRay(P, item, o, d, shadow, sq);
-            const Hit h = qt.run(o, d, shadow, &sq, cnt);
-            wfStoreHit(P, item, h);
+            sq.t_near = r.t_near;
+            sq.t_far = r.t_far;
+            sq.light = r.light;
+            const Hit h = qt.run(r.o, r.d, (r.item & 1u) != 0u, &sq, cnt);
+            wfStoreHit(P, r.item, h);
         }
     }
     if (fr.film.type != MCRT_FILM_BOX && !film_out)

@@ -246,3 +246,25 @@ def test_flat_cull_keeps_every_primitive_the_fp64_tests_accept(pkg, emu, manifes
     accepted, survivors = out[:, 2:].sum() / n, out[:, :2].sum() / n
     assert accepted > 0.5               # the rays do hit things
     assert survivors < accepted + max(2.0, 0.2 * img.scene.num_surfaces)   # and the cull does cull, even on these rays
+
+
+@pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "hexagon_room", "quadric"])
+def test_fp32_block_visit_keeps_what_the_fp64_visit_keeps(pkg, emu, manifest, name):
+    """travInnerStepQ (FP32 slab tests with error margins, mcrt_qbvh.hpp) against travInnerStepQ64 at every inner visit of
+    200 000 rays: a superset of the children, entry keys not larger; and the margins cost next to nothing in extra children."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    sc = img.scene
+    rng = np.random.default_rng(11)
+    lo, hi = np.array(sc.bb_min[:]), np.array(sc.bb_max[:])
+    n = 200000
+    a = rng.uniform(lo - 0.5 * (hi - lo), hi + 0.5 * (hi - lo), (n, 3))
+    b = rng.uniform(lo, hi, (n, 3))
+    d = b - a
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 20] = np.round(d[: n // 20], 1)  # some directions with tiny / exactly representable components
+    keep = np.linalg.norm(d, axis=1) > 0
+    a, d = np.ascontiguousarray(a[keep]), np.ascontiguousarray(d[keep] / np.linalg.norm(d[keep], axis=1, keepdims=True))
+    out = (C.c_uint64 * 3)()
+    bad = emu.emu_qstep_check(C.byref(sc), len(a), a.ctypes.data, d.ctypes.data, out)
+    assert bad == 0
+    assert out[0] > 0 and out[2] >= out[1] and out[2] <= 1.01 * out[1] + 10
