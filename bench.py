@@ -319,7 +319,20 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     wl.integrator = m.INTEGRATOR_PATH_TRACER
     wl.pm_maps, wl.emit_info = None, None
     wl.photon = name in ("pm", "c5")
-    if wl.photon:
+    if wl.photon and world == 1 and not args.host_octree:
+        # one GPU: the whole photon pass on the device (mcrt_photon_pass_device: emission, sort, octants, boxes, record lists;
+        # no photon list crosses PCIe)
+        wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
+        sc = img.scene
+        t_pass = time.perf_counter()
+        ps = wl.ctx.photon_pass_device(args.emissions, 10.0, SEED, sc.bb_min[:], sc.bb_max[:], 200, 50, False)
+        wl.emit_info = dict(paths=ps["emission_paths"], rays=ps["rays"], kernel_ms=ps["emission_ms"], global_photons=int(ps["global_count"]),
+                            caustic_photons=int(ps["caustic_count"]), octree_build_s=(ps["total_ms"] - ps["emission_ms"]) * 1e-3,
+                            octree_builder="device (mcrt_photon_pass_device)", photon_pass_s=time.perf_counter() - t_pass,
+                            map_ms=dict(sort=ps["sort_ms"], octants=ps["octant_ms"], boxes_and_lists=ps["finish_ms"]),
+                            octants=[int(ps["global_octants"]), int(ps["caustic_octants"])],
+                            emission_Mray_per_s=ps["rays"] / max(ps["emission_ms"], 1e-9) / 1e3)
+    elif wl.photon:
         # emission pass on the GPU (sharded over the ranks and all-gathered), octrees GPU-assisted, upload
         wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
         em = wl.ctx.emit_photons(args.emissions, 10.0, SEED, rank, world)
@@ -493,6 +506,8 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
             result["parity"] = par
         counts = None
         if world == 1 and want_cpu:
+            if wl.photon and wl.pm_maps is None:  # device-built maps: host copies for the CPU leg only (same maps the GPU searched)
+                wl.pm_maps = (wl.ctx.download_map(0), wl.ctx.download_map(1))
             base, counts = cpu_baseline(m, wl.img, wl.full, args.cpu_seconds if headline else args.cpu_seconds * 0.6, wl.integrator, wl.pm_maps,
                                         scan_threads=headline, ref_threads=ref_threads)
             result["cpu_baseline"] = base

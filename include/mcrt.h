@@ -273,6 +273,43 @@ int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, ui
 int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed,
                             uint32_t shard_index, uint32_t shard_count, mcrt_photon_emission* out);
 
+/* ---- The photon pass without host round trips (SURVEY.md §8(f) ranks 1 + 2; replaces PhotonMapper::PhotonMapper,
+ * integrator/photon-mapper/photon-mapper.cpp:31-203, as a whole): the emission pass, then both maps built where the
+ * photons are — cell codes, radix sort, gather, the octants level by level from the sorted codes, depth-first numbering,
+ * leaf boxes merged upwards, the search's record lists — and installed as mcrt_upload_photons installs them. Same photons
+ * as mcrt_emit_photons, same octants / boxes / photons per leaf as mcrt_photon_map_build (Octree<Photon>::insert,
+ * octree/octree.cpp:35-80 + LinearOctree, octree/linear-octree.cpp:202-244) with root cell [bb_min, bb_max] = Scene::BB().
+ * Only counters cross PCIe. MCRT_ERR_UNSUPPORTED when more than max_photons_per_leaf photons share one 2^-21 cell (the
+ * recursive host builder's case). */
+typedef struct mcrt_photon_pass_stats {
+    uint64_t global_count, caustic_count;   /* photons stored */
+    uint64_t global_octants, caustic_octants;
+    uint64_t emission_paths, rays;
+    double emission_ms;                     /* emission kernel (HIP events) */
+    double sort_ms, octant_ms, finish_ms;   /* both maps: codes + sort + gather / octants + numbering / boxes + record lists (host clock) */
+    double total_ms;                        /* whole call (host clock) */
+} mcrt_photon_pass_stats;
+int mcrt_photon_pass_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, const double bb_min[3],
+                            const double bb_max[3], uint32_t max_photons_per_leaf, uint32_t k_nearest_photons,
+                            int direct_visualization, mcrt_photon_pass_stats* stats);
+/* The emission pass alone with the lists left in device memory (owned by the context, valid until the next emission): for
+ * hosts that exchange the lists between GPUs (RCCL all-gather on the device pointers) before building the maps. */
+typedef struct mcrt_photon_emission_device {
+    uint64_t global_count, caustic_count;
+    const float* d_global_photons;    /* DEVICE [global_count][8]  */
+    const float* d_caustic_photons;   /* DEVICE [caustic_count][8] */
+    uint64_t emission_paths, rays;
+    double kernel_ms;
+} mcrt_photon_emission_device;
+int mcrt_emit_photons_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
+                             uint32_t shard_count, mcrt_photon_emission_device* out);
+/* Both maps from photon lists in device memory (not modified), installed like mcrt_upload_photons. */
+int mcrt_upload_photons_device(mcrt_ctx* ctx, const float* d_global_photons, uint64_t global_count, const float* d_caustic_photons,
+                               uint64_t caustic_count, const double bb_min[3], const double bb_max[3], uint32_t max_photons_per_leaf,
+                               uint32_t k_nearest_photons, int direct_visualization, mcrt_photon_pass_stats* stats);
+/* Copy of an installed map (0 global, 1 caustic) as a host object — octants, boxes, photons — for inspection and tests. */
+int mcrt_photon_map_download(mcrt_ctx* ctx, int which, struct mcrt_photon_map** out);
+
 /* ---- operator-level entry points (each mirrors one reference function; used by parity tests
  * and by hosts that only want the traversal / kNN engine) -------------------------------- */
 

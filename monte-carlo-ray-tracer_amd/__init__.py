@@ -142,6 +142,20 @@ class PhotonEmission(C.Structure):
     ]
 
 
+class PhotonPassStats(C.Structure):
+    _fields_ = [("global_count", C.c_uint64), ("caustic_count", C.c_uint64), ("global_octants", C.c_uint64), ("caustic_octants", C.c_uint64),
+                ("emission_paths", C.c_uint64), ("rays", C.c_uint64), ("emission_ms", C.c_double), ("sort_ms", C.c_double),
+                ("octant_ms", C.c_double), ("finish_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PhotonEmissionDevice(C.Structure):
+    _fields_ = [("global_count", C.c_uint64), ("caustic_count", C.c_uint64), ("d_global_photons", C.c_void_p), ("d_caustic_photons", C.c_void_p),
+                ("emission_paths", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double)]
+
+
 def render_multi(contexts, cam, global_seed, integrator=INTEGRATOR_PATH_TRACER):
     """mcrt_render_multi: one frame over several contexts (one per GPU, scene already uploaded), one host thread each ->
     (image[H,W,3] float64, stats dict)."""
@@ -195,6 +209,10 @@ def lib():
     L.mcrt_shard_rows.restype = C.c_uint32
     L.mcrt_emit_photons.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.POINTER(PhotonEmission)]
     L.mcrt_emit_photons_shard.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PhotonEmission)]
+    L.mcrt_photon_pass_device.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, _dp, _dp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(PhotonPassStats)]
+    L.mcrt_emit_photons_device.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PhotonEmissionDevice)]
+    L.mcrt_upload_photons_device.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, _dp, _dp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(PhotonPassStats)]
+    L.mcrt_photon_map_download.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.mcrt_intersect.argtypes = [vp, C.c_uint64, _dp, _dp, _dp, _u32p, _dp]
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
@@ -357,6 +375,13 @@ class PhotonMap:
     """mcrt_photon_map: linear photon octree built from a photon list — on the host (mcrt_photon_map_build) or,
     given a Context, with its GPU (mcrt_photon_map_build_gpu: cell codes, radix sort, gather, leaf boxes)."""
 
+    @classmethod
+    def _from_handle(cls, handle):
+        m = cls.__new__(cls)
+        m._lib = lib()
+        m._h = handle
+        return m
+
     def __init__(self, photons, bb_min, bb_max, max_photons_per_leaf=200, ctx=None):
         self._lib = lib()
         self._h = C.c_void_p()
@@ -493,6 +518,41 @@ class Context:
         return dict(global_=grab(pe.global_photons, pe.global_keys, pe.global_count),
                     caustic=grab(pe.caustic_photons, pe.caustic_keys, pe.caustic_count),
                     paths=int(pe.emission_paths), rays=int(pe.rays), kernel_ms=pe.kernel_ms)
+
+    def photon_pass_device(self, emissions, caustic_factor, global_seed, bb_min, bb_max, max_photons_per_leaf=200, k_nearest=50,
+                           direct_visualization=False):
+        """mcrt_photon_pass_device: emission + both maps on the device, installed for the eye pass. Returns the stats dict."""
+        st = PhotonPassStats()
+        lo, hi = (C.c_double * 3)(*bb_min), (C.c_double * 3)(*bb_max)
+        self._check(self._lib.mcrt_photon_pass_device(self._h, float(emissions), float(caustic_factor), int(global_seed), lo, hi,
+                                                      int(max_photons_per_leaf), int(k_nearest), 1 if direct_visualization else 0, C.byref(st)),
+                    "mcrt_photon_pass_device")
+        return st.as_dict()
+
+    def emit_photons_device(self, emissions, caustic_factor, global_seed, shard_index=0, shard_count=1):
+        """mcrt_emit_photons_device -> dict(global_=(device pointer, count), caustic=(...), paths, rays, kernel_ms); the lists
+        stay in device memory owned by the context."""
+        pe = PhotonEmissionDevice()
+        self._check(self._lib.mcrt_emit_photons_device(self._h, float(emissions), float(caustic_factor), int(global_seed), int(shard_index),
+                                                       int(shard_count), C.byref(pe)), "mcrt_emit_photons_device")
+        return dict(global_=(pe.d_global_photons or 0, int(pe.global_count)), caustic=(pe.d_caustic_photons or 0, int(pe.caustic_count)),
+                    paths=int(pe.emission_paths), rays=int(pe.rays), kernel_ms=pe.kernel_ms)
+
+    def upload_photons_device(self, d_global, global_count, d_caustic, caustic_count, bb_min, bb_max, max_photons_per_leaf=200, k_nearest=50,
+                              direct_visualization=False):
+        """mcrt_upload_photons_device: both maps from photon lists in device memory (raw pointers, e.g. tensor.data_ptr())."""
+        st = PhotonPassStats()
+        lo, hi = (C.c_double * 3)(*bb_min), (C.c_double * 3)(*bb_max)
+        self._check(self._lib.mcrt_upload_photons_device(self._h, C.c_void_p(int(d_global)), int(global_count), C.c_void_p(int(d_caustic)),
+                                                         int(caustic_count), lo, hi, int(max_photons_per_leaf), int(k_nearest),
+                                                         1 if direct_visualization else 0, C.byref(st)), "mcrt_upload_photons_device")
+        return st.as_dict()
+
+    def download_map(self, which):
+        """mcrt_photon_map_download: host copy (PhotonMap) of installed map 0 (global) / 1 (caustic)."""
+        h = C.c_void_p()
+        self._check(self._lib.mcrt_photon_map_download(self._h, int(which), C.byref(h)), "mcrt_photon_map_download")
+        return PhotonMap._from_handle(h)
 
     def intersect(self, start, direction):
         start = np.ascontiguousarray(start, dtype=np.float64)

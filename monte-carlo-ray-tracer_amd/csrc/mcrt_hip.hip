@@ -18,6 +18,9 @@
 #include "mcrt_layout.hpp"
 #include "mcrt_internal.hpp"
 #include "mcrt_plan.hpp"
+#include "mcrt_octree_shared.hpp"
+
+#include <hipcub/hipcub.hpp>
 
 using namespace mcrt;
 
@@ -832,6 +835,8 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     return MCRT_OK;
 }
 
+#include "mcrt_photon_device.hpp"
+
 }  // namespace
 
 // ================================================================================================
@@ -1136,15 +1141,19 @@ int mcrt_emit_photons(mcrt_ctx* ctx, double emissions, double caustic_factor, ui
     return mcrt_emit_photons_shard(ctx, emissions, caustic_factor, global_seed, 0, 1, out);
 }
 
-int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
-                            uint32_t shard_count, mcrt_photon_emission* out) {
-    if (!ctx) return MCRT_ERR_INVALID;
-    if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
+}  // extern "C"
+
+namespace {
+// The emission pass; the lists stay in ctx->emit_photons / emit_keys. h = the kernel's counters ([1] global, [2] caustic
+// photons, [3] paths, [4] rays).
+int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index, uint32_t shard_count,
+                 unsigned long long h[8], float& ms) {
+    for (int i = 0; i < 8; i++) h[i] = 0ull;
+    ms = 0.f;
     if (shard_count == 0 || shard_index >= shard_count) return fail(ctx, MCRT_ERR_INVALID, "shard_index >= shard_count");
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_emit_photons before mcrt_upload_scene");
     REJECT_IF_PENDING(ctx, "mcrt_emit_photons");
     if (!(emissions >= 0.0) || !(caustic_factor > 0.0)) return fail(ctx, MCRT_ERR_INVALID, "emissions must be >= 0 and caustic_factor > 0");
-    memset(out, 0, sizeof(*out));
     const uint32_t nl = ctx->scene.num_lights;
     if (nl == 0 || nl > 0xFFFFu) return nl == 0 ? MCRT_OK : fail(ctx, MCRT_ERR_UNSUPPORTED, "more than 65535 lights");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1181,8 +1190,6 @@ int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_fact
     if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
 
     unsigned long long cap[2] = {std::max<unsigned long long>(1ull << 16, total), std::max<unsigned long long>(1ull << 16, total)};
-    unsigned long long h[8] = {0};
-    float ms = 0.f;
     for (int attempt = 0; attempt < 3; attempt++) {
         for (int w = 0; w < 2; w++) {
             if (ctx->emit_photons[w].bytes < cap[w] * 32) HIP_TRY(ctx, ctx->emit_photons[w].alloc(cap[w] * 32));
@@ -1212,7 +1219,7 @@ int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_fact
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-        HIP_TRY(ctx, hipMemcpy(h, ctx->emit_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(h, ctx->emit_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow in the emission pass");
         if (h[1] <= cap[0] && h[2] <= cap[1]) break;
@@ -1220,6 +1227,20 @@ int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_fact
         cap[1] = std::max(cap[1], h[2]);
         if (attempt == 2) return fail(ctx, MCRT_ERR_HIP, "photon lists kept overflowing");
     }
+    return MCRT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
+                            uint32_t shard_count, mcrt_photon_emission* out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    unsigned long long h[8];
+    float ms = 0.f;
+    if (int rc = emitOnDevice(ctx, emissions, caustic_factor, global_seed, shard_index, shard_count, h, ms)) return rc;
     for (int w = 0; w < 2; w++) {
         const size_t n = (size_t)h[1 + w];
         ctx->host_photons[w].resize(n * 8);
@@ -1238,6 +1259,105 @@ int mcrt_emit_photons_shard(mcrt_ctx* ctx, double emissions, double caustic_fact
     out->emission_paths = h[3];
     out->rays = h[4];
     out->kernel_ms = ms;
+    return MCRT_OK;
+}
+
+int mcrt_emit_photons_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
+                             uint32_t shard_count, mcrt_photon_emission_device* out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!out) return fail(ctx, MCRT_ERR_INVALID, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    unsigned long long h[8];
+    float ms = 0.f;
+    if (int rc = emitOnDevice(ctx, emissions, caustic_factor, global_seed, shard_index, shard_count, h, ms)) return rc;
+    out->global_count = h[1];
+    out->caustic_count = h[2];
+    out->d_global_photons = ctx->emit_photons[0].as<float>();
+    out->d_caustic_photons = ctx->emit_photons[1].as<float>();
+    out->emission_paths = h[3];
+    out->rays = h[4];
+    out->kernel_ms = ms;
+    return MCRT_OK;
+}
+
+int mcrt_upload_photons_device(mcrt_ctx* ctx, const float* d_global_photons, uint64_t global_count, const float* d_caustic_photons,
+                               uint64_t caustic_count, const double bb_min[3], const double bb_max[3], uint32_t max_photons_per_leaf,
+                               uint32_t k_nearest_photons, int direct_visualization, mcrt_photon_pass_stats* stats) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (k_nearest_photons == 0 || max_photons_per_leaf == 0 || !bb_min || !bb_max) return fail(ctx, MCRT_ERR_INVALID, "mcrt_upload_photons_device: bad argument");
+    if ((global_count && !d_global_photons) || (caustic_count && !d_caustic_photons)) return fail(ctx, MCRT_ERR_INVALID, "mcrt_upload_photons_device: null photon list");
+    REJECT_IF_PENDING(ctx, "mcrt_upload_photons_device");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    ctx->has_photons = false;
+    ctx->k_nearest = k_nearest_photons;  // before the maps: the record lists expand octants with more than k photons
+    double timing[3] = {0.0, 0.0, 0.0};
+    if (int rc = buildMapOnDevice(ctx, 0, d_global_photons, global_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
+    if (int rc = buildMapOnDevice(ctx, 1, d_caustic_photons, caustic_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
+    ctx->direct_visualization = direct_visualization ? 1 : 0;
+    ctx->has_photons = true;
+    if (stats) {
+        stats->global_count = global_count;
+        stats->caustic_count = caustic_count;
+        stats->global_octants = ctx->maps[0].num_octants;
+        stats->caustic_octants = ctx->maps[1].num_octants;
+        stats->sort_ms = timing[0];
+        stats->octant_ms = timing[1];
+        stats->finish_ms = timing[2];
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return MCRT_OK;
+}
+
+int mcrt_photon_pass_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, const double bb_min[3],
+                            const double bb_max[3], uint32_t max_photons_per_leaf, uint32_t k_nearest_photons, int direct_visualization,
+                            mcrt_photon_pass_stats* stats) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    mcrt_photon_emission_device em;
+    if (int rc = mcrt_emit_photons_device(ctx, emissions, caustic_factor, global_seed, 0, 1, &em)) return rc;
+    mcrt_photon_pass_stats st;
+    memset(&st, 0, sizeof(st));
+    if (int rc = mcrt_upload_photons_device(ctx, em.d_global_photons, em.global_count, em.d_caustic_photons, em.caustic_count, bb_min, bb_max,
+                                            max_photons_per_leaf, k_nearest_photons, direct_visualization, &st))
+        return rc;
+    st.emission_paths = em.emission_paths;
+    st.rays = em.rays;
+    st.emission_ms = em.kernel_ms;
+    st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    return MCRT_OK;
+}
+
+int mcrt_photon_map_download(mcrt_ctx* ctx, int which, mcrt_photon_map** out) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (!out || which < 0 || which > 1) return fail(ctx, MCRT_ERR_INVALID, "mcrt_photon_map_download: bad argument");
+    if (!ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "mcrt_photon_map_download before the maps exist");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const PhotonMapView& v = ctx->maps[which];
+    mcrt_photon_map* M = new mcrt_photon_map();
+    const size_t no = v.num_octants, np = (size_t)v.num_photons;
+    if (no) {
+        std::vector<uint32_t> start(no), contained(no);
+        M->bounds.resize(no * 6);
+        M->next.resize(no);
+        M->leaf.resize(no);
+        M->photons.resize(np * 8);
+        hipError_t e = hipMemcpy(M->bounds.data(), v.octant_bounds, no * 48, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(start.data(), v.octant_start, no * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(contained.data(), v.octant_contained, no * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(M->next.data(), v.octant_next, no * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(M->leaf.data(), v.octant_leaf, no, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && np) e = hipMemcpy(M->photons.data(), v.photons, np * 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            delete M;
+            return fail(ctx, MCRT_ERR_HIP, std::string("mcrt_photon_map_download: ") + hipGetErrorString(e));
+        }
+        M->start.assign(start.begin(), start.end());
+        M->contained.assign(contained.begin(), contained.end());
+    }
+    finishMapDesc(M);
+    *out = M;
     return MCRT_OK;
 }
 

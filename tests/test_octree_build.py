@@ -130,3 +130,66 @@ def test_gpu_builder_on_emitted_photons(pkg, manifest):
     # inside an estimate may differ in the last bits
     assert np.abs(outs[0] - outs[1]).max() <= 1e-12 * max(1.0, np.abs(outs[0]).max())
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_photon_pass(pkg, manifest):
+    """mcrt_photon_pass_device: emission, sort, octants, boxes and record lists without leaving the device. The installed
+    maps, read back, are the trees the host builder makes from the same photon set (octants, boxes, photons per leaf), the
+    photon sets are the emission pass's, a k-NN search on them returns what it returns on host-built maps, and a
+    photon-mapped frame is within the summation-order noise of the frame rendered with host-built maps."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    s = img.scene
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    for emissions, cap in ((4000, 200), (1e5, 200), (3e4, 7)):
+        st = ctx.photon_pass_device(emissions, 10.0, manifest["seed"], s.bb_min[:], s.bb_max[:], cap, 50, False)
+        em = ctx.emit_photons(emissions, 10.0, manifest["seed"])
+        assert st["global_count"] == len(em["global_"][0]) and st["caustic_count"] == len(em["caustic"][0])
+        assert st["emission_paths"] == em["paths"] and st["rays"] == em["rays"]
+        search = cap >= 50  # (leaves of 7 photons with k = 50: the wave search's 128-entry frontier is not made for that tree)
+        pts = (em["global_"][0][::97, 3:6].astype(np.float64) + 1e-3)[:2000].copy()
+        dev_knn = [ctx.knn(w, pts, 50) for w in (0, 1)] if search else []
+        host_maps = []
+        for which, key in ((0, "global_"), (1, "caustic")):
+            dev = ctx.download_map(which)
+            host = pkg.PhotonMap(em[key][0], s.bb_min[:], s.bb_max[:], cap)
+            assert dev.desc.num_octants == st["global_octants" if which == 0 else "caustic_octants"]
+            assert_same_octree(host.arrays(), dev.arrays())
+            dev.close()
+            host_maps.append(host)
+        if not search:
+            continue
+        cam = img.camera.copy()
+        cam.width, cam.height, cam.sqrtspp = 96, 72, 2
+        frame_dev, st_dev = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        ctx.upload_photons(host_maps[0].desc, host_maps[1].desc, 50, False)
+        host_knn = [ctx.knn(w, pts, 50) for w in (0, 1)]
+        frame_host, st_host = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        for a, b in zip(dev_knn, host_knn):
+            np.testing.assert_array_equal(a[0], b[0])   # counts
+            np.testing.assert_array_equal(a[2], b[2])   # distances (indices differ: the photons of a leaf are ordered differently)
+        assert st_dev["knn_searches"] == st_host["knn_searches"] > 0
+        rel = np.abs(frame_dev - frame_host) / np.maximum(np.abs(frame_host), 1e-3)
+        assert rel.max() < 1e-9, rel.max()
+        for h in host_maps:
+            h.close()
+    # one cell deeper than the codes: refused, the recursive host builder is the one for that
+    ph = np.zeros((300, 8), dtype=np.float32)
+    ph[:, 3:6] = 0.25
+    import torch
+    t = torch.from_numpy(ph).to("cuda:0")
+    with pytest.raises(pkg.McrtError):
+        ctx.upload_photons_device(t.data_ptr(), 300, t.data_ptr(), 300, [0, 0, 0], [1, 1, 1], 200, 50, False)
+    # ... while lists in device memory that do fit give the host builder's trees
+    rng = np.random.default_rng(5)
+    ph = rng.random((50000, 8)).astype(np.float32)
+    t = torch.from_numpy(ph).to("cuda:0")
+    ctx.upload_photons_device(t.data_ptr(), 50000, t.data_ptr(), 1000, [0, 0, 0], [1, 1, 1], 64, 50, False)
+    for which, n in ((0, 50000), (1, 1000)):
+        dev = ctx.download_map(which)
+        host = pkg.PhotonMap(ph[:n], [0, 0, 0], [1, 1, 1], 64)
+        assert_same_octree(host.arrays(), dev.arrays())
+        dev.close()
+        host.close()
+    ctx.close()
