@@ -216,48 +216,53 @@ constexpr int kCoarseBits = 20;
 __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2, uint32_t slack = 0) {
     const uint32_t lane = __lane_id();
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
-    unsigned long long key[4];
-    uint32_t my_i[4];
-    bool valid[4];
+    uint32_t hi[4], lo[4], my_i[4];
     for (int s = 0; s < 4; s++) {
         const uint32_t j = lane + 64u * s;
-        valid[s] = j < count;
-        union { double d; unsigned long long u; } c;
-        c.d = valid[s] ? W.d2[j] : 0.0;
-        key[s] = c.u;
-        my_i[s] = valid[s] ? W.idx[j] : 0xFFFFFFFFu;
+        const bool valid = j < count;
+        union { double d; uint32_t u[2]; } c;
+        c.d = valid ? W.d2[j] : 0.0;
+        hi[s] = valid ? c.u[1] : 0xFFFFFFFFu;
+        lo[s] = c.u[0];
+        my_i[s] = valid ? W.idx[j] : 0xFFFFFFFFu;
     }
-    unsigned long long T = 0ull;
+    // The bits searched (62 .. 44) all lie in the keys' high words and every trial value has all lower bits set, so
+    // key <= trial is hi(key) <= hi(trial): 32-bit compares (full rate; the 64-bit integer ones are not) and 32-bit scalar
+    // arithmetic in the chain from one step to the next. Invalid entries carry the largest high word.
+    uint32_t Th = 0u;
     bool settled = false;
-    for (int bit = 62; bit >= 64 - kCoarseBits; bit--) {  // bit 63 (sign) is clear in every key
-        const unsigned long long trial = T | ((1ull << bit) - 1ull);
+    for (int bit = 30; bit >= 32 - kCoarseBits; bit--) {  // bit 31 of the high word (the sign) is clear in every key
+        const uint32_t trial = Th | ((1u << bit) - 1u);
         uint32_t n_le = 0;
         for (int s = 0; s < 4; s++)
-            if (s < rows) n_le += __popcll(waveBallot(valid[s] && key[s] <= trial));
+            if (s < rows) n_le += __popcll(waveBallot(hi[s] <= trial));
         if (n_le < k) {
-            T |= (1ull << bit);
+            Th |= (1u << bit);
         } else if (n_le <= k + slack) {  // k .. k + slack entries below this trial value: good enough a bound
-            T = trial;
+            Th = trial;
             settled = true;
             break;
         }
     }
-    if (!settled) T |= (1ull << (64 - kCoarseBits)) - 1ull;
+    // (two bits per step — three trial values counted side by side, half the dependent steps — measured slower: 196 -> 180 M/s)
+    if (!settled) Th |= (1u << (32 - kCoarseBits)) - 1u;
     uint32_t out = 0;
     for (int s = 0; s < 4; s++) {
-        const bool keep = valid[s] && key[s] <= T;
+        const bool keep = hi[s] <= Th;  // (an invalid entry's high word is above every Th: bit 31 of Th is clear)
         const unsigned long long m_keep = waveBallot(keep);
         if (keep) {
             const uint32_t slot = out + __popcll(m_keep & ((1ull << lane) - 1ull));
-            union { double d; unsigned long long u; } c;
-            c.u = key[s];
+            union { double d; uint32_t u[2]; } c;
+            c.u[1] = hi[s];
+            c.u[0] = lo[s];
             W.d2[slot] = c.d;
             W.idx[slot] = my_i[s];
         }
         out += __popcll(m_keep);
     }
-    union { double d; unsigned long long u; } c;
-    c.u = T;
+    union { double d; uint32_t u[2]; } c;
+    c.u[1] = Th;
+    c.u[0] = 0xFFFFFFFFu;
     bound_d2 = c.d;
     return out;
 }
