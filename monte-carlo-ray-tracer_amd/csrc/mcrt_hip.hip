@@ -49,6 +49,8 @@ struct DevBuf {
         else p = nullptr;
         return e;
     }
+    // grow-only: keeps the allocation when it is already large enough (the operator-level entry points' scratch)
+    hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(n); }
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -80,6 +82,10 @@ struct mcrt_ctx {
     DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
     size_t spill_bytes = 0;
     uint32_t knn_lanes = 0, knn_k = 0;
+
+    // scratch of the operator-level entry points (mcrt_intersect / mcrt_knn / mcrt_sampler / mcrt_bsdf): kept between calls, grown
+    // on demand, so that a host that only wants traversal or k-NN does not pay five hipMalloc / hipFree pairs per call
+    DevBuf op_buf[6];
 
     // photon emission pass
     std::vector<double> host_light_flux;  // [num_lights][3] emittance * area (photon-mapper.cpp:64)
@@ -124,6 +130,13 @@ int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
     return MCRT_OK;
 }
 
+
+template <class T>
+int uploadInto(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {  // like uploadArray, into a grow-only buffer
+    HIP_TRY(ctx, buf.reserve(std::max<size_t>(count * sizeof(T), 1)));
+    if (count) HIP_TRY(ctx, hipMemcpy(buf.p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return MCRT_OK;
+}
 
 // Control words of the wavefront pipeline, one allocation of this size wherever it is made: {count[2], pop, -} per half of
 // the pool (words 0..3 and 4..7; the photon mapper uses 4..6 as {rcount[2], rpop}). mcrt_intersect uses words 0..3.
@@ -1374,12 +1387,12 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         auto trace = wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
         if (int rc = planTrace(ctx, trace, n, tp)) return rc;
-        DevBuf ds, dd, dt, dsf, duv;
-        if (int rc = uploadArray(ctx, ds, start, n * 3)) return rc;
-        if (int rc = uploadArray(ctx, dd, direction, n * 3)) return rc;
-        HIP_TRY(ctx, dt.alloc(n * 8));
-        HIP_TRY(ctx, dsf.alloc(n * 4));
-        HIP_TRY(ctx, duv.alloc(n * 16));
+        DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
+        if (int rc = uploadInto(ctx, ds, start, n * 3)) return rc;
+        if (int rc = uploadInto(ctx, dd, direction, n * 3)) return rc;
+        HIP_TRY(ctx, dt.reserve(n * 8));
+        HIP_TRY(ctx, dsf.reserve(n * 4));
+        HIP_TRY(ctx, duv.reserve(n * 16));
         if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
         const unsigned long long ctrl_init[4] = {n, 0ull, 0ull, 0ull};
         HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_ctrl.p, ctrl_init, sizeof(ctrl_init), hipMemcpyHostToDevice, ctx->stream));
@@ -1403,12 +1416,12 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     auto ikernel = ctx->scene.stage_all ? intersectKernel<true> : intersectKernel<false>;
     if (int rc = launchGeometry(ctx, ikernel, ctx->scene, g)) return rc;
     if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
-    DevBuf ds, dd, dt, dsf, duv;
-    if (int rc = uploadArray(ctx, ds, start, n * 3)) return rc;
-    if (int rc = uploadArray(ctx, dd, direction, n * 3)) return rc;
-    HIP_TRY(ctx, dt.alloc(n * 8));
-    HIP_TRY(ctx, dsf.alloc(n * 4));
-    HIP_TRY(ctx, duv.alloc(n * 16));
+    DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
+    if (int rc = uploadInto(ctx, ds, start, n * 3)) return rc;
+    if (int rc = uploadInto(ctx, dd, direction, n * 3)) return rc;
+    HIP_TRY(ctx, dt.reserve(n * 8));
+    HIP_TRY(ctx, dsf.reserve(n * 4));
+    HIP_TRY(ctx, duv.reserve(n * 16));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(ikernel, dim3(grid), dim3(kBlock), g.lds_bytes, ctx->stream, ctx->scene, n, ds.as<double>(),
                        dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>(), ctx->spill.as<StackEntry>(),
@@ -1428,10 +1441,10 @@ int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_
     if (!pixel || !index || !out) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     REJECT_IF_PENDING(ctx, "mcrt_sampler");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dp, di, dout;
-    if (int rc = uploadArray(ctx, dp, pixel, n)) return rc;
-    if (int rc = uploadArray(ctx, di, index, n)) return rc;
-    HIP_TRY(ctx, dout.alloc(n * 7 * 8));
+    DevBuf &dp = ctx->op_buf[0], &di = ctx->op_buf[1], &dout = ctx->op_buf[2];
+    if (int rc = uploadInto(ctx, dp, pixel, n)) return rc;
+    if (int rc = uploadInto(ctx, di, index, n)) return rc;
+    HIP_TRY(ctx, dout.reserve(n * 7 * 8));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(samplerKernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->sobol_tab.as<uint32_t>(), n, dp.as<uint32_t>(),
                        di.as<uint32_t>(), shuffles, global_seed, dout.as<double>());
@@ -1459,9 +1472,9 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
     c.rough.A = 1.0 - 0.5 * (variance / (variance + 0.33));
     c.rough.B = 0.45 * (variance / (variance + 0.09));
     c.rough.flags = MCRT_MAT_ROUGH;
-    DevBuf din, dout;
-    if (int rc = uploadArray(ctx, din, in, n * 11)) return rc;
-    HIP_TRY(ctx, dout.alloc(n * 18 * 8));
+    DevBuf &din = ctx->op_buf[0], &dout = ctx->op_buf[1];
+    if (int rc = uploadInto(ctx, din, in, n * 11)) return rc;
+    HIP_TRY(ctx, dout.reserve(n * 18 * 8));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n + 255) / 256);
     hipLaunchKernelGGL(bsdfKernel, dim3(grid), dim3(256), 0, ctx->stream, n, din.as<double>(), c, dout.as<double>());
     HIP_TRY(ctx, hipGetLastError());
@@ -1481,12 +1494,12 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const char* kenv = getenv("MCRT_KERNEL");
     if (k <= 128 && !(kenv && strcmp(kenv, "legacy") == 0)) {  // wave-cooperative search (mcrt_waveknn.hpp)
-        DevBuf dp, dc, di, dd, flags;
-        if (int rc = uploadArray(ctx, dp, p, n * 3)) return rc;
-        HIP_TRY(ctx, dc.alloc(n * 4));
-        HIP_TRY(ctx, di.alloc(n * k * 4));
-        HIP_TRY(ctx, dd.alloc(n * k * 8));
-        HIP_TRY(ctx, flags.alloc(8));
+        DevBuf &dp = ctx->op_buf[0], &dc = ctx->op_buf[1], &di = ctx->op_buf[2], &dd = ctx->op_buf[3], &flags = ctx->op_buf[4];
+        if (int rc = uploadInto(ctx, dp, p, n * 3)) return rc;
+        HIP_TRY(ctx, dc.reserve(n * 4));
+        HIP_TRY(ctx, di.reserve(n * k * 4));
+        HIP_TRY(ctx, dd.reserve(n * k * 8));
+        HIP_TRY(ctx, flags.reserve(8));
         HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
         const PhotonMapViewW mv = waveMapView(ctx, which);
         // MCRT_KNN_BLOCKS: 256-lane workgroups per CU (occupancy experiments); MCRT_KNN_TIME=1: kernel time on stderr
