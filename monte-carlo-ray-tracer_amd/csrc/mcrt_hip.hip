@@ -86,6 +86,7 @@ struct mcrt_ctx {
     // scratch of the operator-level entry points (mcrt_intersect / mcrt_knn / mcrt_sampler / mcrt_bsdf): kept between calls, grown
     // on demand, so that a host that only wants traversal or k-NN does not pay five hipMalloc / hipFree pairs per call
     DevBuf op_buf[6];
+    DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
 
     // photon emission pass
     std::vector<double> host_light_flux;  // [num_lights][3] emittance * area (photon-mapper.cpp:64)
@@ -622,12 +623,16 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         // spills to HBM); a staged BVH walked by the wave-synchronous code needs its 16 entries (512 lanes).
         const int want = getenv("MCRT_PM_BLOCK") ? atoi(getenv("MCRT_PM_BLOCK")) : 1024;
         g.block = kBlock;
-        auto ldsBytes = [&](uint32_t block, uint32_t depth) { return alignUp(planLds(launch_scene, block, true, depth).total, 16) + (block / 64) * kWaveCand * 12u; };
+        // (the 1024-lane instance keeps two refraction-history entries per lane in LDS, the deeper ones in global memory)
+        auto ldsBytes = [&](uint32_t block, uint32_t depth) {
+            return alignUp(planLds(launch_scene, block, true, depth, block != 1024u ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) + (block / 64) * kWaveKnnBytes;
+        };
         if (want == 1024) {
             if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= ctx->max_lds) {
                 g.block = 1024;
             } else if (!launch_scene.stage_all) {
-                for (uint32_t depth = 8; depth >= 2 && g.block == kBlock; depth -= 2)
+                const uint32_t depth_max = getenv("MCRT_PM_STACK") ? (uint32_t)std::max(2, atoi(getenv("MCRT_PM_STACK"))) & ~1u : 16u;
+                for (uint32_t depth = depth_max; depth >= 2 && g.block == kBlock; depth -= 2)
                     if (ldsBytes(1024, depth) <= ctx->max_lds) {
                         g.block = 1024;
                         pm_stack_depth = depth;
@@ -730,6 +735,11 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             pmx.global_map = waveMapView(ctx, 0);
             pmx.caustic_map = waveMapView(ctx, 1);
             pmx.stack_depth = pm_stack_depth;
+            pmx.iors_global = nullptr;
+            if (g.block == 1024u) {
+                HIP_TRY(ctx, ctx->pm_iors.reserve((size_t)kMaxIors * g.total_lanes * sizeof(double)));
+                pmx.iors_global = ctx->pm_iors.as<double>();
+            }
         }
         for (uint32_t row = 0; row < prm.owned_rows; row += (uint32_t)pass_rows) {
             prm.row_base = row;

@@ -113,6 +113,8 @@ __device__ inline void storeSample(const RenderParams& prm, uint32_t sample, uin
 constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
+constexpr uint32_t kPmLdsIors = 2;  // refraction-history entries per lane the 1024-lane photon-mapping kernel keeps in LDS
+
 struct LdsPlan {
     uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material,
         surf_kind, materials, light_surface, light_cdf, total;
@@ -120,12 +122,13 @@ struct LdsPlan {
 
 __host__ __device__ inline uint32_t alignUp(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block, bool with_stack = true, uint32_t stack_depth = kLdsStackDepth) {
+__host__ __device__ inline LdsPlan planLds(const DeviceScene& s, uint32_t block, bool with_stack = true, uint32_t stack_depth = kLdsStackDepth,
+                                           uint32_t iors_depth = kMaxIors) {
     LdsPlan p;
     uint32_t off = 0;
     p.sobol = off; off += kSobolTableWords * 4;
     p.stack = off; off += (with_stack && !s.flat) ? stack_depth * block * (uint32_t)sizeof(StackEntry) : 0u;  // the flat loop has no stack
-    p.iors = off; off += kMaxIors * block * 8u;
+    p.iors = off; off += iors_depth * block * 8u;
     off = alignUp(off, 16);
     const uint32_t nn = s.stage_all ? s.num_nodes : s.stage_nodes;
     p.node_bounds = off; off += nn * 48;
@@ -169,8 +172,11 @@ __device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t coun
 template <bool kAll, bool kFlat = false>
 __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
                                   SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes,
-                                  uint32_t stack_depth = kLdsStackDepth) {
-    const LdsPlan p = planLds(s, blockDim.x, !kFlat, stack_depth);
+                                  uint32_t stack_depth = kLdsStackDepth, double* iors_global = nullptr) {
+    const LdsPlan p = planLds(s, blockDim.x, !kFlat, stack_depth, iors_global ? kPmLdsIors : (uint32_t)kMaxIors);
+    rh.giors = iors_global ? iors_global + (size_t)blockIdx.x * blockDim.x + threadIdx.x : nullptr;
+    rh.gstride = total_lanes;
+    rh.lds_depth = iors_global ? (int)kPmLdsIors : kMaxIors;
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
     rh.stride = blockDim.x;
     rh.size = 0;
@@ -971,10 +977,12 @@ struct WfKnnArgs {
 __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     __shared__ double s_d2[4 * kWaveCand];
     __shared__ uint32_t s_idx[4 * kWaveCand];
+    __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
     const unsigned long long n = *a.count;
     const uint32_t slots = a.pool.n;
     uint32_t overflow = 0, visits = 0, searches = 0;
@@ -1041,8 +1049,9 @@ struct QWalk {
     QView<true> qv;
     SmStack stk;
 };
-__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q, uint32_t stack_depth) {  // every thread calls
-    const LdsPlan lp = planLds(scene, blockDim.x, true, stack_depth);
+__device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, const LaneStack& lstk, QWalk& q, uint32_t stack_depth,
+                                  bool with_iors = true) {  // every thread calls
+    const LdsPlan lp = planLds(scene, blockDim.x, true, stack_depth, with_iors ? (uint32_t)kMaxIors : kPmLdsIors);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, lp.node_bounds);
     const uint32_t room = scene.stage_nodes * 56u / 64u;
     q.qv.blocks = scene.qblocks;
@@ -1069,6 +1078,7 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
 struct PmExtra {
     PhotonMapViewW global_map, caustic_map;
     uint32_t stack_depth;  // traversal-stack entries per lane kept in LDS (tree in HBM: the state machine's stack, any depth; else kLdsStackDepth)
+    double* iors_global;   // refraction-history entries beyond the first kPmLdsIors, [kMaxIors - kPmLdsIors][lanes] (1024-lane instance), or null: all in LDS
 };
 
 // kLanes: 512 (2 waves per SIMD, 256 VGPRs) or 1024 (4 waves per SIMD, 128 VGPRs). The kernel spends 97.6 % of its wave
@@ -1083,11 +1093,11 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
     SobolTab tab;
     LaneStack stk;
     RefractionHistory rh;
-    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes, pmx.stack_depth);
+    setupViews<kAll>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes, pmx.stack_depth, pmx.iors_global);
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     // tree in HBM: walk it through the quantised child blocks
     QWalk qw;
-    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw, pmx.stack_depth);
+    if constexpr (!kAll) setupQWalk(scene, lds, stk, qw, pmx.stack_depth, pmx.iors_global == nullptr);
     auto intersect = [&](const Ray& ray, bool shadow, const ShadowQuery* sq) {
         if constexpr (kAll) {
             return shadow ? sceneIntersect<kAll, kCount, true>(sv, ray, stk, cnt, sq) : sceneIntersect<kAll, kCount, false>(sv, ray, stk, cnt);
@@ -1098,10 +1108,11 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
     // per-wave candidate buffer behind the common LDS plan
     WaveKnnLds W;
     {
-        const uint32_t base = alignUp(planLds(scene, blockDim.x, true, pmx.stack_depth).total, 16);
+        const uint32_t base = alignUp(planLds(scene, blockDim.x, true, pmx.stack_depth, pmx.iors_global ? kPmLdsIors : (uint32_t)kMaxIors).total, 16);
         const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
         W.d2 = ldsAt<double>(lds, base) + wave * kWaveCand;
         W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
+        W.hist = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 12u) + wave * kWaveHist;
     }
 
     PathState st;
@@ -1224,10 +1235,12 @@ __global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, u
                                                      uint32_t* out_index, double* out_d2, unsigned long long* flags) {
     __shared__ double s_d2[4 * kWaveCand];
     __shared__ uint32_t s_idx[4 * kWaveCand];
+    __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
     const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t overflow = 0, visits = 0;
     for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {

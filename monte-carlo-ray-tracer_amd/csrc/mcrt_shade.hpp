@@ -185,14 +185,25 @@ struct RefractionHistory {
     MCRT_LDS_AS double* iors;  // &lds_iors[lane]; stride = block size
     uint32_t stride;
     int size;
+    // The 1024-lane photon-mapping kernel keeps only the first two entries in LDS and the rest in global memory
+    // ([kMaxIors - 2][lanes], interleaved by lane): 48 KB of LDS go to the traversal stacks and the estimates' buffers.
+    // Everywhere else all kMaxIors entries are in LDS and giors is null.
+    double* giors = nullptr;
+    uint32_t gstride = 0;
+    int lds_depth = kMaxIors;  // entries [0, lds_depth) in LDS, the rest (nesting deeper than that: rare) in giors
+    MCRT_HD double at(int i) const { return i < lds_depth ? iors[(uint32_t)i * stride] : giors[(size_t)(i - lds_depth) * gstride]; }
+    MCRT_HD void put(int i, double v) {
+        if (i < lds_depth) iors[(uint32_t)i * stride] = v;
+        else giors[(size_t)(i - lds_depth) * gstride] = v;
+    }
     MCRT_HD void init(const Ray& ray) {
-        iors[0] = ray.medium_ior;
+        put(0, ray.medium_ior);
         size = 1;
     }
     MCRT_HD void update(const Ray& ray) {
         if (ray.refraction_level > 0) {
             if (ray.refraction_level == size) {
-                if (size < kMaxIors) iors[(uint32_t)(size++) * stride] = ray.medium_ior;
+                if (size < kMaxIors) put(size++, ray.medium_ior);
             } else if (ray.refraction_level < size - 1) {
                 size--;
             }
@@ -202,7 +213,7 @@ struct RefractionHistory {
         int i = ray.refraction_level - 1;
         i = i < 0 ? 0 : i;
         i = i > size - 1 ? size - 1 : i;
-        return iors[(uint32_t)i * stride];
+        return at(i);
     }
 };
 

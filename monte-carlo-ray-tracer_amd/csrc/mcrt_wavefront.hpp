@@ -265,7 +265,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         sample_end = (uint32_t)P.getu(kWfSampleEnd, slot);
         rh.size = (int)((flags >> kWfRhShift) & 15u);
         for (int i = 0; i < kMaxIors; i++)
-            if (i < rh.size) rh.iors[(uint32_t)i * rh.stride] = P.getd(kWfIors + (uint32_t)i, slot);
+            if (i < rh.size) rh.put(i, P.getd(kWfIors + (uint32_t)i, slot));
 
         // ---- second half of the previous bounce's Integrator::sampleDirect, now that its shadow ray is back
         if (nee_was_pending) {
@@ -423,7 +423,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             P.setu(kWfPixel, slot, (unsigned long long)px | ((unsigned long long)ly << 32));
             P.setu(kWfSampleEnd, slot, sample_end);
             for (int i = 0; i < kMaxIors; i++)
-                if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.iors[(uint32_t)i * rh.stride]);
+                if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.at(i));
         }
     }
     env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending, st.ray.start, st.ray.direction, sh_o, sh_d, sh_near, sh_far,

@@ -31,9 +31,13 @@ namespace mcrt {
 
 constexpr uint32_t kWaveCand = 256;   // candidate buffer entries per wave (prune when > kWaveCand - 64)
 
+constexpr uint32_t kWaveHist = 128;   // bins of the per-wave distance histogram (see "Selection by histogram")
+constexpr uint32_t kWaveKnnBytes = kWaveCand * 12u + kWaveHist * 4u;  // LDS per wave: candidates + histogram
+
 struct WaveKnnLds {
-    MCRT_LDS_AS double* d2;     // [kWaveCand] this wave's candidate distances
-    MCRT_LDS_AS uint32_t* idx;  // [kWaveCand] photon indices
+    MCRT_LDS_AS double* d2;      // [kWaveCand] this wave's candidate distances
+    MCRT_LDS_AS uint32_t* idx;   // [kWaveCand] photon indices
+    MCRT_LDS_AS uint32_t* hist;  // [kWaveHist] candidates per distance2 bin
 };
 
 // What one step of the descent reads: for an inner octant, up to 64 records — its children that can be scanned right
@@ -332,6 +336,147 @@ __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
     }
 }
 
+// ---- Selection by histogram. The two key searches of a query — the bound once k candidates exist, the exact k-set at
+// the end — cost 12 500 of the 29 000 cycles a search takes: chains of dependent scalar instructions, 19 + 19 steps. For
+// photons on surfaces the squared distances of the candidates are spread almost evenly over [0, R] (the count within
+// radius r grows like r^2), so a histogram of distance2 over the bound R in force when scanning starts answers both:
+// every candidate adds itself to its bin on the way into the buffer (one LDS atomic), the k-th nearest lies in the first
+// bin whose running count reaches k (a wave prefix sum over 128 bins), that bin's upper edge bounds the search, and at
+// the end everything in lower bins belongs to the result while only the boundary bin — a candidate or two — needs an
+// exact selection. Entries beyond the buffer's last reduction are re-added when the buffer is reduced (rare).
+struct WaveHist {
+    bool on;          // a finite bound existed when scanning started: the histogram is in use
+    double scale;     // bins per unit of distance2: kWaveHist / R
+    double inv_scale;
+};
+__device__ inline uint32_t histBin(const WaveHist& H, double d2v) {
+    const double b = d2v * H.scale;
+    return b < (double)(kWaveHist - 1u) ? (uint32_t)b : kWaveHist - 1u;
+}
+__device__ inline void histClear(const WaveKnnLds& W) {
+    const uint32_t lane = __lane_id();
+    W.hist[lane] = 0u;
+    W.hist[lane + 64u] = 0u;
+}
+__device__ inline void histAdd(const WaveKnnLds& W, const WaveHist& H, double d2v) { __atomic_fetch_add(W.hist + histBin(H, d2v), 1u, __ATOMIC_RELAXED); }
+// inclusive prefix sum over the 64 lanes
+__device__ inline uint32_t wavePrefixU32(uint32_t v) {
+    const uint32_t lane = __lane_id();
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+        if ((int)lane >= off) v += t;
+    }
+    return v;
+}
+// The bin in which the running count first reaches k: returns true and the bin, the count in lower bins and the count up
+// to and including it; false when fewer than k candidates are in the histogram. All lanes must call.
+__device__ inline bool histKthBin(const WaveKnnLds& W, uint32_t k, uint32_t& bin, uint32_t& below, uint32_t& upto) {
+    const uint32_t lane = __lane_id();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t h0 = W.hist[2u * lane], h1 = W.hist[2u * lane + 1u];
+    const uint32_t incl = wavePrefixU32(h0 + h1);  // through bin 2 lane + 1
+    const unsigned long long reached = waveBallot(incl >= k);
+    if (!reached) return false;
+    const int l = __ffsll((long long)reached) - 1;
+    const uint32_t incl_l = (uint32_t)__builtin_amdgcn_readlane((int)incl, l);
+    const uint32_t h0_l = (uint32_t)__builtin_amdgcn_readlane((int)h0, l), h1_l = (uint32_t)__builtin_amdgcn_readlane((int)h1, l);
+    const uint32_t before = incl_l - h0_l - h1_l;  // bins below 2 l
+    if (before + h0_l >= k) {
+        bin = 2u * (uint32_t)l;
+        below = before;
+        upto = before + h0_l;
+    } else {
+        bin = 2u * (uint32_t)l + 1u;
+        below = before + h0_l;
+        upto = incl_l;
+    }
+    return true;
+}
+
+// The exact k nearest from the histogram: all candidates of the bins below the k-th one's, and of the boundary bin the
+// (k - below) smallest (the largest is dropped until that many are left — among equal keys the one latest in the buffer
+// first). Result compacted into slots [0, k); kth_d2 = the largest distance kept. Falls back (returns 0) when the
+// boundary bin holds too many candidates for that (the caller then runs the general selection). All lanes must call.
+__device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, uint32_t count, uint32_t k, double& kth_d2) {
+    const uint32_t lane = __lane_id();
+    uint32_t bin, below, upto;
+    if (!histKthBin(W, k, bin, below, upto)) return 0u;
+    const uint32_t need = k - below, have = upto - below;  // of the boundary bin
+    if (have > 64u || have - need > 6u) return 0u;
+    const int rows = (int)((count + 63u) / 64u);
+    // pass 1: entries of lower bins keep their relative order at the front; boundary entries are gathered in registers (one per lane)
+    double keep_d[4];
+    uint32_t keep_i[4];
+    bool low[4], edge[4];
+    for (int s = 0; s < 4; s++) {
+        const uint32_t j = lane + 64u * s;
+        const bool valid = s < rows && j < count;
+        keep_d[s] = valid ? W.d2[j] : 0.0;
+        keep_i[s] = valid ? W.idx[j] : 0xFFFFFFFFu;
+        const uint32_t b = valid ? histBin(H, keep_d[s]) : 0xFFFFFFFFu;
+        low[s] = valid && b < bin;
+        edge[s] = valid && b == bin;
+    }
+    // boundary entries -> lanes 0 .. have-1 (in buffer order) through LDS slots [kWaveCand - 64, kWaveCand) ... they may still hold
+    // live entries, so use registers + a staging pass: first write the low entries, then stage the boundary ones behind them
+    uint32_t out = 0;
+    for (int s = 0; s < 4; s++) {
+        if (s >= rows) break;
+        const unsigned long long m = waveBallot(low[s]);
+        if (low[s]) {
+            const uint32_t slot = out + __popcll(m & ((1ull << lane) - 1ull));
+            W.d2[slot] = keep_d[s];   // slot <= j: never overwrites an entry that has not been read (all reads are done above)
+            W.idx[slot] = keep_i[s];
+        }
+        out += __popcll(m);
+    }
+    uint32_t eout = 0;
+    for (int s = 0; s < 4; s++) {
+        if (s >= rows) break;
+        const unsigned long long m = waveBallot(edge[s]);
+        if (edge[s]) {
+            const uint32_t slot = out + eout + __popcll(m & ((1ull << lane) - 1ull));
+            W.d2[slot] = keep_d[s];
+            W.idx[slot] = keep_i[s];
+        }
+        eout += __popcll(m);
+    }
+    // (out == below and eout == have by construction; the boundary entries now sit in slots [below, below + have))
+    // pass 2: of the boundary entries keep the `need` smallest
+    bool valid = lane < eout;
+    union { double d; uint32_t u[2]; } c;
+    c.d = valid ? W.d2[out + lane] : 0.0;
+    const uint32_t my_i = valid ? W.idx[out + lane] : 0xFFFFFFFFu;
+    auto largest = [&](uint32_t& mh, uint32_t& ml) {
+        mh = waveMaxU32(valid ? c.u[1] : 0u);
+        ml = waveMaxU32((valid && c.u[1] == mh) ? c.u[0] : 0u);
+    };
+    uint32_t n = eout;
+    while (n > need) {  // wave-uniform, at most 6 rounds
+        uint32_t mh, ml;
+        largest(mh, ml);
+        const unsigned long long owners = waveBallot(valid && c.u[1] == mh && c.u[0] == ml);
+        const int drop = 63 - __clzll((long long)owners);
+        if ((int)lane == drop) valid = false;
+        n--;
+    }
+    uint32_t mh = 0u, ml = 0u;
+    largest(mh, ml);  // need >= 1: the k-th nearest is in the boundary bin
+    union { double d; uint32_t u[2]; } r;
+    r.u[1] = mh;
+    r.u[0] = ml;
+    kth_d2 = r.d;
+    if (n != eout) {
+        const unsigned long long keep = waveBallot(valid);
+        if (valid) {
+            const uint32_t slot = out + __popcll(keep & ((1ull << lane) - 1ull));
+            W.d2[slot] = c.d;
+            W.idx[slot] = my_i;
+        }
+    }
+    return out + n;
+}
+
 // k-NN of point p (wave-uniform) in `map`. On return the buffer holds the result (unordered) in slots
 // [0, n) and r2_max the largest of its distances; returns n. All 64 lanes must call with the same arguments.
 //
@@ -357,11 +502,20 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     uint32_t count = 0;
     bool dirty = false;    // candidates appended since the buffer was last reduced
     bool bounded = false;  // max_distance2 has been tightened to a k-photon radius at least once
+    WaveHist H;
+    H.on = false;
+    H.scale = H.inv_scale = 0.0;
     uint32_t cur_a = map.root_a, cur_b = map.root_m;  // root
     for (;;) {
         octant_visits++;
         if (cur_b & kScan) {
             const uint32_t start = cur_a, contained = cur_b & ~kScan;
+            if (!H.on && count == 0u && max_distance2 < kDblMax) {  // first scan under a finite bound: the histogram spans [0, bound]
+                H.on = true;
+                H.scale = (double)kWaveHist / max_distance2;
+                H.inv_scale = max_distance2 / (double)kWaveHist;
+                histClear(W);
+            }
             // 4 x 64 photons per round trip: the four position loads of a lane are issued together
             for (uint32_t base = 0; base < contained; base += 256) {
                 float px[4], py[4], pz[4];
@@ -385,6 +539,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         if (cand) {
                             W.d2[slot] = d2v;
                             W.idx[slot] = start + i;
+                            if (H.on) histAdd(W, H, d2v);
                         }
                         count += __popcll(mask);
                         dirty = true;
@@ -395,6 +550,11 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                             dirty = false;
                             bounded = true;
                             max_distance2 = gmin(max_distance2, bound);
+                            if (H.on) {  // the histogram follows the buffer
+                                histClear(W);
+                                __builtin_amdgcn_wave_barrier();
+                                for (uint32_t j = lane; j < count; j += 64u) histAdd(W, H, W.d2[j]);
+                            }
                         }
                     }
                 }
@@ -402,7 +562,19 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
             // The k-th best so far bounds the answer (linear-octree.cpp:79): taken once, as soon as k candidates
             // exist (it shrinks the bound from an octant diagonal to the k-photon radius); afterwards only when
             // the buffer fills, since every later candidate already lies within that radius.
-            if (dirty && count >= k && !bounded) {
+            if (H.on) {
+                // ... with the histogram after every scan that added candidates: the upper edge of the bin that holds the k-th
+                // nearest so far (nothing is dropped from the buffer: later candidates are simply held to the tighter bound)
+                if (dirty && count >= k) {
+                    uint32_t bin, below, upto;
+                    if (histKthBin(W, k, bin, below, upto)) {
+                        const double edge = (double)(bin + 1u) * H.inv_scale * 1.000000000001;  // (an entry of this bin may sit a rounding above the exact edge)
+                        max_distance2 = gmin(max_distance2, edge);
+                        bounded = true;
+                    }
+                    dirty = false;
+                }
+            } else if (dirty && count >= k && !bounded) {
                 double bound;
                 count = waveSelectBound(W, count, k, bound, 4u);
                 dirty = false;
@@ -480,6 +652,10 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     }
     // exact selection, once: shrink to the entries that can still matter (k of them plus the few that share the k-th key's
     // leading bits), then drop the largest until k are left — instead of a 63-step search for the exact k-th key
+    if (H.on && count > k) {
+        const uint32_t n = histSelectK(W, H, count, k, r2_max);
+        if (n) return n;
+    }
     if (count > k) {
         double bound;
         count = waveSelectBound(W, count, k, bound, 2u);
