@@ -359,13 +359,16 @@ __device__ inline void histClear(const WaveKnnLds& W) {
     W.hist[lane + 64u] = 0u;
 }
 __device__ inline void histAdd(const WaveKnnLds& W, const WaveHist& H, double d2v) { __atomic_fetch_add(W.hist + histBin(H, d2v), 1u, __ATOMIC_RELAXED); }
-// inclusive prefix sum over the 64 lanes
+// inclusive prefix sum over the 64 lanes through the DPP network: shifts by 1, 2, 4, 8 inside the rows of 16 (zeros shifted
+// in), then the last lane of row 0 / 2 onto rows 1 / 3 and the last lane of row 1 onto rows 2 and 3. (__shfl_up would be
+// six LDS-crossbar permutes in a chain.)
 __device__ inline uint32_t wavePrefixU32(uint32_t v) {
-    const uint32_t lane = __lane_id();
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
-        if ((int)lane >= off) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
     return v;
 }
 // The bin in which the running count first reaches k: returns true and the bin, the count in lower bins and the count up
