@@ -1036,7 +1036,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     // (scene.cpp:161-173); the closest hit is the same.
     const char* fm = getenv("MCRT_FLAT_MAX");
     const uint32_t flat_max = fm ? (uint32_t)strtoul(fm, nullptr, 0) : 64u;
-    d.flat = (d.stage_all && d.num_surfaces <= flat_max && L.num_quadric_surfaces == 0) ? 1u : 0u;  // the flat loop knows triangles and spheres
+    d.flat = (d.stage_all && d.num_surfaces <= flat_max && !L.flat_prim.empty() && L.num_quadric_surfaces == 0) ? 1u : 0u;  // the flat loop knows triangles and spheres
     ctx->has_scene = true;
     return MCRT_OK;
 }
@@ -1392,7 +1392,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     if (n == 0) return MCRT_OK;
     if (!start || !direction || !out_t || !out_surface) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFFFFFFFull) {
+    if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFF00000ull) {  // (32-bit queue cursors with room for the waves' overshoot)
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
         auto trace = wfTraceKernel<ArrayRays, false>;
         TracePlan tp;

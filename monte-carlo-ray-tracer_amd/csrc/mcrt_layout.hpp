@@ -14,6 +14,8 @@
 
 namespace mcrt {
 
+constexpr size_t kFlatCopyMax = 4096;  // surfaces up to which the kind-sorted flat copy is built (the flat loop itself: MCRT_FLAT_MAX, default 64)
+
 struct HostLayout {
     std::vector<double> node_bounds;   // [n][6], breadth-first, children contiguous
     std::vector<NodeMeta> node_meta;   // [n]
@@ -340,11 +342,14 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             err = "light surface index out of range";
             return MCRT_ERR_INVALID;
         }
-    L.flat_prim.assign(ns * kPrimStride, 0.0);
-    L.flat_index.assign(ns, 0u);
+    // (only scenes small enough to ever be staged whole get the flat copy and its cull records: for a multi-million-triangle
+    // scene they would be hundreds of MB of host work and upload that no kernel reads)
+    const bool flat_possible = ns <= kFlatCopyMax;
+    L.flat_prim.assign(flat_possible ? ns * kPrimStride : 0, 0.0);
+    L.flat_index.assign(flat_possible ? ns : 0, 0u);
     L.flat_tris = 0;
     size_t slot = 0;
-    for (int pass = 0; pass < 2; pass++)
+    for (int pass = 0; pass < 2 && flat_possible; pass++)
         for (size_t i = 0; i < ns; i++) {
             const bool sphere = s->surf_kind[i] == MCRT_SURF_SPHERE;
             if (sphere != (pass == 1)) continue;
@@ -353,7 +358,11 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             slot++;
             if (!sphere) L.flat_tris++;
         }
-    buildFlatCull(L, (uint32_t)ns);
+    if (flat_possible) buildFlatCull(L, (uint32_t)ns);
+    else {
+        L.flat_pre.clear();
+        L.pre_tri_pairs = L.pre_sph_pairs = 0;
+    }
     if (int rc = convertNodes(s, L.node_bounds, L.node_meta, err)) return rc;
     L.nodes64.assign(s->num_nodes, Node64{});
     for (uint32_t i = 0; i < s->num_nodes; i++) {
