@@ -257,6 +257,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 24);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
+    ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 8), 6), 20);
     return MCRT_OK;
 }
 
@@ -1411,9 +1412,17 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         ta.count = ctx->wf_ctrl.as<unsigned long long>();
         ta.pop = ctx->wf_ctrl.as<unsigned long long>() + 2;
         ArrayRays ar{ds.as<double>(), dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>()};
+        const bool op_time = getenv("MCRT_OP_TIME") && atoi(getenv("MCRT_OP_TIME")) != 0;  // kernel time of the operator to stderr
+        if (op_time) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, ctx->stream, ta, ar);
         HIP_TRY(ctx, hipGetLastError());
+        if (op_time) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (op_time) {
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            fprintf(stderr, "[mcrt op] intersect (trace kernel): %llu rays in %.3f ms = %.1f Mray/s\n", (unsigned long long)n, ms, n / (ms * 1e3));
+        }
         unsigned long long h[kStatsWords];
         HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
         if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");

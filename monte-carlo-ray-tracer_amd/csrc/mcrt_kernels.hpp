@@ -713,6 +713,7 @@ struct WfTraceArgs {
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
+    uint32_t deal_shift;                // queue entries are dealt to the workgroups in blocks of 2^deal_shift
 };
 
 // Where the rays of a trace launch come from and where their hits go.
@@ -772,16 +773,22 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     qv.lds_ptr = lq;
     qv.root_a = a.q_root_a;
     qv.root_m = a.q_root_m;
-    // The queue is dealt to the workgroups in equal contiguous shares and a workgroup's waves take entries from its share
-    // through a cursor in LDS. (One global cursor for all waves was the kernel's bottleneck: a refill every 32 rays is
-    // ~45 M atomics per second on one address, about what an L2 channel serves — refilling at 16 idle lanes instead of
-    // 32 cost 37 % of the frame. Neighbouring entries are similar rays from the same part of the image, and a share holds
-    // thousands of them, so the shares finish within a per cent of each other.)
+    // The queue is dealt to the workgroups in blocks of 2^deal_shift consecutive entries, round robin (workgroup g takes
+    // blocks g, g + G, g + 2G, ...), and a workgroup's waves take entries from its blocks through a cursor in LDS. (One
+    // global cursor for all waves was the kernel's bottleneck: a refill every 32 rays is ~45 M atomics per second on one
+    // address, about what an L2 channel serves — refilling at 16 idle lanes instead of 32 cost 37 % of the frame. One
+    // contiguous share per workgroup has no atomics either, but neighbouring entries are rays from the same part of the
+    // image and the parts differ in cost: the same rays in random order traced 12 % faster than in pixel order, sorted by
+    // origin 20 % slower, tools/ray_sort_probe.py. Interleaved blocks keep a refill's reads consecutive and give every
+    // workgroup a sample of the whole queue.)
     const unsigned long long n = *a.count;
     MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
-    const uint32_t share_begin = (uint32_t)(n * blockIdx.x / gridDim.x), share_end = (uint32_t)(n * (blockIdx.x + 1ull) / gridDim.x);
-    if (threadIdx.x == 0) *cursor = share_begin;
+    const uint32_t deal_shift = a.deal_shift, deal_mask = (1u << deal_shift) - 1u;
+    if (threadIdx.x == 0) *cursor = 0u;
     __syncthreads();
+    auto dealt = [&](uint32_t v) -> unsigned long long {  // the v-th entry of this workgroup
+        return ((((unsigned long long)(v >> deal_shift) * gridDim.x + blockIdx.x) << deal_shift) | (v & deal_mask));
+    };
 
     Trav T;
     T.active = false;
@@ -789,7 +796,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     T.fast = true;
     T.sp = 0;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
-    bool have = false, exhausted = share_begin == share_end;
+    bool have = false, exhausted = dealt(0u) >= n;
     uint32_t item = 0;
     for (;;) {
         if (have && !T.active) {  // finished since the last look: hand the hit back
@@ -798,17 +805,17 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
         }
         const unsigned long long m_have = waveBallot(have);
         if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
-            unsigned long long w = share_end;
+            unsigned long long w = n;
             {
                 const unsigned long long need = waveBallot(!have);  // (not empty here)
                 const int leader = __ffsll((long long)need) - 1;
                 uint32_t base = 0u;
                 if ((int)laneId() == leader) base = __atomic_fetch_add(cursor, (uint32_t)__popcll(need), __ATOMIC_RELAXED);  // ds_add_rtn_u32
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                const uint32_t mine = base + (uint32_t)__popcll(need & ((1ull << laneId()) - 1ull));
-                if (!have && base < share_end) w = mine;  // (base >= share_end: the cursor has run past the share; it cannot wrap: < 2^32 entries, < 2^20 lanes)
+                // (the cursor cannot wrap: a workgroup's entries number < 2^32 / G + a block, and it stops within 2^20 of the end)
+                if (!have) w = dealt(base + (uint32_t)__popcll(need & ((1ull << laneId()) - 1ull)));
             }
-            if (!have && w < share_end) {
+            if (!have && w < n) {
                 d3 o, d;
                 bool shadow;
                 ShadowQuery sq;
