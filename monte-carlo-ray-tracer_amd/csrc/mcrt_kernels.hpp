@@ -778,9 +778,9 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     // global cursor for all waves was the kernel's bottleneck: a refill every 32 rays is ~45 M atomics per second on one
     // address, about what an L2 channel serves — refilling at 16 idle lanes instead of 32 cost 37 % of the frame. One
     // contiguous share per workgroup has no atomics either, but neighbouring entries are rays from the same part of the
-    // image and the parts differ in cost: the same rays in random order traced 12 % faster than in pixel order, sorted by
-    // origin 20 % slower, tools/ray_sort_probe.py. Interleaved blocks keep a refill's reads consecutive and give every
-    // workgroup a sample of the whole queue.)
+    // image and the parts differ in cost: the same rays traced 12 % faster shuffled than in pixel order and 20 % slower
+    // sorted by origin; dealt in blocks of 64 every order gains and pixel order is the fastest, tools/ray_sort_probe.py.
+    // Interleaved blocks keep a refill's reads consecutive and give every workgroup a sample of the whole queue.)
     const unsigned long long n = *a.count;
     MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
     const uint32_t deal_shift = a.deal_shift, deal_mask = (1u << deal_shift) - 1u;

@@ -2,7 +2,5 @@
 O=gpurun_out/r02_ab5
 mkdir -p $O
 export TMPDIR=/tmp
-( timeout 900 python tools/ab_probe.py c3 --sqrtspp 8 --steps 2 "hoist:" ) > $O/c3_hoist.log 2>&1
-grep -v "amdgpu.ids" $O/c3_hoist.log | tail -3
-( timeout 900 python tools/ab_probe.py c4 --sqrtspp 8 --steps 2 "hoist:" ) > $O/c4_hoist.log 2>&1
-grep -v "amdgpu.ids" $O/c4_hoist.log | tail -3
+( MCRT_WF_DEAL=6 timeout 900 python tools/ray_sort_probe.py c3 ) > $O/sort_c3_deal6.log 2>&1
+grep -v "amdgpu.ids" $O/sort_c3_deal6.log | grep -A2 "^==" | grep -v "^--" | awk '/^==/{l=$0; getline; getline; print l " :: " $0}'
