@@ -15,6 +15,7 @@
 #include "mcrt_qbvh.hpp"
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
+#include "mcrt_groupknn.hpp"
 #include "mcrt_layout.hpp"
 #include "mcrt_internal.hpp"
 #include "mcrt_plan.hpp"
@@ -1524,9 +1525,15 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         // MCRT_KNN_BLOCKS: 256-lane workgroups per CU (occupancy experiments); MCRT_KNN_TIME=1: kernel time on stderr
         const int per_cu = getenv("MCRT_KNN_BLOCKS") ? std::max(1, atoi(getenv("MCRT_KNN_BLOCKS"))) : 8;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu, (n + 3) / 4);
+        // MCRT_KNN_GROUPS=1: four queries per wave, one per row of 16 lanes (mcrt_groupknn.hpp)
+        const bool groups = k <= kGrpMaxK && getenv("MCRT_KNN_GROUPS") && atoi(getenv("MCRT_KNN_GROUPS")) != 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
-                           di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
+        if (groups)
+            hipLaunchKernelGGL(knnGroupKernel, dim3(std::min<uint32_t>(grid, (uint32_t)((n + 15) / 16))), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k,
+                               dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
+                               di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1264,6 +1264,78 @@ __global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, u
     if (overflow && lane == 0) atomicAdd(flags, 1ull);
 }
 
+// LinearOctree::knnSearch operator, four queries at a time per wave (mcrt_groupknn.hpp); a row that gives up has its query
+// repeated by the whole wave
+__global__ void __launch_bounds__(256) knnGroupKernel(const PhotonMapViewW map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
+                                                      uint32_t* out_index, double* out_d2, unsigned long long* flags) {
+    __shared__ __align__(16) unsigned char s_buf[4 * kGroupKnnBytes];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, group = lane >> 4, l16 = lane & 15u;
+    MCRT_LDS_AS unsigned char* wb = (MCRT_LDS_AS unsigned char*)s_buf + wave * kGroupKnnBytes;
+    const GroupKnnLds G = groupKnnLds(wb, group);
+    const WaveKnnLds W = waveKnnLdsOver(wb);
+    const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint32_t overflow = 0, visits = 0;
+    for (uint64_t q0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 4u; q0 < n; q0 += waves_total * 4u) {
+        const uint64_t q = q0 + group;
+        const bool on = q < n;
+        const d3 pt = on ? ld3(p + 3 * q) : splat(0.0);
+        uint32_t c = 0;
+        double r2 = 0.0;
+        bool redo = false;
+        groupKnnSearch(map, pt, on, k, G, c, r2, redo, visits);
+        // the row's result ascending by (distance2, index): ranks by counting, written straight to the output
+        __builtin_amdgcn_wave_barrier();
+        {
+            double my_d[4];
+            uint32_t my_i[4], rank[4];
+            for (int s = 0; s < 4; s++) {
+                const uint32_t j = l16 + 16u * s;
+                const bool v = on && !redo && j < c;
+                my_d[s] = v ? G.d2[j] : INFINITY;
+                my_i[s] = v ? G.idx[j] : 0xFFFFFFFFu;
+                rank[s] = 0;
+            }
+            for (uint32_t i = 0; waveBallot(on && !redo && i < c); i++) {
+                const bool v = on && !redo && i < c;
+                const double d = v ? G.d2[i] : INFINITY;
+                const uint32_t id = v ? G.idx[i] : 0xFFFFFFFFu;
+                for (int s = 0; s < 4; s++) rank[s] += (d < my_d[s] || (d == my_d[s] && id < my_i[s])) ? 1u : 0u;
+            }
+            if (on && !redo) {
+                if (l16 == 0) out_count[q] = c;
+                for (int s = 0; s < 4; s++) {
+                    const uint32_t j = l16 + 16u * s;
+                    if (j < c) {
+                        out_index[q * k + rank[s]] = my_i[s];
+                        out_d2[q * k + rank[s]] = my_d[s];
+                    } else if (j < k) {
+                        out_index[q * k + j] = 0xFFFFFFFFu;
+                        out_d2[q * k + j] = INFINITY;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long rm = waveBallot(on && redo && l16 == 0u);
+        while (rm) {  // (rare) rows that gave up: their queries one at a time by the whole wave
+            const int src = __ffsll((long long)rm) - 1;
+            rm &= rm - 1;
+            const uint64_t qq = q0 + ((uint32_t)src >> 4);
+            const d3 qp = waveShfl3(pt, src);
+            double rr;
+            const uint32_t cc = waveKnnSearch(map, qp, k, W, rr, overflow, visits);
+            waveSortResult(W, cc);
+            if (lane == 0) out_count[qq] = cc;
+            for (uint32_t j = lane; j < k; j += 64) {
+                out_index[qq * k + j] = j < cc ? W.idx[j] : 0xFFFFFFFFu;
+                out_d2[qq * k + j] = j < cc ? W.d2[j] : INFINITY;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (overflow && lane == 0) atomicAdd(flags, 1ull);
+}
+
 // ------------------------------------------------------------------------------------------------
 // photon emission pass (§8(f) rank 1): one photon path per lane at a time, regenerated like the eye paths
 // ------------------------------------------------------------------------------------------------

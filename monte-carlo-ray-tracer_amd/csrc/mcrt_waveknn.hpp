@@ -667,9 +667,64 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     return waveTrimToK(W, count, k, r2_max);
 }
 
-// estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) for every lane of the
-// wave that asks for one (`want`), served one query at a time by the whole wave. Returns the estimate
-// to the asking lane (zero elsewhere).
+// The sum of estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) over the n photons in (d2, idx) for
+// the Interaction of lane `src`: the photons are evaluated by n lanes in parallel, the asking lane's Interaction (as far as
+// Interaction::BSDF reads it) is broadcast from its registers, the contributions are summed by a wave reduction. r2 =
+// photons.top().distance2, the farthest of the k. All lanes must call; returns the estimate in every lane.
+template <bool L>
+__device__ inline d3 waveEvalPhotons(const InteractionT<L>& ia, int src, d3 qpos, const PhotonMapViewW& map, bool caustic, const MCRT_LDS_AS double* d2,
+                                     const MCRT_LDS_AS uint32_t* idx, uint32_t n, double r2) {
+    const uint32_t lane = __lane_id();
+    d3 sum = splat(0.0);
+    if (n == 0) return sum;
+    InteractionT<L> q;
+    q.position = qpos;
+    q.out = waveShfl3(ia.out, src);
+    q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
+    q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
+    q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
+    q.n1 = waveShflD(ia.n1, src);
+    q.n2 = waveShflD(ia.n2, src);
+    q.R = waveShflD(ia.R, src);
+    q.T = waveShflD(ia.T, src);
+    q.type = __builtin_amdgcn_readlane(ia.type, src);
+    q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
+    {
+        // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
+        union { cptr<mcrt_material, L> p; unsigned long long u; } c;
+        c.u = 0ull;
+        c.p = ia.material;
+        unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
+        lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+        hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
+        c.u = ((unsigned long long)hi << 32) | lo;
+        q.material = c.p;
+    }
+    const double inv_max_squared_radius = 1.0 / r2;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t j = base + lane;
+        d3 contrib = splat(0.0);
+        if (j < n) {
+            const float* ph = map.base.photons + (size_t)idx[j] * 8;
+            d3 bsdf_absIdotN;
+            double bsdf_pdf;
+            if (interactionBSDF(q, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
+                const d3 flux = d3{(double)ph[0], (double)ph[1], (double)ph[2]};
+                if (caustic) {
+                    const double wp = gmax(0.0, 1.0 - sqrt(d2[j] * inv_max_squared_radius));
+                    contrib = (flux * bsdf_absIdotN * wp) / bsdf_pdf;
+                } else {
+                    contrib = flux * bsdf_absIdotN / bsdf_pdf;
+                }
+            }
+        }
+        sum = sum + d3{waveSumD(contrib.x), waveSumD(contrib.y), waveSumD(contrib.z)};
+    }
+    return caustic ? 3.0 * sum * inv_max_squared_radius * kInvPi : sum / (r2 * kPi);
+}
+
+// The radiance estimate for every lane of the wave that asks for one (`want`), served one query at a time by the whole
+// wave. Returns the estimate to the asking lane (zero elsewhere).
 template <bool L>
 __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const PhotonMapViewW& map, uint32_t k, bool caustic,
                                   const WaveKnnLds& W, uint32_t& searches, uint32_t& octant_visits, uint32_t& overflow) {
@@ -680,58 +735,12 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         if ((int)lane == src) searches++;
-        // the asking lane's position now; the rest of its Interaction (as far as Interaction::BSDF reads it) only once the
-        // search is over — 32 fewer wave-uniform registers live across the search
+        // the asking lane's position now; the rest of its Interaction only once the search is over — 32 fewer wave-uniform
+        // registers live across the search
         const d3 qpos = waveShfl3(ia.position, src);
         double r2 = 0.0;
         const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
-        d3 sum = splat(0.0);
-        if (n > 0) {  // r2 = photons.top().distance2: the farthest of the k
-            InteractionT<L> q;
-            q.position = qpos;
-            q.out = waveShfl3(ia.out, src);
-            q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
-            q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
-            q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
-            q.n1 = waveShflD(ia.n1, src);
-            q.n2 = waveShflD(ia.n2, src);
-            q.R = waveShflD(ia.R, src);
-            q.T = waveShflD(ia.T, src);
-            q.type = __builtin_amdgcn_readlane(ia.type, src);
-            q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
-            {
-                // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
-                union { cptr<mcrt_material, L> p; unsigned long long u; } c;
-                c.u = 0ull;
-                c.p = ia.material;
-                unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
-                lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
-                hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
-                c.u = ((unsigned long long)hi << 32) | lo;
-                q.material = c.p;
-            }
-            const double inv_max_squared_radius = 1.0 / r2;
-            for (uint32_t base = 0; base < n; base += 64) {
-                const uint32_t j = base + lane;
-                d3 contrib = splat(0.0);
-                if (j < n) {
-                    const float* ph = map.base.photons + (size_t)W.idx[j] * 8;
-                    d3 bsdf_absIdotN;
-                    double bsdf_pdf;
-                    if (interactionBSDF(q, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
-                        const d3 flux = d3{(double)ph[0], (double)ph[1], (double)ph[2]};
-                        if (caustic) {
-                            const double wp = gmax(0.0, 1.0 - sqrt(W.d2[j] * inv_max_squared_radius));
-                            contrib = (flux * bsdf_absIdotN * wp) / bsdf_pdf;
-                        } else {
-                            contrib = flux * bsdf_absIdotN / bsdf_pdf;
-                        }
-                    }
-                }
-                sum = sum + d3{waveSumD(contrib.x), waveSumD(contrib.y), waveSumD(contrib.z)};
-            }
-            sum = caustic ? 3.0 * sum * inv_max_squared_radius * kInvPi : sum / (r2 * kPi);
-        }
+        const d3 sum = waveEvalPhotons(ia, src, qpos, map, caustic, W.d2, W.idx, n, r2);
         if ((int)lane == src) result = sum;
     }
     return result;

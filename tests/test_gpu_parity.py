@@ -275,6 +275,30 @@ def test_knn_exact(pkg, ctx, manifest):
         np.testing.assert_array_equal(d2, np.fromfile(os.path.join(d, "knn_%s_d2.f64" % tag)).reshape(-1, k))
 
 
+def test_knn_exact_four_queries_per_wave(pkg, ctx, manifest, monkeypatch):
+    """mcrt_groupknn.hpp (MCRT_KNN_GROUPS=1: one query per row of 16 lanes, four per wave) against the reference's vectors,
+    for the reference's k and for k that leave the buffer nearly empty / nearly full."""
+    monkeypatch.setenv("MCRT_KNN_GROUPS", "1")
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    ctx.upload_image(img)
+    k = img.param("k_nearest_photons")
+    d = golden_path(case["kat"])
+    for which, tag in ((0, "g"), (1, "c")):
+        pts = np.fromfile(os.path.join(d, "knn_%s_points.f64" % tag)).reshape(-1, 3)
+        cnt, idx, d2 = ctx.knn(which, pts, k)
+        np.testing.assert_array_equal(cnt, np.fromfile(os.path.join(d, "knn_%s_count.u32" % tag), dtype=np.uint32))
+        np.testing.assert_array_equal(idx, np.fromfile(os.path.join(d, "knn_%s_index.u32" % tag), dtype=np.uint32).reshape(-1, k))
+        np.testing.assert_array_equal(d2, np.fromfile(os.path.join(d, "knn_%s_d2.f64" % tag)).reshape(-1, k))
+        for kk in (1, 7, 64):  # ... and the same answers as one query per wave
+            got = ctx.knn(which, pts[:1000], kk)
+            monkeypatch.setenv("MCRT_KNN_GROUPS", "0")
+            want = ctx.knn(which, pts[:1000], kk)
+            monkeypatch.setenv("MCRT_KNN_GROUPS", "1")
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b)
+
+
 def test_deterministic_and_shard_invariant(pkg, ctx, manifest):
     case = manifest["cases"]["hexagon_room"]
     img = pkg.SceneImage(golden_path(case["image"]))
