@@ -488,8 +488,12 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
 // list, b = number of records — so that popping an octant costs no memory access and a visit is ONE round trip (its
 // record list, or its photons). Lane l tests record l and drops it, if kept, into its own two frontier slots; only when a
 // lane's slots are both taken does the wave look for a free slot elsewhere.
+//
+// `bound2`: an upper bound of the k-th nearest photon's squared distance known beforehand (kDblMax: none). The search then
+// starts pruning where it would otherwise arrive after its first scans; the k-set is the same (every one of the k nearest
+// lies within ANY upper bound, and all comparisons against the bound are inclusive).
 __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
-                                         uint32_t& overflow, uint32_t& octant_visits) {
+                                         uint32_t& overflow, uint32_t& octant_visits, double bound2 = kDblMax) {
     r2_max = 0.0;
     const PhotonMapView& m = map.base;
     if (m.num_octants == 0) return 0;
@@ -501,7 +505,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     // smaller key can only postpone the end (linear-octree.cpp:113 stays conservative)
     float f_d2[2] = {INFINITY, INFINITY};
     uint32_t f_a[2] = {kNone, kNone}, f_b[2] = {0u, 0u};  // b == 0 marks a free slot (an inner entry has b = 1)
-    double max_distance2 = kDblMax;
+    double max_distance2 = bound2;
     uint32_t count = 0;
     bool dirty = false;    // candidates appended since the buffer was last reduced
     bool bounded = false;  // max_distance2 has been tightened to a k-photon radius at least once
@@ -731,6 +735,13 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
     d3 result = splat(0.0);
     const uint32_t lane = __lane_id();
     unsigned long long mask = waveBallot(want);
+    // The asking lanes of a wave are mostly neighbouring pixels: the k photons found for the previous query, all within
+    // r_prev of it, lie within r_prev + |p - p_prev| of this one (triangle inequality) — an upper bound of this query's k-th
+    // distance before the search has seen a photon. When the lanes have scattered the bound is loose and changes nothing.
+    const uint32_t k_all = (uint64_t)k > map.base.num_photons ? (uint32_t)map.base.num_photons : k;
+    bool have_prev = false;
+    d3 prev_p = splat(0.0);
+    double prev_r = 0.0;
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -738,10 +749,19 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
         // the asking lane's position now; the rest of its Interaction only once the search is over — 32 fewer wave-uniform
         // registers live across the search
         const d3 qpos = waveShfl3(ia.position, src);
+        double bound2 = kDblMax;
+        if (have_prev) {
+            const d3 dp = qpos - prev_p;
+            const double b = prev_r + sqrt(dot(dp, dp));
+            bound2 = b * b * 1.00000001;  // (rounding of the three operations: parts in 1e16)
+        }
         double r2 = 0.0;
-        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
+        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits, bound2);
         const d3 sum = waveEvalPhotons(ia, src, qpos, map, caustic, W.d2, W.idx, n, r2);
         if ((int)lane == src) result = sum;
+        have_prev = n == k_all && n > 0u;
+        prev_p = qpos;
+        prev_r = sqrt(r2);
     }
     return result;
 }
