@@ -50,14 +50,15 @@ inline bool quantiseAxis(const double* lo, const double* hi, int n, float& origi
     if ((double)o > lo_min) o = nextafterf(o, -INFINITY);
     origin = o;
     const double extent = hi_max - (double)o;
-    int e = -kQExpBias;  // smallest cell
+    constexpr int kMinExp = -126;  // smallest cell: a normal float (the FP32 block visit builds 2^e from the exponent byte)
+    int e = kMinExp;
     if (extent > 0.0) {
         int ex;
         frexp(extent / 255.0, &ex);  // extent/255 = f * 2^ex, f in [0.5, 1)  ->  2^ex >= extent/255
         e = ex;
     }
     for (;; e++) {
-        if (e < -kQExpBias) e = -kQExpBias;
+        if (e < kMinExp) e = kMinExp;
         if (e > 255 - kQExpBias) return false;
         const double cell = qCell((uint32_t)(e + kQExpBias));
         bool ok = true;

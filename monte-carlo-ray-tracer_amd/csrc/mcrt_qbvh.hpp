@@ -160,20 +160,21 @@ MCRT_HD void travInnerStepQ64(const QView<kLds>& qv, Trav& T, const SmStack& stk
 }
 
 // The same visit with the slab tests in FP32 — the trace kernels' form. Per block and axis, with A = cell / d and
-// C = (origin - o) / d (both FP64, then rounded to float), the plane of cell coordinate q is crossed at t = q A + C; the
-// entry side uses C - m and the exit side C + m, where m = 2^-21 (255 |A| + |C|) + 2^-44 |o / d| covers the two
-// conversions, the FP32 multiply-add (each <= 2^-24 of 255 |A| + |C|) and the rounding of the FP64 form it replaces
-// (<= 2^-51 of |o / d| + |C|). So every FP32 entry distance is <= the FP64 one, every exit distance >=: a child the FP64
-// form keeps is kept here, with a key that is not larger — the walk visits a superset of the nodes again, and the
-// result (a minimum over exact FP64 primitive tests) is unchanged. A child's {entry distance, link meta} travel as one
-// word — the stack's key format (float bits, low 9 bits = m) — so the children are ordered with integer min / max and
-// pushed as they are. About half the instructions of the FP64 form (24 conversions + 24 multiply-adds + 28 min / max /
-// compare instead of 24 + 24 FP64 decodes, 48 FP64 slab operations and a 64-bit sorting network).
+// C = (origin - o) / d, the plane of cell coordinate q is crossed at t = q A + C; the entry side uses C - m and the exit
+// side C + m, where the margin m covers every rounding between the FP64 form above and the FP32 one (ray rounded to float,
+// difference, products, multiply-add; the bound is derived where m is computed). So every FP32 entry distance is <= the
+// FP64 one, every exit distance >=: a child the FP64 form keeps is kept here, with a key that is not larger — the walk
+// visits a superset of the nodes again, and the result (a minimum over exact FP64 primitive tests) is unchanged. A
+// child's {entry distance, link meta} travel as one word — the stack's key format (float bits, low 9 bits = m) — so the
+// children are ordered with integer min / max and pushed as they are. (Round 2, second pass: A and C themselves in FP32 —
+// six conversions of the ray per visit instead of nine FP64 operations and six conversions per block.)
 constexpr uint32_t kQMissKey = 0xFFFFFFFFu;
 template <bool kLds, bool kCount>
 MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const float best_up = floatAbove(T.best.t);  // smallest float >= best.t
-    const double o[3] = {T.o.x, T.o.y, T.o.z}, inv[3] = {T.inv.x, T.inv.y, T.inv.z};
+    // the ray in FP32, rounded to nearest: |of - o| <= u |o|, invf = inv (1 + e), |e| <= u = 2^-24 (|inv| <= 1e25: T.fast)
+    const float of[3] = {(float)T.o.x, (float)T.o.y, (float)T.o.z}, invf[3] = {(float)T.inv.x, (float)T.inv.y, (float)T.inv.z};
+    const bool pos[3] = {T.inv.x >= 0.0, T.inv.y >= 0.0, T.inv.z >= 0.0};
     uint32_t near_key = kQMissKey, near_a = 0;
     auto push = [&](uint32_t key, uint32_t a) {
         if (T.sp < kMaxStackDepth) {
@@ -194,17 +195,20 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
         float A[3], Cn[3], Cf[3];
         uint32_t wn[3], wf[3];  // cell coordinates of the planes the ray enters / leaves through, four children per word
         for (int ax = 0; ax < 3; ax++) {
-            const double cell = qCell((b.w[3] >> (8 * ax)) & 0xFFu);
-            const double Ad = cell * inv[ax];
-            const double Cd = ((double)bitsFloat(b.w[ax]) - o[ax]) * inv[ax];
-            A[ax] = (float)Ad;
-            const float C = (float)Cd;
-            const float m = fmaf(fmaf(255.0f, fabsf(A[ax]), fabsf(C)), 4.76837158203125e-07f, fmaf(fabsf((float)(o[ax] * inv[ax])), 5.6843418860808015e-14f, 1e-30f));
+            // t(q) = (origin + q cell - o) inv = q A + C with A = cell inv, C = (origin - o) inv, all in FP32: cell is a power of
+            // two >= 2^-126 (quantiseAxis), so A = cell invf is exact and off by <= u |A|; d = fl(origin - of) is off the true
+            // difference by <= u |d| + u |o|, so C = fl(d invf) by <= 3u |C| + 1.01u |o inv|; the fma rounds by <= u |t|. The
+            // margin m = 8u (255 |A| + |C|) + 4u |of invf| covers the sum with room: the planes the ray enters through move
+            // towards it, the others away, every slab only grows (by ~1e-7 of the ray's distance from the coordinate origin —
+            // nothing next to the 1/255 quantisation of the boxes).
+            const float cell = bitsFloat((((b.w[3] >> (8 * ax)) & 0xFFu) - 1u) << 23);  // 2^(e - 128)
+            A[ax] = cell * invf[ax];
+            const float C = (bitsFloat(b.w[ax]) - of[ax]) * invf[ax];
+            const float m = fmaf(fmaf(255.0f, fabsf(A[ax]), fabsf(C)), 4.76837158203125e-07f, fmaf(fabsf(of[ax] * invf[ax]), 2.384185791015625e-07f, 1e-30f));
             Cn[ax] = C - m;
             Cf[ax] = C + m;
-            const bool pos = inv[ax] >= 0.0;
-            wn[ax] = pos ? b.w[4 + 2 * ax] : b.w[5 + 2 * ax];
-            wf[ax] = pos ? b.w[5 + 2 * ax] : b.w[4 + 2 * ax];
+            wn[ax] = pos[ax] ? b.w[4 + 2 * ax] : b.w[5 + 2 * ax];
+            wf[ax] = pos[ax] ? b.w[5 + 2 * ax] : b.w[4 + 2 * ax];
         }
         uint32_t key[4], a[4];
 #if defined(__HIP_DEVICE_COMPILE__)
