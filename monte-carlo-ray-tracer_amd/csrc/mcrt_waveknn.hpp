@@ -735,13 +735,6 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
     d3 result = splat(0.0);
     const uint32_t lane = __lane_id();
     unsigned long long mask = waveBallot(want);
-    // The asking lanes of a wave are mostly neighbouring pixels: the k photons found for the previous query, all within
-    // r_prev of it, lie within r_prev + |p - p_prev| of this one (triangle inequality) — an upper bound of this query's k-th
-    // distance before the search has seen a photon. When the lanes have scattered the bound is loose and changes nothing.
-    const uint32_t k_all = (uint64_t)k > map.base.num_photons ? (uint32_t)map.base.num_photons : k;
-    bool have_prev = false;
-    d3 prev_p = splat(0.0);
-    double prev_r = 0.0;
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -749,19 +742,10 @@ __device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const Ph
         // the asking lane's position now; the rest of its Interaction only once the search is over — 32 fewer wave-uniform
         // registers live across the search
         const d3 qpos = waveShfl3(ia.position, src);
-        double bound2 = kDblMax;
-        if (have_prev) {
-            const d3 dp = qpos - prev_p;
-            const double b = prev_r + sqrt(dot(dp, dp));
-            bound2 = b * b * 1.00000001;  // (rounding of the three operations: parts in 1e16)
-        }
         double r2 = 0.0;
-        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits, bound2);
+        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
         const d3 sum = waveEvalPhotons(ia, src, qpos, map, caustic, W.d2, W.idx, n, r2);
         if ((int)lane == src) result = sum;
-        have_prev = n == k_all && n > 0u;
-        prev_p = qpos;
-        prev_r = sqrt(r2);
     }
     return result;
 }
