@@ -152,7 +152,8 @@ typedef struct mcrt_camera_desc {
      * Film(width, height): radius 0.5, every sample lands in its own pixel with weight 1. Any other filter makes every
      * sample a splat over the pixels within film_radius (0 = the filter's default radius, film.cpp:31-44), weights from
      * the filter function or, when film_cache_size > 0, from a table of that many samples of it (film.cpp:49-57,86-97);
-     * such frames are rendered by the wavefront pipeline (path tracer, scenes with a BVH, shard_count <= 1). */
+     * such frames are rendered by the wavefront pipeline (either integrator; shard_count <= 1, or sharded through
+     * mcrt_render_film_device; a scene without a BVH is walked through a tree over index ranges there). */
     uint32_t film_filter;
     double   film_radius;
     uint32_t film_cache_size;
@@ -226,7 +227,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);
  * buffers (one RCCL all-reduce / reduce; with shard_count 1 there is nothing to sum) and mcrt_film_resolve_device applies
  * Splat::get (film.hpp:31-35, Film::scan film.cpp:81-84) to the sum: width*height*3 doubles, full frame. The reference
  * adds the same splats with std::atomic<double> in thread-timing order, so sums agree to rounding (1e-12), not bits.
- * cam->film_filter must not be MCRT_FILM_BOX; path tracer only. Returns when the shard's samples are complete
+ * cam->film_filter must not be MCRT_FILM_BOX. Returns when the shard's samples are complete
  * (mcrt_render_finish() then collects the statistics). */
 int mcrt_render_film_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_rgbw,
                             void* stream);

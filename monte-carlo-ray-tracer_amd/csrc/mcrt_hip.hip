@@ -247,7 +247,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.stats = ctx->stats.as<unsigned long long>();
     ta.nodes = ctx->scene.nodes64;
     ta.qblocks = ctx->scene.qblocks;
-    ta.num_nodes = ctx->scene.num_nodes;
+    ta.num_nodes = ctx->scene.q_nodes;
     ta.lds_blocks = lds_blocks;
     ta.q_root_a = ctx->scene.q_root_a;
     ta.q_root_m = ctx->scene.q_root_m;
@@ -566,10 +566,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
     const bool filtered = cam->film_filter != MCRT_FILM_BOX;  // per-sample splats: the wavefront pipeline's shade kernel has them
-    if (film_out && (!filtered || photon))
-        return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for path-traced frames with a reconstruction filter (film_filter != box)");
-    if (filtered && ctx->scene.num_nodes == 0)
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters are implemented for scenes with a BVH");
+    if (film_out && !filtered)
+        return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for frames with a reconstruction filter (film_filter != box)");
+    // (a scene without a BVH is walked through a tree over index ranges by the pipeline's trace kernel, mcrt_layout.hpp)
+    const bool has_tree = ctx->scene.q_nodes > 0;
+    if (filtered && !has_tree)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters need the wavefront pipeline, and this scene has neither a BVH nor finite surface bounds to build its stand-in from");
     // Film::Film(w, h, json) with "filter": "box" and a radius other than the default 0.5 splats too (film.cpp:27-30); that case
     // is not built, so it is refused rather than rendered as the default box
     if (!filtered && cam->film_radius != 0.0 && cam->film_radius != 0.5)
@@ -581,14 +583,14 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
     const char* mn = getenv("MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
-    if (!photon && ctx->scene.num_nodes > 0 && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
+    if (!photon && has_tree && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false, film_out);
     // photon-mapped frames go through the pipeline (trace / kNN / shade launches) on request only: measured slower than
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
     // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
     // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
-    if (photon && ctx->scene.num_nodes > 0 && ctx->k_nearest <= 128 && want_wf)
-        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true);
+    if (photon && has_tree && ctx->k_nearest <= 128 && want_wf)
+        return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true, film_out);
     // workgroup size of the state-machine kernel for trees that stay in HBM (MCRT_SM_BLOCK: 512 / 768 / 1024 lanes) and the
     // stack entries per lane it keeps in LDS (MCRT_SM_STACK; the rest of a lane's stack is in the HBM spill area)
     int sm_block = (int)kBlock, sm_depth = kLdsStackDepth;
@@ -995,6 +997,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.nodes64 = ctx->nodes64.as<Node64>();
     d.qblocks = ctx->qblocks.as<QBlock>();
     d.num_qblocks = (uint32_t)L.qblocks.size();
+    d.q_nodes = (uint32_t)L.nodes64.size();
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
     d.prim = ctx->prim.as<double>();

@@ -27,6 +27,7 @@ struct DeviceScene {
     const Node64* nodes64;
     const QBlock* qblocks;        // quantised child blocks of the trace kernel (mcrt_qbvh.hpp)
     uint32_t num_qblocks, q_root_a, q_root_m;
+    uint32_t q_nodes;             // records in nodes64 = num_nodes, or — scene without a BVH — the nodes of the index-range tree the wavefront pipeline walks (mcrt_layout.hpp)
     const double* prim;
     const double* flat_prim;      // kind-sorted copy (flat mode)
     const uint32_t* flat_index;

@@ -11,6 +11,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_scene.hpp"
 #include "mcrt_qbvh.hpp"
+#include "mcrt_bvh_shared.hpp"  // surfaceBounds
 
 namespace mcrt {
 
@@ -297,6 +298,53 @@ inline void buildFlatCull(HostLayout& L, uint32_t ns) {
     }
 }
 
+// A tree over INDEX RANGES for scenes that come without a BVH (Scene::intersect then loops over every surface,
+// scene.cpp:163-174): node = a run of consecutive surfaces in the scene's own order, split into up to four consecutive runs
+// until four surfaces or fewer are left. Poor as a BVH (the order of a scene file says little about position), but it
+// gives the wavefront pipeline's trace kernel something to walk without renumbering anything — only the pipeline uses it
+// (reconstruction filters need its shade kernel); the megakernels keep testing every surface. Arrays in the reference's
+// linear form (children of node i: i + 1 and its next_sibling chain, bvh.cpp:110-119).
+inline void synthRangeTree(const mcrt_scene_desc* s, std::vector<double>& bounds, std::vector<uint32_t>& start, std::vector<uint32_t>& count,
+                           std::vector<uint32_t>& next) {
+    const uint32_t ns = s->num_surfaces;
+    std::vector<double> sb((size_t)ns * 6);
+    for (uint32_t i = 0; i < ns; i++) surfaceBounds(s->surf_kind[i], s->surf_v + (size_t)i * 9, s->quadrics, &sb[(size_t)i * 6]);
+    struct Rec {
+        static uint32_t build(uint32_t a, uint32_t b, const std::vector<double>& sb, std::vector<double>& bounds, std::vector<uint32_t>& start,
+                              std::vector<uint32_t>& count, std::vector<uint32_t>& next) {
+            const uint32_t me = (uint32_t)start.size();
+            double bb[6] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308,
+                            -1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
+            for (uint32_t i = a; i < b; i++)
+                for (int c = 0; c < 3; c++) {
+                    bb[c] = sb[(size_t)i * 6 + c] < bb[c] ? sb[(size_t)i * 6 + c] : bb[c];
+                    bb[3 + c] = sb[(size_t)i * 6 + 3 + c] > bb[3 + c] ? sb[(size_t)i * 6 + 3 + c] : bb[3 + c];
+                }
+            bounds.insert(bounds.end(), bb, bb + 6);
+            start.push_back(a);
+            next.push_back(0u);
+            if (b - a <= 4u) {
+                count.push_back(b - a);
+                return me;
+            }
+            count.push_back(0u);
+            const uint32_t part = (b - a + 3u) / 4u;
+            uint32_t prev = 0;
+            for (uint32_t x = a; x < b; x += part) {
+                const uint32_t child = build(x, x + part < b ? x + part : b, sb, bounds, start, count, next);
+                if (prev) next[prev] = child;
+                prev = child;
+            }
+            return me;
+        }
+    };
+    bounds.clear();
+    start.clear();
+    count.clear();
+    next.clear();
+    if (ns) Rec::build(0u, ns, sb, bounds, start, count, next);
+}
+
 inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err) {
     const size_t ns = s->num_surfaces;
     L.prim.assign(ns * kPrimStride, 0.0);
@@ -364,30 +412,57 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
         L.flat_pre.clear();
         L.pre_tri_pairs = L.pre_sph_pairs = 0;
     }
-    if (int rc = convertNodes(s, L.node_bounds, L.node_meta, err)) return rc;
-    L.nodes64.assign(s->num_nodes, Node64{});
-    for (uint32_t i = 0; i < s->num_nodes; i++) {
-        Node64& n = L.nodes64[i];
-        memcpy(n.b, &L.node_bounds[(size_t)i * 6], 48);
-        const NodeMeta& m = L.node_meta[i];
-        n.a = m.a;
-        if (m.b & kInnerFlag) {
-            const uint32_t count = m.b & ~kInnerFlag;
-            if (count > 255) {
-                err = "BVH node with more than 255 children";
-                return MCRT_ERR_UNSUPPORTED;
+    // node records and child blocks: of the scene's BVH, or — for a scene without one — of a tree over index ranges that only
+    // the wavefront pipeline walks (L.node_bounds / L.node_meta stay empty: the megakernels test every surface)
+    auto nodeRecords = [&](const mcrt_scene_desc* d, std::vector<double>& nb, std::vector<NodeMeta>& nm) -> int {
+        if (int rc = convertNodes(d, nb, nm, err)) return rc;
+        L.nodes64.assign(d->num_nodes, Node64{});
+        for (uint32_t i = 0; i < d->num_nodes; i++) {
+            Node64& n = L.nodes64[i];
+            memcpy(n.b, &nb[(size_t)i * 6], 48);
+            const NodeMeta& m = nm[i];
+            n.a = m.a;
+            if (m.b & kInnerFlag) {
+                const uint32_t count = m.b & ~kInnerFlag;
+                if (count > 255) {
+                    err = "BVH node with more than 255 children";
+                    return MCRT_ERR_UNSUPPORTED;
+                }
+                n.m = kSmInner | count;
+            } else {
+                if (m.b > 255) {
+                    err = "BVH leaf with more than 255 primitives";
+                    return MCRT_ERR_UNSUPPORTED;
+                }
+                n.m = m.b;
             }
-            n.m = kSmInner | count;
-        } else {
-            if (m.b > 255) {
-                err = "BVH leaf with more than 255 primitives";
-                return MCRT_ERR_UNSUPPORTED;
-            }
-            n.m = m.b;
+            n.pad0 = n.pad1 = 0;
         }
-        n.pad0 = n.pad1 = 0;
+        return buildQBlocks(L, err);
+    };
+    if (s->num_nodes) return nodeRecords(s, L.node_bounds, L.node_meta);
+    L.node_bounds.clear();
+    L.node_meta.clear();
+    std::vector<double> tb;
+    std::vector<uint32_t> ts, tc, tn;
+    synthRangeTree(s, tb, ts, tc, tn);
+    mcrt_scene_desc t = *s;
+    t.num_nodes = (uint32_t)ts.size();
+    t.node_bounds = tb.data();
+    t.node_start_surface = ts.data();
+    t.node_num_surfaces = tc.data();
+    t.node_next_sibling = tn.data();
+    std::vector<double> nb;
+    std::vector<NodeMeta> nm;
+    std::string ignored;
+    std::swap(err, ignored);
+    if (nodeRecords(&t, nb, nm) != MCRT_OK) {  // (surfaces without finite bounds: no tree, the pipeline stays closed to this scene)
+        L.nodes64.clear();
+        L.qblocks.clear();
+        L.q_root_a = L.q_root_m = 0;
     }
-    return buildQBlocks(L, err);
+    std::swap(err, ignored);
+    return MCRT_OK;
 }
 
 // Quadric surfaces: put the address of each one's record (`records` = where the [n][22] array lives for the code that

@@ -212,7 +212,7 @@ struct QTrace {
         stk.lds_stride = 1;
         stk.spill = s_spill.data();
         stk.spill_stride = 1;
-        sv.num_nodes = scene->num_nodes;
+        sv.num_nodes = (uint32_t)E.L.nodes64.size();  // (a scene without a BVH: the index-range tree of mcrt_layout.hpp)
         sv.nodes = E.L.nodes64.data();
         sv.prim = E.L.prim.data();
         sv.lds_nodes = 0;
@@ -499,7 +499,7 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
         pm.k = k_nearest;
         pm.direct_visualization = direct_visualization != 0;
     }
-    if (scene->num_nodes == 0 || slots == 0) return -200;
+    if (slots == 0 || E.L.nodes64.empty()) return -200;
     QTrace qt;
     qt.init(E, scene);
 

@@ -78,6 +78,14 @@ CASES = [
     dict(name="film_lanczos", scene="quadric.json", args=["--film-filter", "lanczos", "--film-radius", "1.5"],
          image=dict(width=96, height=72, sqrtspp=2),
          renders=[dict(tag="lanczos_96x72_s2", width=96, height=72, sqrtspp=2)]),
+    # ... on the one shipped scene without a "bvh" key (Scene::intersect loops over the surfaces, scene.cpp:163-174)
+    dict(name="film_gaussian_nobvh", scene="ior_test.json", args=["--film-filter", "gaussian"],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="gaussian_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    # ... and on a photon-mapped frame
+    dict(name="film_mitchell_pm", scene="hexagon_room.json", photon=True, args=["--emissions", "4000", "--film-filter", "mitchell-netravali"],
+         image=dict(width=96, height=72, sqrtspp=2),
+         renders=[dict(tag="mitchell_pm_96x72_s2", width=96, height=72, sqrtspp=2)]),
     dict(name="ggx_test", scene="ggx_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="ggx_96x54_s3", width=96, height=54, sqrtspp=3)]),

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import camera_for, golden_path, load_radiance, rel_error
 
-CASES = ["film_mitchell", "film_gaussian_cached", "film_lanczos"]
+CASES = ["film_mitchell", "film_gaussian_cached", "film_lanczos", "film_gaussian_nobvh"]  # the last: a scene without a BVH
 TOL = 1e-12
 
 
@@ -36,7 +36,7 @@ def test_filter_is_not_a_no_op(pkg, oracle, manifest):
     assert rel_error(out, load_radiance(r)).max() > 1e-3
 
 
-@pytest.mark.parametrize("name,slots", [("film_mitchell", 777), ("film_gaussian_cached", 100000), ("film_lanczos", 64)])
+@pytest.mark.parametrize("name,slots", [("film_mitchell", 777), ("film_gaussian_cached", 100000), ("film_lanczos", 64), ("film_gaussian_nobvh", 500)])
 def test_wavefront_device_code_film(pkg, emu, manifest, name, slots):
     """mcrt_film.hpp + the splat branch of wfShadeSlot, host build."""
     img, cam, r = _case(pkg, manifest, name)
@@ -157,6 +157,48 @@ def test_gpu_film_shards_sum_to_the_frame(pkg, manifest, name, world):
     box.film_filter = 0
     with pytest.raises(pkg.McrtError):
         ctx.render_film_device(box, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, total.data_ptr())
+    ctx.close()
+
+
+def test_oracle_film_photon_mapped_equals_reference(pkg, oracle, manifest):
+    img, cam, r = _case(pkg, manifest, "film_mitchell_pm")
+    out, _ = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER, rows=r["rows"])
+    assert rel_error(out, load_radiance(r)).max() < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_film_photon_mapped(pkg, manifest):
+    """A reconstruction filter on a photon-mapped frame (trace / kNN / shade launches with splats): the whole frame at once,
+    and as three shards through mcrt_render_film_device + sum + mcrt_film_resolve_device."""
+    import torch
+    img, cam, r = _case(pkg, manifest, "film_mitchell_pm")
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons") or 50, bool(img.param("direct_visualization")))
+    ref = load_radiance(r)
+
+    def check(frame, what):
+        rel = rel_error(frame, ref).max(axis=2)
+        print("%s: max rel %.3e" % (what, rel.max()))
+        assert (rel > 1e-4).sum() <= max(2, int(0.002 * rel.size)) and np.quantile(rel, 0.99) < 1e-9
+
+    out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    check(out, "whole frame")
+    assert st["kernel_id"] == pkg.KERNEL_WAVEFRONT_PM and st["knn_searches"] > 0
+    total = torch.zeros((cam.height, cam.width, 4), dtype=torch.float64, device="cuda:0")
+    searches = 0
+    for index in range(3):
+        shard = cam.copy()
+        shard.shard_index, shard.shard_count, shard.shard_rows = index, 3, 8
+        rgbw = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+        ctx.render_film_device(shard, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER, rgbw.data_ptr())
+        searches += ctx.render_finish()["knn_searches"]
+        total += rgbw
+    res = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda:0")
+    ctx.film_resolve_device(cam.width, cam.height, total.data_ptr(), res.data_ptr())
+    torch.cuda.synchronize()
+    check(res.cpu().numpy(), "three shards")
+    assert searches == st["knn_searches"]
     ctx.close()
 
 
