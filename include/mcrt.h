@@ -402,6 +402,12 @@ int  mcrt_bvh_build_octree(mcrt_ctx* ctx /* may be NULL */, const mcrt_scene_des
  * builders (bvh/bvh.cpp:165-426) restated with the same arithmetic and tie rules — same tree — and run on `threads` host
  * threads (0 = all), one subtree per thread. bins_per_axis 0 = the reference's default (16 / 8). Host only. */
 int  mcrt_bvh_build_sah(const mcrt_scene_desc* scene, int arity, uint32_t bins_per_axis, uint32_t threads, mcrt_bvh** out);
+/* The same two hierarchies built LEVEL BY LEVEL — all open nodes of a depth at once: centroid bounds, binning and the
+ * order-preserving partition are passes over the surfaces on the GPU of ctx (atomics on exact minima / maxima / counts, one
+ * prefix sum per level), the split of every open node is decided by one thread with the reference's cost loop, the host
+ * only strings the nodes together (csrc/mcrt_sah_shared.hpp, mcrt_sah_gpu.hip). Same tree as mcrt_bvh_build_sah and the
+ * reference, bit for bit. ctx == NULL runs the same level loop on the host (one thread). bins_per_axis <= 16. */
+int  mcrt_bvh_build_sah_gpu(mcrt_ctx* ctx /* may be NULL */, const mcrt_scene_desc* scene, int arity, uint32_t bins_per_axis, mcrt_bvh** out);
 const mcrt_bvh_desc* mcrt_bvh_get(const mcrt_bvh* bvh);
 void mcrt_bvh_free(mcrt_bvh* bvh);
 /* `scene` with its surfaces put in bvh->order, its lights re-indexed and the node arrays of `bvh`: an owning copy whose

@@ -219,6 +219,7 @@ def lib():
     L.mcrt_bsdf.argtypes = [vp, C.c_uint64, _dp, _dp, _dp]
     L.mcrt_bvh_build_octree.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mcrt_bvh_build_sah.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.mcrt_bvh_build_sah_gpu.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.POINTER(vp)]
     L.mcrt_bvh_get.argtypes = [vp]
     L.mcrt_bvh_get.restype = C.POINTER(BvhDesc)
     L.mcrt_bvh_free.argtypes = [vp]
@@ -302,9 +303,18 @@ class Bvh:
     """mcrt_bvh: the reference's default ("octree") BVH of a scene's surfaces, built by sorting centroid path codes
     (mcrt_bvh_build_octree; with a Context the per-surface work and the sort run on its GPU)."""
 
-    def __init__(self, scene_desc, ctx=None, kind="octree", bins_per_axis=0, threads=0):
+    def __init__(self, scene_desc, ctx=None, kind="octree", bins_per_axis=0, threads=0, levels=False):
         self._lib = lib()
         self._h = C.c_void_p()
+        if kind in ("binary_sah", "quaternary_sah") and (ctx is not None or levels):
+            # level-synchronous build: on the GPU of ctx, or (levels=True, no ctx) the same passes as host loops
+            rc = self._lib.mcrt_bvh_build_sah_gpu(ctx._h if ctx is not None else None, C.byref(scene_desc), 2 if kind == "binary_sah" else 4,
+                                                  int(bins_per_axis), C.byref(self._h))
+            if rc != 0:
+                if ctx is not None:
+                    ctx._check(rc, "mcrt_bvh_build_sah_gpu")
+                raise McrtError("mcrt_bvh_build_sah_gpu failed: %d" % rc)
+            return
         if kind in ("binary_sah", "quaternary_sah"):  # the reference's binned-SAH builders on all host threads
             rc = self._lib.mcrt_bvh_build_sah(C.byref(scene_desc), 2 if kind == "binary_sah" else 4, int(bins_per_axis), int(threads), C.byref(self._h))
             if rc != 0:

@@ -36,7 +36,7 @@ def sources():
     return src
 
 
-TUS = ["mcrt_hip.hip", "mcrt_octree_gpu.hip", "mcrt_output.hip", "mcrt_multi.hip", "mcrt_image.cpp", "mcrt_octree.cpp", "mcrt_bvh.cpp"]
+TUS = ["mcrt_hip.hip", "mcrt_octree_gpu.hip", "mcrt_sah_gpu.hip", "mcrt_output.hip", "mcrt_multi.hip", "mcrt_image.cpp", "mcrt_octree.cpp", "mcrt_bvh.cpp"]
 OBJ = os.path.join(CSRC, "_obj")
 
 

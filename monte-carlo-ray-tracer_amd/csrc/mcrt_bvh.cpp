@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "mcrt_bvh_shared.hpp"
+#include "mcrt_sah_shared.hpp"
 #include "mcrt_internal.hpp"
 
 using namespace mcrt;
@@ -359,6 +360,33 @@ int mcrt_bvh_build_sah(const mcrt_scene_desc* scene, int arity, uint32_t bins_pe
     if (!out || !sceneUsable(scene) || (arity != 2 && arity != 4) || bins_per_axis == 1 || bins_per_axis > 1024) return MCRT_ERR_INVALID;
     mcrt_bvh* B = new mcrt_bvh();
     const int rc = buildSah(scene, arity, bins_per_axis, threads, B);
+    if (rc != MCRT_OK) {
+        delete B;
+        return rc;
+    }
+    *out = B;
+    return MCRT_OK;
+}
+
+int mcrt_bvh_build_sah_gpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, int arity, uint32_t bins_per_axis, mcrt_bvh** out) {
+    const uint32_t bins = bins_per_axis ? bins_per_axis : (arity == 4 ? 8u : 16u);  // bvh.cpp:29,36
+    if (!out || !sceneUsable(scene) || (arity != 2 && arity != 4) || bins < 2)
+        return ctx ? ctxFail(ctx, MCRT_ERR_INVALID, "mcrt_bvh_build_sah_gpu: bad scene descriptor, arity or bin count") : MCRT_ERR_INVALID;
+    if (bins > kSahMaxBins)
+        return ctx ? ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "mcrt_bvh_build_sah_gpu: more than 16 bins per axis (mcrt_bvh_build_sah has no limit)") : MCRT_ERR_UNSUPPORTED;
+    mcrt_bvh* B = new mcrt_bvh();
+    int rc;
+    if (ctx) {
+        rc = bvhSahGpu(ctx, scene, arity, (int)bins, B);
+    } else {  // the same level-synchronous build with its passes as host loops
+        const uint64_t n = scene->num_surfaces;
+        std::vector<double> bb(n * 6), centroid(n * 3);
+        for (uint64_t i = 0; i < n; i++) {
+            surfaceBounds(scene->surf_kind[i], scene->surf_v + 9 * i, scene->quadrics, &bb[i * 6]);
+            for (int c = 0; c < 3; c++) centroid[i * 3 + c] = (bb[i * 6 + 3 + c] + bb[i * 6 + c]) / 2.0;  // BB().centroid()
+        }
+        rc = buildSahLevelsHost(bb.data(), centroid.data(), n, scene->bb_min, scene->bb_max, arity, (int)bins, B);
+    }
     if (rc != MCRT_OK) {
         delete B;
         return rc;

@@ -13,4 +13,6 @@ void* ctxStream(const mcrt_ctx* ctx);  // the context's hipStream_t
 int ctxFail(mcrt_ctx* ctx, int code, const std::string& msg);  // records the message for mcrt_last_error, returns code
 // mcrt_octree_gpu.hip: the octree BVH of `scene` with the per-surface work on the GPU of ctx (mcrt_bvh_shared.hpp)
 int bvhOctreeGpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, struct ::mcrt_bvh* out);
+// mcrt_sah_gpu.hip: the binned-SAH hierarchies level by level with the per-surface passes on the GPU of ctx (mcrt_sah_shared.hpp)
+int bvhSahGpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, int arity, int bins, struct ::mcrt_bvh* out);
 }  // namespace mcrt

@@ -22,9 +22,9 @@ def _image_nodes(img):
                 count=g(s.node_num_surfaces, n, np.uint32), next=g(s.node_next_sibling, n, np.uint32))
 
 
-def _check_same_tree(pkg, img, ctx=None, kind="octree", threads=0):
+def _check_same_tree(pkg, img, ctx=None, kind="octree", threads=0, levels=False):
     ref = _image_nodes(img)
-    bvh = pkg.Bvh(img.scene, ctx=ctx, kind=kind, threads=threads)
+    bvh = pkg.Bvh(img.scene, ctx=ctx, kind=kind, threads=threads, levels=levels)
     got = bvh.arrays()
     for k in ("bounds", "start", "count", "next"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
@@ -47,6 +47,64 @@ def test_rebuilds_the_reference_sah_bvh(pkg, manifest, name, kind, threads):
     assert _check_same_tree(pkg, img, kind=kind, threads=threads) == img.scene.num_nodes > 0
 
 
+@pytest.mark.parametrize("name,kind", [("coffee_maker_qsah", "quaternary_sah"), ("coffee_maker_bsah", "binary_sah")])
+def test_level_synchronous_sah_host(pkg, manifest, name, kind):
+    """mcrt_bvh_build_sah_gpu with ctx = NULL: the GPU path's level loop (mcrt_sah_shared.hpp) with its passes as host loops —
+    all open nodes of a depth at once instead of the reference's recursion, same tree."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    assert _check_same_tree(pkg, img, kind=kind, levels=True) == img.scene.num_nodes > 0
+
+
+def test_level_synchronous_sah_equals_recursive_on_awkward_input(pkg):
+    """Surfaces the split rules have trouble with: 700 triangles sharing one centroid (no usable axis, more than a leaf
+    holds: arbitrarySplit, bvh.cpp:451-473), a line of centroids (the quaternary rule falls back to the binary one for the
+    whole subtree, bvh.cpp:313-318) and a cloud; the level-synchronous build against the recursive restatement."""
+    rng = np.random.default_rng(5)
+    tris = []
+    for i in range(700):  # same centroid, different sizes
+        r = 0.1 + 0.001 * i
+        tris.append([[-r, -r, 0.0], [r, -r, 0.0], [0.0, 2 * r, 0.0]])
+    for i in range(900):  # centroids on a line along x
+        x = rng.random() * 50.0
+        tris.append([[x - 0.5, 1.0, 5.0], [x + 0.5, 1.0, 5.0], [x, 1.0, 5.0]])
+    for i in range(3000):
+        c = rng.random(3) * 20.0 - 10.0
+        tris.append((c[None, :] + rng.normal(scale=0.2, size=(3, 3))).tolist())
+    v = np.ascontiguousarray(np.array(tris, dtype=np.float64).reshape(-1, 9))
+    n = v.shape[0]
+    e = np.zeros((n, 9))
+    e[:, 0:3] = v[:, 3:6] - v[:, 0:3]
+    e[:, 3:6] = v[:, 6:9] - v[:, 0:3]
+    kind = np.zeros(n, dtype=np.uint8)
+    interp = np.zeros(n, dtype=np.uint8)
+    mat = np.zeros(n, dtype=np.uint32)
+    area = np.ones(n)
+    m = pkg.Material()
+    sc = pkg.SceneDesc()
+    sc.abi_version = 2
+    sc.num_surfaces = n
+    sc.surf_kind = kind.ctypes.data_as(C.POINTER(C.c_uint8))
+    sc.surf_interpolate = interp.ctypes.data_as(C.POINTER(C.c_uint8))
+    sc.surf_material = mat.ctypes.data_as(C.POINTER(C.c_uint32))
+    sc.surf_area = area.ctypes.data_as(C.POINTER(C.c_double))
+    sc.surf_v = v.ctypes.data_as(C.POINTER(C.c_double))
+    sc.surf_e = e.ctypes.data_as(C.POINTER(C.c_double))
+    sc.num_materials = 1
+    sc.materials = C.pointer(m)
+    pts = v.reshape(-1, 3)
+    sc.bb_min[:] = pts.min(axis=0).tolist()
+    sc.bb_max[:] = pts.max(axis=0).tolist()
+    for kind_name in ("quaternary_sah", "binary_sah"):
+        a = pkg.Bvh(sc, kind=kind_name, threads=1)
+        b = pkg.Bvh(sc, kind=kind_name, levels=True)
+        ra, rb = a.arrays(), b.arrays()
+        assert len(ra["start"]) > 500
+        for k in ("bounds", "start", "count", "next", "order"):
+            np.testing.assert_array_equal(ra[k], rb[k], err_msg="%s %s" % (kind_name, k))
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize("name,nodes", [("c3", 169162), ("c4", 153801), ("spaceship", 23187)])
 def test_large_scene_sah(pkg, name, nodes):
     """Quaternary SAH trees of the full-size C3 / C4 stand-ins and of the spaceship cockpit, all host threads."""
@@ -60,6 +118,9 @@ def test_large_scene_sah(pkg, name, nodes):
     t = time.perf_counter()
     assert _check_same_tree(pkg, img, kind="quaternary_sah") == nodes
     print("%s: quaternary SAH of %d surfaces rebuilt and compared in %.2f s" % (name, img.scene.num_surfaces, time.perf_counter() - t))
+    t = time.perf_counter()
+    assert _check_same_tree(pkg, img, kind="quaternary_sah", levels=True) == nodes
+    print("%s: ... level-synchronous build on one host thread: %.2f s" % (name, time.perf_counter() - t))
 
 
 def test_shuffled_surfaces_give_the_same_hits(pkg, oracle, manifest):
@@ -113,6 +174,39 @@ def test_gpu_path_rebuilds_the_reference_octree_bvh(pkg, manifest, name):
     ctx = pkg.Context(0)
     img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
     _check_same_tree(pkg, img, ctx=ctx)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind", [("coffee_maker_qsah", "quaternary_sah"), ("coffee_maker_bsah", "binary_sah")])
+def test_gpu_path_rebuilds_the_reference_sah_bvh(pkg, manifest, name, kind):
+    """mcrt_bvh_build_sah_gpu: the level-synchronous binned-SAH build with its per-surface passes on the GPU."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    ctx = pkg.Context(0)
+    assert _check_same_tree(pkg, img, ctx=ctx, kind=kind) == img.scene.num_nodes > 0
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nodes", [("c3", 169162), ("c4", 153801)])
+def test_gpu_path_large_scene_sah(pkg, name, nodes):
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    import make_large
+    p = make_large.image_path(name)
+    if not os.path.exists(p) and make_large.ensure_image(name) is None:
+        pytest.skip("%s image not built on this machine" % name)
+    img = pkg.SceneImage(p)
+    ctx = pkg.Context(0)
+    pkg.Bvh(img.scene, ctx=ctx, kind="quaternary_sah").close()  # first call: allocations, module load
+    t = time.perf_counter()
+    assert _check_same_tree(pkg, img, ctx=ctx, kind="quaternary_sah") == nodes
+    t_gpu = time.perf_counter() - t
+    t = time.perf_counter()
+    _check_same_tree(pkg, img, kind="quaternary_sah")
+    t_host = time.perf_counter() - t
+    print("%s: quaternary SAH of %d surfaces: GPU level-synchronous %.3f s, host threads %.3f s (both incl. the comparison)" % (
+        name, img.scene.num_surfaces, t_gpu, t_host))
     ctx.close()
 
 
