@@ -5,9 +5,9 @@
 //   3. plan per open node (one thread each): rule, axes, or "no usable axis"
 //   4. bin of every surface; per (node, bin) an atomic count and an atomic box
 //   5. split per open node (one thread each, the reference's cost loop over the bins — tiny next to the passes)
-//   6. order-preserving partition: child of every surface, ONE exclusive prefix sum over four packed 16-bit... no: over
-//      two 64-bit words holding the four children's indicator counts, new position = child's offset + own rank; the parts
-//      of an arbitrary split are dealt in closed form; surfaces of closed nodes stay where they are
+//   6. order-preserving partition: child of every surface, exclusive prefix sums over the four children's indicators (two
+//      64-bit words of two 32-bit counters each), new position = run start + child's offset + own rank; the parts of an
+//      arbitrary split are dealt in closed form; surfaces of closed nodes stay where they are
 //   7. (rare) boxes of round-robin parts: one more atomic pass over those runs
 // The host reads back the splits (a few hundred bytes per open node), appends the children to the node table and uploads
 // the next level's open nodes; the depth-first numbering (BVH::compact) is a host pass over the finished table.
