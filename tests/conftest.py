@@ -72,7 +72,9 @@ def load_emu():
     deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, src])
+        tmp = "%s.%d.tmp" % (out, os.getpid())  # (several pytest-xdist workers may get here at once: build aside, rename into place)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        os.replace(tmp, out)
     L = C.CDLL(out)
     vp = C.c_void_p
     L.emu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
