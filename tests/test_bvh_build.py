@@ -230,6 +230,19 @@ def test_gpu_path_large_scene_and_render(pkg):
     _check_same_tree(pkg, img)
     t_host = time.perf_counter() - t
     print("octree BVH of 6 898 815 triangles: GPU-assisted %.2f s, host %.2f s (incl. the comparison with the reference's arrays)" % (t_gpu, t_host))
+    # the same 6.9 M surfaces under the quaternary SAH rule: level-synchronous on the GPU against the recursive host build
+    t = time.perf_counter()
+    a = pkg.Bvh(img.scene, ctx=ctx, kind="quaternary_sah")
+    t_gpu = time.perf_counter() - t
+    t = time.perf_counter()
+    b = pkg.Bvh(img.scene, kind="quaternary_sah")
+    t_host = time.perf_counter() - t
+    ra, rb = a.arrays(), b.arrays()
+    for k in ("bounds", "start", "count", "next", "order"):
+        np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+    print("quaternary SAH of the same surfaces (%d nodes): GPU level-synchronous %.2f s, host threads %.2f s" % (len(ra["start"]), t_gpu, t_host))
+    a.close()
+    b.close()
     ctx.close()
 
 
