@@ -299,6 +299,36 @@ def test_knn_exact_four_queries_per_wave(pkg, ctx, manifest, monkeypatch):
                 np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("count", [1, 7, 49, 50, 51, 300, 5000])
+def test_knn_small_and_odd_maps(pkg, ctx, manifest, monkeypatch, count):
+    """k-NN on maps with fewer photons than k, exactly k, just more, and a few leaves: one query per wave and four per wave
+    against a brute-force selection with the reference's distance expression (glm::distance2 on the float positions)."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    ctx.upload_image(img)
+    rng = np.random.default_rng(count)
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    ph[:, 0:3] = 1.0
+    m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), 200)
+    ctx.upload_photons(m.desc, m.desc, 50, False)
+    pts = lo + rng.random((257, 3)) * (hi - lo)
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)  # in the map's order
+    d = pts[:, None, :] - pos[None, :, :]
+    d2_all = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    for k in (1, 50):
+        want = np.sort(d2_all, axis=1)[:, :min(k, count)]
+        for groups in ("0", "1"):
+            monkeypatch.setenv("MCRT_KNN_GROUPS", groups)
+            cnt, idx, d2 = ctx.knn(0, pts, k)
+            assert np.all(cnt == min(k, count))
+            np.testing.assert_array_equal(d2[:, :min(k, count)], want)
+            assert np.all(np.isinf(d2[:, min(k, count):])) and np.all(idx[:, min(k, count):] == 0xFFFFFFFF)
+            rows = np.arange(len(pts))[:, None]
+            np.testing.assert_array_equal(d2_all[rows, idx[:, :min(k, count)]], want)
+    m.close()
+
+
 def test_deterministic_and_shard_invariant(pkg, ctx, manifest):
     case = manifest["cases"]["hexagon_room"]
     img = pkg.SceneImage(golden_path(case["image"]))
