@@ -70,6 +70,18 @@ CONFIGS = {
                golden="water_caustics_c5.rows500_504.f64", image="water_caustics_c5.mcrt",
                surfaces=6898815, nodes=1925901),
 }
+# Three more of the reference's own scenes, as far as their meshes are in the tree (.MISSING_LARGE_BLOBS lists the rest; the
+# reference's loader skips a missing file): real meshes, metals with tabulated spectra, glass, 2 - 546 emissive surfaces, the
+# scene files' own cameras (16 spp), quaternary-SAH trees of 18 k - 124 k nodes. No stand-in meshes.
+CONFIGS["baroque"] = dict(scene="baroque_table.json", copy=["data/baroque_table", "data/spectral-distributions"], meshes={}, flags=[],
+                          width=1280, height=720, sqrtspp=4, rows=(360, 363), photon=False,
+                          golden="baroque_table.rows360_363.f64", image="baroque_table.mcrt", surfaces=51304, nodes=18249)
+CONFIGS["lego"] = dict(scene="lego_bulldozer.json", copy=["data/lego_bulldozer"], meshes={}, flags=[],
+                       width=1280, height=720, sqrtspp=4, rows=(360, 363), photon=False,
+                       golden="lego_bulldozer.rows360_363.f64", image="lego_bulldozer.mcrt", surfaces=122917, nodes=41304)
+CONFIGS["pipes"] = dict(scene="pipes.json", copy=["data/pipes", "data/spectral-distributions"], meshes={}, flags=[],
+                        width=960, height=600, sqrtspp=4, rows=(300, 304), photon=False,
+                        golden="pipes.rows300_304.f64", image="pipes.mcrt", surfaces=357765, nodes=124259)
 # The same C5 scene and photon map at the spp the bench times (256 instead of the scene file's 16): one full-width row by the
 # reference (its photon pass is reproducible: same photon sets for the same seed, radiance equal to 1e-15). Rendered against the
 # c5 image with the camera's sqrtspp overridden (tests/test_gpu_large_scene.py).

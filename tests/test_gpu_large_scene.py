@@ -75,11 +75,12 @@ def _config(pkg, name):
     return pkg.SceneImage(p), make_large.CONFIGS[name], make_large.golden_path(name)
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm", "c5_s16"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm", "c5_s16", "baroque", "lego", "pipes"])
 def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
-    @ 1024 spp; C5: 6 898 815 triangles, photon-mapped — against the reference's radiance for the same rows
-    (committed goldens made by tests/large/make_large.py)."""
+    @ 1024 spp; C5: 6 898 815 triangles, photon-mapped; baroque_table / lego_bulldozer / pipes: the reference's own scene
+    files as far as their meshes exist (51 k / 123 k / 358 k triangles, up to 546 lights and 560 materials) — against the
+    reference's radiance for the same rows (committed goldens made by tests/large/make_large.py)."""
     kernel = None
     if ":" in name:  # the same rows through the other kernel (default for these trees: the wavefront pipeline)
         name, kernel = name.split(":")
@@ -108,12 +109,13 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     print("%s rows %d-%d: max rel %.3e, outliers %d / %d, %.1f Mray/s, %.2f rays/path" %
           (name, r0, r1, rel.max(), bad, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
     assert bad <= max(4, int(0.002 * rel.size))
-    want = pkg.KERNEL_PM_WAVE if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" else pkg.KERNEL_WAVEFRONT
+    # (the pipeline is the default for trees of 65 536 nodes or more: baroque_table and lego_bulldozer stay with the lane state machine)
+    want = pkg.KERNEL_PM_WAVE if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" or c["nodes"] < 65536 else pkg.KERNEL_WAVEFRONT
     assert st["kernel_id"] == want, pkg.KERNEL_NAMES.get(st["kernel_id"])
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "baroque", "lego", "pipes"])
 def test_full_size_traversal_equals_oracle(pkg, oracle, name):
     img, _, _ = _config(pkg, name)
     rng = np.random.default_rng(11)

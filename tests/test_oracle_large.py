@@ -24,7 +24,7 @@ def test_synthetic_bunny_is_reproducible(tmp_path):
     assert hashlib.md5(open(p, "rb").read()).hexdigest() == make_large.BUNNY_MD5
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c5_s16"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c5_s16", "baroque", "lego", "pipes"])
 def test_oracle_rows_equal_reference(pkg, oracle, name):
     import make_large
     p = make_large.ensure_image(name)  # also verifies the md5 of the generated meshes
