@@ -86,6 +86,14 @@ CASES = [
     dict(name="film_mitchell_pm", scene="hexagon_room.json", photon=True, args=["--emissions", "4000", "--film-filter", "mitchell-netravali"],
          image=dict(width=96, height=72, sqrtspp=2),
          renders=[dict(tag="mitchell_pm_96x72_s2", width=96, height=72, sqrtspp=2)]),
+    # shell.json and stanford_dragon.json without the meshes of .MISSING_LARGE_BLOBS (the loader skips them): the rooms, their
+    # 6 / 3 lights and 7 / 14 materials
+    dict(name="shell_room", scene="shell.json", args=[],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="shell_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    dict(name="dragon_room", scene="stanford_dragon.json", args=[],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="dragon_96x54_s3", width=96, height=54, sqrtspp=3)]),
     dict(name="ggx_test", scene="ggx_test.json", args=[],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="ggx_96x54_s3", width=96, height=54, sqrtspp=3)]),

@@ -59,7 +59,7 @@ def _check(out, ref, what):
 
 
 @pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah",
-                                  "coffee_maker_bsah", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test", "quadric"])
+                                  "coffee_maker_bsah", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test", "quadric", "shell_room", "dragon_room"])
 def test_path_tracer_matches_reference(pkg, ctx, manifest, name):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))

@@ -28,7 +28,7 @@ def test_c1_anchor_matches_survey_appendix_b2():
 
 @pytest.mark.parametrize("name", ["hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_pm", "hexagon_room_dof",
                                   "coffee_maker_qsah", "coffee_maker_bsah", "ior_test", "veach_mis", "metals",
-                                  "oren_nayar_test", "ggx_test", "quadric"])
+                                  "oren_nayar_test", "ggx_test", "quadric", "shell_room", "dragon_room"])
 def test_oracle_radiance_equals_reference(pkg, oracle, manifest, name):
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
