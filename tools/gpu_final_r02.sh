@@ -15,5 +15,5 @@ cd $R
 python tools/summarize_rocprof.py $O > $O/rocprof_summary.md 2>&1
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete; find $O -type d -empty -delete
 head -40 $O/rocprof_summary.md
-( python tools/ab_probe.py c4 --steps 1 "c4_full:"; python tools/ab_probe.py c5 --steps 1 "c5_full:"; python bench.py --workload c5 --no-secondary --no-counters --no-cpu --steps 1 --emissions 1e7 | tail -1 ) > $O/full_size_frames.log 2>&1
+( python tools/ab_probe.py c4 --steps 1 "c4_full:"; python bench.py --workload c5 --no-secondary --no-counters --no-cpu --steps 1 --emissions 1e7 | tail -1 ) > $O/full_size_frames.log 2>&1
 grep "variant\|photon_pass" $O/full_size_frames.log | cut -c1-400
