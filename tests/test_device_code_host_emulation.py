@@ -93,6 +93,25 @@ def test_wavefront_equals_reference(pkg, emu, oracle, manifest, name, slots):
     assert 0 <= info["rays"] - cnt[0] <= 0.03 * info["rays"]
 
 
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "quadric", "ior_test"])
+def test_wavefront_walks_the_index_range_tree_when_the_scene_has_no_bvh(pkg, emu, manifest, name):
+    """A scene handed over WITHOUT its node arrays (and ior_test.json, which never had any): the pipeline's trace kernel then
+    walks the tree over index ranges that mcrt_layout.hpp builds (synthRangeTree) — another set of boxes, the same
+    primitives, the same closest hits: the reference's bits again."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    bare = pkg.SceneDesc()
+    C.memmove(C.byref(bare), C.byref(img.scene), C.sizeof(pkg.SceneDesc))
+    bare.num_nodes = 0
+    out = np.zeros((cam.height, cam.width, 3))
+    cnt = (C.c_uint64 * 6)()
+    assert emu.emu_render_wf(C.byref(bare), C.byref(cam), manifest["seed"], 777, cam.height, out.ctypes.data, cnt) == 0 and cnt[3] == 0
+    ref = load_radiance(r)
+    assert np.array_equal(out, ref), "max rel err %.3e" % rel_error(out, ref).max()
+
+
 def test_wavefront_sharded_rows(pkg, emu, manifest):
     """Rows dealt to shards: the union of two shards' packed rows is the full frame."""
     case = manifest["cases"]["metals"]
