@@ -79,9 +79,20 @@ REF_SCENES = {
     "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
     "spaceship_c4.mcrt": ("spaceship.json", []),
     "spaceship.mcrt": ("spaceship_cockpit.json", []),
+    "hexagon_room_pm.mcrt": ("hexagon_room.json", []),
+    "water_caustics_c5.mcrt": ("water_caustics.json", []),
 }
-SECONDARY = ("spaceship", "pm", "c3", "c5")
-NO_COUNTER_LEGS = ("c5",)  # their PMC child passes would each repeat 25 s of scene set-up: timed and priced, traffic left null
+SECONDARY = ("spaceship", "pm", "c3", "c4", "c5")
+# per leg: timed steps (None = --secondary-steps), spp of the untimed warm-up frame (None = the leg's own), spp of the frame the PMC
+# child passes count (None = the leg's own; per-sample work is the same at any spp, the scale is stated in frame_scale)
+LEG_PLAN = {"c3": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=8),
+            "c4": dict(steps=1, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~35 s: one timed frame after a 16 spp warm-up frame
+            "c5": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=4)}
+# photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths): BASELINE configs[4] says 1e8 emission paths for C5
+EMISSIONS = {"pm": 1e6, "c5": 1e7}
+# emissions of the REFERENCE's own photon pass in the cpu_baseline leg of C5 (its CPU emission pass at 1e8 paths takes minutes; the
+# timed part is its eye pass only, and paths / rays / searches per row do not depend on the map)
+REF_EMISSIONS = {"pm": 1e6, "c5": 1e6}
 SEED = 0x12345678
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector-ALU peak in FP64-rate lane slots: 256 CUs x 4 SIMDs, a wave64 FP64 instruction occupies its SIMD for 4 cycles
@@ -101,8 +112,9 @@ DEFAULT_COUNTS = dict(node_per_ray=13.82, tri_per_ray=8.61, sphere_per_ray=6.31)
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (checker code: oracle/ and oracle/_ref are used here and nowhere in the timed region)
 # ------------------------------------------------------------------------------------------------------------------
-def _run_reference(img_path, cam, r0, r1, threads):
-    """Rows [r0, r1) of the frame by the reference binary; returns its JSON record or None."""
+def _run_reference(img_path, cam, r0, r1, threads, photon_emissions=None, timeout=600):
+    """Rows [r0, r1) of the frame by the reference binary; returns its JSON record or None. With photon_emissions the reference
+    runs its own photon pass first (PhotonMapper's constructor, untimed) and the record's seconds cover its eye pass only."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mcrt_ref")
     ref_name, ref_flags = REF_SCENES.get(os.path.basename(img_path), (None, []))
     ref_scene = os.path.join(ROOT, "oracle", "_ref", "scenes", ref_name or "-")
@@ -112,12 +124,14 @@ def _run_reference(img_path, cam, r0, r1, threads):
                                                                    "--rows", str(r0), str(r1), "--out-radiance", "/dev/null"]
     if threads:
         cmd += ["--threads", str(threads)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
+    if photon_emissions:
+        cmd += ["--photon", "--emissions", str(int(photon_emissions))]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, MCRT_REF_SEED=str(SEED)))
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     return json.loads(lines[-1]) if lines else None
 
 
-def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_threads=True, ref_threads=None):
+def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_threads=True, ref_threads=None, ref_emissions=None):
     """Times the CPU integrator on rows of the same frame. Prefers the reference itself (oracle/_ref/mcrt_ref +
     oracle/_ref/scenes, produced by oracle/Makefile in the build container); otherwise the C restatement (oracle/, kind
     "port"). Also returns the per-ray node/primitive test counts of the reference-equivalent traversal (for the
@@ -188,6 +202,24 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
                             port_value=port["value"], port_cores=threads)
         except Exception as ex:  # keep the port numbers
             base = dict(port, note="reference run failed: %r" % (ex,))
+    elif ref_emissions:
+        # photon-mapped legs: the reference's own PhotonMapper::sampleRay (photon-mapper.cpp:279-391) on rows of the same frame. One
+        # process = scene load + its CPU photon pass (both untimed) + the timed eye pass over the rows. Rays and searches of a row do
+        # not depend on the photon map (estimates are only added up), so the port's per-row counts price the reference's rows too.
+        try:
+            rays_per_row, knn_per_row = rays / rows, info["knn_searches"] / rows
+            t = ref_threads or threads
+            n_rows = max(1, rows // 8)  # the port took ~budget/2 for `rows` rows; the reference is several times slower per row
+            q0 = max(0, mid - n_rows // 2)
+            r = _run_reference(img.path, cam, q0, q0 + n_rows, t, photon_emissions=ref_emissions, timeout=900)
+            if r:
+                base = dict(value=rays_per_row * n_rows / r["seconds"] / 1e6, unit="Mray/s", cores=t, kind="reference",
+                            knn_searches_per_s=knn_per_row * n_rows / r["seconds"],
+                            sample="reference PhotonMapper::sampleRay (eye pass only; its own photon pass of %.0e x 10 emission paths untimed), rows %d-%d of %dx%d @ %d spp at %d threads (%d paths, %.1f s)"
+                                   % (ref_emissions, q0, q0 + n_rows, cam.width, cam.height, spp, t, r["paths"], r["seconds"]),
+                            port_value=port["value"], port_cores=threads, port_knn_searches_per_s=port.get("knn_searches_per_s"))
+        except Exception as ex:
+            base = dict(port, note="reference run failed: %r" % (ex,))
     return base, counts
 
 
@@ -196,56 +228,101 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
 # ------------------------------------------------------------------------------------------------------------------
 SQ_SET = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
           "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
-PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET))
+# Two passes (TCC has 4 counter slots, SQ 8, GRBM 2 - MI355X_MICROARCH.md "rocprofv3 PMC slots"): reads by request size class
+# together with the SQ set, then writes + L2 hit/miss. Calibrated on known byte counts in the kernels' own access patterns
+# (tools/calibrate_traffic.py -> profiles/r03_traffic_calibration.json): every fabric read is a 128-byte L2 line, so
+# read bytes = 32 n32 + 64 n64 + 128 n128 = 2 x FETCH_SIZE for streams, 8 KB photon runs, 64-byte blocks and 80-byte records alike
+# (a scattered 64-byte block MOVES 128 bytes); WRITE_SIZE is exact for streamed stores and counts 32-byte sectors for scattered ones.
+PMC_PASSES = (("read+sq", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"] + SQ_SET),
+              ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]))
+PMC_FALLBACK = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET))  # round 2's passes, if a combined pass is refused
 INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKernel")
+PROFILE_DIR = os.path.join(ROOT, "gpurun_out", "bench_profiles")  # per-leg counter summaries of THIS run (copied to profiles/ when committed)
 
 
-def collect_counters(workload, sqrtspp=None, emissions=None, passes=PMC_PASSES, timeout=300):
-    """Returns {"counters": {name: sum over the integrator dispatches of ONE frame}, "kernel_ms": ..., "per_kernel": ...}
-    or {"error": ...}. Separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit together)."""
+def _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out):
+    """One rocprofv3 --pmc pass over one frame (child process). Returns True when counters came back."""
+    tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
+    got = False
+    try:
+        cmd = [rocprof, "--kernel-trace", "--pmc"] + names + ["-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--child-frame", "--workload", workload]
+        if sqrtspp:
+            cmd += ["--sqrtspp", str(sqrtspp)]
+        if emissions:
+            cmd += ["--emissions", str(emissions)]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        frames = [l for l in p.stdout.splitlines() if l.startswith('{"child_frame"')]
+        if p.returncode != 0 or not frames:
+            out.setdefault("errors", []).append("%s pass: rc %d: %s" % (tag, p.returncode, (p.stderr or p.stdout)[-300:]))
+            return False
+        out["frame"] = json.loads(frames[-1])
+        out.setdefault("pass_wall_s", {})[tag] = time.perf_counter() - t0
+        for db in glob.glob(os.path.join(tmp, "**", "*_results.db"), recursive=True):
+            con = sqlite3.connect(db)
+            try:
+                rows = list(con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"))
+                durs = list(con.execute("select name, total_calls, total_duration from top_kernels"))
+            except sqlite3.Error as ex:
+                out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
+                rows, durs = [], []
+            con.close()
+
+            def bucket(kname):
+                key = next((k for k in INTEGRATOR_KERNELS if k in kname), None)
+                if key is None:
+                    return None  # sampleResolveKernel, memsets, torch kernels, the photon pass
+                if "renderKernelSM" in kname:
+                    return "renderKernelSM"
+                if "renderKernelPM" in kname:
+                    return "renderKernelPM"
+                return key
+            for kname, cname, val, n in rows:
+                kk = bucket(kname)
+                if kk is None:
+                    continue
+                got = True
+                d = out["per_kernel"].setdefault(kk, {})
+                d[cname] = d.get(cname, 0.0) + float(val)
+                d["dispatches"] = max(d.get("dispatches", 0), int(n))
+                out["counters"][cname] = out["counters"].get(cname, 0.0) + float(val)
+            for kname, calls, total in durs:
+                kk = bucket(kname)
+                if kk is not None:
+                    d = out["per_kernel"].setdefault(kk, {})
+                    d["duration_ms_" + tag] = d.get("duration_ms_" + tag, 0.0) + float(total) / 1e6
+    except Exception as ex:
+        out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return got
+
+
+def collect_counters(workload, sqrtspp=None, emissions=None, passes=None, timeout=420):
+    """Returns {"counters": {name: sum over the integrator dispatches of ONE frame}, "per_kernel": ..., "frame": ...}
+    or {"error": ...}. Separate passes as MI355X_MICROARCH.md prescribes (the read and the write counters do not fit together)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return {"error": "rocprofv3 not found"}
     out = {"counters": {}, "per_kernel": {}, "frame": None}
-    for tag, names in passes:
-        tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
-        try:
-            cmd = [rocprof, "--kernel-trace", "--pmc"] + names + ["-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--child-frame", "--workload", workload]
-            if sqrtspp:
-                cmd += ["--sqrtspp", str(sqrtspp)]
-            if emissions:
-                cmd += ["--emissions", str(emissions)]
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            frames = [l for l in p.stdout.splitlines() if l.startswith('{"child_frame"')]
-            if p.returncode != 0 or not frames:
-                out.setdefault("errors", []).append("%s pass: rc %d: %s" % (tag, p.returncode, (p.stderr or p.stdout)[-300:]))
-                continue
-            out["frame"] = json.loads(frames[-1])
-            for db in glob.glob(os.path.join(tmp, "**", "*_results.db"), recursive=True):
-                con = sqlite3.connect(db)
-                try:
-                    rows = list(con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"))
-                except sqlite3.Error as ex:
-                    out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
-                    rows = []
-                con.close()
-                for kname, cname, val, _n in rows:
-                    key = next((k for k in INTEGRATOR_KERNELS if k in kname), None)
-                    if key is None:
-                        continue  # sampleResolveKernel, memsets, torch kernels
-                    kk = "renderKernel" if key == "renderKernel" else key
-                    if "renderKernelSM" in kname:
-                        kk = "renderKernelSM"
-                    elif "renderKernelPM" in kname:
-                        kk = "renderKernelPM"
-                    out["per_kernel"].setdefault(kk, {})
-                    out["per_kernel"][kk][cname] = out["per_kernel"][kk].get(cname, 0.0) + float(val)
-                    out["counters"][cname] = out["counters"].get(cname, 0.0) + float(val)
-        except Exception as ex:
-            out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+    plan = passes or PMC_PASSES
+    ok = [_pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out) for tag, names in plan]
+    if passes is None and not ok[0]:
+        # the combined read + SQ pass was refused: the three separate passes of round 2
+        out["counters"], out["per_kernel"] = {}, {}
+        for tag, names in PMC_FALLBACK:
+            _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out)
     return out
+
+
+def read_bytes_of(c):
+    """Bytes the L2s asked the fabric for (HBM or Infinity Cache), from whichever read counters the pass had."""
+    if "TCC_EA0_RDREQ_sum" in c:
+        n, n32, n128 = c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        return 32.0 * n32 + 128.0 * n128 + 64.0 * (n - n32 - n128)
+    if "FETCH_SIZE" in c:
+        return c["FETCH_SIZE"] * 1024.0 * 2.0  # = the size-class sum on gfx950 (profiles/r03_traffic_calibration.json)
+    return None
 
 
 def counters_summary(pmc, scale=1.0):
@@ -253,12 +330,16 @@ def counters_summary(pmc, scale=1.0):
     if not pmc or not pmc.get("counters"):
         return None
     c = pmc["counters"]
-    s = {"source": "rocprofv3 --pmc passes of one frame, child processes of this run", "frame_scale": scale}
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # counters are in KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)
-        s["fetch_bytes"] = c["FETCH_SIZE"] * 1024.0 * 2.0 * scale
+    s = {"source": "rocprofv3 --pmc passes of one frame, child processes of this run", "frame_scale": scale,
+         "calibration": "profiles/r03_traffic_calibration.json: read bytes = 128-byte lines moved (= 2 x FETCH_SIZE on gfx950, exact for streams, 8 KB runs, "
+                        "scattered 64-byte blocks and 80-byte records); WRITE_SIZE exact for streamed stores, 32-byte sectors for scattered ones"}
+    rb = read_bytes_of(c)
+    if rb is not None and "WRITE_SIZE" in c:
+        s["fetch_bytes"] = rb * scale
         s["write_bytes"] = c["WRITE_SIZE"] * 1024.0 * scale
         s["traffic_bytes"] = s["fetch_bytes"] + s["write_bytes"]
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) > 0:
+        s["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "SQ_ACTIVE_INST_VALU" in c and pmc.get("frame"):
         # SQ counters tick in quad-cycles (MI355X_MICROARCH.md, per-instruction constants). SIMD time is priced at the 2.4 GHz
         # spec clock over the counted frame's own kernel time, so "busy" is a share of what the chip could issue at full clock.
@@ -279,7 +360,33 @@ def counters_summary(pmc, scale=1.0):
         s["errors"] = pmc["errors"]
     if pmc.get("frame"):
         s["frame"] = pmc["frame"]
+    if pmc.get("pass_wall_s"):
+        s["pass_wall_s"] = pmc["pass_wall_s"]
     return s
+
+
+def write_leg_profile(name, desc, pmc_raw, summary, roofline):
+    """The counters behind a leg's roofline block as a file (gpurun_out/bench_profiles/pmc_<leg>.md; committed as
+    profiles/rNN_pmc_<leg>.md): raw sums per kernel, the derived figures and the arithmetic that leads to frac / traffic."""
+    try:
+        os.makedirs(PROFILE_DIR, exist_ok=True)
+        with open(os.path.join(PROFILE_DIR, "pmc_%s.md" % name), "w") as f:
+            f.write("# rocprofv3 PMC summary of bench.py leg `%s`\n\n%s\n\n" % (name, desc))
+            fr = (pmc_raw or {}).get("frame") or {}
+            f.write("Counted frame (child process of bench.py under `rocprofv3 --kernel-trace --pmc ...`, one pass per counter set): "
+                    "%s spp, %s rays, %s paths, %s kNN searches, kernel time %.3f ms (HIP events)\n\n"
+                    % (fr.get("spp"), fr.get("rays"), fr.get("paths"), fr.get("knn_searches"), fr.get("kernel_ms", float("nan"))))
+            f.write("## raw counter sums per kernel (all dispatches of the counted frame)\n\n| kernel | counter | sum |\n|---|---|---:|\n")
+            for k, d in sorted(((pmc_raw or {}).get("per_kernel") or {}).items()):
+                for cn, v in sorted(d.items()):
+                    f.write("| `%s` | %s | %.6g |\n" % (k, cn, v))
+            f.write("\n## derived (frame_scale = timed frame / counted frame)\n\n```json\n%s\n```\n" % json.dumps(summary, indent=1))
+            f.write("\n## roofline block of the bench line\n\n```json\n%s\n```\n" % json.dumps(roofline, indent=1))
+            f.write("\nRecompute: read bytes = 32 n32 + 128 n128 + 64 (RDREQ - n32 - n128); write bytes = WRITE_SIZE x 1024; traffic = (read + write) x frame_scale; "
+                    "traffic_GBs = traffic / kernel_ms of the timed frame; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x counted kernel time x 2.4 GHz); "
+                    "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU).\n")
+    except OSError:
+        pass
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -320,13 +427,14 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     wl.integrator = m.INTEGRATOR_PATH_TRACER
     wl.pm_maps, wl.emit_info = None, None
     wl.photon = name in ("pm", "c5")
+    wl.emissions = args.emissions or EMISSIONS.get(name, 1e6)
     if wl.photon and world == 1 and not args.host_octree:
         # one GPU: the whole photon pass on the device (mcrt_photon_pass_device: emission, sort, octants, boxes, record lists;
         # no photon list crosses PCIe)
         wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
         sc = img.scene
         t_pass = time.perf_counter()
-        ps = wl.ctx.photon_pass_device(args.emissions, 10.0, SEED, sc.bb_min[:], sc.bb_max[:], 200, 50, False)
+        ps = wl.ctx.photon_pass_device(wl.emissions, 10.0, SEED, sc.bb_min[:], sc.bb_max[:], 200, 50, False)
         wl.emit_info = dict(paths=ps["emission_paths"], rays=ps["rays"], kernel_ms=ps["emission_ms"], global_photons=int(ps["global_count"]),
                             caustic_photons=int(ps["caustic_count"]), octree_build_s=(ps["total_ms"] - ps["emission_ms"]) * 1e-3,
                             octree_builder="device (mcrt_photon_pass_device)", photon_pass_s=time.perf_counter() - t_pass,
@@ -336,7 +444,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     elif wl.photon:
         # emission pass on the GPU (sharded over the ranks and all-gathered), octrees GPU-assisted, upload
         wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
-        em = wl.ctx.emit_photons(args.emissions, 10.0, SEED, rank, world)
+        em = wl.ctx.emit_photons(wl.emissions, 10.0, SEED, rank, world)
         wl.emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
         lists = []
         for key in ("global_", "caustic"):
@@ -367,12 +475,13 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     return wl
 
 
-def run_steps(wl, steps, warmup, world, dist):
-    """W untimed steps, then exactly K timed steps between barrier + synchronize; returns (seconds, per-step stats)."""
+def run_steps(wl, steps, warmup, world, dist, warm_sqrtspp=None):
+    """W untimed steps, then exactly K timed steps between barrier + synchronize; returns (seconds, per-step stats).
+    warm_sqrtspp (secondary legs whose frame takes tens of seconds): the untimed frame runs at that spp."""
     import torch
 
-    def step():
-        wl.ctx.render_device(wl.cam, SEED, wl.integrator, wl.tile.data_ptr(), wl.stream)
+    def step(cam=None):
+        wl.ctx.render_device(cam or wl.cam, SEED, wl.integrator, wl.tile.data_ptr(), wl.stream)
         st = wl.ctx.render_finish()
         if world > 1:
             dist.gather(wl.tile, wl.gathered, dst=0)  # the single collective of the data path
@@ -383,8 +492,12 @@ def run_steps(wl, steps, warmup, world, dist):
             dist.barrier()
         torch.cuda.synchronize(wl.dev)
 
+    warm_cam = None
+    if warm_sqrtspp:
+        warm_cam = wl.cam.copy()
+        warm_cam.sqrtspp = int(warm_sqrtspp)
     for _ in range(warmup):
-        step()
+        step(warm_cam)
     sync()
     t0 = time.perf_counter()
     stats = [step() for _ in range(steps)]
@@ -416,7 +529,8 @@ def hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, knn_per
         if pmc.get("traffic_bytes"):
             r["traffic_GBs"] = pmc["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9
             r["traffic_frac"] = r["traffic_GBs"] / HBM_PEAK_GBS
-        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "fetch_bytes", "write_bytes", "frame_scale", "errors") if k in pmc}
+            r["traffic_over_algorithmic"] = pmc["traffic_bytes"] / (r["achieved"] * 1e9 * kernel_ms * 1e-3)
+        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "fetch_bytes", "write_bytes", "l2_hit_rate", "frame_scale", "pass_wall_s", "errors") if k in pmc}
     if r["frac"] > 1.0:  # more algorithmic bytes than HBM could move: the caches serve them; not an HBM fraction
         r["note"] += "; algorithmic rate above the HBM peak (cache-served): frac withheld"
         r["algorithmic_frac"] = r["frac"]
@@ -436,6 +550,17 @@ def valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc):
          "note": "scene resident in LDS: bound = vector ALU. achieved = lane-slots executing VALU work per second (SQ_THREAD_CYCLES_VALU of one frame, "
                  "rocprofv3 PMC pass made in this run, / kernel time of the timed steps); frac = achieved / peak = VALU busy x lane utilisation (SIMD time priced at the 2.4 GHz spec clock). "
                  "algorithmic_GBs = reference-equivalent bytes (SURVEY.md 8(d)) per second: a work rate, not HBM traffic; traffic = measured HBM bytes of one frame"}
+    # Necessary work of the REFERENCE's algorithm on the same rays, in FP64 lane-ops (one +, -, x, /, sqrt, min, max or compare = 1): the
+    # oracle's per-ray test counts (best-first traversal of the reference's tree) x the operation count of each test as the reference
+    # writes it - BoundingBox::intersect 24 (bounding-box.cpp:9-17), Triangle::intersect 28 at the u exit ... 54 accepted, priced 41
+    # (triangle.cpp:23-63), Sphere::intersect 21 at the discriminant exit ... 31 accepted, priced 26 (sphere.cpp:13-26) - plus shading:
+    # ~640 per path vertex (Interaction, emissive, light sample + BSDF value/pdf, BSDF sample, roulette, next ray; static FP64 count of
+    # the shading code's common path) / 1.6 rays per vertex = 400 per ray. frac_necessary = that rate / the chip's FP64-rate lane slots.
+    ops = {"box_test": 24.0, "triangle_test": 41.0, "sphere_test": 26.0, "shading_per_ray": 400.0}
+    necessary = counts["node_per_ray"] * ops["box_test"] + counts["tri_per_ray"] * ops["triangle_test"] + counts["sphere_per_ray"] * ops["sphere_test"] + ops["shading_per_ray"]
+    r["necessary_lane_ops_per_ray"] = necessary
+    r["necessary_lane_ops_prices"] = ops
+    r["frac_necessary"] = necessary * rays_per_launch / (kernel_ms * 1e-3) / 1e9 / VALU_PEAK_GLANEOPS
     if pmc and pmc.get("valu_lane_ops"):
         r["achieved"] = pmc["valu_lane_ops"] / (kernel_ms * 1e-3) / 1e9
         r["frac"] = r["achieved"] / VALU_PEAK_GLANEOPS
@@ -465,8 +590,10 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
     """One leg: set up, time, describe. Returns (result dict on rank 0 | None, best reference thread count)."""
     import torch
 
+    plan = {} if headline else LEG_PLAN.get(name, {})
+    steps = plan.get("steps") or steps
     wl = setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp=args.sqrtspp if headline else None)
-    elapsed, stats = run_steps(wl, steps, warmup, world, dist)
+    elapsed, stats = run_steps(wl, steps, warmup, world, dist, warm_sqrtspp=plan.get("warm_sqrtspp"))
     dev = wl.dev
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     acc = torch.tensor([float(sum(s["rays"] for s in stats)), float(sum(s["paths"] for s in stats)),
@@ -510,11 +637,13 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
             if wl.photon and wl.pm_maps is None:  # device-built maps: host copies for the CPU leg only (same maps the GPU searched)
                 wl.pm_maps = (wl.ctx.download_map(0), wl.ctx.download_map(1))
             base, counts = cpu_baseline(m, wl.img, wl.full, args.cpu_seconds if headline else args.cpu_seconds * 0.6, wl.integrator, wl.pm_maps,
-                                        scan_threads=headline, ref_threads=ref_threads)
+                                        scan_threads=headline, ref_threads=ref_threads, ref_emissions=REF_EMISSIONS.get(name) if wl.photon else None)
             result["cpu_baseline"] = base
             ref_threads = base.get("best_cores", ref_threads)
+        counts_source = "oracle, rows of this frame, this run"
         if counts is None:
             counts = STORED_COUNTS.get(name, DEFAULT_COUNTS)
+            counts_source = "stored (cpu leg skipped: --no-cpu or N > 1): oracle counts of an earlier run of the same frame"
     # the context's memory goes back before the counter passes (child processes) need the GPU
     frame = None
     wl.ctx.close()
@@ -525,8 +654,8 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
         if world == 1 and want_counters:
             # counters of ONE frame; C3's frame takes 8 s under nothing and longer under counters: taken at 64 spp and scaled
             # (per-sample work is the same; stated in frame_scale)
-            scale_spp = 8 if name == "c3" else None
-            raw = collect_counters(name, sqrtspp=scale_spp or (args.sqrtspp if headline else None), emissions=args.emissions if wl.photon else None)
+            scale_spp = plan.get("pmc_sqrtspp")
+            raw = collect_counters(name, sqrtspp=scale_spp or (args.sqrtspp if headline else None), emissions=wl.emissions if wl.photon else None)
             scale = (wl.sqrtspp / scale_spp) ** 2 if scale_spp else 1.0
             pmc = counters_summary(raw, scale) or {"errors": raw.get("errors") or [raw.get("error")]}
         launches = steps
@@ -536,6 +665,9 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
             result["roofline"] = valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc)
         else:
             result["roofline"] = hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, total_knn / steps / world, pmc)
+        result["roofline"]["per_ray_counts_source"] = counts_source
+        if world == 1 and want_counters:
+            write_leg_profile(name, wl.desc, raw, pmc, result["roofline"])
     return result, ref_threads
 
 
@@ -567,7 +699,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sqrtspp", type=int, default=None, help="override the workload's samples per pixel (debugging; the line says so)")
     ap.add_argument("--host-octree", action="store_true", help="build the photon octrees with the host builder instead of the GPU-assisted one")
-    ap.add_argument("--emissions", type=float, default=1e6, help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths)")
+    ap.add_argument("--emissions", type=float, default=None,
+                    help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths); default: pm 1e6, c5 1e7 (BASELINE configs[4]: 1e8 emission paths)")
     ap.add_argument("--child-frame", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -609,8 +742,7 @@ def main():
             t0 = time.perf_counter()
             try:
                 leg, _ = measure(name, args, m, tiling, rank, world, local_rank, dist, args.secondary_steps, 1,
-                                 want_cpu=not args.no_cpu, want_counters=not args.no_counters and name not in NO_COUNTER_LEGS, headline=False,
-                                 ref_threads=ref_threads)
+                                 want_cpu=not args.no_cpu, want_counters=not args.no_counters, headline=False, ref_threads=ref_threads)
                 leg["leg_wall_s"] = time.perf_counter() - t0
                 for k in ("metric", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus"):
                     leg.pop(k, None)
