@@ -290,7 +290,7 @@ def _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out):
                 kk = bucket(kname)
                 if kk is not None:
                     d = out["per_kernel"].setdefault(kk, {})
-                    d["duration_ms_" + tag] = d.get("duration_ms_" + tag, 0.0) + float(total) / 1e6
+                    d["duration_ms_" + tag] = d.get("duration_ms_" + tag, 0.0) + float(total) / 1e3  # top_kernels durations are in microseconds
     except Exception as ex:
         out.setdefault("errors", []).append("%s pass: %r" % (tag, ex))
     finally:

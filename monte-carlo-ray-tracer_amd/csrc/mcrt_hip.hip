@@ -88,6 +88,7 @@ struct mcrt_ctx {
     // on demand, so that a host that only wants traversal or k-NN does not pay five hipMalloc / hipFree pairs per call
     DevBuf op_buf[6];
     DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
+    DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
 
     // photon emission pass
     std::vector<double> host_light_flux;  // [num_lights][3] emittance * area (photon-mapper.cpp:64)
@@ -740,6 +741,8 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             pmx.caustic_map = waveMapView(ctx, 1);
             pmx.stack_depth = pm_stack_depth;
             pmx.iors_global = nullptr;
+            HIP_TRY(ctx, ctx->pm_stage.reserve((size_t)kStageDoubles * g.total_lanes * sizeof(double)));
+            pmx.stage = ctx->pm_stage.as<double>();
             if (g.block == 1024u) {
                 HIP_TRY(ctx, ctx->pm_iors.reserve((size_t)kMaxIors * g.total_lanes * sizeof(double)));
                 pmx.iors_global = ctx->pm_iors.as<double>();

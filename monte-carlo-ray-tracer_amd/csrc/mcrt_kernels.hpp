@@ -1087,6 +1087,7 @@ struct PmExtra {
     PhotonMapViewW global_map, caustic_map;
     uint32_t stack_depth;  // traversal-stack entries per lane kept in LDS (tree in HBM: the state machine's stack, any depth; else kLdsStackDepth)
     double* iors_global;   // refraction-history entries beyond the first kPmLdsIors, [kMaxIors - kPmLdsIors][lanes] (1024-lane instance), or null: all in LDS
+    double* stage;         // estimate requests, [lanes][kStageDoubles]: what Interaction::BSDF reads of a lane's Interaction (mcrt_waveknn.hpp)
 };
 
 // kLanes: 512 (2 waves per SIMD, 256 VGPRs) or 1024 (4 waves per SIMD, 128 VGPRs). The kernel spends 97.6 % of its wave
@@ -1122,6 +1123,9 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
         W.hist = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 12u) + wave * kWaveHist;
     }
+
+    double* const stage_lane = pmx.stage + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStageDoubles;
+    double* const stage_wave = pmx.stage + ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) * kStageDoubles;
 
     PathState st;
     uint32_t paths = 0, searches = 0, octant_visits = 0, knn_overflow = 0;
@@ -1191,9 +1195,11 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         }
         // ---- part 2 (whole wave): caustic estimates, then global estimates
         const unsigned long long t_est = kCount ? clock64() : 0ull;
-        const d3 C = waveEstimate(needC, ia, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
+        if (needC) stageInteraction(stage_lane, ia);  // needG implies needC
+        __threadfence_block();                        // the records are read by the other lanes of the wave
+        const d3 C = waveEstimate<kAll>(needC, stage_wave, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
         if (needC) st.radiance = st.radiance + C * st.throughput;
-        const d3 G = waveEstimate(needG, ia, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
+        const d3 G = waveEstimate<kAll>(needG, stage_wave, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
         if (needG) {
             st.radiance = st.radiance + G * st.throughput;  // :330, the path ends here
             ended = true;

@@ -671,39 +671,75 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     return waveTrimToK(W, count, k, r2_max);
 }
 
-// The sum of estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) over the n photons in (d2, idx) for
-// the Interaction of lane `src`: the photons are evaluated by n lanes in parallel, the asking lane's Interaction (as far as
-// Interaction::BSDF reads it) is broadcast from its registers, the contributions are summed by a wave reduction. r2 =
-// photons.top().distance2, the farthest of the k. All lanes must call; returns the estimate in every lane.
+// ---- Estimate requests staged in memory ------------------------------------------------------------------------------------
+// What Interaction::BSDF reads of the asking lane's Interaction (interaction.cpp:56-153), written by the lane to its own record
+// before the estimates of a wave are served: position, out, the shading frame, n1, n2, R, T, type / inside, material. The
+// serving loop reads the asking lane's record with wave-uniform loads AFTER the search and moves it to scalar registers. Round 2
+// broadcast the fields out of the asking lane's vector registers (v_readlane): the whole Interaction then had to stay in VGPRs
+// (or be reloaded from scratch) inside the serving loop, and the 128-VGPR instance ran ~90 scratch instructions per search
+// (23 KB of spill traffic per search next to 13 KB of photons and octant records: measured 1.93 x the algorithmic bytes).
+// With the record in memory nothing of the path state is touched between the first and the last search of a wave, so the
+// register allocator spills it ONCE around the loop.
+constexpr uint32_t kStageDoubles = 24;  // 19 values + flags + material (21), then the estimate coming back (3)
+constexpr uint32_t kStageResult = 21;
+
 template <bool L>
-__device__ inline d3 waveEvalPhotons(const InteractionT<L>& ia, int src, d3 qpos, const PhotonMapViewW& map, bool caustic, const MCRT_LDS_AS double* d2,
+__device__ inline void stageInteraction(double* rec, const InteractionT<L>& ia) {
+    double2* r = reinterpret_cast<double2*>(rec);
+    r[0] = double2{ia.position.x, ia.position.y};
+    r[1] = double2{ia.position.z, ia.out.x};
+    r[2] = double2{ia.out.y, ia.out.z};
+    r[3] = double2{ia.shading_cs.c0.x, ia.shading_cs.c0.y};
+    r[4] = double2{ia.shading_cs.c0.z, ia.shading_cs.c1.x};
+    r[5] = double2{ia.shading_cs.c1.y, ia.shading_cs.c1.z};
+    r[6] = double2{ia.shading_cs.c2.x, ia.shading_cs.c2.y};
+    r[7] = double2{ia.shading_cs.c2.z, ia.n1};
+    r[8] = double2{ia.n2, ia.R};
+    union { cptr<mcrt_material, L> p; unsigned long long u; } c;
+    c.u = 0ull;
+    c.p = ia.material;
+    r[9] = double2{ia.T, __longlong_as_double((long long)(((unsigned long long)(uint32_t)ia.type) | (ia.inside ? 0x100000000ull : 0ull)))};
+    r[10] = double2{__longlong_as_double((long long)c.u), 0.0};
+}
+
+// a value every lane holds (loaded from a wave-uniform address) moved to scalar registers
+__device__ inline double uniformD(double v) {
+    union { double d; int u[2]; } c;
+    c.d = v;
+    c.u[0] = __builtin_amdgcn_readfirstlane(c.u[0]);
+    c.u[1] = __builtin_amdgcn_readfirstlane(c.u[1]);
+    return c.d;
+}
+
+template <bool L>
+__device__ inline void loadStagedInteraction(const double* rec, InteractionT<L>& q) {  // rec wave-uniform
+    const double2* r = reinterpret_cast<const double2*>(rec);
+    const double2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4], a5 = r[5], a6 = r[6], a7 = r[7], a8 = r[8], a9 = r[9], a10 = r[10];
+    q.position = d3{uniformD(a0.x), uniformD(a0.y), uniformD(a1.x)};
+    q.out = d3{uniformD(a1.y), uniformD(a2.x), uniformD(a2.y)};
+    q.shading_cs.c0 = d3{uniformD(a3.x), uniformD(a3.y), uniformD(a4.x)};
+    q.shading_cs.c1 = d3{uniformD(a4.y), uniformD(a5.x), uniformD(a5.y)};
+    q.shading_cs.c2 = d3{uniformD(a6.x), uniformD(a6.y), uniformD(a7.x)};
+    q.n1 = uniformD(a7.y);
+    q.n2 = uniformD(a8.x);
+    q.R = uniformD(a8.y);
+    q.T = uniformD(a9.x);
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(uniformD(a9.y));
+    q.type = (int)(uint32_t)fl;
+    q.inside = (fl >> 32) != 0ull;
+    union { cptr<mcrt_material, L> p; unsigned long long u; } c;
+    c.u = (unsigned long long)__double_as_longlong(uniformD(a10.x));
+    q.material = c.p;
+}
+
+// The sum of estimateGlobalRadiance / estimateCausticRadiance (photon-mapper.cpp:343-391) over the n photons in (d2, idx) for
+// the Interaction q (wave-uniform): the photons are evaluated by n lanes in parallel, the contributions are summed by a wave
+// reduction. r2 = photons.top().distance2, the farthest of the k. All lanes must call; returns the estimate in every lane.
+template <bool L>
+__device__ inline d3 waveEvalPhotons(const InteractionT<L>& q, const PhotonMapViewW& map, bool caustic, const MCRT_LDS_AS double* d2,
                                      const MCRT_LDS_AS uint32_t* idx, uint32_t n, double r2) {
     const uint32_t lane = __lane_id();
     d3 sum = splat(0.0);
-    if (n == 0) return sum;
-    InteractionT<L> q;
-    q.position = qpos;
-    q.out = waveShfl3(ia.out, src);
-    q.shading_cs.c0 = waveShfl3(ia.shading_cs.c0, src);
-    q.shading_cs.c1 = waveShfl3(ia.shading_cs.c1, src);
-    q.shading_cs.c2 = waveShfl3(ia.shading_cs.c2, src);
-    q.n1 = waveShflD(ia.n1, src);
-    q.n2 = waveShflD(ia.n2, src);
-    q.R = waveShflD(ia.R, src);
-    q.T = waveShflD(ia.T, src);
-    q.type = __builtin_amdgcn_readlane(ia.type, src);
-    q.inside = __builtin_amdgcn_readlane((int)ia.inside, src) != 0;
-    {
-        // material pointer: broadcast as an offset from a wave-uniform base would need the base; shuffle the bits
-        union { cptr<mcrt_material, L> p; unsigned long long u; } c;
-        c.u = 0ull;
-        c.p = ia.material;
-        unsigned lo = (unsigned)c.u, hi = (unsigned)(c.u >> 32);
-        lo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
-        hi = (unsigned)__builtin_amdgcn_readlane((int)hi, src);
-        c.u = ((unsigned long long)hi << 32) | lo;
-        q.material = c.p;
-    }
     const double inv_max_squared_radius = 1.0 / r2;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t j = base + lane;
@@ -728,24 +764,44 @@ __device__ inline d3 waveEvalPhotons(const InteractionT<L>& ia, int src, d3 qpos
 }
 
 // The radiance estimate for every lane of the wave that asks for one (`want`), served one query at a time by the whole
-// wave. Returns the estimate to the asking lane (zero elsewhere).
+// wave from the staged records (`stage_wave` = the record of the wave's lane 0; every asking lane has called stageInteraction
+// and the stores are visible: __threadfence_block() in between). Returns the estimate to the asking lane (zero elsewhere).
 template <bool L>
-__device__ inline d3 waveEstimate(bool want, const InteractionT<L>& ia, const PhotonMapViewW& map, uint32_t k, bool caustic,
+__device__ inline d3 waveEstimate(bool want, double* stage_wave, const PhotonMapViewW& map, uint32_t k, bool caustic,
                                   const WaveKnnLds& W, uint32_t& searches, uint32_t& octant_visits, uint32_t& overflow) {
-    d3 result = splat(0.0);
     const uint32_t lane = __lane_id();
     unsigned long long mask = waveBallot(want);
+    if (!mask) return splat(0.0);
+    if (lane == 0) searches += (uint32_t)__popcll(mask);
+    // Nothing per-lane is carried through the serving loop: the estimate goes back through the asking lane's record (its last
+    // three values), written by one lane, read by the asking lane after the loop.
     while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        if ((int)lane == src) searches++;
-        // the asking lane's position now; the rest of its Interaction only once the search is over — 32 fewer wave-uniform
-        // registers live across the search
-        const d3 qpos = waveShfl3(ia.position, src);
+        double* rec = stage_wave + (size_t)src * kStageDoubles;
+        // the asking lane's position now; the rest of its record only once the search is over (fewer wave-uniform registers
+        // live across the search)
+        const double2 p01 = reinterpret_cast<const double2*>(rec)[0];
+        const d3 qpos = d3{uniformD(p01.x), uniformD(p01.y), uniformD(rec[2])};
         double r2 = 0.0;
         const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
-        const d3 sum = waveEvalPhotons(ia, src, qpos, map, caustic, W.d2, W.idx, n, r2);
-        if ((int)lane == src) result = sum;
+        d3 sum = splat(0.0);
+        if (n) {  // else photons.empty(): the estimate is zero (photon-mapper.cpp:347, :374)
+            InteractionT<L> q;
+            loadStagedInteraction(rec, q);
+            sum = waveEvalPhotons(q, map, caustic, W.d2, W.idx, n, r2);
+        }
+        if (lane == 0) {
+            rec[kStageResult] = sum.x;
+            rec[kStageResult + 1] = sum.y;
+            rec[kStageResult + 2] = sum.z;
+        }
+    }
+    __threadfence_block();
+    d3 result = splat(0.0);
+    if (want) {
+        const double* mine = stage_wave + (size_t)lane * kStageDoubles + kStageResult;
+        result = d3{mine[0], mine[1], mine[2]};
     }
     return result;
 }
