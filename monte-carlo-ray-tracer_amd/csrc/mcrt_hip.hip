@@ -260,6 +260,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 6), 6), 20);
+    ta.defer_leaves = (int)envi("MCRT_WF_DEFER", 1);
     return MCRT_OK;
 }
 

@@ -715,6 +715,7 @@ struct WfTraceArgs {
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
     uint32_t deal_shift;                // queue entries are dealt to the workgroups in blocks of 2^deal_shift
+    int defer_leaves;                   // 1: deferred leaves (mcrt_lanesm.hpp); 0: a lane waits at its leaf (round 2)
 };
 
 // Where the rays of a trace launch come from and where their hits go.
@@ -796,11 +797,12 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     T.shadow = false;
     T.fast = true;
     T.sp = 0;
+    PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     bool have = false, exhausted = dealt(0u) >= n;
     uint32_t item = 0;
     for (;;) {
-        if (have && !T.active) {  // finished since the last look: hand the hit back
+        if (have && !T.active && P.n == 0u) {  // finished since the last look: hand the hit back
             rays.store(item, T.best);
             have = false;
         }
@@ -828,6 +830,21 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
         }
         if (!waveBallot(have)) {
             if (exhausted) break;
+            continue;
+        }
+        if (a.defer_leaves) {
+            // a lane standing at a leaf (new ray whose root is a leaf, pending slot freed by the last leaf step) parks it and moves on
+            if (have) travParkLeaf(T, P, stk);
+            const bool inner = have && T.active && (T.node_m & kSmInner);
+            if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
+            if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
+            if (inner) travParkLeaf(T, P, stk);  // landed on a leaf: it joins this iteration's leaf step
+            const bool pend = have && P.n != 0u;
+            const unsigned long long m_pend = waveBallot(pend);
+            const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
+            if (m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+                if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
+            }
             continue;
         }
         const bool inner = have && T.active && (T.node_m & kSmInner);

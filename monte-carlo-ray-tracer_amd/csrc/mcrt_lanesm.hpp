@@ -255,6 +255,67 @@ MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& s
     }
 }
 
+// ---- Deferred leaves (round 3) ---------------------------------------------------------------------------------------------
+// The lanes of a wave reach leaves at different moments, and a leaf step (FP64 primitive tests) is only worth issuing when many
+// lanes take part - so a lane at a leaf used to WAIT (idle through the other lanes' inner steps) until enough lanes had arrived:
+// 39 % VALU lane utilisation in the trace kernel. Now a lane that reaches a leaf PARKS it (one pending leaf per lane, two
+// registers) and keeps walking: it pops its next node and takes part in the following inner steps. The pending leaves of the
+// wave are tested together once enough lanes have one, or when few lanes are left with inner nodes to visit. The closest hit is
+// a minimum over exact FP64 primitive tests with the lowest-index tie rule, so it does not depend on WHEN a leaf is tested; what
+// changes is pruning: nodes visited while a leaf is pending are not yet cut off by that leaf's hit (a few more box tests), and
+// a node selected before the hit arrived is still visited once. A ray is finished when it has neither a node nor a pending leaf.
+struct PendLeaf {
+    uint32_t a = 0, n = 0;  // first primitive, primitives left (0: none pending)
+};
+
+// The lane stands at a leaf and its pending slot is free: park the leaf, move on to the next node of the stack.
+MCRT_HD void travParkLeaf(Trav& T, PendLeaf& P, const SmStack& stk) {
+    if (T.active && !(T.node_m & kSmInner) && P.n == 0u) {
+        P.a = T.node_a;
+        P.n = T.node_m;
+        travPop(T, stk);
+    }
+}
+
+// One step on the pending leaf: its next two primitives (as travLeafStep; both records requested before either is tested).
+template <bool kAll, bool kCount>
+MCRT_HD void travPendStep(const SmSceneView<kAll>& sv, Trav& T, PendLeaf& P, TraceCounters& cnt) {
+    const uint32_t i = P.a, count = P.n;
+    if (count == 0u) return;
+    const Ray r = travRay(T);
+    bool decided = false;
+    {
+        const bool two = count > 1u;
+        const uint32_t j = two ? i + 1 : i;
+        const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
+        const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
+        Hit h0, h1;
+        if (kCount) cnt.prim_tests += two ? 2u : 1u;
+        const bool ok0 = primTestRec<QuadricsIn<kAll>::value>(r0, r, h0);
+        const bool ok1 = primTestRec<QuadricsIn<kAll>::value>(r1, r, h1) && two;
+        if (ok0 && closer(h0.t, i, T.best)) {
+            T.best = h0;
+            T.best.surface = i;
+            if (T.shadow && i != T.light && h0.t < T.t_near) decided = true;  // occluded for sure
+        }
+        if (ok1 && closer(h1.t, j, T.best)) {
+            T.best = h1;
+            T.best.surface = j;
+            if (T.shadow && j != T.light && h1.t < T.t_near) decided = true;
+        }
+    }
+    if (decided) {
+        T.sp = 0;
+        T.active = false;
+        P.n = 0u;
+    } else if (count > 2u) {
+        P.a = i + 2u;
+        P.n = count - 2u;
+    } else {
+        P.n = 0u;
+    }
+}
+
 // What the next-event estimate of a bounce needs once its shadow ray has been traced.
 struct NeePending {
     bool pending;  // a shadow ray is being traced for this bounce

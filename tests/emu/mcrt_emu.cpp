@@ -200,6 +200,7 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
 // One ray through the trace kernel's per-lane code: quantised child blocks (mcrt_qbvh.hpp) with the first
 // half of the blocks on the "LDS" side, exact records for rays with a zero direction component.
 namespace {
+int g_defer = 0;
 struct QTrace {
     SmSceneView<false> sv;
     QView<true> qv;
@@ -223,9 +224,27 @@ struct QTrace {
         qv.root_a = E.L.q_root_a;
         qv.root_m = E.L.q_root_m;
     }
+    // g_defer: 0 = a leaf is tested when it is reached (round 2's order); 1 = deferred leaves (mcrt_lanesm.hpp), the pending leaf
+    // tested only when the lane has nothing else to do - the longest a wave's gating can postpone it; k >= 2 = also every k-th
+    // iteration (a gate that opens now and then)
     Hit run(d3 o, d3 d, bool shadow, const ShadowQuery* sq, TraceCounters& cnt) {
         Trav T;
         travBeginQ<false, true, true>(sv, qv, T, o, d, rcp3(d), shadow, sq, cnt);
+        if (g_defer) {
+            PendLeaf P;
+            travParkLeaf(T, P, stk);
+            for (uint64_t it = 0; T.active || P.n; it++) {
+                if (T.active && (T.node_m & kSmInner)) {
+                    if (T.fast) travInnerStepQ<true, true>(qv, T, stk, cnt);
+                    else travInnerStep<false, true>(sv, T, stk, cnt);
+                }
+                travParkLeaf(T, P, stk);
+                const bool forced = P.n && (!T.active || !(T.node_m & kSmInner));
+                if (P.n && (forced || (g_defer >= 2 && it % (uint64_t)g_defer == 0))) travPendStep<false, true>(sv, T, P, cnt);
+                travParkLeaf(T, P, stk);
+            }
+            return T.best;
+        }
         while (T.active) {
             if (T.node_m & kSmInner) {
                 if (T.fast) travInnerStepQ<true, true>(qv, T, stk, cnt);
@@ -651,6 +670,24 @@ int emu_emit_photons(const mcrt_scene_desc* scene, double emissions, double caus
     *ccount = nc;
     *rays = cnt.rays;
     return (ng > gcap || nc > ccap) ? -1 : (cnt.overflow ? -100 : 0);
+}
+
+// Leaf-deferral policy of the trace kernel's per-lane code in this emulation (QTrace::run) and its test counts.
+void emu_set_defer(int policy) { g_defer = policy; }
+int emu_trace_counts(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int policy, uint64_t* out /* node tests, primitive tests */) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return rc;
+    if (scene->num_nodes == 0) return -200;
+    QTrace qt;
+    qt.init(E, scene);
+    TraceCounters cnt = {0, 0, 0, 0};
+    const int keep = g_defer;
+    g_defer = policy;
+    for (uint64_t i = 0; i < n; i++) qt.run(ld3(start + 3 * i), ld3(direction + 3 * i), false, nullptr, cnt);
+    g_defer = keep;
+    out[0] = cnt.node_tests;
+    out[1] = cnt.prim_tests;
+    return cnt.overflow ? -100 : 0;
 }
 
 int emu_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int stage_lds,

@@ -57,6 +57,9 @@ def main():
         line = dict(variant=name, env=assigns, ms_best=round(min(ms), 3), ms_mean=round(sum(ms) / len(ms), 3),
                     Mray_s=round(rays / min(ms) / 1e3, 1), rays=rays, kernel_id=stats[-1].get("kernel_id"),
                     searches=stats[-1].get("knn_searches"), checksum=checksum, same_bits_as_first=same)
+        if stats[-1].get("node_tests"):  # MCRT_COUNT_TESTS=1
+            line["node_tests_per_ray"] = round(stats[-1]["node_tests"] / rays, 3)
+            line["prim_tests_per_ray"] = round(stats[-1]["prim_tests"] / rays, 3)
         if stats[-1].get("knn_searches"):
             line["Msearch_s"] = round(stats[-1]["knn_searches"] / min(ms) / 1e3, 1)
         print(json.dumps(line), flush=True)
