@@ -13,6 +13,7 @@
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
 #include "mcrt_qbvh.hpp"
+#include "mcrt_wbvh.hpp"
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_groupknn.hpp"
@@ -68,7 +69,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, qblocks, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -221,8 +222,16 @@ struct TracePlan {
     WfTraceArgs args;
 };
 
+// MCRT_WF_WIDE=1: the trace kernel walks the eight-wide nodes (mcrt_wbvh.hpp) instead of the 4-wide blocks. Bit-identical frames;
+// measured on C3: 12.1 instead of 15.7 inner steps per ray but 7.0 instead of 6.1 leaf steps and a costlier step - 469 vs 466 ms
+// per 64-spp frame, so the 4-wide blocks stay the default.
+bool useWideNodes(const mcrt_ctx* ctx) {
+    const char* v = getenv("MCRT_WF_WIDE");
+    return ctx->scene.wnodes != nullptr && v && atoi(v) != 0;
+}
+
 template <class K>
-int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
+int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false) {
     auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
     const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
@@ -230,7 +239,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
     if ((long)stack_bytes + 64 > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
-    const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u) / 64u);
+    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u) / 64u);
     tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u;  // + the workgroup's queue cursor
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     int per_cu = 0;
@@ -248,11 +257,17 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.stats = ctx->stats.as<unsigned long long>();
     ta.nodes = ctx->scene.nodes64;
     ta.qblocks = ctx->scene.qblocks;
+    ta.wnodes = ctx->scene.wnodes;
     ta.num_nodes = ctx->scene.q_nodes;
     ta.lds_blocks = lds_blocks;
     ta.q_root_a = ctx->scene.q_root_a;
     ta.q_root_m = ctx->scene.q_root_m;
     ta.prim = ctx->scene.prim;
+    ta.leaf_pre = ctx->scene.leaf_pre;
+    ta.leaf_cx = ctx->scene.leaf_cx;
+    ta.leaf_cy = ctx->scene.leaf_cy;
+    ta.leaf_cz = ctx->scene.leaf_cz;
+    ta.leaf_bound = ctx->scene.leaf_bound;
     ta.spill = ctx->spill.as<SmStackEntry>();
     ta.total_lanes = total_lanes;
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
@@ -260,7 +275,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 6), 6), 20);
-    ta.defer_leaves = (int)envi("MCRT_WF_DEFER", 1);
+    ta.defer_leaves = (int)envi("MCRT_WF_DEFER", 0);
     return MCRT_OK;
 }
 
@@ -357,10 +372,12 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
 
-    auto trace = count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>;
+    const bool wide = useWideNodes(ctx);
+    auto trace = wide ? (count_tests ? wfTraceKernel<PoolRays, true, true> : wfTraceKernel<PoolRays, false, true>)
+                      : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
     TracePlan tp;
-    if (int rc = planTrace(ctx, trace, slots * 2, tp)) return rc;
+    if (int rc = planTrace(ctx, trace, slots * 2, tp, wide)) return rc;
 
     // MCRT_WF_HALVES=2 (experiment, off by default): two halves of the pool on two streams, so that while one half's trace
     // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
@@ -961,6 +978,13 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
+    // leaf cull (mcrt_lanesm.hpp): built and bit-exact, measured SLOWER inside the wave-level steps (C3 466 -> 544 ms, spaceship
+    // 318 -> 385 ms: a wave still runs the exact test whenever one of its lanes has a survivor) - off unless MCRT_LEAF_CULL=1
+    const bool leaf_cull = !L.leaf_pre.empty() && getenv("MCRT_LEAF_CULL") && atoi(getenv("MCRT_LEAF_CULL")) != 0;
+    if (!leaf_cull) ctx->leaf_pre.release();
+    else if (int rc = uploadArray(ctx, ctx->leaf_pre, L.leaf_pre.data(), L.leaf_pre.size())) return rc;
+    if (L.wnodes.empty()) ctx->wnodes.release();
+    else if (int rc = uploadArray(ctx, ctx->wnodes, L.wnodes.data(), L.wnodes.size())) return rc;
     // quadric records first: the primitive records and surf_v of quadric surfaces carry their device addresses
     if (L.num_quadric_surfaces) {
         for (uint32_t i = 0; i < s->num_lights; i++)
@@ -1004,6 +1028,13 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.q_nodes = (uint32_t)L.nodes64.size();
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
+    d.wnodes = L.wnodes.empty() ? nullptr : ctx->wnodes.as<WNode>();
+    d.num_wnodes = (uint32_t)L.wnodes.size();
+    d.leaf_pre = leaf_cull ? ctx->leaf_pre.as<float>() : nullptr;
+    d.leaf_cx = L.leaf_centre[0];
+    d.leaf_cy = L.leaf_centre[1];
+    d.leaf_cz = L.leaf_centre[2];
+    d.leaf_bound = L.leaf_bound;
     d.prim = ctx->prim.as<double>();
     d.flat_prim = ctx->flat_prim.as<double>();
     d.flat_index = ctx->flat_index.as<uint32_t>();
@@ -1123,6 +1154,12 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
             fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
                     h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
     }
+    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0)
+        fprintf(stderr, "[mcrt trace] per wave iteration: %.1f lanes hold a ray; inner step in %.1f%% of the iterations with %.1f lanes, leaf step in %.1f%% with %.1f lanes, "
+                        "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%%; per ray: %.2f inner steps, %.2f leaf steps\n",
+                (double)h[9] / h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
+                (double)h[14] / h[8], 100.0 * h[15] / (double)h[17], 100.0 * h[16] / (double)h[17], 100.0 * (h[17] - h[15] - h[16]) / (double)h[17],
+                (double)h[11] / (double)(h[1] ? h[1] : 1), (double)h[13] / (double)(h[1] ? h[1] : 1));
     if (ctx->kernel_id == MCRT_KERNEL_PM_WAVE && h[9] && getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0)
         fprintf(stderr, "[mcrt pm] wave cycles inside the radiance estimates: %.1f%% of the kernel (%llu searches, %.1f octants per search)\n",
                 100.0 * (double)h[8] / (double)h[9], h[4], h[4] ? (double)h[6] / (double)h[4] : 0.0);
@@ -1403,9 +1440,10 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFF00000ull) {  // (32-bit queue cursors with room for the waves' overshoot)
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
-        auto trace = wfTraceKernel<ArrayRays, false>;
+        const bool wide = useWideNodes(ctx);
+        auto trace = wide ? wfTraceKernel<ArrayRays, false, true> : wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
-        if (int rc = planTrace(ctx, trace, n, tp)) return rc;
+        if (int rc = planTrace(ctx, trace, n, tp, wide)) return rc;
         DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
         if (int rc = uploadInto(ctx, ds, start, n * 3)) return rc;
         if (int rc = uploadInto(ctx, dd, direction, n * 3)) return rc;

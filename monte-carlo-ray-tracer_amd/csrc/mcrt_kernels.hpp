@@ -27,6 +27,10 @@ struct DeviceScene {
     const Node64* nodes64;
     const QBlock* qblocks;        // quantised child blocks of the trace kernel (mcrt_qbvh.hpp)
     uint32_t num_qblocks, q_root_a, q_root_m;
+    const WNode* wnodes;          // eight-wide quantised nodes (mcrt_wbvh.hpp); null: the tree has none
+    uint32_t num_wnodes;
+    const float* leaf_pre;        // FP32 cull records of the primitives in BVH order (mcrt_lanesm.hpp "leaf cull"); null: none
+    double leaf_cx, leaf_cy, leaf_cz, leaf_bound;
     uint32_t q_nodes;             // records in nodes64 = num_nodes, or — scene without a BVH — the nodes of the index-range tree the wavefront pipeline walks (mcrt_layout.hpp)
     const double* prim;
     const double* flat_prim;      // kind-sorted copy (flat mode)
@@ -115,6 +119,15 @@ constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
 constexpr uint32_t kPmLdsIors = 2;  // refraction-history entries per lane the 1024-lane photon-mapping kernel keeps in LDS
+
+template <class SV>
+__host__ __device__ inline void setLeafCull(SV& sv, const float* pre, double cx, double cy, double cz, double bound) {
+    sv.pre = pre;
+    sv.pre_cx = cx;
+    sv.pre_cy = cy;
+    sv.pre_cz = cz;
+    sv.pre_bound = bound;
+}
 
 struct LdsPlan {
     uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material,
@@ -542,6 +555,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
     } else {
         sv.nodes = scene.nodes64;
         sv.prim = scene.prim;
+        setLeafCull(sv, scene.leaf_pre, scene.leaf_cx, scene.leaf_cy, scene.leaf_cz, scene.leaf_bound);
         sh.surf_v = scene.surf_v;
         sh.surf_normal = scene.surf_normal;
         sh.surf_vn = scene.surf_vn;
@@ -709,8 +723,11 @@ struct WfTraceArgs {
     unsigned long long* stats;
     const Node64* nodes;                // exact records: root test, rays with a zero direction component
     const QBlock* qblocks;
+    const WNode* wnodes;                // kWide instance: eight-wide nodes (mcrt_wbvh.hpp)
     uint32_t num_nodes, lds_blocks, q_root_a, q_root_m;
     const double* prim;
+    const float* leaf_pre;              // leaf cull records (mcrt_lanesm.hpp), or null
+    double leaf_cx, leaf_cy, leaf_cz, leaf_bound;
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
@@ -751,12 +768,13 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
 // traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
 // are visited through quantised child blocks, the top of the tree from LDS.
-template <class Rays, bool kCount>
+template <class Rays, bool kCount, bool kWide = false>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     extern __shared__ __align__(64) unsigned char lds[];
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
-    for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
-        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
+    if constexpr (!kWide)
+        for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
+            reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
     SmStack stk;
     stk.lds = ldsAt<SmStackEntry>(lds, a.lds_blocks * 64u) + threadIdx.x;
     stk.lds_stride = blockDim.x;
@@ -769,6 +787,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     sv.prim = a.prim;
     sv.lds_nodes = 0;
     sv.lds_node_ptr = nullptr;
+    setLeafCull(sv, a.leaf_pre, a.leaf_cx, a.leaf_cy, a.leaf_cz, a.leaf_bound);
     QView<true> qv;
     qv.blocks = a.qblocks;
     qv.lds_blocks = a.lds_blocks;
@@ -797,12 +816,19 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     T.shadow = false;
     T.fast = true;
     T.sp = 0;
-    PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking
+    PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking; kWide: the leaf being tested
+    WLeaves Lv;  // kWide: hit leaf children still to be tested
+    WView wv;
+    wv.nodes = a.wnodes;
     TraceCounters cnt = {0u, 0u, 0u, 0u};
+    // MCRT_COUNT_TESTS: where the wave's issue slots go (per wave: iterations, lanes holding a ray, inner / leaf steps and the lanes
+    // that took part, leaf lanes kept waiting by the gate, wave cycles inside the two steps and in all)
+    unsigned long long ph_iter = 0, ph_have = 0, ph_in_steps = 0, ph_in_lanes = 0, ph_lf_steps = 0, ph_lf_lanes = 0, ph_lf_wait = 0, ph_in_cyc = 0, ph_lf_cyc = 0;
+    const unsigned long long ph_begin = kCount ? clock64() : 0ull;
     bool have = false, exhausted = dealt(0u) >= n;
     uint32_t item = 0;
     for (;;) {
-        if (have && !T.active && P.n == 0u) {  // finished since the last look: hand the hit back
+        if (have && !T.active && (kWide || P.n == 0u)) {  // finished since the last look: hand the hit back (kWide: `active` covers the leaves)
             rays.store(item, T.best);
             have = false;
         }
@@ -823,13 +849,53 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 bool shadow;
                 ShadowQuery sq;
                 item = rays.load(w, o, d, shadow, sq);
-                travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
+                if constexpr (kWide) travBeginW<false, kCount>(sv, T, Lv, P, o, d, rcp3(d), shadow, &sq, cnt);
+                else travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
                 have = true;
             }
             exhausted = waveBallot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
         }
         if (!waveBallot(have)) {
             if (exhausted) break;
+            continue;
+        }
+        if constexpr (kWide) {
+            // eight-wide nodes (mcrt_wbvh.hpp): a lane with hit leaves works them off first (their hits prune what follows), the
+            // others take one wide step; rays with a zero direction component walk the exact records
+            const bool fast = T.fast;
+            const bool leaf0 = have && T.active && (fast ? (P.n | Lv.bits) != 0u : !(T.node_m & kSmInner));
+            const bool inner = have && T.active && !leaf0;
+            unsigned long long tc = 0ull;
+            if (kCount) {
+                const unsigned long long mi = waveBallot(inner);
+                ph_iter++;
+                ph_have += __popcll(waveBallot(have));
+                ph_in_steps += mi ? 1u : 0u;
+                ph_in_lanes += __popcll(mi);
+                tc = clock64();
+            }
+            if (inner && fast) travWideStep<kCount>(wv, T, Lv, stk, cnt);
+            if (inner && !fast) travInnerStep<false, kCount>(sv, T, stk, cnt);
+            if (kCount) ph_in_cyc += clock64() - tc;
+            const bool leaf = have && T.active && (fast ? (P.n | Lv.bits) != 0u : !(T.node_m & kSmInner));
+            const unsigned long long m_leaf = waveBallot(leaf);
+            const unsigned long long m_inner = waveBallot(have && T.active && !leaf);
+            if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+                if (kCount) {
+                    ph_lf_steps++;
+                    ph_lf_lanes += __popcll(m_leaf);
+                    tc = clock64();
+                }
+                if (leaf && fast) {
+                    travWideNextLeaf(wv, T, Lv, P);
+                    travPendStep<false, kCount>(sv, T, P, cnt);
+                    travWideAfterLeaf(T, Lv, P);
+                }
+                if (leaf && !fast) travLeafStep<false, kCount>(sv, T, stk, cnt);
+                if (kCount) ph_lf_cyc += clock64() - tc;
+            } else if (kCount) {
+                ph_lf_wait += __popcll(m_leaf);
+            }
             continue;
         }
         if (a.defer_leaves) {
@@ -848,14 +914,44 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             continue;
         }
         const bool inner = have && T.active && (T.node_m & kSmInner);
+        unsigned long long tc = 0ull;
+        if (kCount) {
+            const unsigned long long mi = waveBallot(inner);
+            ph_iter++;
+            ph_have += __popcll(waveBallot(have));
+            ph_in_steps += mi ? 1u : 0u;
+            ph_in_lanes += __popcll(mi);
+            tc = clock64();
+        }
         if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
         if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
+        if (kCount) ph_in_cyc += clock64() - tc;
         const bool leaf = have && T.active && !(T.node_m & kSmInner);
         const unsigned long long m_leaf = waveBallot(leaf);
         const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
         if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+            if (kCount) {
+                ph_lf_steps++;
+                ph_lf_lanes += __popcll(m_leaf);
+                tc = clock64();
+            }
             if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
+            if (kCount) ph_lf_cyc += clock64() - tc;
+        } else if (kCount) {
+            ph_lf_wait += __popcll(m_leaf);
         }
+    }
+    if (kCount && laneId() == 0) {
+        atomicAdd(a.stats + 8, ph_iter);
+        atomicAdd(a.stats + 9, ph_have);
+        atomicAdd(a.stats + 10, ph_in_steps);
+        atomicAdd(a.stats + 11, ph_in_lanes);
+        atomicAdd(a.stats + 12, ph_lf_steps);
+        atomicAdd(a.stats + 13, ph_lf_lanes);
+        atomicAdd(a.stats + 14, ph_lf_wait);
+        atomicAdd(a.stats + 15, ph_in_cyc);
+        atomicAdd(a.stats + 16, ph_lf_cyc);
+        atomicAdd(a.stats + 17, (unsigned long long)(clock64() - ph_begin));
     }
     waveAccumulate(a.stats + 1, cnt.rays);
     if (kCount) {
@@ -1093,6 +1189,7 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
     q.sv.prim = scene.prim;
     q.sv.lds_nodes = 0;
     q.sv.lds_node_ptr = nullptr;
+    setLeafCull(q.sv, scene.leaf_pre, scene.leaf_cx, scene.leaf_cy, scene.leaf_cz, scene.leaf_bound);
     q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [depth][lanes] region
     q.stk.lds_depth = (int)stack_depth;
     q.stk.lds_stride = lstk.lds_stride;

@@ -34,6 +34,9 @@ struct SmSceneView {
     cptr<double, kAll> prim;
     uint32_t lds_nodes;  // nodes [0, lds_nodes) are also in LDS (used when !kAll)
     MCRT_LDS_AS const Node64* lds_node_ptr;
+    // leaf cull (below): FP32 records of the primitives, one per aligned pair, or null; centre and domain of the records
+    const float* pre = nullptr;
+    double pre_cx = 0.0, pre_cy = 0.0, pre_cz = 0.0, pre_bound = 0.0;
 };
 
 struct SmStackEntry {
@@ -47,13 +50,32 @@ struct SmStack {
     SmStackEntry* spill;
     uint32_t spill_stride;
     int lds_depth = kLdsStackDepth;  // entries per lane kept in LDS (the trace kernel trades some of them for more tree blocks)
+    // (the empty asm statements keep the two address spaces in separate branches: merged into one generic-pointer access the
+    // compiler emits flat_load / flat_store, which wait on both the LDS and the vector-memory counters)
     MCRT_HD void put(int sp, SmStackEntry e) const {
-        if (sp < lds_depth) lds[(uint32_t)sp * lds_stride] = e;
-        else spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride] = e;
+        if (sp < lds_depth) {
+            lds[(uint32_t)sp * lds_stride] = e;
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
+            spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride] = e;
+        }
     }
     MCRT_HD SmStackEntry get(int sp) const {
-        if (sp < lds_depth) return lds[(uint32_t)sp * lds_stride];
-        return spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride];
+        SmStackEntry e;
+        if (sp < lds_depth) {
+            e = lds[(uint32_t)sp * lds_stride];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(e.key), "+v"(e.a));  // the value exists HERE: the load cannot sink below the join
+#endif
+        } else {
+            e = spill[(uint32_t)(sp - lds_depth) * (size_t)spill_stride];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(e.key), "+v"(e.a));
+#endif
+        }
+        return e;
     }
 };
 
@@ -215,41 +237,73 @@ MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
     return ok;
 }
 
-// One step at a LEAF: test its next two primitives (bvh.cpp:92-107; both records are requested before either is tested:
-// one dependent memory round trip per pair); the lane stays at the leaf while primitives are left, then pops. A step is
-// ONE pair, not the whole leaf: the lanes of a wave sit at leaves of different sizes, and a loop over the whole leaf keeps
-// the lanes of the small ones idle until the largest is done (measured on the trace kernel: VALU lane utilisation 39 %).
+// ---- Leaf cull (round 3) ---------------------------------------------------------------------------------------------------
+// A leaf step used to run the reference's FP64 Moeller-Trumbore on two primitives (~170 instructions and two 80-byte records),
+// and nine tests in ten end in a reject (C3: 13.4 tests per ray for one hit). Now the step first decides in packed FP32 which
+// of an ALIGNED pair of consecutive primitives cannot be hit - the cull of the flat loop (mcrt_scene.hpp "FP32 cull": one
+// 128-byte record per pair, error-bounded thresholds, a certain reject or a survivor) - and runs the exact test on the
+// survivors only. Survivors are a superset of what the exact tests accept, the exact tests and the tie rule are unchanged, so
+// the closest hit is the same. A range that starts at an odd index spends its first step on one primitive.
+//
+// Tests the next primitive(s) of the range [i, i + count) against the ray of T; returns how many were consumed (1 or 2).
+template <bool kAll, bool kCount>
+MCRT_HD uint32_t leafTestNext(const SmSceneView<kAll>& sv, Trav& T, uint32_t i, uint32_t count, TraceCounters& cnt, bool& decided) {
+    const Ray r = travRay(T);
+    if (!kAll && sv.pre != nullptr) {
+        const uint32_t pb = i & ~1u;
+        const uint32_t in_range = ((i & 1u) ? 2u : 3u) & ((pb + 1u < i + count) ? 3u : 1u);
+        const CullRay cr = cullRayAt(sv.pre_cx, sv.pre_cy, sv.pre_cz, sv.pre_bound, T.o, T.d);
+        uint32_t surv = cullTriangles(sv.pre + (size_t)(pb >> 1) * kTriPairFloats, 1u, 2u, cr) & in_range;
+        while (surv) {
+            const uint32_t j = pb + lowestBit(surv);
+            surv &= surv - 1u;
+            const PrimRec rec = loadPrim(sv.prim + (size_t)j * kPrimStride);
+            Hit h;
+            if (kCount) cnt.prim_tests++;
+            if (primTestRec<QuadricsIn<kAll>::value>(rec, r, h) && closer(h.t, j, T.best)) {
+                T.best = h;
+                T.best.surface = j;
+                if (T.shadow && j != T.light && h.t < T.t_near) decided = true;  // occluded for sure
+            }
+        }
+        const uint32_t used = 2u - (i & 1u);
+        return used < count ? used : count;
+    }
+    const bool two = count > 1u;
+    const uint32_t j = two ? i + 1 : i;
+    const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
+    const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
+    Hit h0, h1;
+    if (kCount) cnt.prim_tests += two ? 2u : 1u;
+    const bool ok0 = primTestRec<QuadricsIn<kAll>::value>(r0, r, h0);
+    const bool ok1 = primTestRec<QuadricsIn<kAll>::value>(r1, r, h1) && two;
+    if (ok0 && closer(h0.t, i, T.best)) {
+        T.best = h0;
+        T.best.surface = i;
+        if (T.shadow && i != T.light && h0.t < T.t_near) decided = true;  // occluded for sure
+    }
+    if (ok1 && closer(h1.t, j, T.best)) {
+        T.best = h1;
+        T.best.surface = j;
+        if (T.shadow && j != T.light && h1.t < T.t_near) decided = true;
+    }
+    return two ? 2u : 1u;
+}
+
+// One step at a LEAF: test its next (pair of) primitives (bvh.cpp:92-107); the lane stays at the leaf while primitives are
+// left, then pops. A step is ONE pair, not the whole leaf: the lanes of a wave sit at leaves of different sizes, and a loop over
+// the whole leaf keeps the lanes of the small ones idle until the largest is done.
 template <bool kAll, bool kCount>
 MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const uint32_t i = T.node_a, count = T.node_m;
-    const Ray r = travRay(T);
     bool decided = false;
-    {
-        const bool two = count > 1u;
-        const uint32_t j = two ? i + 1 : i;
-        const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
-        const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
-        Hit h0, h1;
-        if (kCount) cnt.prim_tests += two ? 2u : 1u;
-        const bool ok0 = primTestRec<QuadricsIn<kAll>::value>(r0, r, h0);
-        const bool ok1 = primTestRec<QuadricsIn<kAll>::value>(r1, r, h1) && two;
-        if (ok0 && closer(h0.t, i, T.best)) {
-            T.best = h0;
-            T.best.surface = i;
-            if (T.shadow && i != T.light && h0.t < T.t_near) decided = true;  // occluded for sure
-        }
-        if (ok1 && closer(h1.t, j, T.best)) {
-            T.best = h1;
-            T.best.surface = j;
-            if (T.shadow && j != T.light && h1.t < T.t_near) decided = true;
-        }
-    }
+    const uint32_t used = leafTestNext<kAll, kCount>(sv, T, i, count, cnt, decided);
     if (decided) {
         T.sp = 0;
         T.active = false;
-    } else if (count > 2u) {
-        T.node_a = i + 2u;
-        T.node_m = count - 2u;
+    } else if (count > used) {
+        T.node_a = i + used;
+        T.node_m = count - used;
     } else {
         travPop(T, stk);
     }
@@ -257,13 +311,14 @@ MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& s
 
 // ---- Deferred leaves (round 3) ---------------------------------------------------------------------------------------------
 // The lanes of a wave reach leaves at different moments, and a leaf step (FP64 primitive tests) is only worth issuing when many
-// lanes take part - so a lane at a leaf used to WAIT (idle through the other lanes' inner steps) until enough lanes had arrived:
-// 39 % VALU lane utilisation in the trace kernel. Now a lane that reaches a leaf PARKS it (one pending leaf per lane, two
-// registers) and keeps walking: it pops its next node and takes part in the following inner steps. The pending leaves of the
-// wave are tested together once enough lanes have one, or when few lanes are left with inner nodes to visit. The closest hit is
-// a minimum over exact FP64 primitive tests with the lowest-index tie rule, so it does not depend on WHEN a leaf is tested; what
-// changes is pruning: nodes visited while a leaf is pending are not yet cut off by that leaf's hit (a few more box tests), and
-// a node selected before the hit arrived is still visited once. A ray is finished when it has neither a node nor a pending leaf.
+// lanes take part - so a lane at a leaf WAITS (idle through the other lanes' inner steps) until enough lanes have arrived. As an
+// option (MCRT_WF_DEFER=1) a lane that reaches a leaf PARKS it (one pending leaf per lane, two registers) and keeps walking: it
+// pops its next node and takes part in the following inner steps; the pending leaves of the wave are tested together once enough
+// lanes have one, or when few lanes are left with inner nodes to visit. The closest hit is a minimum over exact FP64 primitive
+// tests with the lowest-index tie rule, so it does not depend on WHEN a leaf is tested; what changes is pruning: nodes visited
+// while a leaf is pending are not yet cut off by that leaf's hit. Measured on C3: + 3.4 % box tests, + 4 % primitive tests, the
+// same frame time - the waiting lanes rarely have useful work on their stacks. The pending-leaf slot is also what the
+// eight-wide walk (mcrt_wbvh.hpp) keeps its current leaf in.
 struct PendLeaf {
     uint32_t a = 0, n = 0;  // first primitive, primitives left (0: none pending)
 };
@@ -277,42 +332,20 @@ MCRT_HD void travParkLeaf(Trav& T, PendLeaf& P, const SmStack& stk) {
     }
 }
 
-// One step on the pending leaf: its next two primitives (as travLeafStep; both records requested before either is tested).
+// One step on the pending leaf: its next (pair of) primitives, as travLeafStep.
 template <bool kAll, bool kCount>
 MCRT_HD void travPendStep(const SmSceneView<kAll>& sv, Trav& T, PendLeaf& P, TraceCounters& cnt) {
     const uint32_t i = P.a, count = P.n;
     if (count == 0u) return;
-    const Ray r = travRay(T);
     bool decided = false;
-    {
-        const bool two = count > 1u;
-        const uint32_t j = two ? i + 1 : i;
-        const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
-        const PrimRec r1 = loadPrim(sv.prim + (size_t)j * kPrimStride);
-        Hit h0, h1;
-        if (kCount) cnt.prim_tests += two ? 2u : 1u;
-        const bool ok0 = primTestRec<QuadricsIn<kAll>::value>(r0, r, h0);
-        const bool ok1 = primTestRec<QuadricsIn<kAll>::value>(r1, r, h1) && two;
-        if (ok0 && closer(h0.t, i, T.best)) {
-            T.best = h0;
-            T.best.surface = i;
-            if (T.shadow && i != T.light && h0.t < T.t_near) decided = true;  // occluded for sure
-        }
-        if (ok1 && closer(h1.t, j, T.best)) {
-            T.best = h1;
-            T.best.surface = j;
-            if (T.shadow && j != T.light && h1.t < T.t_near) decided = true;
-        }
-    }
+    const uint32_t used = leafTestNext<kAll, kCount>(sv, T, i, count, cnt, decided);
     if (decided) {
         T.sp = 0;
         T.active = false;
         P.n = 0u;
-    } else if (count > 2u) {
-        P.a = i + 2u;
-        P.n = count - 2u;
     } else {
-        P.n = 0u;
+        P.a = i + used;
+        P.n = count - used;
     }
 }
 

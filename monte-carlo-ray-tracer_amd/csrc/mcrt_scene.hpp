@@ -396,17 +396,22 @@ struct CullRay {
     f2 sx, sy, sz, dx, dy, dz;  // start - centre and direction, each splat over the pair
     bool in_domain;
 };
-template <bool kAll>
-MCRT_HD CullRay cullRay(const SceneViewT<kAll>& sv, d3 start, d3 direction) {
+// (the thresholds of the records assume a UNIT direction: a longer one - mcrt_intersect takes what the caller passes - scales the
+// error terms by |d|^2 and is therefore out of the domain, like a start beyond `bound`; out of domain = every primitive survives)
+MCRT_HD CullRay cullRayAt(double cx, double cy, double cz, double bound, d3 start, d3 direction) {
     CullRay r;
-    const double x = start.x - sv.pre_cx, y = start.y - sv.pre_cy, z = start.z - sv.pre_cz;
-    r.in_domain = fabs(x) <= sv.pre_bound && fabs(y) <= sv.pre_bound && fabs(z) <= sv.pre_bound &&
-                  fabs(direction.x) <= 1.0000001 && fabs(direction.y) <= 1.0000001 && fabs(direction.z) <= 1.0000001;
+    const double x = start.x - cx, y = start.y - cy, z = start.z - cz;
+    r.in_domain = fabs(x) <= bound && fabs(y) <= bound && fabs(z) <= bound &&
+                  (direction.x * direction.x + direction.y * direction.y + direction.z * direction.z) <= 1.000001;
     const float fx = (float)x, fy = (float)y, fz = (float)z;
     const float gx = (float)direction.x, gy = (float)direction.y, gz = (float)direction.z;
     r.sx = f2{fx, fx}; r.sy = f2{fy, fy}; r.sz = f2{fz, fz};
     r.dx = f2{gx, gx}; r.dy = f2{gy, gy}; r.dz = f2{gz, gz};
     return r;
+}
+template <bool kAll>
+MCRT_HD CullRay cullRay(const SceneViewT<kAll>& sv, d3 start, d3 direction) {
+    return cullRayAt(sv.pre_cx, sv.pre_cy, sv.pre_cz, sv.pre_bound, start, direction);
 }
 
 // Bit i of the result is set when triangle i of the pairs given may be hit; pairs <= 16 (one mask word).

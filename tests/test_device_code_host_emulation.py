@@ -287,3 +287,54 @@ def test_fp32_block_visit_keeps_what_the_fp64_visit_keeps(pkg, emu, manifest, na
     bad = emu.emu_qstep_check(C.byref(sc), len(a), a.ctypes.data, d.ctypes.data, out)
     assert bad == 0
     assert out[0] > 0 and out[2] >= out[1] and out[2] <= 1.01 * out[1] + 10
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "coffee_maker_bsah", "quadric", "ior_test"])
+def test_optional_traversal_forms_return_the_same_hits(pkg, emu, manifest, name, monkeypatch):
+    """Round 3's optional forms of the tree walk - deferred leaves, the eight-wide nodes (mcrt_wbvh.hpp), the FP32 leaf cull
+    (mcrt_lanesm.hpp) - against the 4-wide block walk: t, surface and uv bit for bit on the reference's KAT rays and on random
+    rays (origins inside the scene box, some with zero direction components = the exact-record path), for the octree, binary
+    and quaternary hierarchies, quadrics and the index-range tree of a scene without a BVH."""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    monkeypatch.setenv("MCRT_LEAF_CULL", "1")  # the emulation builds the records like mcrt_upload_scene does; emu_set_leaf_cull switches their use
+    img = pkg.SceneImage(golden_path(case["image"]))
+    sc = img.scene
+    rng = np.random.default_rng(5)
+    lo, hi = np.array(sc.bb_min[:]), np.array(sc.bb_max[:])
+    n = 6000
+    start = lo + (hi - lo) * rng.random((n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:60, rng.integers(0, 3)] = 0.0
+    d[:60] /= np.linalg.norm(d[:60], axis=1, keepdims=True)
+    kat = os.path.join(golden_path(case["kat"]), "isect_rays.f64") if case.get("kat") else ""
+    if kat and os.path.exists(kat):
+        rays = np.fromfile(kat).reshape(-1, 6)
+        start, d = np.vstack([start, rays[:, :3]]), np.vstack([d, rays[:, 3:]])
+    start, d = np.ascontiguousarray(start), np.ascontiguousarray(d)
+    n = start.shape[0]
+
+    def walk(defer, wide, cull):
+        emu.emu_set_defer(defer)
+        emu.emu_set_wide(wide)
+        emu.emu_set_leaf_cull(cull)
+        t, surf, uv = np.empty(n), np.empty(n, dtype=np.uint32), np.empty((n, 2))
+        try:
+            rc = emu.emu_intersect(C.byref(sc), n, start.ctypes.data, d.ctypes.data, 3, t.ctypes.data, surf.ctypes.data, uv.ctypes.data)
+        finally:
+            emu.emu_set_defer(0)
+            emu.emu_set_wide(0)
+            emu.emu_set_leaf_cull(1)
+        assert rc == 0
+        return t, surf, uv
+
+    base = walk(0, 0, 0)
+    assert (base[1] != 0xFFFFFFFF).sum() > n // 20
+    for form in ((1, 0, 0), (3, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (2, 0, 1)):
+        if form[1] and emu.emu_wide_nodes(C.byref(sc)) == 0:
+            continue
+        got = walk(*form)
+        for a, b in zip(base, got):
+            np.testing.assert_array_equal(a, b, err_msg="defer/wide/cull = %r" % (form,))

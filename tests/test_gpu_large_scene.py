@@ -115,8 +115,14 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "baroque", "lego", "pipes"])
-def test_full_size_traversal_equals_oracle(pkg, oracle, name):
+# (name, environment): the default walk on every scene, and the two optional forms of round 3 - the eight-wide nodes
+# (mcrt_wbvh.hpp) and the FP32 leaf cull (mcrt_lanesm.hpp) - on the quaternary SAH tree (C3) and the octree hierarchy (C5)
+@pytest.mark.parametrize("name,env", [("c3", {}), ("c4", {}), ("c5", {}), ("baroque", {}), ("lego", {}), ("pipes", {}),
+                                      ("c3", {"MCRT_WF_WIDE": "1"}), ("c5", {"MCRT_WF_WIDE": "1"}), ("c3", {"MCRT_LEAF_CULL": "1"}),
+                                      ("c5", {"MCRT_LEAF_CULL": "1", "MCRT_WF_WIDE": "1"})])
+def test_full_size_traversal_equals_oracle(pkg, oracle, name, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     img, _, _ = _config(pkg, name)
     rng = np.random.default_rng(11)
     s = img.scene
