@@ -289,12 +289,12 @@ def test_fp32_block_visit_keeps_what_the_fp64_visit_keeps(pkg, emu, manifest, na
     assert out[0] > 0 and out[2] >= out[1] and out[2] <= 1.01 * out[1] + 10
 
 
-@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "coffee_maker_bsah", "quadric", "ior_test"])
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "coffee_maker_bsah", "quadric"])
 def test_optional_traversal_forms_return_the_same_hits(pkg, emu, manifest, name, monkeypatch):
     """Round 3's optional forms of the tree walk - deferred leaves, the eight-wide nodes (mcrt_wbvh.hpp), the FP32 leaf cull
     (mcrt_lanesm.hpp) - against the 4-wide block walk: t, surface and uv bit for bit on the reference's KAT rays and on random
     rays (origins inside the scene box, some with zero direction components = the exact-record path), for the octree, binary
-    and quaternary hierarchies, quadrics and the index-range tree of a scene without a BVH."""
+    and quaternary hierarchies and quadrics."""
     case = manifest["cases"].get(name)
     if case is None:
         pytest.skip("no such golden case")
