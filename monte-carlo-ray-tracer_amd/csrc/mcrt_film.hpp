@@ -3,6 +3,7 @@
 #pragma once
 
 #include "mcrt_math.hpp"
+#include "mcrt_libm.hpp"
 #include "../../include/mcrt.h"
 
 namespace mcrt {
@@ -36,7 +37,7 @@ MCRT_HD double filmFilterFunction(uint32_t type, double x) {  // filter.hpp
         }
         case MCRT_FILM_LANCZOS:                                                // :65-69
             if (x == 0.0) return 1.0;
-            return 2.0 * sin(kPi * x) * sin(kPi * x / 2.0) / (kPi * kPi * x * x);
+            return 2.0 * refSin(kPi * x) * refSin(kPi * x / 2.0) / (kPi * kPi * x * x);  // two sin calls of different arguments: glibc's sin (mcrt_libm.hpp)
         default: return 1.0;  // box
     }
 }

@@ -1,0 +1,203 @@
+// sin and cos as the REFERENCE computes them - bit for bit.
+//
+// Where the reference takes the sine AND the cosine of one angle - every such call on the path: sampling/sampling.hpp:29-44
+// (uniform disk, cosWeightedHemi), material/ggx.cpp:77-79, surface/sphere.cpp:43 - g++ merges the pair into ONE call of glibc's
+// sincos (its cse_sincos pass; `nm -D` of the reference binary: it imports sincos, sincosf and sin, and no cos at all). glibc
+// 2.35 (sysdeps/ieee754/dbl-64/s_sincos.c + s_sin.c, IBM Accurate Mathematical Library; a dependency of the reference that is
+// not in /root/reference) builds sincos from the inline kernels do_sin / do_cos / TAYLOR_SIN / reduce_sincos of s_sin.c. ocml's
+// sin / cos differ from it in the last bit for a few arguments in ten thousand, and one such bit can send one of a pixel's 256
+// paths down another branch: the only source of per-pixel outliers in path-traced frames of rounds 1 and 2 (every +, -, x, /,
+// sqrt is IEEE-exact on gfx950 and the code is built with -ffp-contract=off). This header restates glibc's algorithm so that
+// the device produces glibc's bits.
+//
+// WHICH code, exactly. x86-64 glibc has two compilations of those kernels:
+//   * sincos is an ordinary function built for baseline x86-64 (no FMA instruction in it): the C source as written, every
+//     operation rounded - refSinCos below (kFused = false);
+//   * sin and cos are IFUNCs (sysdeps/x86_64/fpu/multiarch/s_sin.c): on a CPU with FMA and AVX2 - the build container and the
+//     GPU box's EPYC included - the dynamic linker selects __sin_fma / __cos_fma, the same source compiled with -mfma, in which
+//     the compiler contracted a*b + c into fused multiply-adds. The reference calls sin alone once (the Lanczos film filter,
+//     camera/filter.hpp:64): refSin (kFused = true) restates those contractions, read off the instruction sequence of Ubuntu's
+//     glibc 2.35-0ubuntu3.11 (every fused a*b + c below is an fma there; with kFused = false the same expression is the
+//     source's two roundings). The two results differ for about one argument in a thousand.
+// tests/test_libm.py checks all three against the running host's libm (sincos, sin, cos called separately) on millions of
+// arguments - dense in [0, 2 pi], the range the path uses (2 pi u, u in [0, 1)), wider ranges, the branch boundaries.
+// Table: mcrt_glibc_sincostab.inc (tools/make_glibc_sincos_table.py).
+//
+// Range: |x| < 105414350 (the Cody-Waite reduction of reduce_sincos); beyond that - never reached by the path - the platform's
+// sin / cos answer.
+#pragma once
+
+#include "mcrt_math.hpp"
+
+namespace mcrt {
+namespace glibc235 {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MCRT_LIBM_TABLE __device__ const
+#else
+#define MCRT_LIBM_TABLE static const
+#endif
+MCRT_LIBM_TABLE unsigned long long kSinCosTab[440] = {
+#include "mcrt_glibc_sincostab.inc"
+};
+
+MCRT_HD double tabAt(int i) { return bitsD(kSinCosTab[i]); }
+// a*b + c: one rounding where the FMA build of glibc fused it (kFused), two as the source is written otherwise
+template <bool kFused>
+MCRT_HD double fmaD(double a, double b, double c) {
+    if (kFused) return __builtin_fma(a, b, c);  // (host emulation: correctly rounded with or without FMA hardware)
+    return a * b + c;
+}
+MCRT_HD double absD(double v) { return bitsD(dBits(v) & 0x7FFFFFFFFFFFFFFFull); }
+MCRT_HD double copySign(double mag, double sgn) { return bitsD((dBits(mag) & 0x7FFFFFFFFFFFFFFFull) | (dBits(sgn) & 0x8000000000000000ull)); }
+
+// usncs.h / s_sin.c constants (bit patterns checked against the binary)
+constexpr double kS1 = -0x1.5555555555555p-3, kS2 = 0x1.1111111110ecep-7, kS3 = -0x1.a01a019db08b8p-13, kS4 = 0x1.71de27b9a7ed9p-19,
+                 kS5 = -0x1.addffc2fcdf59p-26;
+constexpr double kSn3 = -0x1.5555555555515p-3, kSn5 = 0x1.11110e829872fp-7, kCs2 = 0x1.0000000000000p-1, kCs4 = -0x1.5555555555535p-5,
+                 kCs6 = 0x1.6c16bedd9e239p-10;
+constexpr double kBig = 0x1.8000000000000p+45, kToInt = 0x1.8000000000000p+52, kHpInv = 0x1.45f306dc9c883p-1;
+constexpr double kHp0 = 0x1.921fb54442d18p+0, kHp1 = 0x1.1a62633145c07p-54;
+constexpr double kMp1 = 0x1.921fb58000000p+0, kMp2 = -0x1.dde973c000000p-27, kPp3 = -0x1.cb3b398000000p-55, kPp4 = -0x1.d747f23e32ed7p-83;
+
+// TAYLOR_SIN(xx, x, dx): t = ((POLYNOMIAL(xx) * x - 0.5 * dx) * xx + dx); res = x + t
+template <bool kFused>
+MCRT_HD double taylorSin(double xx, double x, double dx) {
+    double p = fmaD<kFused>(xx, kS5, kS4);  // s5 * xx + s4
+    p = fmaD<kFused>(xx, p, kS3);
+    p = fmaD<kFused>(xx, p, kS2);
+    p = fmaD<kFused>(xx, p, kS1);           // POLYNOMIAL2(xx) + s1
+    const double t = fmaD<kFused>(fmaD<kFused>(p, x, -(0.5 * dx)), xx, dx);
+    return x + t;
+}
+
+// do_cos(x, dx)
+template <bool kFused>
+MCRT_HD double doCos(double x, double dx) {
+    if (x < 0.0) dx = -dx;
+    const double ax = absD(x);
+    const double u = kBig + ax;
+    x = (ax - (u - kBig)) + dx;
+    const int k = (int)(unsigned)(dBits(u) & 0xFFFFFFFFull) * 4;
+    const double xx = x * x;
+    const double s = fmaD<kFused>(x * xx, fmaD<kFused>(xx, kSn5, kSn3), x);                // s = x + x * xx * (sn3 + xx * sn5)
+    const double c = xx * fmaD<kFused>(xx, fmaD<kFused>(xx, kCs6, kCs4), kCs2);            // c = xx * (cs2 + xx * (cs4 + xx * cs6))
+    const double sn = tabAt(k), ssn = tabAt(k + 1), cs = tabAt(k + 2), ccs = tabAt(k + 3);
+    const double cor = fmaD<kFused>(-s, sn, fmaD<kFused>(-c, cs, fmaD<kFused>(-s, ssn, ccs)));     // cor = (ccs - s * ssn - cs * c) - sn * s
+    return cs + cor;
+}
+
+// do_sin(x, dx)
+template <bool kFused>
+MCRT_HD double doSin(double x, double dx) {
+    const double xold = x;
+    if (absD(x) < 0.126) return taylorSin<kFused>(x * x, x, dx);
+    if (x <= 0.0) dx = -dx;
+    const double ax = absD(x);
+    const double u = kBig + ax;
+    x = ax - (u - kBig);
+    const int k = (int)(unsigned)(dBits(u) & 0xFFFFFFFFull) * 4;
+    const double xx = x * x;
+    const double s = x + fmaD<kFused>(x * xx, fmaD<kFused>(xx, kSn5, kSn3), dx);           // s = x + (dx + x * xx * (sn3 + xx * sn5))
+    const double c = fmaD<kFused>(x, dx, xx * fmaD<kFused>(xx, fmaD<kFused>(xx, kCs6, kCs4), kCs2));  // c = x * dx + xx * (cs2 + xx * (cs4 + xx * cs6))
+    const double sn = tabAt(k), ssn = tabAt(k + 1), cs = tabAt(k + 2), ccs = tabAt(k + 3);
+    const double cor = fmaD<kFused>(s, cs, fmaD<kFused>(-c, sn, fmaD<kFused>(s, ccs, ssn)));       // cor = (ssn + s * ccs - sn * c) + cs * s
+    return copySign(sn + cor, xold);
+}
+
+// reduce_sincos(x, &a, &da): returns n (quadrant)
+template <bool kFused>
+MCRT_HD int reduceSinCos(double x, double& a, double& da) {
+    const double t = fmaD<kFused>(x, kHpInv, kToInt);                              // t = x * hpinv + toint
+    const double xn = t - kToInt;
+    const double y = fmaD<kFused>(-xn, kMp2, fmaD<kFused>(-xn, kMp1, x));                  // y = (x - xn * mp1) - xn * mp2
+    const int n = (int)(unsigned)(dBits(t) & 3ull);
+    const double t2 = fmaD<kFused>(-xn, kPp3, y);                                  // t1 = xn * pp3; t2 = y - t1
+    double db = fmaD<kFused>(-xn, kPp3, y - t2);                                   // db = (y - t2) - t1
+    const double b = fmaD<kFused>(-xn, kPp4, t2);                                  // t1 = xn * pp4; b = t2 - t1
+    db = db + fmaD<kFused>(-xn, kPp4, t2 - b);                                     // db += (t2 - b) - t1
+    a = b;
+    da = db;
+    return n;
+}
+
+// do_sincos(a, da, n)
+template <bool kFused>
+MCRT_HD double doSinCos(double a, double da, int n) {
+    const double r = (n & 1) ? doCos<kFused>(a, da) : doSin<kFused>(a, da);
+    return (n & 2) ? -r : r;
+}
+
+}  // namespace glibc235
+
+// __sin of the FMA build (s_sin.c:201-251)
+MCRT_HD double refSin(double x) {
+    using namespace glibc235;
+    constexpr bool kFused = true;
+    const unsigned k = (unsigned)(dBits(x) >> 32) & 0x7FFFFFFFu;
+    if (k < 0x3e500000u) return x;                                                        // |x| < 2^-26
+    if (k < 0x3feb6000u) return doSin<kFused>(x, 0.0);                                    // |x| < 0.855469
+    if (k < 0x400368fdu) return copySign(doCos<kFused>(kHp0 - absD(x), kHp1), x);         // |x| < 2.426265
+    if (k < 0x419921FBu) {                                                                // |x| < 105414350
+        double a, da;
+        const int n = reduceSinCos<kFused>(x, a, da);
+        return doSinCos<kFused>(a, da, n);
+    }
+    return sin(x);
+}
+
+// __cos of the FMA build (s_sin.c:258-308)
+MCRT_HD double refCos(double x) {
+    using namespace glibc235;
+    constexpr bool kFused = true;
+    const unsigned k = (unsigned)(dBits(x) >> 32) & 0x7FFFFFFFu;
+    if (k < 0x3e400000u) return 1.0;                                                      // |x| < 2^-27
+    if (k < 0x3feb6000u) return doCos<kFused>(x, 0.0);
+    if (k < 0x400368fdu) {
+        const double y = kHp0 - absD(x);
+        const double a = y + kHp1;
+        const double da = (y - a) + kHp1;
+        return doSin<kFused>(a, da);
+    }
+    if (k < 0x419921FBu) {
+        double a, da;
+        const int n = reduceSinCos<kFused>(x, a, da);
+        return doSinCos<kFused>(a, da, n + 1);
+    }
+    return cos(x);
+}
+
+// __sincos (s_sincos.c:28-104), the baseline build: what the reference's sin / cos PAIRS compute
+MCRT_HD void refSinCos(double x, double& sn, double& cs) {
+    using namespace glibc235;
+    constexpr bool kFused = false;
+    const unsigned k = (unsigned)(dBits(x) >> 32) & 0x7FFFFFFFu;
+    if (k < 0x400368fdu) {
+        if (k < 0x3e400000u) {                                                            // |x| < 2^-27
+            sn = x;
+            cs = 1.0;
+            return;
+        }
+        if (k < 0x3feb6000u) {                                                            // |x| < 0.855469
+            sn = doSin<kFused>(x, 0.0);
+            cs = doCos<kFused>(x, 0.0);
+            return;
+        }
+        const double y = kHp0 - absD(x);                                                  // |x| < 2.426265
+        const double a = y + kHp1;
+        const double da = (y - a) + kHp1;
+        sn = copySign(doCos<kFused>(a, da), x);
+        cs = doSin<kFused>(a, da);
+        return;
+    }
+    if (k < 0x419921FBu) {                                                                // |x| < 105414350
+        double a, da;
+        const int n = reduceSinCos<kFused>(x, a, da);
+        sn = doSinCos<kFused>(a, da, n);
+        cs = doSinCos<kFused>(a, da, n + 1);
+        return;
+    }
+    sincos(x, &sn, &cs);  // (|x| >= 105414350, never reached by the path: the platform's own)
+}
+
+}  // namespace mcrt

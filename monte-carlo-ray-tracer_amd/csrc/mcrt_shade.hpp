@@ -7,6 +7,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_sampler.hpp"
 #include "mcrt_scene.hpp"
+#include "mcrt_libm.hpp"
 
 namespace mcrt {
 
@@ -89,8 +90,10 @@ MCRT_HD d3 ggxVisibleMicrofacet(double u, double v, d3 wo, double ax, double ay)
     d3 T2 = cross(Vh, T1);
     double r = sqrt(u);
     double phi = v * kTwoPi;
-    double t1 = r * cos(phi);
-    double t2 = r * sin(phi);
+    double sin_phi, cos_phi;
+    refSinCos(phi, sin_phi, cos_phi);  // glibc's sincos, bit for bit (mcrt_libm.hpp)
+    double t1 = r * cos_phi;
+    double t2 = r * sin_phi;
     double s = 0.5 * (1.0 + Vh.z);
     t2 = (1.0 - s) * sqrt(1.0 - sq(t1)) + s * t2;
     d3 Nh = t1 * T1 + t2 * T2 + sqrt(gmax(0.0, 1.0 - sq(t1) - sq(t2))) * Vh;
@@ -169,7 +172,9 @@ MCRT_HD d3 surfSample(const ShadeViewT<L>& sh, uint32_t i, double u, double v) {
         double z = 1.0 - 2.0 * u;
         double r = sqrt(1.0 - sq(z));
         double phi = kTwoPi * v;
-        return ld3(p) + p[3] * d3{r * cos(phi), r * sin(phi), z};
+        double sin_phi, cos_phi;
+        refSinCos(phi, sin_phi, cos_phi);
+        return ld3(p) + p[3] * d3{r * cos_phi, r * sin_phi, z};
     }
     double su = sqrt(u);
     return (1 - su) * ld3(p) + ((1 - v) * su) * ld3(p + 3) + (v * su) * ld3(p + 6);
@@ -347,7 +352,9 @@ MCRT_HD bool interactionBSDF(const InteractionT<L>& ia, d3& bsdf_absIdotN, d3 wo
 MCRT_HD d3 cosWeightedHemi(double u, double v) {  // sampling/sampling.hpp:35-44
     double r = sqrt(u);
     double azimuth = v * kTwoPi;
-    return d3{r * cos(azimuth), r * sin(azimuth), sqrt(1 - u)};
+    double sin_a, cos_a;
+    refSinCos(azimuth, sin_a, cos_a);
+    return d3{r * cos_a, r * sin_a, sqrt(1 - u)};
 }
 
 template <bool L>
@@ -536,7 +543,9 @@ MCRT_HD Ray cameraRay(const mcrt_camera_desc& cam, double scene_ior, uint32_t x,
         double u0 = smp.get(kDimLens, tab), u1 = smp.get(kDimLens + 1, tab);
         double azimuth = u1 * kTwoPi;  // Sampling::uniformDisk, sampling.hpp:29-33
         double su = sqrt(u0);
-        double ax = cos(azimuth) * su * cam.aperture_radius, ay = sin(azimuth) * su * cam.aperture_radius;
+        double sin_a, cos_a;
+        refSinCos(azimuth, sin_a, cos_a);
+        double ax = cos_a * su * cam.aperture_radius, ay = sin_a * su * cam.aperture_radius;
         d3 focus_point = ray.start + ray.direction * (cam.focus_distance / dot(ray.direction, forward));
         d3 start = eye + left * ax + up * ay;
         ray = makeRay(start, normalize(focus_point - start), scene_ior);

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_libm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
@@ -713,6 +714,53 @@ int emu_emit_photons(const mcrt_scene_desc* scene, double emissions, double caus
 
 // Leaf-deferral policy of the trace kernel's per-lane code in this emulation (QTrace::run) and its test counts.
 void emu_set_defer(int policy) { g_defer = policy; }
+// refSinCos / refSin / refCos (mcrt_libm.hpp) against this host's libm on n arguments: uniform in [lo, hi] (splitmix64 stream),
+// then - when edges != 0 - the same count again clustered within a few thousand ulps of the branch boundaries of s_sin.c. The
+// three libm functions are called through function pointers, one per call: a sin and a cos of the same argument in one
+// expression would be merged into sincos by the compiler. out[0..3] = arguments on which sincos' sine / sincos' cosine / sin /
+// cos differ (bitwise) from the restatement; out[4..7] = the first such argument of each (bit pattern), if any.
+void emu_libm_check(uint64_t n, uint64_t seed, double lo, double hi, int edges, uint64_t* out) {
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    double (*volatile libm_sin)(double) = ::sin;
+    double (*volatile libm_cos)(double) = ::cos;
+    void (*volatile libm_sincos)(double, double*, double*) = ::sincos;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    auto note = [&](int w, double got, double want, double x) {
+        if (memcmp(&got, &want, 8) != 0) {
+            if (!out[w]) memcpy(&out[4 + w], &x, 8);
+            out[w]++;
+        }
+    };
+    auto check = [&](double x) {
+        double s2, c2, rs, rc;
+        libm_sincos(x, &s2, &c2);
+        refSinCos(x, rs, rc);
+        note(0, rs, s2, x);
+        note(1, rc, c2, x);
+        note(2, refSin(x), libm_sin(x), x);
+        note(3, refCos(x), libm_cos(x), x);
+    };
+    for (uint64_t i = 0; i < n; i++) check(lo + (hi - lo) * ((double)(next() >> 11) * 0x1.0p-53));
+    if (edges) {
+        const double marks[] = {0x1.0p-26, 0x1.0p-27, 0.126, 0.855469, 2.426265, 0.78539816339744831, 1.5707963267948966, 3.1415926535897931,
+                                4.7123889803846897, 6.2831853071795862, 105414350.0, 0.0078125, 0.5, 1.0, 2.0};
+        for (uint64_t i = 0; i < n; i++) {
+            double m = marks[next() % (sizeof(marks) / sizeof(marks[0]))];
+            long long b;
+            memcpy(&b, &m, 8);
+            b += (long long)(next() % 8192) - 4096;
+            memcpy(&m, &b, 8);
+            check((next() & 1) ? m : -m);
+        }
+    }
+}
+
 void emu_set_wide(int on) { g_wide = on; }
 void emu_set_leaf_cull(int on) { g_leaf_cull = on; }
 uint64_t emu_wide_nodes(const mcrt_scene_desc* scene) {

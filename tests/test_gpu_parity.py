@@ -3,9 +3,13 @@ against the reference's golden dumps (tests/golden/, made by the reference itsel
 
 Tolerance (BASELINE.json north_star): per-pixel radiance within 1e-4 relative of the CPU reference at
 fixed seed, measured as |gpu-ref| / max(|ref|, 1e-3) per channel. Integer/index work (sampler bits,
-hit surface indices, kNN photon indices) must be exact. A GPU libm (ocml sin/cos/asin differ from
-glibc in the last ulp) can flip a branch of an individual path; such pixels are counted as outliers
-and must stay below 0.2 % of the pixels of a frame."""
+hit surface indices, kNN photon indices) must be exact.
+
+Round 3: the device computes the reference's sin / cos pairs with glibc's own sincos algorithm (csrc/mcrt_libm.hpp), which was
+the last arithmetic difference on the path: path-traced frames of scenes WITHOUT a sky are now required to be the reference's
+bits (EXACT below), no pixel of any path-traced frame may be off by more than 1e-12 (scenes with a sky go through asin, where
+ocml and glibc differ in the last bit of a smooth term: measured <= 4e-16), and the outlier allowance is gone. Photon-mapped
+frames keep their own bar (the k photons of an estimate are summed by a wave reduction, not in heap order: 1e-12)."""
 import ctypes as C
 import os
 
@@ -16,7 +20,10 @@ from conftest import camera_for, check_hits_against_reference, golden_path, load
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-OUTLIER_FRACTION = 0.002
+SMOOTH_TOL = 1e-12  # path-traced frames whose only non-identical operation is asin in Scene::skyColor
+# scenes without a sky: every operation of a path is reproduced bit for bit
+EXACT = {"hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah", "coffee_maker_bsah", "shell_room",
+         "dragon_room"}
 
 
 @pytest.fixture(scope="module")
@@ -49,12 +56,14 @@ def expected_kernel(pkg, img, integrator, forced=None):
     return pkg.KERNEL_LANE_SM
 
 
-def _check(out, ref, what):
+def _check(out, ref, what, exact=False, tol=SMOOTH_TOL):
     rel = rel_error(out, ref).max(axis=2)
-    bad = int((rel > TOL).sum())
-    print("%s: max rel %.3e, 99.9th pct %.3e, outliers %d / %d" % (what, rel.max(), np.quantile(rel, 0.999), bad, rel.size))
+    bad = int((rel > tol).sum())
+    print("%s: max rel %.3e, 99.9th pct %.3e, pixels beyond %g: %d / %d" % (what, rel.max(), np.quantile(rel, 0.999), tol, bad, rel.size))
     assert np.isfinite(out).all()
-    assert bad <= max(2, int(OUTLIER_FRACTION * rel.size)), "%s: %d pixels differ by more than %g" % (what, bad, TOL)
+    if exact:
+        np.testing.assert_array_equal(out, ref, err_msg="%s: not the reference's bits" % what)
+    assert bad == 0, "%s: %d pixels differ by more than %g" % (what, bad, tol)
     return rel
 
 
@@ -70,7 +79,7 @@ def test_path_tracer_matches_reference(pkg, ctx, manifest, name):
         if (r0, r1) != (0, r["height"]):
             continue  # crops of the full-size frame: test_c2_full_size_frame
         out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
-        _check(out, load_radiance(r), "%s %s" % (name, r["file"]))
+        _check(out, load_radiance(r), "%s %s" % (name, r["file"]), exact=name in EXACT)
         assert st["paths"] == r["width"] * r["height"] * r["sqrtspp"] ** 2
         assert st["rays"] >= st["paths"] and st["kernel_launches"] >= 1
         assert st["kernel_id"] == expected_kernel(pkg, img, pkg.INTEGRATOR_PATH_TRACER), pkg.KERNEL_NAMES.get(st["kernel_id"])
@@ -106,7 +115,7 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
             out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
         finally:
             os.environ.pop("MCRT_WF_SLOTS", None)
-        _check(out, load_radiance(r), "%s wavefront (%s slots)" % (name, slots))
+        _check(out, load_radiance(r), "%s wavefront (%s slots)" % (name, slots), exact=name in EXACT)
         assert st["paths"] == st0["paths"] and st["kernel_launches"] > 2
         assert st["kernel_id"] == pkg.KERNEL_WAVEFRONT and st0["kernel_id"] == expected_kernel(pkg, img, pkg.INTEGRATOR_PATH_TRACER)
         np.testing.assert_array_equal(out, base)
@@ -377,7 +386,7 @@ def test_c2_full_size_frame(pkg, ctx, manifest):
     cam = camera_for(img, r)
     out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     r0, r1 = r["rows"]
-    _check(out[r0:r1], load_radiance(r), "C2 full-size rows %d-%d" % (r0, r1))
+    _check(out[r0:r1], load_radiance(r), "C2 full-size rows %d-%d" % (r0, r1), exact=True)  # BASELINE configs[1]: the reference's bits
     assert st["paths"] == 1920 * 1080 * 256 and st["kernel_id"] == pkg.KERNEL_FLAT
     assert np.isfinite(out).all() and (out >= 0).all()
     print("C2 full frame: %.1f Mray/s, %.2f rays/path, kernel %.1f ms" %
