@@ -167,37 +167,74 @@ MCRT_HD double refCos(double x) {
     return cos(x);
 }
 
-// __sincos (s_sincos.c:28-104), the baseline build: what the reference's sin / cos PAIRS compute
-MCRT_HD void refSinCos(double x, double& sn, double& cs) {
+// __sincos (s_sincos.c:28-104), the baseline build: what the reference's sin / cos PAIRS compute. In every range it evaluates
+// ONE do_sin and ONE do_cos of the same reduced argument (X, DX) - (x, 0) below 0.855469, (a, da) = hp0 - |x| in two pieces up
+// to 2.426265, the Cody-Waite remainder beyond - and hands them out with the quadrant's signs; both kernels look up the same
+// table entry. Written that way here (one table read, no branch repeated), every operation as in the source.
+MCRT_HD void refSinCos(double x, double& sn_out, double& cs_out) {
     using namespace glibc235;
     constexpr bool kFused = false;
     const unsigned k = (unsigned)(dBits(x) >> 32) & 0x7FFFFFFFu;
-    if (k < 0x400368fdu) {
-        if (k < 0x3e400000u) {                                                            // |x| < 2^-27
-            sn = x;
-            cs = 1.0;
-            return;
-        }
-        if (k < 0x3feb6000u) {                                                            // |x| < 0.855469
-            sn = doSin<kFused>(x, 0.0);
-            cs = doCos<kFused>(x, 0.0);
-            return;
-        }
-        const double y = kHp0 - absD(x);                                                  // |x| < 2.426265
-        const double a = y + kHp1;
-        const double da = (y - a) + kHp1;
-        sn = copySign(doCos<kFused>(a, da), x);
-        cs = doSin<kFused>(a, da);
+    if (k < 0x3e400000u) {                                                                // |x| < 2^-27
+        sn_out = x;
+        cs_out = 1.0;
         return;
     }
-    if (k < 0x419921FBu) {                                                                // |x| < 105414350
-        double a, da;
-        const int n = reduceSinCos<kFused>(x, a, da);
-        sn = doSinCos<kFused>(a, da, n);
-        cs = doSinCos<kFused>(a, da, n + 1);
+    if (!(k < 0x419921FBu)) {                                                             // |x| >= 105414350, never reached by the path
+        sincos(x, &sn_out, &cs_out);
         return;
     }
-    sincos(x, &sn, &cs);  // (|x| >= 105414350, never reached by the path: the platform's own)
+    double X, DX;
+    bool swap, neg_s, neg_c, sin_takes_sign_of_x = false;  // sin = +-(swap ? do_cos : do_sin)(X, DX), cos = +-(swap ? do_sin : do_cos)(X, DX)
+    if (k < 0x3feb6000u) {                                                                // |x| < 0.855469: sin = do_sin (x, 0), cos = do_cos (x, 0)
+        X = x;
+        DX = 0.0;
+        swap = neg_s = neg_c = false;
+    } else if (k < 0x400368fdu) {                                                         // |x| < 2.426265: sin = copysign (do_cos (a, da), x), cos = do_sin (a, da)
+        const double y = kHp0 - absD(x);
+        X = y + kHp1;
+        DX = (y - X) + kHp1;
+        swap = true;
+        neg_s = neg_c = false;
+        sin_takes_sign_of_x = true;
+    } else {                                                                              // |x| < 105414350: do_sincos (a, da, n) and (a, da, n + 1)
+        const int n = reduceSinCos<kFused>(x, X, DX);
+        swap = (n & 1) != 0;
+        neg_s = (n & 2) != 0;
+        neg_c = ((n + 1) & 2) != 0;
+    }
+    // do_sin (X, DX) and do_cos (X, DX): same u, same table entry
+    const double ax = absD(X);
+    const double u = kBig + ax;
+    const double xr = ax - (u - kBig);
+    const int ti = (int)(unsigned)(dBits(u) & 0xFFFFFFFFull) * 4;
+    const double sn = tabAt(ti), ssn = tabAt(ti + 1), cs = tabAt(ti + 2), ccs = tabAt(ti + 3);
+    double S;
+    if (ax < 0.126) {
+        S = taylorSin<kFused>(X * X, X, DX);
+    } else {
+        const double dx = X <= 0.0 ? -DX : DX;
+        const double xx = xr * xr;
+        const double s = xr + (dx + xr * xx * (kSn3 + xx * kSn5));
+        const double c = xr * dx + xx * (kCs2 + xx * (kCs4 + xx * kCs6));
+        const double cor = (ssn + s * ccs - sn * c) + cs * s;
+        S = copySign(sn + cor, X);
+    }
+    double C;
+    {
+        const double dx = X < 0.0 ? -DX : DX;
+        const double xc = xr + dx;
+        const double xx = xc * xc;
+        const double s = xc + xc * xx * (kSn3 + xx * kSn5);
+        const double c = xx * (kCs2 + xx * (kCs4 + xx * kCs6));
+        const double cor = (ccs - s * ssn - cs * c) - sn * s;
+        C = cs + cor;
+    }
+    double rs = swap ? C : S, rc = swap ? S : C;
+    if (neg_s) rs = -rs;
+    if (neg_c) rc = -rc;
+    sn_out = sin_takes_sign_of_x ? copySign(rs, x) : rs;
+    cs_out = rc;
 }
 
 }  // namespace mcrt
