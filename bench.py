@@ -57,12 +57,12 @@ WORKLOADS = {
     # photon-mapped frame (BASELINE configs[4] class of work on the scene that is available): photon paths emitted on the
     # GPU, maps built GPU-assisted, then timed eye passes with kNN estimates
     "pm": ("hexagon_room_pm.mcrt", 1920, 1080, 2, "hexagon_room.json photon mapping: 1e6 emissions x caustic_factor 10, k=50, 1920x1080 @ 4 spp"),
-    # a real BVH that does not fit in LDS; image made by tests/large/make_large.py
+    # a real BVH that does not fit in LDS; image made by integration/large_scenes/make_large.py
     "spaceship": ("../../oracle/_ref/images/spaceship.mcrt", 1920, 1080, 8,
                   "spaceship.json (68 760 of 457 200 triangles present), quaternary SAH, 1920x1080 @ 64 spp"),
     # BASELINE configs[2] at full size; the Stanford bunny is not in the reference tree (.MISSING_LARGE_BLOBS), a
-    # synthetic 81 920-triangle stand-in is (tests/large/make_synthetic.py). The 120 MB image is flattened on this
-    # machine by the reference's loader + BVH builder (tests/large/make_large.py:ensure_image)
+    # synthetic 81 920-triangle stand-in is (integration/large_scenes/make_synthetic.py). The 120 MB image is flattened on this
+    # machine by the reference's loader + BVH builder (integration/large_scenes/make_large.py:ensure_image)
     "c3": ("../../oracle/_ref/images/metal_bunnies_c3.mcrt", 1920, 1080, 32,
            "metal_bunnies.json (stand-in bunny mesh, 491 592 triangles), quaternary SAH, 1920x1080 @ 1024 spp (BASELINE configs[2])"),
     # BASELINE configs[3] on ONE GPU: the two missing hull meshes replaced by stand-ins of the same triangle counts
@@ -73,7 +73,7 @@ WORKLOADS = {
            "water_caustics.json (stand-in water surface, 6 898 815 triangles), octree BVH, photon map, 1000x1000 @ 256 spp (BASELINE configs[4])"),
 }
 # reference-side scene + flags for the cpu_baseline "reference" leg (scene copies under oracle/_ref/scenes, made by
-# tests/large/make_large.py in the build container; they travel to the GPU box with the snapshot)
+# integration/large_scenes/make_large.py in the build container; they travel to the GPU box with the snapshot)
 REF_SCENES = {
     "hexagon_room.mcrt": ("hexagon_room.json", []),
     "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
@@ -408,7 +408,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
         desc += " [spp overridden to %d]" % (s * s)
     wl.W, wl.H, wl.sqrtspp, wl.desc = W, H, s, desc
     if name in ("c3", "c4", "c5"):
-        sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+        sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
         import make_large
         if local_rank == 0 and make_large.ensure_image(name) is None:
             raise RuntimeError("%s needs oracle/_ref (python __graft_entry__.py build in the build container)" % name)

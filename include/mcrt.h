@@ -198,6 +198,15 @@ int  mcrt_create(mcrt_ctx** out, int device_id);
 void mcrt_destroy(mcrt_ctx* ctx);
 const char* mcrt_last_error(const mcrt_ctx* ctx); /* ctx may be NULL: last create error */
 
+/* Run-time options of a context: kernel selection and tuning knobs for A/B runs and parity tests (DESIGN.md "Run-time
+ * options" lists them; defaults are the measured best). Keys are MCRT_* names, values decimal numbers or words. The process
+ * environment SEEDS the options once, in mcrt_create (so `MCRT_KERNEL=wf ./host` still works); after that the library never
+ * reads the environment: a host changes behaviour with mcrt_set_option, between frames (value NULL = back to the default).
+ * Options that shape the uploaded scene (MCRT_LEAF_CULL, MCRT_FLAT_MAX) take effect at the next mcrt_upload_scene.
+ * The reference has no counterpart (its knobs are compile-time constants); mcrt_get_option returns the value or NULL. */
+int mcrt_set_option(mcrt_ctx* ctx, const char* key, const char* value);
+const char* mcrt_get_option(const mcrt_ctx* ctx, const char* key);
+
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* scene);
 int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map,
                         const mcrt_photon_map_desc* caustic_map,

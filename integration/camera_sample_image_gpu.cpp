@@ -1,4 +1,4 @@
-// tests/integration/camera_sample_image_gpu.cpp — the drop-in, built for real: the replacement body of
+// integration/camera_sample_image_gpu.cpp — the drop-in, built for real: the replacement body of
 //
 //     void Camera::sampleImage();          // reference: source/camera/camera.cpp:101-145
 //

@@ -1,4 +1,4 @@
-/* tests/large/gen_mesh.c — deterministic stand-ins for the big meshes the reference tree lists in
+/* integration/large_scenes/gen_mesh.c — deterministic stand-ins for the big meshes the reference tree lists in
  * .MISSING_LARGE_BLOBS. Only +,-,*,/ and sqrt on doubles and an integer
  * hash: every machine writes the same bytes (the build compiles this with -O2 -ffp-contract=off).
  *

@@ -2,7 +2,7 @@
 """Large-scene fixtures (too big for git). Everything here is produced by the REFERENCE (oracle/_ref/mcrt_ref
 = the reference's translation units compiled in place + oracle/ref_main.cpp) under oracle/_ref/ (git-ignored),
 from scene copies whose missing meshes (.MISSING_LARGE_BLOBS) are replaced by deterministic synthetic stand-ins
-(tests/large/make_synthetic.py, tests/large/gen_mesh.c).
+(integration/large_scenes/make_synthetic.py, integration/large_scenes/gen_mesh.c).
 
 Build container (/root/reference present; main(), called from __graft_entry__.build()):
   oracle/_ref/bin/gen_mesh                              the C mesh generator

@@ -73,7 +73,7 @@ def write_bunny(path, level=6, seed=1):
     p = v * r[:, None] + np.array([0.0, 0.75, 0.0])
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as out:
-        out.write("# synthetic stand-in for data/bunny.obj (tests/large/make_synthetic.py)\n")
+        out.write("# synthetic stand-in for data/bunny.obj (tests/large/make_synthetic.py)\n")  # (the file lived there when its md5 was pinned: the line is part of the fingerprint)
         for x, y, z in p:
             out.write("v %.17g %.17g %.17g\n" % (x, y, z))
         for a, b, c in f + 1:

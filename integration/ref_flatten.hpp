@@ -1,8 +1,8 @@
-// tests/integration/ref_flatten.hpp — the FLATTENER a maintainer of the reference adds next to its sources:
+// integration/ref_flatten.hpp — the FLATTENER a maintainer of the reference adds next to its sources:
 // walks the reference's already-built Scene / BVH / LinearOctree<Photon> / Camera objects and fills the descriptors of
 // include/mcrt.h. Reference-side integration code, compiled only into hosts that link the reference's own translation units
 // (oracle/_ref/mcrt_ref: the checker; oracle/_ref/mcrt_ref_gpu: the reference's main() with Camera::sampleImage() replaced by
-// libmcrt_hip.so, tests/integration/camera_sample_image_gpu.cpp). Never part of the product library.
+// libmcrt_hip.so, integration/camera_sample_image_gpu.cpp). Never part of the product library.
 //
 // Private members (BVH::linear_tree, Triangle::v0 …, PhotonMapper::global_map, Film::filter_function) are reached by compiling
 // the including TU with -fno-access-control (layout is unaffected); a maintainer would add friend declarations instead.
@@ -29,7 +29,7 @@
 #include "scene/scene.hpp"
 #include "surface/surface.hpp"
 
-#include "../../include/mcrt.h"
+#include "../include/mcrt.h"
 
 namespace {
 
@@ -232,10 +232,9 @@ mcrt_camera_desc flattenCamera(const Camera& c) {
     d.sqrtspp = (uint32_t)c.sqrtspp;
     d.shard_index = 0; d.shard_count = 1; d.shard_rows = 1;
     d.film_filter = filmFilterKind(c.film);
-    if (d.film_filter != MCRT_FILM_BOX) {
-        d.film_radius = c.film.radius;
-        d.film_cache_size = (uint32_t)c.film.filter_cache.size();
-    }
+    // (the box filter's radius too: with another radius than its default 0.5 the film splats, film.cpp:44-46)
+    d.film_radius = c.film.radius;
+    d.film_cache_size = (uint32_t)c.film.filter_cache.size();
     return d;
 }
 

@@ -199,6 +199,9 @@ def lib():
     L.mcrt_destroy.restype = None
     L.mcrt_last_error.argtypes = [vp]
     L.mcrt_last_error.restype = C.c_char_p
+    L.mcrt_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.mcrt_get_option.argtypes = [vp, C.c_char_p]
+    L.mcrt_get_option.restype = C.c_char_p
     L.mcrt_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
     L.mcrt_upload_photons.argtypes = [vp, C.POINTER(PhotonMapDesc), C.POINTER(PhotonMapDesc),
                                       C.c_uint32, C.c_int]
@@ -445,15 +448,39 @@ class Context:
             msg = self._lib.mcrt_last_error(None)
             raise McrtError("mcrt_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
 
+        self._env = {k: v for k, v in os.environ.items() if k.startswith("MCRT_")}  # what mcrt_create seeded the options with
+
     def _check(self, rc, what):
         if rc != 0:
             msg = self._lib.mcrt_last_error(self._h)
             raise McrtError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
+    def set_option(self, key, value):
+        """mcrt_set_option: a run-time option of this context (value None = back to the default)."""
+        self._check(self._lib.mcrt_set_option(self._h, key.encode(), None if value is None else str(value).encode()), "mcrt_set_option")
+
+    def get_option(self, key):
+        v = self._lib.mcrt_get_option(self._h, key.encode())
+        return v.decode() if v is not None else None
+
+    def _sync_env(self):
+        """The library reads the MCRT_* environment once, in mcrt_create. The tests and A/B tools of this repo switch kernels by
+        changing os.environ between calls; the binding mirrors such changes into mcrt_set_option before a call that launches."""
+        now = {k: v for k, v in os.environ.items() if k.startswith("MCRT_")}
+        if now != self._env:
+            for k in set(self._env) - set(now):
+                self.set_option(k, None)
+            for k, v in now.items():
+                if self._env.get(k) != v:
+                    self.set_option(k, v)
+            self._env = now
+
     def upload_scene(self, scene_desc):
+        self._sync_env()
         self._check(self._lib.mcrt_upload_scene(self._h, C.byref(scene_desc)), "mcrt_upload_scene")
 
     def upload_photons(self, global_map, caustic_map, k_nearest, direct_visualization=False):
+        self._sync_env()
         g = C.byref(global_map) if global_map is not None else None
         c = C.byref(caustic_map) if caustic_map is not None else None
         self._check(self._lib.mcrt_upload_photons(self._h, g, c, int(k_nearest),
@@ -470,6 +497,7 @@ class Context:
 
     def sample_image(self, cam, global_seed, integrator=INTEGRATOR_PATH_TRACER):
         """mcrt_render -> (image[H,W,3] float64, stats dict)."""
+        self._sync_env()
         out = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
         st = Stats()
         self._check(self._lib.mcrt_render(self._h, C.byref(cam), int(global_seed), int(integrator),
@@ -477,6 +505,7 @@ class Context:
         return out, st.as_dict()
 
     def render_device(self, cam, global_seed, integrator, device_ptr, stream=None):
+        self._sync_env()
         self._check(self._lib.mcrt_render_device(self._h, C.byref(cam), int(global_seed),
                                                  int(integrator), C.c_void_p(int(device_ptr)),
                                                  C.c_void_p(int(stream)) if stream else None),
@@ -484,6 +513,7 @@ class Context:
 
     def render_film_device(self, cam, global_seed, integrator, rgbw_ptr, stream=None):
         """mcrt_render_film_device: this shard's splats into a full-frame RGBW device buffer (width*height*4 doubles)."""
+        self._sync_env()
         self._check(self._lib.mcrt_render_film_device(self._h, C.byref(cam), int(global_seed), int(integrator), C.c_void_p(int(rgbw_ptr)),
                                                       C.c_void_p(int(stream)) if stream else None), "mcrt_render_film_device")
 
@@ -515,6 +545,7 @@ class Context:
 
     def emit_photons(self, emissions, caustic_factor, global_seed, shard_index=0, shard_count=1):
         """mcrt_emit_photons[_shard] -> dict(global_=(photons[n,8] f32, keys[n] u64), caustic=(...), paths, rays, kernel_ms)."""
+        self._sync_env()
         pe = PhotonEmission()
         self._check(self._lib.mcrt_emit_photons_shard(self._h, float(emissions), float(caustic_factor), int(global_seed),
                                                       int(shard_index), int(shard_count), C.byref(pe)), "mcrt_emit_photons")
@@ -532,6 +563,7 @@ class Context:
     def photon_pass_device(self, emissions, caustic_factor, global_seed, bb_min, bb_max, max_photons_per_leaf=200, k_nearest=50,
                            direct_visualization=False):
         """mcrt_photon_pass_device: emission + both maps on the device, installed for the eye pass. Returns the stats dict."""
+        self._sync_env()
         st = PhotonPassStats()
         lo, hi = (C.c_double * 3)(*bb_min), (C.c_double * 3)(*bb_max)
         self._check(self._lib.mcrt_photon_pass_device(self._h, float(emissions), float(caustic_factor), int(global_seed), lo, hi,
@@ -542,6 +574,7 @@ class Context:
     def emit_photons_device(self, emissions, caustic_factor, global_seed, shard_index=0, shard_count=1):
         """mcrt_emit_photons_device -> dict(global_=(device pointer, count), caustic=(...), paths, rays, kernel_ms); the lists
         stay in device memory owned by the context."""
+        self._sync_env()
         pe = PhotonEmissionDevice()
         self._check(self._lib.mcrt_emit_photons_device(self._h, float(emissions), float(caustic_factor), int(global_seed), int(shard_index),
                                                        int(shard_count), C.byref(pe)), "mcrt_emit_photons_device")
@@ -551,6 +584,7 @@ class Context:
     def upload_photons_device(self, d_global, global_count, d_caustic, caustic_count, bb_min, bb_max, max_photons_per_leaf=200, k_nearest=50,
                               direct_visualization=False):
         """mcrt_upload_photons_device: both maps from photon lists in device memory (raw pointers, e.g. tensor.data_ptr())."""
+        self._sync_env()
         st = PhotonPassStats()
         lo, hi = (C.c_double * 3)(*bb_min), (C.c_double * 3)(*bb_max)
         self._check(self._lib.mcrt_upload_photons_device(self._h, C.c_void_p(int(d_global)), int(global_count), C.c_void_p(int(d_caustic)),
@@ -565,6 +599,7 @@ class Context:
         return PhotonMap._from_handle(h)
 
     def intersect(self, start, direction):
+        self._sync_env()
         start = np.ascontiguousarray(start, dtype=np.float64)
         direction = np.ascontiguousarray(direction, dtype=np.float64)
         n = start.shape[0]
@@ -595,6 +630,7 @@ class Context:
         return out
 
     def knn(self, which, points, k):
+        self._sync_env()
         points = np.ascontiguousarray(points, dtype=np.float64)
         n = points.shape[0]
         cnt = np.empty(n, dtype=np.uint32)

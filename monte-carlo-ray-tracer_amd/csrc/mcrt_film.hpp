@@ -52,6 +52,16 @@ inline double filmDefaultRadius(uint32_t type) {  // film.cpp:31-44
     }
 }
 
+// A frame is SPLATTED (Film::deposit with a window, film.cpp:61-79) whenever the camera names a reconstruction filter - or keeps
+// the box filter but gives it another radius than its default 0.5 (film.cpp:44-46: `set(Filter::box, 0.5)`, then
+// `radius = getOptional(j, "radius", radius)`): every pixel within the radius then receives the sample with weight 1. Only the
+// default box (a sample lands in its own pixel) takes the per-pixel sums. kFilmBoxSplat is FilmView::type of the widened box.
+constexpr uint32_t kFilmBoxSplat = 0x100u;
+MCRT_HD bool filmSplats(uint32_t film_filter, double film_radius) {
+    return film_filter != MCRT_FILM_BOX || (film_radius != 0.0 && film_radius != 0.5);
+}
+MCRT_HD uint32_t filmViewType(uint32_t film_filter) { return film_filter == MCRT_FILM_BOX ? kFilmBoxSplat : film_filter; }
+
 struct FilmView {
     uint32_t type;          // MCRT_FILM_*; MCRT_FILM_BOX = no splatting (per-pixel sums, film.cpp:13-17)
     uint32_t cache_size;

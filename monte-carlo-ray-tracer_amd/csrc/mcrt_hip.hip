@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,8 @@
 #include "mcrt_octree_shared.hpp"
 
 #include <hipcub/hipcub.hpp>
+
+extern char** environ;
 
 using namespace mcrt;
 
@@ -88,6 +91,7 @@ struct mcrt_ctx {
     // scratch of the operator-level entry points (mcrt_intersect / mcrt_knn / mcrt_sampler / mcrt_bsdf): kept between calls, grown
     // on demand, so that a host that only wants traversal or k-NN does not pay five hipMalloc / hipFree pairs per call
     DevBuf op_buf[6];
+    std::map<std::string, std::string> options;  // mcrt_set_option; seeded from the MCRT_* environment variables at mcrt_create
     DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
     DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
 
@@ -222,17 +226,37 @@ struct TracePlan {
     WfTraceArgs args;
 };
 
+}  // namespace
+namespace mcrt {
+const char* ctxOpt(const mcrt_ctx* ctx, const char* key) {
+    if (!ctx) return nullptr;
+    auto it = ctx->options.find(key);
+    return it == ctx->options.end() ? nullptr : it->second.c_str();
+}
+long ctxOptL(const mcrt_ctx* ctx, const char* key, long dflt) {
+    const char* v = ctxOpt(ctx, key);
+    return v ? atol(v) : dflt;
+}
+bool ctxOptOn(const mcrt_ctx* ctx, const char* key) {
+    const char* v = ctxOpt(ctx, key);
+    return v && atoi(v) != 0;
+}
+}  // namespace mcrt
+namespace {
+using mcrt::ctxOpt;
+using mcrt::ctxOptL;
+using mcrt::ctxOptOn;
+
 // MCRT_WF_WIDE=1: the trace kernel walks the eight-wide nodes (mcrt_wbvh.hpp) instead of the 4-wide blocks. Bit-identical frames;
 // measured on C3: 12.1 instead of 15.7 inner steps per ray but 7.0 instead of 6.1 leaf steps and a costlier step - 469 vs 466 ms
 // per 64-spp frame, so the 4-wide blocks stay the default.
 bool useWideNodes(const mcrt_ctx* ctx) {
-    const char* v = getenv("MCRT_WF_WIDE");
-    return ctx->scene.wnodes != nullptr && v && atoi(v) != 0;
+    return ctx->scene.wnodes != nullptr && ctxOptOn(ctx, "MCRT_WF_WIDE");
 }
 
 template <class K>
 int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false) {
-    auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
+    auto envi = [ctx](const char* k, long d) { return ctxOptL(ctx, k, d); };
     const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
     const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
@@ -286,7 +310,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
 // and the resolve is left to mcrt_film_resolve_device, after the caller has summed the shards' buffers.
 int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, double* d_out, hipStream_t stream,
                     bool count_tests, bool photon, double* film_out = nullptr) {
-    auto envi = [](const char* k, long d) { const char* v = getenv(k); return v ? atol(v) : d; };
+    auto envi = [ctx](const char* k, long d) { return ctxOptL(ctx, k, d); };
     WfFrame fr;
     memset(&fr, 0, sizeof(fr));
     fr.cam = *cam;
@@ -295,13 +319,13 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const uint32_t owned_rows = mcrt_shard_rows(cam, nullptr);
     fr.tiles_x = (cam->width + 7) / 8;
     fr.film.type = MCRT_FILM_BOX;
-    if (cam->film_filter != MCRT_FILM_BOX) {  // Film::Film(width, height, json), film.cpp:19-58
+    if (filmSplats(cam->film_filter, cam->film_radius)) {  // Film::Film(width, height, json), film.cpp:19-58
         if (cam->film_filter > MCRT_FILM_LANCZOS) return fail(ctx, MCRT_ERR_INVALID, "camera: unknown film filter");
         if (cam->shard_count > 1 && !film_out)
             return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters splat across row groups: render them unsharded (shard_count <= 1) "
                                                    "or with mcrt_render_film_device + mcrt_film_resolve_device");
         FilmView& f = fr.film;
-        f.type = cam->film_filter;
+        f.type = filmViewType(cam->film_filter);
         f.width = cam->width;
         f.height = cam->height;
         f.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);
@@ -341,7 +365,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool splats = fr.film.type != MCRT_FILM_BOX;
     uint64_t pass_rows = owned_rows;
     if (!splats) {
-        const PassPlan pp = planPasses(cam->width, owned_rows, fr.spp, sampleStoreGb());
+        const PassPlan pp = planPasses(cam->width, owned_rows, fr.spp, sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB")));
         pass_rows = pp.pass_rows;
         if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         fr.samples = ctx->samples.as<double>();
@@ -354,7 +378,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     slots = std::min<uint64_t>(slots, (std::max<uint64_t>(pixels * fr.spp / 64, 1) + kWfBlock - 1) / kWfBlock * kWfBlock);
     slots = std::max<uint64_t>(slots, kWfBlock);
     {
-        const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels));
+        const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
         fr.chunk_shift = cp.shift;
         fr.chunk = cp.chunk;
     }
@@ -493,7 +517,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
                 if (photon)  // (one half only) requests count as work too
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + 1, ctrl + 4 + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
                 HIP_TRY(ctx, hipStreamSynchronize(hs[h]));
-                static const bool wf_log = getenv("MCRT_WF_LOG") && atoi(getenv("MCRT_WF_LOG")) != 0;  // queue length over the frame
+                const bool wf_log = ctxOptOn(ctx, "MCRT_WF_LOG");  // queue length over the frame
                 if (wf_log)
                     fprintf(stderr, "[mcrt wf] iteration %llu queued %llu at %.2f ms\n", (unsigned long long)it, ctx->wf_host[h],
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
@@ -555,7 +579,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     if (ctx->pending) return fail(ctx, MCRT_ERR_INVALID, "a render is already in flight: call mcrt_render_finish");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    static const bool count_tests = getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0;
+    const bool count_tests = ctxOptOn(ctx, "MCRT_COUNT_TESTS");
     using KernelT = void (*)(const DeviceScene, const RenderParams);
     const bool all = ctx->scene.stage_all != 0;
     constexpr int PT = MCRT_INTEGRATOR_PATH_TRACER, PM = MCRT_INTEGRATOR_PHOTON_MAPPER;
@@ -563,9 +587,9 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         {{renderKernel<PT, false, false>, renderKernel<PT, false, true>}, {renderKernel<PT, true, false>, renderKernel<PT, true, true>}},
         {{renderKernel<PM, false, false>, renderKernel<PM, false, true>}, {renderKernel<PM, true, false>, renderKernel<PM, true, true>}}};
     KernelT kernel = table[photon ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
-    static const bool profile_phases = getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0;
+    const bool profile_phases = ctxOptOn(ctx, "MCRT_PROFILE_PHASES");
     if (profile_phases && !photon) kernel = all ? renderKernel<PT, false, true, true> : renderKernel<PT, false, false, true>;
-    const bool flat_only = !photon && ctx->scene.flat && ctx->scene.flat_pre && all && !count_tests && !profile_phases && !(getenv("MCRT_FLAT_GENERIC") && atoi(getenv("MCRT_FLAT_GENERIC")));
+    const bool flat_only = !photon && ctx->scene.flat && ctx->scene.flat_pre && all && !count_tests && !profile_phases && !ctxOptOn(ctx, "MCRT_FLAT_GENERIC");
     // Flat-mode scenes get their own instance of the kernel: without the BVH walk in the code it needs no traversal stack
     // (64 KB of LDS at 512 lanes), so a CU can hold more waves; measured on the C2 frame (ms): generic instance 862,
     // flat instance with 512 lanes (2 waves/SIMD, 256 VGPRs, no scratch) 795, 768 lanes (3, 168 VGPRs, 336 B/lane of
@@ -574,33 +598,31 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     // With the FP32 cull in front of the FP64 tests (mcrt_scene.hpp) the order is reversed: 512 lanes 448.7 ms, 768 lanes 455.8,
     // 1024 lanes 485.2 (split next-event estimate: 454 / 493 / 563) — fewer instructions per ray, and the spills of the
     // narrow instances (107 / 169 VGPRs) now cost more than the extra waves hide.
-    const int flat_block = getenv("MCRT_FLAT_BLOCK") ? atoi(getenv("MCRT_FLAT_BLOCK")) : 512;
+    const int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", 512);
     if (flat_only)
         kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
     // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
     // wave-synchronous one for A/B runs)
-    const char* kenv = getenv("MCRT_KERNEL");
+    const char* kenv = ctxOpt(ctx, "MCRT_KERNEL");
     const bool use_sm = !photon && !ctx->scene.flat && !(kenv && strcmp(kenv, "legacy") == 0);
     // ... and when the tree lives in HBM, the wavefront pipeline (MCRT_KERNEL=sm keeps the megakernel, MCRT_KERNEL=wf
     // forces the wavefront pipeline for any scene that has a BVH)
-    const bool filtered = cam->film_filter != MCRT_FILM_BOX;  // per-sample splats: the wavefront pipeline's shade kernel has them
+    const bool filtered = filmSplats(cam->film_filter, cam->film_radius);  // per-sample splats: the wavefront pipeline's shade kernel has them
     if (film_out && !filtered)
-        return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for frames with a reconstruction filter (film_filter != box)");
+        return fail(ctx, MCRT_ERR_INVALID, "mcrt_render_film_device is for splatted frames (a reconstruction filter, or the box filter with a radius other than 0.5)");
     // (a scene without a BVH is walked through a tree over index ranges by the pipeline's trace kernel, mcrt_layout.hpp)
     const bool has_tree = ctx->scene.q_nodes > 0;
     if (filtered && !has_tree)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters need the wavefront pipeline, and this scene has neither a BVH nor finite surface bounds to build its stand-in from");
     // Film::Film(w, h, json) with "filter": "box" and a radius other than the default 0.5 splats too (film.cpp:27-30); that case
     // is not built, so it is refused rather than rendered as the default box
-    if (!filtered && cam->film_radius != 0.0 && cam->film_radius != 0.5)
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "box film filter with a radius other than 0.5 (film_radius 0 = default) is not supported");
     if (filtered && photon && ctx->k_nearest > 128)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters on photon-mapped frames need k_nearest_photons <= 128 (wavefront pipeline)");
     const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
-    const char* mn = getenv("MCRT_WF_MIN_NODES");
+    const char* mn = ctxOpt(ctx, "MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
     if (!photon && has_tree && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false, film_out);
@@ -618,13 +640,13 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
                                                {renderKernelSM<true, false>, renderKernelSM<true, true>}};
         kernel = sm_table[count_tests ? 1 : 0][all ? 1 : 0];
         if (profile_phases) kernel = all ? renderKernelSM<false, true, true> : renderKernelSM<false, false, true>;
-        const int want = getenv("MCRT_SM_BLOCK") ? atoi(getenv("MCRT_SM_BLOCK")) : (int)kBlock;
+        const int want = (int)ctxOptL(ctx, "MCRT_SM_BLOCK", (long)kBlock);
         if (!all && !count_tests && !profile_phases && (want == 768 || want == 1024)) {
             sm_block = want;
             sm_depth = want == 768 ? 8 : 6;
             kernel = want == 768 ? renderKernelSM<false, false, false, 768> : renderKernelSM<false, false, false, 1024>;
         }
-        if (getenv("MCRT_SM_STACK")) sm_depth = std::min(std::max(atoi(getenv("MCRT_SM_STACK")), 2), (int)kLdsStackDepth);
+        if (ctxOpt(ctx, "MCRT_SM_STACK")) sm_depth = std::min(std::max((int)ctxOptL(ctx, "MCRT_SM_STACK", 0), 2), (int)kLdsStackDepth);
     }
 
     // photon mapping: wave-cooperative estimates unless k is too large for the per-wave buffer
@@ -632,7 +654,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
     PmKernelT pm_kernel = nullptr;
     DeviceScene launch_scene = ctx->scene;
-    if (getenv("MCRT_FLAT_CULL") && atoi(getenv("MCRT_FLAT_CULL")) == 0) launch_scene.flat_pre = nullptr;  // A/B: every primitive in FP64
+    if (ctxOpt(ctx, "MCRT_FLAT_CULL") && !ctxOptOn(ctx, "MCRT_FLAT_CULL")) launch_scene.flat_pre = nullptr;  // A/B: every primitive in FP64
     LaunchGeom g;
     uint32_t pm_stack_depth = kLdsStackDepth;
     if (use_pm_wave) {
@@ -644,7 +666,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         // 1024 lanes per workgroup (4 waves per SIMD) when the LDS plan allows it: flat scenes have no traversal stack; a tree in
         // HBM is walked with the state machine's stack, of which then only a few entries per lane stay in LDS (the rest
         // spills to HBM); a staged BVH walked by the wave-synchronous code needs its 16 entries (512 lanes).
-        const int want = getenv("MCRT_PM_BLOCK") ? atoi(getenv("MCRT_PM_BLOCK")) : 1024;
+        const int want = (int)ctxOptL(ctx, "MCRT_PM_BLOCK", 1024);
         g.block = kBlock;
         // (the 1024-lane instance keeps two refraction-history entries per lane in LDS, the deeper ones in global memory)
         auto ldsBytes = [&](uint32_t block, uint32_t depth) {
@@ -654,7 +676,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= ctx->max_lds) {
                 g.block = 1024;
             } else if (!launch_scene.stage_all) {
-                const uint32_t depth_max = getenv("MCRT_PM_STACK") ? (uint32_t)std::max(2, atoi(getenv("MCRT_PM_STACK"))) & ~1u : 16u;
+                const uint32_t depth_max = ctxOpt(ctx, "MCRT_PM_STACK") ? (uint32_t)std::max(2, (int)ctxOptL(ctx, "MCRT_PM_STACK", 16)) & ~1u : 16u;
                 for (uint32_t depth = depth_max; depth >= 2 && g.block == kBlock; depth -= 2)
                     if (ldsBytes(1024, depth) <= ctx->max_lds) {
                         g.block = 1024;
@@ -708,7 +730,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     prm.spill = ctx->spill.as<StackEntry>();
     prm.total_lanes = g.total_lanes;
     {
-        auto envi = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
+        auto envi = [ctx](const char* k, int d) { return (int)ctxOptL(ctx, k, d); };
         prm.sm_shade_lanes = envi("MCRT_SM_SHADE", 40);
         prm.sm_regen_lanes = envi("MCRT_SM_REGEN", 16);
         prm.sm_min_trav = envi("MCRT_SM_MINTRAV", 20);
@@ -749,7 +771,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
         // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
         // store holds (MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB), each pass = one
         // integrator launch + the in-order resolve.
-        const PassPlan pp = planPasses(cam->width, prm.owned_rows, prm.spp, sampleStoreGb());
+        const PassPlan pp = planPasses(cam->width, prm.owned_rows, prm.spp, sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB")));
         const uint64_t pass_rows = pp.pass_rows;
         if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         prm.samples = ctx->samples.as<double>();
@@ -773,7 +795,7 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
             // units per pixel: a power of two that gives every resident lane >= 128 units, chunks of at least 4 samples
             // (measured on the 1080p @ 256 spp frame, ms per shard for 1 / 8 shards: whole pixels 887 / 162, 2 chunks
             // 864 / 133, 8 chunks 848 / 111, 64 chunks 844 / 107)
-            const ChunkPlan cp = planChunks(prm.spp, unitsWanted(g.total_lanes, 128, prm.pass_pixels));
+            const ChunkPlan cp = planChunks(prm.spp, unitsWanted(g.total_lanes, 128, prm.pass_pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
             const uint32_t shift = cp.shift;
             prm.chunk_shift = cp.shift;
             prm.chunk = cp.chunk;
@@ -908,6 +930,13 @@ int mcrt_create(mcrt_ctx** out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess)
         return fail(nullptr, MCRT_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     mcrt_ctx* ctx = new mcrt_ctx();
+    // The MCRT_* environment variables seed the context's options HERE, once; afterwards only mcrt_set_option changes them
+    // (no getenv on the launch path).
+    for (char** e = environ; e && *e; e++) {
+        if (strncmp(*e, "MCRT_", 5) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        if (eq) ctx->options[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->max_lds = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 65536;
@@ -951,6 +980,15 @@ void mcrt_destroy(mcrt_ctx* ctx) {
 
 const char* mcrt_last_error(const mcrt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+int mcrt_set_option(mcrt_ctx* ctx, const char* key, const char* value) {
+    if (!ctx || !key || strncmp(key, "MCRT_", 5) != 0) return ctx ? fail(ctx, MCRT_ERR_INVALID, "mcrt_set_option: keys are the MCRT_* names of include/mcrt.h") : MCRT_ERR_INVALID;
+    if (value) ctx->options[key] = value;
+    else ctx->options.erase(key);
+    return MCRT_OK;
+}
+
+const char* mcrt_get_option(const mcrt_ctx* ctx, const char* key) { return (ctx && key) ? mcrt::ctxOpt(ctx, key) : nullptr; }
+
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!s || s->abi_version != MCRT_ABI_VERSION) return fail(ctx, MCRT_ERR_INVALID, "scene descriptor: wrong abi_version");
@@ -967,7 +1005,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     const size_t ns = s->num_surfaces;
     HostLayout L;
     std::string lerr;
-    if (int rc = buildLayout(s, L, lerr)) return fail(ctx, rc, lerr);
+    if (int rc = buildLayout(s, L, lerr, ctxOptOn(ctx, "MCRT_LEAF_CULL"))) return fail(ctx, rc, lerr);
     const bool any_vn = L.any_vn;
     std::vector<double>& prim = L.prim;
     std::vector<double>& normal = L.normal;
@@ -980,7 +1018,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
     // leaf cull (mcrt_lanesm.hpp): built and bit-exact, measured SLOWER inside the wave-level steps (C3 466 -> 544 ms, spaceship
     // 318 -> 385 ms: a wave still runs the exact test whenever one of its lanes has a survivor) - off unless MCRT_LEAF_CULL=1
-    const bool leaf_cull = !L.leaf_pre.empty() && getenv("MCRT_LEAF_CULL") && atoi(getenv("MCRT_LEAF_CULL")) != 0;
+    const bool leaf_cull = !L.leaf_pre.empty();
     if (!leaf_cull) ctx->leaf_pre.release();
     else if (int rc = uploadArray(ctx, ctx->leaf_pre, L.leaf_pre.data(), L.leaf_pre.size())) return rc;
     if (L.wnodes.empty()) ctx->wnodes.release();
@@ -1074,7 +1112,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     // its own node sequence) than it saves in tests. With <= MCRT_FLAT_MAX primitives (default 64) all
     // lanes test all primitives in one wave-uniform loop, as Scene::intersect does without a "bvh" key
     // (scene.cpp:161-173); the closest hit is the same.
-    const char* fm = getenv("MCRT_FLAT_MAX");
+    const char* fm = ctxOpt(ctx, "MCRT_FLAT_MAX");
     const uint32_t flat_max = fm ? (uint32_t)strtoul(fm, nullptr, 0) : 64u;
     d.flat = (d.stage_all && d.num_surfaces <= flat_max && !L.flat_prim.empty() && L.num_quadric_surfaces == 0) ? 1u : 0u;  // the flat loop knows triangles and spheres
     ctx->has_scene = true;
@@ -1146,7 +1184,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     unsigned long long h[kStatsWords];
     HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (getenv("MCRT_PROFILE_PHASES") && atoi(getenv("MCRT_PROFILE_PHASES")) != 0) {
+    if (ctxOptOn(ctx, "MCRT_PROFILE_PHASES")) {
         static const char* names[kNumPhases] = {"regen", "trav/inner", "shade", "shadow/leaf", "sample", "loop"};
         unsigned long long tw = 0;
         for (int i = 0; i < kNumPhases; i++) tw += h[8 + i];
@@ -1154,13 +1192,13 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
             fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
                     h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
     }
-    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0)
+    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt trace] per wave iteration: %.1f lanes hold a ray; inner step in %.1f%% of the iterations with %.1f lanes, leaf step in %.1f%% with %.1f lanes, "
                         "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%%; per ray: %.2f inner steps, %.2f leaf steps\n",
                 (double)h[9] / h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
                 (double)h[14] / h[8], 100.0 * h[15] / (double)h[17], 100.0 * h[16] / (double)h[17], 100.0 * (h[17] - h[15] - h[16]) / (double)h[17],
                 (double)h[11] / (double)(h[1] ? h[1] : 1), (double)h[13] / (double)(h[1] ? h[1] : 1));
-    if (ctx->kernel_id == MCRT_KERNEL_PM_WAVE && h[9] && getenv("MCRT_COUNT_TESTS") && atoi(getenv("MCRT_COUNT_TESTS")) != 0)
+    if (ctx->kernel_id == MCRT_KERNEL_PM_WAVE && h[9] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt pm] wave cycles inside the radiance estimates: %.1f%% of the kernel (%llu searches, %.1f octants per search)\n",
                 100.0 * (double)h[8] / (double)h[9], h[4], h[4] ? (double)h[6] / (double)h[4] : 0.0);
     float ms = 0.f;
@@ -1178,6 +1216,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_id = ctx->kernel_id;
     }
     if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
+    if (h[7]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "a path entered more than 8 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to 8 entries per lane)");
     return MCRT_OK;
 }
 
@@ -1458,7 +1497,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         ta.count = ctx->wf_ctrl.as<unsigned long long>();
         ta.pop = ctx->wf_ctrl.as<unsigned long long>() + 2;
         ArrayRays ar{ds.as<double>(), dd.as<double>(), dt.as<double>(), dsf.as<uint32_t>(), duv.as<double>()};
-        const bool op_time = getenv("MCRT_OP_TIME") && atoi(getenv("MCRT_OP_TIME")) != 0;  // kernel time of the operator to stderr
+        const bool op_time = ctxOptOn(ctx, "MCRT_OP_TIME");  // kernel time of the operator to stderr
         if (op_time) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, ctx->stream, ta, ar);
         HIP_TRY(ctx, hipGetLastError());
@@ -1557,7 +1596,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
     if (n == 0) return MCRT_OK;
     if (!p || !out_count || !out_index || !out_distance2) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const char* kenv = getenv("MCRT_KERNEL");
+    const char* kenv = ctxOpt(ctx, "MCRT_KERNEL");
     if (k <= 128 && !(kenv && strcmp(kenv, "legacy") == 0)) {  // wave-cooperative search (mcrt_waveknn.hpp)
         DevBuf &dp = ctx->op_buf[0], &dc = ctx->op_buf[1], &di = ctx->op_buf[2], &dd = ctx->op_buf[3], &flags = ctx->op_buf[4];
         if (int rc = uploadInto(ctx, dp, p, n * 3)) return rc;
@@ -1568,10 +1607,10 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
         const PhotonMapViewW mv = waveMapView(ctx, which);
         // MCRT_KNN_BLOCKS: 256-lane workgroups per CU (occupancy experiments); MCRT_KNN_TIME=1: kernel time on stderr
-        const int per_cu = getenv("MCRT_KNN_BLOCKS") ? std::max(1, atoi(getenv("MCRT_KNN_BLOCKS"))) : 8;
+        const int per_cu = std::max(1, (int)ctxOptL(ctx, "MCRT_KNN_BLOCKS", 8));
         const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu, (n + 3) / 4);
         // MCRT_KNN_GROUPS=1: four queries per wave, one per row of 16 lanes (mcrt_groupknn.hpp)
-        const bool groups = k <= kGrpMaxK && getenv("MCRT_KNN_GROUPS") && atoi(getenv("MCRT_KNN_GROUPS")) != 0;
+        const bool groups = k <= kGrpMaxK && ctxOptOn(ctx, "MCRT_KNN_GROUPS");
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (groups)
             hipLaunchKernelGGL(knnGroupKernel, dim3(std::min<uint32_t>(grid, (uint32_t)((n + 15) / 16))), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k,
@@ -1582,7 +1621,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (getenv("MCRT_KNN_TIME") && atoi(getenv("MCRT_KNN_TIME")) != 0) {
+        if (ctxOptOn(ctx, "MCRT_KNN_TIME")) {
             float ms = 0.f;
             HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             fprintf(stderr, "[mcrt knn] map %d: %llu searches, k = %u, %d workgroups per CU: %.3f ms = %.1f M searches/s\n", which,

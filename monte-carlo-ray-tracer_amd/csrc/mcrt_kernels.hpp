@@ -424,6 +424,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
     }
     waveAccumulate(prm.stats + 4, searches);
     waveAccumulate(prm.stats + 5, cnt.overflow);
+    waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     waveAccumulate(prm.stats + 6, octant_visits);
     if constexpr (kProf) {
         prof.mark(kPhLoop);
@@ -703,6 +704,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
         waveAccumulate(prm.stats + 3, cnt.prim_tests);
     }
     waveAccumulate(prm.stats + 5, cnt.overflow);
+    waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     if constexpr (kProf) {
         for (int i = 0; i < kNumPhases; i++) {
             atomicAdd(prm.stats + 8 + i, prof.wave_cycles[i]);
@@ -1052,6 +1054,7 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
     uint32_t paths = 0;
     wfShadeSlot<false, kPhoton>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
     waveAccumulate(a.stats + 0, paths);
+    waveAccumulate(a.stats + 7, rh.overflow ? 1u : 0u);
 }
 
 // The per-sample store of renderKernel / renderKernelSM -> image: rgb_sum += radiance * 1 in sample order (Film::deposit /
@@ -1351,6 +1354,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
     }
     waveAccumulate(prm.stats + 4, searches);
     waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
+    waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     waveAccumulate(prm.stats + 6, octant_visits);
     if (kCount && __lane_id() == 0) {
         atomicAdd(prm.stats + 8, cyc_est);

@@ -553,7 +553,7 @@ inline void synthRangeTree(const mcrt_scene_desc* s, std::vector<double>& bounds
     if (ns) Rec::build(0u, ns, sb, bounds, start, count, next);
 }
 
-inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err) {
+inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err, bool leaf_cull = false) {
     const size_t ns = s->num_surfaces;
     L.prim.assign(ns * kPrimStride, 0.0);
     L.normal.assign(ns * 3, 0.0);
@@ -615,7 +615,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             slot++;
             if (!sphere) L.flat_tris++;
         }
-    if (getenv("MCRT_LEAF_CULL") && atoi(getenv("MCRT_LEAF_CULL")) != 0) buildLeafCull(L, ns);  // (option, see mcrt_upload_scene; 64 bytes per primitive)
+    if (leaf_cull) buildLeafCull(L, ns);  // (option MCRT_LEAF_CULL, see mcrt_upload_scene; 64 bytes per primitive)
     else L.leaf_pre.clear();
     if (flat_possible) buildFlatCull(L, (uint32_t)ns);
     else {

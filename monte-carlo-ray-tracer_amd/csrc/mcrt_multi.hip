@@ -25,7 +25,7 @@ extern "C" int mcrt_render_multi(mcrt_ctx* const* ctxs, uint32_t count, const mc
     if (!cam || !out_rgb) return ctxFail(first, MCRT_ERR_INVALID, "mcrt_render_multi: cam or out_rgb is NULL");
     for (uint32_t i = 0; i < count; i++)
         if (!ctxs[i]) return ctxFail(first, MCRT_ERR_INVALID, "mcrt_render_multi: NULL context");
-    const bool splats = cam->film_filter != MCRT_FILM_BOX;
+    const bool splats = filmSplats(cam->film_filter, cam->film_radius);
     const size_t pixels = (size_t)cam->width * cam->height;
 
     std::vector<int> rc(count, MCRT_OK);

@@ -42,15 +42,15 @@ inline ChunkPlan planChunks(uint32_t spp, uint64_t want) {
     return c;
 }
 
-// Units per pixel that give each of `consumers` (resident lanes, pool slots) `per_consumer` units; MCRT_CHUNKS overrides.
-inline uint64_t unitsWanted(uint64_t consumers, uint64_t per_consumer, uint64_t pass_pixels) {
-    if (const char* e = getenv("MCRT_CHUNKS")) return strtoull(e, nullptr, 0);
+// Units per pixel that give each of `consumers` (resident lanes, pool slots) `per_consumer` units; the option MCRT_CHUNKS
+// (`chunks_override`, its value or null) overrides.
+inline uint64_t unitsWanted(uint64_t consumers, uint64_t per_consumer, uint64_t pass_pixels, const char* chunks_override = nullptr) {
+    if (chunks_override) return strtoull(chunks_override, nullptr, 0);
     return (per_consumer * consumers + pass_pixels - 1) / pass_pixels;
 }
 
-inline double sampleStoreGb() {  // MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB
-    const char* e = getenv("MCRT_SAMPLE_STORE_GB");
-    return e ? atof(e) : 16.0;
+inline double sampleStoreGb(const char* option = nullptr) {  // option MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB
+    return option ? atof(option) : 16.0;
 }
 
 }  // namespace mcrt

@@ -235,7 +235,7 @@ inline uint32_t gridFor(uint64_t n, uint32_t block = 256) { return (uint32_t)((n
 }  // namespace
 
 int mcrt::bvhSahGpu(mcrt_ctx* ctx, const mcrt_scene_desc* s, int arity, int bins, mcrt_bvh* B) {
-    const bool timing = getenv("MCRT_SAH_TIME") && atoi(getenv("MCRT_SAH_TIME")) != 0;  // phase times to stderr
+    const bool timing = ctxOptOn(ctx, "MCRT_SAH_TIME");  // phase times to stderr
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();

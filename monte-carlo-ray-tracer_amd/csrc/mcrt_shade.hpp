@@ -196,6 +196,7 @@ struct RefractionHistory {
     double* giors = nullptr;
     uint32_t gstride = 0;
     int lds_depth = kMaxIors;  // entries [0, lds_depth) in LDS, the rest (nesting deeper than that: rare) in giors
+    bool overflow = false;     // a medium was entered at nesting depth kMaxIors: reported by mcrt_render_finish (the reference's vector is unbounded)
     MCRT_HD double at(int i) const { return i < lds_depth ? iors[(uint32_t)i * stride] : giors[(size_t)(i - lds_depth) * gstride]; }
     MCRT_HD void put(int i, double v) {
         if (i < lds_depth) iors[(uint32_t)i * stride] = v;
@@ -209,6 +210,7 @@ struct RefractionHistory {
         if (ray.refraction_level > 0) {
             if (ray.refraction_level == size) {
                 if (size < kMaxIors) put(size++, ray.medium_ior);
+                else overflow = true;
             } else if (ray.refraction_level < size - 1) {
                 size--;
             }

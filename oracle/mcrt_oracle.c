@@ -1154,7 +1154,9 @@ int oracle_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* glob
     if (threads <= 0) threads = oracle_hardware_threads();
     if (threads > 1024) threads = 1024;
     Film film; memset(&film, 0, sizeof(film));
-    if (cam->film_filter != MCRT_FILM_BOX) { /* Film::Film(width, height, json), film.cpp:19-58 */
+    /* splats for every filter but the default box; a box with another radius than 0.5 splats too (film.cpp:44-46: the radius is
+       read after the filter is chosen, Filter::box is 1 everywhere) */
+    if (cam->film_filter != MCRT_FILM_BOX || (cam->film_radius != 0.0 && cam->film_radius != 0.5)) { /* Film::Film(width, height, json), film.cpp:19-58 */
         film.type = cam->film_filter; film.width = cam->width; film.height = cam->height;
         film.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);
         film.two_inv_radius = 2.0 / film.radius;

@@ -46,7 +46,7 @@
 #include "surface/surface.hpp"
 
 #include "../include/mcrt.h"
-#include "../tests/integration/ref_flatten.hpp"
+#include "../integration/ref_flatten.hpp"
 
 namespace {
 
@@ -157,7 +157,7 @@ nlohmann::json loadScene(Args& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// flatten: tests/integration/ref_flatten.hpp (Flat, FlatMap, flattenScene, flattenMap, flattenCamera)
+// flatten: integration/ref_flatten.hpp (Flat, FlatMap, flattenScene, flattenMap, flattenCamera)
 // ---------------------------------------------------------------------------------------------
 void writeRaw(const std::string& path, const void* data, size_t nbytes) {
     FILE* f = std::fopen(path.c_str(), "wb");

@@ -49,7 +49,7 @@ struct Emu {
 int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     const bool stage_lds = stage_mode != 0;
     std::string err;
-    if (int rc = buildLayout(s, E.L, err)) return rc;
+    if (int rc = buildLayout(s, E.L, err, getenv("MCRT_LEAF_CULL") && atoi(getenv("MCRT_LEAF_CULL")) != 0)) return rc;  // (test harness: the environment is its option channel)
     patchQuadricAddresses(s, E.L, s->quadrics);  // quadric records are read where the descriptor keeps them
     E.tab.resize(kSobolTableWords);
     buildSobolByteTables(E.tab.data());
@@ -515,7 +515,7 @@ int emu_render_wf_pm(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* g
 // mcrt_render_film_device / mcrt_film_resolve_device: one shard's splats into a full-frame RGBW buffer; Splat::get over a buffer
 int emu_render_wf_film(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uint32_t global_seed, uint32_t slots, uint32_t owned_rows,
                        double* rgbw) {
-    if (cam->film_filter == MCRT_FILM_BOX) return -201;
+    if (!filmSplats(cam->film_filter, cam->film_radius)) return -201;
     return renderWf(scene, nullptr, nullptr, 0, 0, cam, global_seed, slots, owned_rows, nullptr, nullptr, rgbw);
 }
 
@@ -582,9 +582,9 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     std::vector<double> samples;
     fr.film.type = MCRT_FILM_BOX;
     std::vector<double> blob, cache;
-    if (cam->film_filter != MCRT_FILM_BOX) {  // as launchWavefront sets the film up
+    if (filmSplats(cam->film_filter, cam->film_radius)) {  // as launchWavefront sets the film up
         FilmView& f = fr.film;
-        f.type = cam->film_filter;
+        f.type = filmViewType(cam->film_filter);
         f.width = cam->width;
         f.height = cam->height;
         f.radius = cam->film_radius > 0.0 ? cam->film_radius : filmDefaultRadius(cam->film_filter);

@@ -82,6 +82,10 @@ CASES = [
     dict(name="film_gaussian_nobvh", scene="ior_test.json", args=["--film-filter", "gaussian"],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="gaussian_96x54_s3", width=96, height=54, sqrtspp=3)]),
+    # ... the box filter with a radius other than its default 0.5 (film.cpp:44-46: still Filter::box = 1, over a wider window)
+    dict(name="film_box_wide", scene="hexagon_room.json", args=["--film-filter", "box", "--film-radius", "1.3"],
+         image=dict(width=96, height=54, sqrtspp=3),
+         renders=[dict(tag="boxwide_96x54_s3", width=96, height=54, sqrtspp=3)]),
     # ... and on a photon-mapped frame
     dict(name="film_mitchell_pm", scene="hexagon_room.json", photon=True, args=["--emissions", "4000", "--film-filter", "mitchell-netravali"],
          image=dict(width=96, height=72, sqrtspp=2),

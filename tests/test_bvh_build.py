@@ -109,7 +109,7 @@ def test_level_synchronous_sah_equals_recursive_on_awkward_input(pkg):
 def test_large_scene_sah(pkg, name, nodes):
     """Quaternary SAH trees of the full-size C3 / C4 stand-ins and of the spaceship cockpit, all host threads."""
     import time
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     p = make_large.image_path(name) if name != "spaceship" else os.path.join(ROOT, "oracle", "_ref", "images", "spaceship.mcrt")
     if not os.path.exists(p):
@@ -159,7 +159,7 @@ def test_shuffled_surfaces_give_the_same_hits(pkg, oracle, manifest):
 
 def test_large_scene_octree(pkg):
     """The 6.9 M-triangle C5 stand-in (octree BVH built by the reference, 1 925 901 nodes), host path."""
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     p = make_large.image_path("c5")
     if not os.path.exists(p):
@@ -191,7 +191,7 @@ def test_gpu_path_rebuilds_the_reference_sah_bvh(pkg, manifest, name, kind):
 @pytest.mark.parametrize("name,nodes", [("c3", 169162), ("c4", 153801)])
 def test_gpu_path_large_scene_sah(pkg, name, nodes):
     import time
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     p = make_large.image_path(name)
     if not os.path.exists(p) and make_large.ensure_image(name) is None:
@@ -216,7 +216,7 @@ def test_gpu_path_large_scene_sah(pkg, name, nodes):
 def test_gpu_path_large_scene_and_render(pkg):
     """C5 stand-in: GPU-assisted build equals the reference's tree; timing printed."""
     import time
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     p = make_large.ensure_image("c5")
     if p is None:

@@ -9,7 +9,8 @@ import pytest
 
 from conftest import camera_for, golden_path, load_radiance, rel_error
 
-CASES = ["film_mitchell", "film_gaussian_cached", "film_lanczos", "film_gaussian_nobvh"]  # the last: a scene without a BVH
+# film_gaussian_nobvh: a scene without a BVH; film_box_wide: the box filter with radius 1.3 (film.cpp:44-46: it splats like the others)
+CASES = ["film_mitchell", "film_gaussian_cached", "film_lanczos", "film_gaussian_nobvh", "film_box_wide"]
 TOL = 1e-12
 
 
@@ -23,7 +24,7 @@ def _case(pkg, manifest, name):
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_film_equals_reference(pkg, oracle, manifest, name):
     img, cam, r = _case(pkg, manifest, name)
-    assert cam.film_filter != 0 and cam.film_radius > 0
+    assert (cam.film_filter != 0 or name == "film_box_wide") and cam.film_radius > 0
     out, _ = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
     assert rel_error(out, load_radiance(r)).max() < TOL
 
@@ -36,7 +37,8 @@ def test_filter_is_not_a_no_op(pkg, oracle, manifest):
     assert rel_error(out, load_radiance(r)).max() > 1e-3
 
 
-@pytest.mark.parametrize("name,slots", [("film_mitchell", 777), ("film_gaussian_cached", 100000), ("film_lanczos", 64), ("film_gaussian_nobvh", 500)])
+@pytest.mark.parametrize("name,slots", [("film_mitchell", 777), ("film_gaussian_cached", 100000), ("film_lanczos", 64), ("film_gaussian_nobvh", 500),
+                                        ("film_box_wide", 333)])
 def test_wavefront_device_code_film(pkg, emu, manifest, name, slots):
     """mcrt_film.hpp + the splat branch of wfShadeSlot, host build."""
     img, cam, r = _case(pkg, manifest, name)
@@ -55,7 +57,7 @@ def test_gpu_film_matches_reference(pkg, manifest, name):
     out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     rel = rel_error(out, load_radiance(r)).max(axis=2)
     print("%s: max rel %.3e" % (name, rel.max()))
-    assert (rel > 1e-4).sum() <= max(2, int(0.002 * rel.size)) and np.quantile(rel, 0.99) < 1e-9
+    assert rel.max() < 1e-9  # (atomics: the order of a splat's additions is not the reference's; exp / sin of the uncached Gaussian / Lanczos)
     assert st["kernel_launches"] > 2  # the wavefront pipeline
     ctx.close()
 

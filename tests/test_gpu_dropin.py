@@ -1,6 +1,6 @@
 """The drop-in, run for real: oracle/_ref/mcrt_ref_gpu is the reference's OWN main() and all of its translation units, compiled
 unmodified (oracle/Makefile, target `dropin`), with ONE function replaced — Camera::sampleImage() (camera/camera.cpp:101-145) —
-by tests/integration/camera_sample_image_gpu.cpp, which flattens the reference's Scene / BVH / photon maps / Camera and renders
+by integration/camera_sample_image_gpu.cpp, which flattens the reference's Scene / BVH / photon maps / Camera and renders
 through libmcrt_hip.so. The binary is driven the way a user drives the reference: a directory of scene files as argv, the menu
 answers on stdin; Camera::capture() then calls the GPU sampleImage and the reference's own Image::save writes `<savename>.tga`.
 

@@ -1,6 +1,6 @@
 """The out-of-LDS traversal path on a real BVH: spaceship.json (quaternary SAH built by the reference,
 23 187 nodes / 68 760 triangles / 354 emissive triangles): top 512 nodes staged in LDS, everything else
-read from HBM/L2. Fixture made by tests/large/make_large.py (reference output, not committed: 17 MB)."""
+read from HBM/L2. Fixture made by integration/large_scenes/make_large.py (reference output, not committed: 17 MB)."""
 import os
 
 import numpy as np
@@ -56,18 +56,18 @@ def test_spaceship_traversal_equals_oracle(pkg, oracle, spaceship):
     ctx.close()
 
 
-# ---- BASELINE configs[2..4] at full size (stand-in meshes: tests/large/) ----
+# ---- BASELINE configs[2..4] at full size (stand-in meshes: integration/large_scenes/) ----
 
 def make_large_config(name):
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     return make_large.CONFIGS[name]
 
 
 def _config(pkg, name):
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
     import make_large
     p = make_large.ensure_image(name)  # flattened here by the reference's loader + BVH builder (5-60 s)
     if p is None:
@@ -80,7 +80,7 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
     @ 1024 spp; C5: 6 898 815 triangles, photon-mapped; baroque_table / lego_bulldozer / pipes: the reference's own scene
     files as far as their meshes exist (51 k / 123 k / 358 k triangles, up to 546 lights and 560 materials) — against the
-    reference's radiance for the same rows (committed goldens made by tests/large/make_large.py)."""
+    reference's radiance for the same rows (committed goldens made by integration/large_scenes/make_large.py)."""
     kernel = None
     if ":" in name:  # the same rows through the other kernel (default for these trees: the wavefront pipeline)
         name, kernel = name.split(":")

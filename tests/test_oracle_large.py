@@ -1,6 +1,6 @@
 """The oracle against the reference on BASELINE configs[2..4] at full size (C3 metal_bunnies
 quaternary SAH 1920x1080 @ 1024 spp, C4 spaceship 3840x2160 @ 1024 spp, C5 water_caustics photon map), the
-missing meshes replaced by the deterministic stand-ins of tests/large/: a few full-width rows of each frame,
+missing meshes replaced by the deterministic stand-ins of integration/large_scenes/: a few full-width rows of each frame,
 rendered by the reference itself at full resolution and spp (committed goldens), must come out of the oracle
 bit for bit. Runs wherever oracle/_ref holds the reference binary and the scene copies (build container, GPU
 box); about a minute on 8 cores plus, the first time, the flattening of the scenes."""
@@ -13,7 +13,7 @@ import pytest
 
 from conftest import ROOT, rel_error
 
-sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
 
 
 def test_synthetic_bunny_is_reproducible(tmp_path):

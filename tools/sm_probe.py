@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "large"))
+sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
 
 
 def main():
