@@ -441,8 +441,45 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
                             map_ms=dict(sort=ps["sort_ms"], octants=ps["octant_ms"], boxes_and_lists=ps["finish_ms"]),
                             octants=[int(ps["global_octants"]), int(ps["caustic_octants"])],
                             emission_Mray_per_s=ps["rays"] / max(ps["emission_ms"], 1e-9) / 1e3)
+    elif wl.photon and not args.host_octree:
+        # N > 1: every rank emits ITS shard of the emission paths, the lists stay in HBM (mcrt_emit_photons_device), ONE all-gather
+        # per map moves them between the GPUs on device pointers (RCCL over xGMI; counts first, then the padded lists), and every
+        # rank builds the same two maps from the concatenation (mcrt_upload_photons_device). No photon list touches the host.
+        wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
+        dev = torch.device("cuda", local_rank)
+        t_pass = time.perf_counter()
+        em = wl.ctx.emit_photons_device(wl.emissions, 10.0, SEED, rank, world)
+        wl.emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
+
+        class _DevList:  # a device pointer as a tensor, no copy
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n, 8), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        lists = []
+        for key in ("global_", "caustic"):
+            ptr, n = em[key]
+            ph = torch.as_tensor(_DevList(ptr, n), device=dev) if n else torch.zeros((0, 8), dtype=torch.float32, device=dev)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+            counts = [int(x.item()) for x in sizes]
+            cap = max(max(counts), 1)
+            pad = torch.zeros((cap, 8), dtype=torch.float32, device=dev)
+            pad[:n] = ph
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            lists.append(torch.cat([parts[r][: counts[r]] for r in range(world)]).contiguous())
+        sc = img.scene
+        t_build = time.perf_counter()
+        ps = wl.ctx.upload_photons_device(lists[0].data_ptr(), lists[0].shape[0], lists[1].data_ptr(), lists[1].shape[0], sc.bb_min[:], sc.bb_max[:],
+                                          200, 50, False)
+        torch.cuda.synchronize(dev)
+        wl.emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
+                            octree_build_s=time.perf_counter() - t_build, octree_builder="device (mcrt_upload_photons_device), lists all-gathered on device pointers",
+                            photon_pass_s=time.perf_counter() - t_pass, octants=[int(ps["global_octants"]), int(ps["caustic_octants"])],
+                            emission_Mray_per_s=wl.emit_info["rays"] / max(wl.emit_info["kernel_ms"], 1e-9) / 1e3)
+        del lists
     elif wl.photon:
-        # emission pass on the GPU (sharded over the ranks and all-gathered), octrees GPU-assisted, upload
+        # --host-octree: the lists over the host, the recursive host builder (A/B runs)
         wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
         em = wl.ctx.emit_photons(wl.emissions, 10.0, SEED, rank, world)
         wl.emit_info = dict(paths=em["paths"], rays=em["rays"], kernel_ms=em["kernel_ms"])
@@ -461,10 +498,9 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
             lists.append(ph.cpu().numpy())
         sc = img.scene
         t_build = time.perf_counter()
-        bctx = None if args.host_octree else wl.ctx
-        wl.pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200, ctx=bctx))
+        wl.pm_maps = (m.PhotonMap(lists[0], sc.bb_min[:], sc.bb_max[:], 200, ctx=None), m.PhotonMap(lists[1], sc.bb_min[:], sc.bb_max[:], 200, ctx=None))
         wl.emit_info.update(global_photons=int(lists[0].shape[0]), caustic_photons=int(lists[1].shape[0]),
-                            octree_build_s=time.perf_counter() - t_build, octree_builder="host" if args.host_octree else "gpu",
+                            octree_build_s=time.perf_counter() - t_build, octree_builder="host",
                             emission_Mray_per_s=wl.emit_info["rays"] / max(wl.emit_info["kernel_ms"], 1e-9) / 1e3)
         wl.ctx.upload_photons(wl.pm_maps[0].desc, wl.pm_maps[1].desc, 50, False)
     wl.my_rows = m.shard_rows(wl.cam)

@@ -374,22 +374,28 @@ int mcrt_bvh_build_sah_gpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, int arit
         return ctx ? ctxFail(ctx, MCRT_ERR_INVALID, "mcrt_bvh_build_sah_gpu: bad scene descriptor, arity or bin count") : MCRT_ERR_INVALID;
     if (bins > kSahMaxBins)
         return ctx ? ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "mcrt_bvh_build_sah_gpu: more than 16 bins per axis (mcrt_bvh_build_sah has no limit)") : MCRT_ERR_UNSUPPORTED;
-    mcrt_bvh* B = new mcrt_bvh();
-    int rc;
-    if (ctx) {
-        rc = bvhSahGpu(ctx, scene, arity, (int)bins, B);
-    } else {  // the same level-synchronous build with its passes as host loops
-        const uint64_t n = scene->num_surfaces;
-        std::vector<double> bb(n * 6), centroid(n * 3);
-        for (uint64_t i = 0; i < n; i++) {
-            surfaceBounds(scene->surf_kind[i], scene->surf_v + 9 * i, scene->quadrics, &bb[i * 6]);
-            for (int c = 0; c < 3; c++) centroid[i * 3 + c] = (bb[i * 6 + 3 + c] + bb[i * 6 + c]) / 2.0;  // BB().centroid()
+    mcrt_bvh* B = nullptr;
+    try {  // (no exception may cross the C boundary: an allocation failure in the level loop is an error code, and B is freed)
+        B = new mcrt_bvh();
+        int rc;
+        if (ctx) {
+            rc = bvhSahGpu(ctx, scene, arity, (int)bins, B);
+        } else {  // the same level-synchronous build with its passes as host loops
+            const uint64_t n = scene->num_surfaces;
+            std::vector<double> bb(n * 6), centroid(n * 3);
+            for (uint64_t i = 0; i < n; i++) {
+                surfaceBounds(scene->surf_kind[i], scene->surf_v + 9 * i, scene->quadrics, &bb[i * 6]);
+                for (int c = 0; c < 3; c++) centroid[i * 3 + c] = (bb[i * 6 + 3 + c] + bb[i * 6 + c]) / 2.0;  // BB().centroid()
+            }
+            rc = buildSahLevelsHost(bb.data(), centroid.data(), n, scene->bb_min, scene->bb_max, arity, (int)bins, B);
         }
-        rc = buildSahLevelsHost(bb.data(), centroid.data(), n, scene->bb_min, scene->bb_max, arity, (int)bins, B);
-    }
-    if (rc != MCRT_OK) {
+        if (rc != MCRT_OK) {
+            delete B;
+            return rc;
+        }
+    } catch (...) {
         delete B;
-        return rc;
+        return ctx ? ctxFail(ctx, MCRT_ERR_HIP, "mcrt_bvh_build_sah_gpu: out of memory") : MCRT_ERR_HIP;
     }
     *out = B;
     return MCRT_OK;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,18 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Work buffers that keep their allocation between calls: take() hands out the next buffer of the pool (the k-th take of a call
+// gets the buffer the k-th take of the previous call got), rewind() starts a call.
+struct DevPool {
+    std::vector<std::unique_ptr<DevBuf>> bufs;
+    size_t next = 0;
+    void rewind() { next = 0; }
+    DevBuf& take() {
+        if (next == bufs.size()) bufs.emplace_back(new DevBuf());
+        return *bufs[next++];
+    }
+};
+
 }  // namespace
 
 struct mcrt_ctx {
@@ -93,6 +106,7 @@ struct mcrt_ctx {
     DevBuf op_buf[6];
     std::map<std::string, std::string> options;  // mcrt_set_option; seeded from the MCRT_* environment variables at mcrt_create
     DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
+    DevPool pass_pool;  // work buffers of the device photon pass (mcrt_photon_device.hpp)
     DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
 
     // photon emission pass
@@ -1443,7 +1457,9 @@ int mcrt_photon_map_download(mcrt_ctx* ctx, int which, mcrt_photon_map** out) {
     if (!ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "mcrt_photon_map_download before the maps exist");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const PhotonMapView& v = ctx->maps[which];
-    mcrt_photon_map* M = new mcrt_photon_map();
+    mcrt_photon_map* M = nullptr;
+    try {  // (host copies of up to GBs: bad_alloc must not cross the C boundary)
+    M = new mcrt_photon_map();
     const size_t no = v.num_octants, np = (size_t)v.num_photons;
     if (no) {
         std::vector<uint32_t> start(no), contained(no);
@@ -1465,6 +1481,10 @@ int mcrt_photon_map_download(mcrt_ctx* ctx, int which, mcrt_photon_map** out) {
         M->contained.assign(contained.begin(), contained.end());
     }
     finishMapDesc(M);
+    } catch (...) {
+        delete M;
+        return fail(ctx, MCRT_ERR_HIP, "mcrt_photon_map_download: out of host memory");
+    }
     *out = M;
     return MCRT_OK;
 }

@@ -67,11 +67,16 @@ def _worker(rank, world, port, image, render, seed, photon, out_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,world,photon", [("hexagon_room", 2, False), ("hexagon_room", 3, False), ("coffee_maker_qsah", 2, False),
-                                               ("hexagon_room_pm", 2, True), ("hexagon_room_pm", 3, True)])
-def test_ranks_sharing_the_gpu_assemble_the_single_rank_frame(pkg, manifest, tmp_path, name, world, photon):
+# The last case is the shape of BASELINE configs[3] on N GPUs (bench.py --gpus N --workload c4): the wavefront pipeline, and a
+# per-sample store so small that every rank goes through its rows in MANY passes (integrator launches + resolve per pass).
+@pytest.mark.parametrize("name,world,photon,env", [("hexagon_room", 2, False, {}), ("hexagon_room", 3, False, {}), ("coffee_maker_qsah", 2, False, {}),
+                                                   ("hexagon_room_pm", 2, True, {}), ("hexagon_room_pm", 3, True, {}),
+                                                   ("coffee_maker_qsah", 3, False, {"MCRT_KERNEL": "wf", "MCRT_SAMPLE_STORE_GB": "0.0002"})])
+def test_ranks_sharing_the_gpu_assemble_the_single_rank_frame(pkg, manifest, tmp_path, name, world, photon, env, monkeypatch):
     import torch.multiprocessing as mp
 
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)  # the ranks inherit it (spawn), mcrt_create seeds their options from it
     case = manifest["cases"][name]
     image = golden_path(case["image"])
     r = case["renders"][0]
@@ -89,6 +94,8 @@ def test_ranks_sharing_the_gpu_assemble_the_single_rank_frame(pkg, manifest, tmp
         ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons") or 50, bool(img.param("direct_visualization")))
     base, st = ctx.sample_image(camera_for(img, r), manifest["seed"], mode)
     ctx.close()
+    if env:
+        assert st["kernel_launches"] > 20  # several passes, each a chain of shade / trace launches
     assert info["paths"] == st["paths"] and info["rays"] == st["rays"] and info["kernel_id"] == st["kernel_id"]
     if photon:
         assert rel_error(frame, base).max() < 1e-12
