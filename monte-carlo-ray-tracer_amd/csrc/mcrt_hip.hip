@@ -106,6 +106,7 @@ struct mcrt_ctx {
     DevBuf op_buf[6];
     std::map<std::string, std::string> options;  // mcrt_set_option; seeded from the MCRT_* environment variables at mcrt_create
     DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
+    DevBuf wf_ray_scratch;  // slot-scheduled trace kernel: the FP64 rays of the slots, [workgroup][slot][8]
     DevPool pass_pool;  // work buffers of the device photon pass (mcrt_photon_device.hpp)
     DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
 
@@ -268,8 +269,42 @@ bool useWideNodes(const mcrt_ctx* ctx) {
     return ctx->scene.wnodes != nullptr && ctxOptOn(ctx, "MCRT_WF_WIDE");
 }
 
+long halvesWanted(const mcrt_ctx* ctx) { return ctxOptL(ctx, "MCRT_WF_HALVES", 1); }
+
 template <class K>
-int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false) {
+int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false, bool sched = false) {
+    if (sched) {  // slot-scheduled kernel: one 1024-lane workgroup per CU, all of its LDS for the ray slots
+        tp.block = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_SCHED_WAVES", 16), 1), kTraceMaxBlock / 64) * 64u;
+        tp.lds_bytes = (uint32_t)sizeof(SchedLds);
+        if (tp.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_UNSUPPORTED, "slot-scheduled trace kernel: needs 156 KB of LDS per workgroup");
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+        tp.grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus, (max_items + kSchedSlots - 1) / kSchedSlots);
+        if (tp.grid < 1) tp.grid = 1;
+        const uint32_t total_slots = tp.grid * kSchedSlots;
+        if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
+        if (int rc = ensureSpill(ctx, (size_t)total_slots * kMaxStackDepth * sizeof(StackEntry))) return rc;
+        HIP_TRY(ctx, ctx->wf_ray_scratch.reserve((size_t)total_slots * 128));
+        WfTraceArgs& ta = tp.args;
+        memset(&ta, 0, sizeof(ta));
+        ta.stats = ctx->stats.as<unsigned long long>();
+        ta.nodes = ctx->scene.nodes64;
+        ta.qblocks = ctx->scene.qblocks;
+        ta.wnodes = ctx->scene.wnodes;
+        ta.num_nodes = ctx->scene.q_nodes;
+        ta.q_root_a = ctx->scene.q_root_a;
+        ta.q_root_m = ctx->scene.q_root_m;
+        ta.prim = ctx->scene.prim;
+        ta.leaf_pre = ctx->scene.leaf_pre;
+        ta.leaf_cx = ctx->scene.leaf_cx;
+        ta.leaf_cy = ctx->scene.leaf_cy;
+        ta.leaf_cz = ctx->scene.leaf_cz;
+        ta.leaf_bound = ctx->scene.leaf_bound;
+        ta.spill = ctx->spill.as<SmStackEntry>();
+        ta.total_lanes = total_slots;
+        ta.lds_stack = (int)kSchedStack;
+        ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_WF_DEAL", 6), 6), 20);
+        return MCRT_OK;
+    }
     auto envi = [ctx](const char* k, long d) { return ctxOptL(ctx, k, d); };
     const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
@@ -411,11 +446,14 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
 
     const bool wide = useWideNodes(ctx);
-    auto trace = wide ? (count_tests ? wfTraceKernel<PoolRays, true, true> : wfTraceKernel<PoolRays, false, true>)
-                      : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
+    // MCRT_WF_SCHED=1: the slot-scheduled trace kernel (ray state in LDS, steps issued for 64 rays that want the same step)
+    const bool sched = ctxOptOn(ctx, "MCRT_WF_SCHED") && halvesWanted(ctx) < 2;
+    void (*trace)(WfTraceArgs, PoolRays) = wide ? (count_tests ? wfTraceKernel<PoolRays, true, true> : wfTraceKernel<PoolRays, false, true>)
+                                                : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
+    void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
     TracePlan tp;
-    if (int rc = planTrace(ctx, trace, slots * 2, tp, wide)) return rc;
+    if (int rc = sched ? planTrace(ctx, trace_sched, slots * 2, tp, false, true) : planTrace(ctx, trace, slots * 2, tp, wide, false)) return rc;
 
     // MCRT_WF_HALVES=2 (experiment, off by default): two halves of the pool on two streams, so that while one half's trace
     // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
@@ -541,7 +579,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
                 }
             }
             ta[h].count = c + (it & 1);
-            hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h]);
+            if (sched) hipLaunchKernelGGL(trace_sched, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h], ctx->wf_ray_scratch.as<double>());
+            else hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h]);
             ctx->launches++;
             if (photon) {
                 ka.count = ctrl + 4 + (it & 1);
@@ -1206,7 +1245,11 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
             fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
                     h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
     }
-    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
+    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS") && ctxOptOn(ctx, "MCRT_WF_SCHED"))
+        fprintf(stderr, "[mcrt trace sched] steps %llu: inner %.1f%% with %.1f slots, leaf %.1f%% with %.1f slots, refill %.1f%%; idle polls per step %.2f\n",
+                h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
+                100.0 * (h[8] - h[10] - h[12]) / h[8], (double)h[14] / h[8]);
+    else if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt trace] per wave iteration: %.1f lanes hold a ray; inner step in %.1f%% of the iterations with %.1f lanes, leaf step in %.1f%% with %.1f lanes, "
                         "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%%; per ray: %.2f inner steps, %.2f leaf steps\n",
                 (double)h[9] / h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
