@@ -348,7 +348,6 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 6), 6), 20);
-    ta.defer_leaves = (int)envi("MCRT_WF_DEFER", 0);
     return MCRT_OK;
 }
 
@@ -448,8 +447,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool wide = useWideNodes(ctx);
     // MCRT_WF_SCHED=1: the slot-scheduled trace kernel (ray state in LDS, steps issued for 64 rays that want the same step)
     const bool sched = ctxOptOn(ctx, "MCRT_WF_SCHED") && halvesWanted(ctx) < 2;
-    void (*trace)(WfTraceArgs, PoolRays) = wide ? (count_tests ? wfTraceKernel<PoolRays, true, true> : wfTraceKernel<PoolRays, false, true>)
-                                                : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
+    const bool defer = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0;  // deferred leaves: the default since round 3 (C3 / C4 -1.3 %)
+    void (*trace)(WfTraceArgs, PoolRays) = wide    ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
+                                           : defer ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
+                                                   : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
     void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
     TracePlan tp;
@@ -1058,7 +1059,12 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     const size_t ns = s->num_surfaces;
     HostLayout L;
     std::string lerr;
-    if (int rc = buildLayout(s, L, lerr, ctxOptOn(ctx, "MCRT_LEAF_CULL"))) return fail(ctx, rc, lerr);
+    #if defined(MCRT_DEVICE_LEAF_CULL)
+    const bool want_leaf_cull = ctxOptOn(ctx, "MCRT_LEAF_CULL");
+#else
+    const bool want_leaf_cull = false;
+#endif
+    if (int rc = buildLayout(s, L, lerr, want_leaf_cull)) return fail(ctx, rc, lerr);
     const bool any_vn = L.any_vn;
     std::vector<double>& prim = L.prim;
     std::vector<double>& normal = L.normal;
@@ -1070,8 +1076,14 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
     // leaf cull (mcrt_lanesm.hpp): built and bit-exact, measured SLOWER inside the wave-level steps (C3 466 -> 544 ms, spaceship
-    // 318 -> 385 ms: a wave still runs the exact test whenever one of its lanes has a survivor) - off unless MCRT_LEAF_CULL=1
+    // 318 -> 385 ms: a wave still runs the exact test whenever one of its lanes has a survivor), and merely compiled into the kernels
+    // it cost the default path 4 %: the device code carries it only in builds made with -DMCRT_DEVICE_LEAF_CULL (+ option MCRT_LEAF_CULL);
+    // the host emulation always has it (tests/test_device_code_host_emulation.py)
+#if defined(MCRT_DEVICE_LEAF_CULL)
     const bool leaf_cull = !L.leaf_pre.empty();
+#else
+    const bool leaf_cull = false;
+#endif
     if (!leaf_cull) ctx->leaf_pre.release();
     else if (int rc = uploadArray(ctx, ctx->leaf_pre, L.leaf_pre.data(), L.leaf_pre.size())) return rc;
     if (L.wnodes.empty()) ctx->wnodes.release();
@@ -1543,7 +1555,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFF00000ull) {  // (32-bit queue cursors with room for the waves' overshoot)
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
         const bool wide = useWideNodes(ctx);
-        auto trace = wide ? wfTraceKernel<ArrayRays, false, true> : wfTraceKernel<ArrayRays, false>;
+        auto trace = wide ? wfTraceKernel<ArrayRays, false, 1> : wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
         if (int rc = planTrace(ctx, trace, n, tp, wide)) return rc;
         DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];

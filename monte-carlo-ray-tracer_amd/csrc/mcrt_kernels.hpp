@@ -734,7 +734,6 @@ struct WfTraceArgs {
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
     uint32_t deal_shift;                // queue entries are dealt to the workgroups in blocks of 2^deal_shift
-    int defer_leaves;                   // 1: deferred leaves (mcrt_lanesm.hpp); 0: a lane waits at its leaf (round 2)
 };
 
 // Where the rays of a trace launch come from and where their hits go.
@@ -770,8 +769,12 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
 // traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
 // are visited through quantised child blocks, the top of the tree from LDS.
-template <class Rays, bool kCount, bool kWide = false>
+// kForm: 0 = the default walk (4-wide quantised blocks, a lane waits at its leaf), 1 = eight-wide nodes (mcrt_wbvh.hpp), 2 = deferred
+// leaves (mcrt_lanesm.hpp). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
+// default form a register spill and ~1 % of a frame.
+template <class Rays, bool kCount, int kForm = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
+    constexpr bool kWide = kForm == 1, kDefer = kForm == 2;
     extern __shared__ __align__(64) unsigned char lds[];
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
     if constexpr (!kWide)
@@ -830,7 +833,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     bool have = false, exhausted = dealt(0u) >= n;
     uint32_t item = 0;
     for (;;) {
-        if (have && !T.active && (kWide || P.n == 0u)) {  // finished since the last look: hand the hit back (kWide: `active` covers the leaves)
+        if (have && !T.active && (!kDefer || P.n == 0u)) {  // finished since the last look: hand the hit back (deferred leaves: none pending either)
             rays.store(item, T.best);
             have = false;
         }
@@ -900,7 +903,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             }
             continue;
         }
-        if (a.defer_leaves) {
+        if constexpr (kDefer) {
             // a lane standing at a leaf (new ray whose root is a leaf, pending slot freed by the last leaf step) parks it and moves on
             if (have) travParkLeaf(T, P, stk);
             const bool inner = have && T.active && (T.node_m & kSmInner);

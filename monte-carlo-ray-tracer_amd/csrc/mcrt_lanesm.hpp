@@ -249,6 +249,9 @@ MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
 template <bool kAll, bool kCount>
 MCRT_HD uint32_t leafTestNext(const SmSceneView<kAll>& sv, Trav& T, uint32_t i, uint32_t count, TraceCounters& cnt, bool& decided) {
     const Ray r = travRay(T);
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(MCRT_DEVICE_LEAF_CULL)
+    // (host emulation, and device builds made with -DMCRT_DEVICE_LEAF_CULL for A/B runs: compiled into the gfx950 kernels the
+    // unused branch alone cost 4 % of a C3 frame and 5 % of the spaceship's - registers and code size of every leaf step)
     if (!kAll && sv.pre != nullptr) {
         const uint32_t pb = i & ~1u;
         const uint32_t in_range = ((i & 1u) ? 2u : 3u) & ((pb + 1u < i + count) ? 3u : 1u);
@@ -269,6 +272,7 @@ MCRT_HD uint32_t leafTestNext(const SmSceneView<kAll>& sv, Trav& T, uint32_t i, 
         const uint32_t used = 2u - (i & 1u);
         return used < count ? used : count;
     }
+#endif
     const bool two = count > 1u;
     const uint32_t j = two ? i + 1 : i;
     const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);
@@ -311,13 +315,14 @@ MCRT_HD void travLeafStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& s
 
 // ---- Deferred leaves (round 3) ---------------------------------------------------------------------------------------------
 // The lanes of a wave reach leaves at different moments, and a leaf step (FP64 primitive tests) is only worth issuing when many
-// lanes take part - so a lane at a leaf WAITS (idle through the other lanes' inner steps) until enough lanes have arrived. As an
-// option (MCRT_WF_DEFER=1) a lane that reaches a leaf PARKS it (one pending leaf per lane, two registers) and keeps walking: it
+// lanes take part - so a lane at a leaf WAITS (idle through the other lanes' inner steps) until enough lanes have arrived. In the
+// wavefront pipeline's trace kernel (MCRT_WF_DEFER, default 1 since round 3) a lane that reaches a leaf PARKS it (one pending leaf per lane, two registers) and keeps walking: it
 // pops its next node and takes part in the following inner steps; the pending leaves of the wave are tested together once enough
 // lanes have one, or when few lanes are left with inner nodes to visit. The closest hit is a minimum over exact FP64 primitive
 // tests with the lowest-index tie rule, so it does not depend on WHEN a leaf is tested; what changes is pruning: nodes visited
-// while a leaf is pending are not yet cut off by that leaf's hit. Measured on C3: + 3.4 % box tests, + 4 % primitive tests, the
-// same frame time - the waiting lanes rarely have useful work on their stacks. The pending-leaf slot is also what the
+// while a leaf is pending are not yet cut off by that leaf's hit. Measured on C3: + 3.4 % box tests, + 4 % primitive
+// tests; compiled next to the waiting form in one kernel it was neutral, as its own lean kernel instance it takes 1.3 % off a C3 and
+// a C4 frame (the waiting form remains as MCRT_WF_DEFER=0 and in the megakernels). The pending-leaf slot is also what the
 // eight-wide walk (mcrt_wbvh.hpp) keeps its current leaf in.
 struct PendLeaf {
     uint32_t a = 0, n = 0;  // first primitive, primitives left (0: none pending)

@@ -124,8 +124,8 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
 @pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "quadric"])
 def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name, monkeypatch):
     """The wavefront pipeline's optional trace kernels - slot-scheduled (MCRT_WF_SCHED: ray state in LDS, steps issued for 64 rays
-    that want the same step), eight-wide nodes (MCRT_WF_WIDE), deferred leaves (MCRT_WF_DEFER), and the FP32 leaf cull
-    (MCRT_LEAF_CULL, an upload-time option) - give the default kernel's frame, bit for bit."""
+    that want the same step), eight-wide nodes (MCRT_WF_WIDE), lanes waiting at their leaves (MCRT_WF_DEFER=0, the round-2 form) -
+    give the default kernel's frame, bit for bit."""
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
     r = case["renders"][0]
@@ -134,15 +134,12 @@ def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name,
     ctx.upload_image(img)
     base, st0 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     assert st0["kernel_id"] == pkg.KERNEL_WAVEFRONT
-    for key in ("MCRT_WF_SCHED", "MCRT_WF_WIDE", "MCRT_WF_DEFER", "MCRT_LEAF_CULL"):
-        monkeypatch.setenv(key, "1")
-        if key == "MCRT_LEAF_CULL":
-            ctx.upload_image(img)  # the records are built at upload
+    for key, value in (("MCRT_WF_SCHED", "1"), ("MCRT_WF_WIDE", "1"), ("MCRT_WF_DEFER", "0")):
+        monkeypatch.setenv(key, value)
         out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
         monkeypatch.delenv(key)
         assert st["rays"] == st0["rays"] and st["kernel_id"] == pkg.KERNEL_WAVEFRONT
         np.testing.assert_array_equal(out, base, err_msg=key)
-    ctx.upload_image(img)
 
 
 @pytest.mark.parametrize("name,kernel,integrator", [("hexagon_room", None, "pt"), ("coffee_maker_qsah", None, "pt"), ("metals", "wf", "pt"),
