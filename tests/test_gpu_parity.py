@@ -419,6 +419,36 @@ def test_c2_full_size_frame(pkg, ctx, manifest):
     assert np.array_equal(part[536:544], out[536:544])
 
 
+def test_options_are_per_context_and_not_the_environment(pkg, manifest, monkeypatch):
+    """mcrt_set_option / mcrt_get_option: the environment seeds a context's options in mcrt_create and is never read again by
+    the library; two contexts in one process can run different kernel forms; NULL restores the default."""
+    case = manifest["cases"]["coffee_maker_qsah"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    monkeypatch.setenv("MCRT_KERNEL", "wf")
+    a = pkg.Context(0)  # seeded with MCRT_KERNEL=wf
+    monkeypatch.delenv("MCRT_KERNEL")
+    b = pkg.Context(0)  # seeded without
+    L = pkg.lib()
+    assert a.get_option("MCRT_KERNEL") == "wf" and b.get_option("MCRT_KERNEL") is None
+    assert L.mcrt_set_option(a._h, b"KERNEL", b"wf") != 0  # keys are the MCRT_* names
+    st = pkg.Stats()
+    frames = {}
+    for name, ctx in (("a", a), ("b", b)):
+        assert L.mcrt_upload_scene(ctx._h, C.byref(img.scene)) == 0  # (the raw entry points: no mirroring of os.environ by the binding)
+        out = np.zeros((cam.height, cam.width, 3))
+        assert L.mcrt_render(ctx._h, C.byref(cam), manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)) == 0
+        frames[name] = (out, st.kernel_id)
+    assert frames["a"][1] == pkg.KERNEL_WAVEFRONT and frames["b"][1] == pkg.KERNEL_LANE_SM
+    np.testing.assert_array_equal(frames["a"][0], frames["b"][0])
+    assert L.mcrt_set_option(a._h, b"MCRT_KERNEL", None) == 0
+    out = np.zeros((cam.height, cam.width, 3))
+    assert L.mcrt_render(a._h, C.byref(cam), manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)) == 0
+    assert st.kernel_id == pkg.KERNEL_LANE_SM
+    a.close()
+    b.close()
+
+
 def test_error_behaviour(pkg, manifest):
     c = pkg.Context(0)
     img = pkg.SceneImage(golden_path("hexagon_room_diffuse.mcrt"))
