@@ -81,7 +81,8 @@ struct mcrt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string error;
     int num_cus = 0;
-    size_t max_lds = 0;
+    size_t max_lds = 0;        // dynamic LDS a kernel that shades may ask for
+    size_t max_lds_trace = 0;  // ... a kernel that only walks the tree (no static LDS)
 
     bool has_scene = false;
     DeviceScene scene{};
@@ -276,7 +277,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     if (sched) {  // slot-scheduled kernel: one 1024-lane workgroup per CU, all of its LDS for the ray slots
         tp.block = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_SCHED_WAVES", 16), 1), kTraceMaxBlock / 64) * 64u;
         tp.lds_bytes = (uint32_t)sizeof(SchedLds);
-        if (tp.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_UNSUPPORTED, "slot-scheduled trace kernel: needs 156 KB of LDS per workgroup");
+        if (tp.lds_bytes > ctx->max_lds_trace) return fail(ctx, MCRT_ERR_UNSUPPORTED, "slot-scheduled trace kernel: needs 156 KB of LDS per workgroup");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
         tp.grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus, (max_items + kSchedSlots - 1) / kSchedSlots);
         if (tp.grid < 1) tp.grid = 1;
@@ -310,7 +311,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     tp.block = waves * 64u;
     const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
-    const long lds_cap = std::min<long>((long)ctx->max_lds, envi("MCRT_TRACE_LDS", (long)ctx->max_lds));
+    const long lds_cap = std::min<long>((long)ctx->max_lds_trace, envi("MCRT_TRACE_LDS", (long)ctx->max_lds_trace));
     if ((long)stack_bytes + 64 > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
     const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u) / 64u);
     tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u;  // + the workgroup's queue cursor
@@ -365,6 +366,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     fr.global_seed = global_seed;
     fr.spp = cam->sqrtspp * cam->sqrtspp;
     const uint32_t owned_rows = mcrt_shard_rows(cam, nullptr);
+    if (cam->width > 0xFFFFu || owned_rows > 0xFFFFu)  // kWfUnit keeps a slot's pixel as two 16-bit numbers
+        return fail(ctx, MCRT_ERR_INVALID, "camera: the wavefront integrator takes at most 65535 columns and 65535 rows per shard");
     fr.tiles_x = (cam->width + 7) / 8;
     fr.film.type = MCRT_FILM_BOX;
     if (filmSplats(cam->film_filter, cam->film_radius)) {  // Film::Film(width, height, json), film.cpp:19-58
@@ -432,8 +435,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     }
     if (ctx->wf_slots != slots) {
         HIP_TRY(ctx, ctx->wf_pool.alloc((size_t)slots * kWfWords * 8));
-        // ray queue, two entries per slot (bounce + shadow ray): item and light words, eight planes of doubles (WfRayQueue)
-        HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * (2 * sizeof(uint32_t) + 8 * sizeof(double))));
+        // ray queue, two entries per slot (bounce + shadow ray): item and light words, and two sets of eight planes of doubles
+        // (WfRayQueue): a shade launch fills one set and reads the bounce rays of its slots back from the other
+        HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * (2 * sizeof(uint32_t) + 2 * 8 * sizeof(double))));
         ctx->wf_slots = (uint32_t)slots;
     }
     if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
@@ -452,7 +456,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
                                            : defer ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
                                                    : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
     void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
-    const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
+    // + the materials and the light tables when they are small (MCRT_WF_LDS_TABLES=0: read them from memory)
+    uint32_t shade_tables = wfShadeTableBytes(ctx->scene.num_materials, ctx->scene.num_lights);
+    if (shade_tables > kWfShadeTableMax || ctxOptL(ctx, "MCRT_WF_LDS_TABLES", 1) == 0) shade_tables = 0;
+    const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u + shade_tables;
     TracePlan tp;
     if (int rc = sched ? planTrace(ctx, trace_sched, slots * 2, tp, false, true) : planTrace(ctx, trace, slots * 2, tp, wide, false)) return rc;
 
@@ -492,7 +499,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             uint32_t* words = ctx->wf_queue.as<uint32_t>();
             pr[h].q.item = words + off;
             pr[h].q.light = words + cap + off;
-            pr[h].q.ray = reinterpret_cast<double*>(words + 2 * cap) + off;
+            pr[h].q.ray = reinterpret_cast<double*>(words + 2 * cap) + off;  // iteration parity 0; parity 1: + 8 * cap
+            pr[h].q.prev_ray = pr[h].q.ray + 8 * cap;
             pr[h].q.cap = cap;
         }
         memset(&sa[h], 0, sizeof(WfShadeArgs));
@@ -504,6 +512,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         sa[h].pop_reset = c + 2;
         sa[h].work = ctx->work_counter.as<unsigned long long>();
         sa[h].stats = ctx->stats.as<unsigned long long>();
+        sa[h].lds_tables = shade_tables;
         shade_grid[h] = (sa[h].slot_count + kWfBlock - 1) / kWfBlock;
     }
 
@@ -555,6 +564,12 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             unsigned long long* c = ctrl + 4 * h;
             sa[h].count_out = c + (it & 1);
             sa[h].count_reset = c + ((it + 1) & 1);
+            {
+                double* set0 = reinterpret_cast<double*>(ctx->wf_queue.as<uint32_t>() + 2 * pr[h].q.cap) + (size_t)h * 2 * half_slots;
+                pr[h].q.ray = set0 + (it & 1) * 8 * pr[h].q.cap;
+                pr[h].q.prev_ray = set0 + ((it + 1) & 1) * 8 * pr[h].q.cap;
+                sa[h].queue = pr[h].q;
+            }
             if (photon) {
                 sa[h].rcount_out = ctrl + 4 + (it & 1);
                 sa[h].rcount_reset = ctrl + 4 + ((it + 1) & 1);
@@ -999,6 +1014,9 @@ int mcrt_create(mcrt_ctx** out, int device_id) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && v > 0)
             ctx->max_lds = std::max(ctx->max_lds, (size_t)v);
     }
+    // the kernels that shade hold the sin/cos table as static LDS (mcrt_libm.hpp): their dynamic LDS plans get the rest
+    ctx->max_lds_trace = ctx->max_lds;
+    ctx->max_lds -= glibc235::kShadeStaticLds;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
         hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;

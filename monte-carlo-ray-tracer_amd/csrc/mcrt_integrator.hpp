@@ -145,7 +145,7 @@ MCRT_HD void emitBegin(EmitState& es, RefractionHistory& rh, const ShadeViewT<L>
     const uint32_t surface = sh.light_surface[light];
     d3 pos = surfSample(sh, surface, u0, u1);
     d3 normal = surfNormal(sh, surface, pos);
-    d3 dir = csFrom(orthonormalBasis(normal), cosWeightedHemi(u2, u3));  // CoordinateSystem::from(v, N)
+    d3 dir = csFrom(orthonormalBasis(normal), cosWeightedHemi<!L>(u2, u3));  // CoordinateSystem::from(v, N)
     pos = pos + normal * kEpsilon;
     es.ray = makeRay(pos, dir, sh.scene_ior);
     es.flux = photon_flux;

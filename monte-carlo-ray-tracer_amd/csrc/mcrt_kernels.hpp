@@ -196,6 +196,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
     rh.size = 0;
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
     stageCopy(ltab, s.sobol_tab, (uint32_t)kSobolTableWords);
+    if constexpr (!kAll) glibc235::stageSinCosTab();  // (kernels of LDS-resident scenes read the sin/cos table from memory: mcrt_libm.hpp)
     tab = ltab;
 
     stk.lds = ldsAt<StackEntry>(lds, p.stack) + threadIdx.x;
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
             if (!path_active) {
                 if (kProf) prof.mark(kPhRegen);
                 st.smp.setIndex(sample);  // camera.cpp:77
-                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                pathBegin(st, rh, cameraRay<!kAll>(prm.cam, sh.scene_ior, px, py, st.smp, tab));
                 path_active = true;
                 paths++;
             }
@@ -484,6 +485,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
     // ---- staging
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, p.sobol);
     stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
+    if constexpr (!kAll) glibc235::stageSinCosTab();
     const SobolTab tab = ltab;
     SmStack stk;
     stk.lds = ldsAt<SmStackEntry>(lds, p.stack) + threadIdx.x;
@@ -647,7 +649,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
             }
             if (state == kStRegen && have_pixel) {
                 st.smp.setIndex(sample);
-                pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                pathBegin(st, rh, cameraRay<!kAll>(prm.cam, sh.scene_ior, px, py, st.smp, tab));
                 paths++;
                 st.smp.shuffle();  // path-tracer.cpp:23, first bounce
                 smBegin( st.ray.start, st.ray.direction, st.ray.inv_direction, false, nullptr, cnt);
@@ -1291,7 +1293,16 @@ struct WfShadeArgs {
     unsigned long long* rcount_reset;
     unsigned long long* rpop_reset;
     WfPmView pm;
+    uint32_t lds_tables;              // bytes of LDS after the refraction histories for the materials and the light tables (0: read from memory)
 };
+
+// The small tables every bounce reads — materials, light distribution — as LDS copies of the shade launch's workgroups: the
+// bounce code reads a material record in six to ten places, each a dependent round trip when the record is in memory (L2 hits,
+// but the launch is bound by the length of exactly that chain). The views keep generic pointers; the accesses become flat loads.
+__host__ __device__ inline uint32_t wfShadeTableBytes(uint32_t num_materials, uint32_t num_lights) {
+    return alignUp(num_materials * (uint32_t)sizeof(mcrt_material), 16) + alignUp(num_lights * 8u, 16) + alignUp(num_lights * 4u, 16);
+}
+constexpr uint32_t kWfShadeTableMax = 12u * 1024u;
 
 struct DevWfEnv {
     unsigned long long* work;
@@ -1312,10 +1323,11 @@ struct DevWfEnv {
     __device__ bool any(bool b) const { return waveBallot(b) != 0ull; }
     __device__ unsigned long long pop(bool need) const { return wavePop(need, work); }
     __device__ void filmAdd(double* a, double v) const { atomicAdd(a, v); }  // std::atomic<double> of Film::Splat
-    __device__ void push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double near1, double far1, uint32_t light1) const {
+    __device__ void prevRay(uint32_t entry, d3& o, d3& d) const { queue.prevRay(entry, o, d); }
+    __device__ uint32_t push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double dist1, uint32_t light1) const {
         const unsigned long long m0 = waveBallot(p0), m1 = waveBallot(p1);
         const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
-        if (!total) return;
+        if (!total) return 0u;
         const uint32_t lane = laneId();
         const int leader = __ffsll((long long)waveBallot(true)) - 1;
         unsigned long long base = 0ull;
@@ -1323,8 +1335,10 @@ struct DevWfEnv {
         base = waveBroadcast64(base, leader);
         const unsigned long long below = (1ull << lane) - 1ull;
         // the wave's bounce rays first, then its shadow rays (neighbouring queue entries = similar rays)
-        if (p0) queue.put(base + __popcll(m0 & below), slot * 2u, o0, d0, 0.0, kDblMax, kNoSurface);
-        if (p1) queue.put(base + n0 + __popcll(m1 & below), slot * 2u + 1u, o1, d1, near1, far1, light1);
+        const uint32_t e0 = (uint32_t)base + (uint32_t)__popcll(m0 & below);
+        if (p0) queue.put(e0, slot * 2u, o0, d0, 0.0, kNoSurface);
+        if (p1) queue.put(base + n0 + __popcll(m1 & below), slot * 2u + 1u, o1, d1, dist1, light1);
+        return e0;
     }
 };
 
@@ -1334,7 +1348,27 @@ template <bool kPhoton>
 __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) wfShadeKernel(const DeviceScene scene, const WfShadeArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, 0);
-    stageCopy(ltab, scene.sobol_tab, (uint32_t)kSobolTableWords);
+    // Staging in ONE round trip: every load of the Sobol tables, the sin/cos table and the lane's own flags word is issued before
+    // the first LDS write (loop after loop, each waiting for its loads, was five to six trips before a workgroup could start).
+    static_assert(kWfBlock == 256 && kSobolTableWords == 6 * 4 * 256 && sizeof(glibc235::kSinCosTab) == 440 * 8, "staging below is written for these sizes");
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = local < a.slot_count;
+    const uint32_t slot = a.slot_base + (valid ? local : 0u);
+    unsigned long long fw;
+    {
+        fw = wfSlotFlags(a.pool, slot, valid);
+        const uint4* s4 = reinterpret_cast<const uint4*>(scene.sobol_tab);
+        uint4 sob[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sob[k] = s4[threadIdx.x + k * 256];
+        const unsigned long long sc0 = glibc235::kSinCosTab[threadIdx.x];
+        const unsigned long long sc1 = glibc235::kSinCosTab[threadIdx.x + 256u < 440u ? threadIdx.x + 256u : 0u];
+        MCRT_LDS_AS uint4* l4 = reinterpret_cast<MCRT_LDS_AS uint4*>(ltab);
+#pragma unroll
+        for (int k = 0; k < 6; k++) l4[threadIdx.x + k * 256] = sob[k];
+        glibc235::ldsTabStore(threadIdx.x, sc0);
+        if (threadIdx.x + 256u < 440u) glibc235::ldsTabStore(threadIdx.x + 256u, sc1);
+    }
     RefractionHistory rh;
     rh.iors = ldsAt<double>(lds, kSobolTableWords * 4u) + threadIdx.x;
     rh.stride = blockDim.x;
@@ -1351,6 +1385,33 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
     sh.materials = scene.materials;
     sh.light_surface = scene.light_surface;
     sh.light_cdf = scene.light_cdf;
+    if (a.lds_tables) {
+        unsigned char* base = lds + kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u;
+        uint64_t* lmat = reinterpret_cast<uint64_t*>(base);
+        double* lcdf = reinterpret_cast<double*>(base + alignUp(scene.num_materials * (uint32_t)sizeof(mcrt_material), 16));
+        uint32_t* lsurf = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lcdf) + alignUp(scene.num_lights * 8u, 16));
+        const uint64_t* gmat = reinterpret_cast<const uint64_t*>(scene.materials);
+        const uint32_t mwords = scene.num_materials * (uint32_t)(sizeof(mcrt_material) / 8), nl = scene.num_lights;
+        // (the first two words per lane of the materials and the first light entry are asked for together: one trip for the usual sizes)
+        const uint32_t t = threadIdx.x;
+        const uint64_t m0 = gmat[t < mwords ? t : 0u], m1 = gmat[t + 256u < mwords ? t + 256u : 0u];
+        const double c0 = nl ? scene.light_cdf[t < nl ? t : 0u] : 0.0;
+        const uint32_t s0 = nl ? scene.light_surface[t < nl ? t : 0u] : 0u;
+        if (t < mwords) lmat[t] = m0;
+        if (t + 256u < mwords) lmat[t + 256u] = m1;
+        if (t < nl) {
+            lcdf[t] = c0;
+            lsurf[t] = s0;
+        }
+        for (uint32_t i = t + 512u; i < mwords; i += blockDim.x) lmat[i] = gmat[i];
+        for (uint32_t i = t + 256u; i < nl; i += blockDim.x) {
+            lcdf[i] = scene.light_cdf[i];
+            lsurf[i] = scene.light_surface[i];
+        }
+        sh.materials = reinterpret_cast<const mcrt_material*>(lmat);
+        sh.light_cdf = lcdf;
+        sh.light_surface = lsurf;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *a.count_reset = 0ull;
         *a.pop_reset = 0ull;
@@ -1360,11 +1421,9 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
         }
     }
     __syncthreads();
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = local < a.slot_count;
     DevWfEnv env{a.work, a.queue, a.count_out, a.requests, a.rcount_out};
     uint32_t paths = 0;
-    wfShadeSlot<false, kPhoton>(env, a.pool, a.slot_base + (valid ? local : 0u), valid, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
+    wfShadeSlot<false, kPhoton>(env, a.pool, slot, fw, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
     waveAccumulate(a.stats + 0, paths);
     waveAccumulate(a.stats + 7, rh.overflow ? 1u : 0u);
 }
@@ -1592,7 +1651,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         }
         if (have_pixel && !path_active) {
             st.smp.setIndex(sample);
-            pathBegin(st, rh, cameraRay(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+            pathBegin(st, rh, cameraRay<!kAll>(prm.cam, sh.scene_ior, px, py, st.smp, tab));
             path_active = true;
             paths++;
         }
@@ -1916,6 +1975,8 @@ struct BsdfKatConsts {
     double real[3], imag[3];
 };
 __global__ void __launch_bounds__(256) bsdfKernel(uint64_t n, const double* in, const BsdfKatConsts c, double* out) {
+    glibc235::stageSinCosTab();
+    __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const double* I = in + 11 * i;
         double* O = out + 18 * i;

@@ -364,14 +364,20 @@ struct NeePending {
 };
 
 // Second half of Integrator::sampleDirect (integrator.cpp:68-86) from the parked data.
+// light_material: sh.surf_material[nee.light], for callers that asked for it ahead of time (mcrt_wavefront.hpp)
 template <bool L>
-MCRT_HD void smNeeFinish(PathState& st, const ShadeViewT<L>& sh, const NeePending& nee, const Hit& shadow_hit) {
+MCRT_HD void smNeeFinish(PathState& st, const ShadeViewT<L>& sh, const NeePending& nee, const Hit& shadow_hit, uint32_t light_material) {
     if (shadow_hit.surface == kNoSurface || shadow_hit.surface != nee.light) return;
     double light_pdf = sq(shadow_hit.t) / nee.area_cos;
     double mis_weight = powerHeuristic(light_pdf, nee.bsdf_pdf);
-    const auto& lm = sh.materials[sh.surf_material[nee.light]];
+    const auto& lm = sh.materials[light_material];
     d3 direct = mis_weight * nee.bsdf_absIdotN * ld3(lm.emittance) / (light_pdf * st.ls.select_probability);
     st.radiance = st.radiance + direct * nee.throughput;
+}
+template <bool L>
+MCRT_HD void smNeeFinish(PathState& st, const ShadeViewT<L>& sh, const NeePending& nee, const Hit& shadow_hit) {
+    if (shadow_hit.surface == kNoSurface || shadow_hit.surface != nee.light) return;
+    smNeeFinish(st, sh, nee, shadow_hit, sh.surf_material[nee.light]);
 }
 
 // The tail of a bounce once the Interaction exists: next-event estimate set-up (cut at its shadow-ray trace), BSDF
@@ -393,7 +399,7 @@ MCRT_HD bool smContinue(PathState& st, RefractionHistory& rh, const ShadeViewT<L
             shadow_q = dq.sq;
             nee.bsdf_absIdotN = bsdf_absIdotN;
             nee.bsdf_pdf = bsdf_pdf;
-            nee.area_cos = sh.surf_area[st.ls.light] * dq.cos_light_theta;
+            nee.area_cos = (L ? sh.surf_area[st.ls.light] : dq.light_area) * dq.cos_light_theta;
             nee.throughput = st.throughput;
         }
     }

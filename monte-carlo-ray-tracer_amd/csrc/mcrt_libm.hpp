@@ -41,7 +41,26 @@ MCRT_LIBM_TABLE unsigned long long kSinCosTab[440] = {
 #include "mcrt_glibc_sincostab.inc"
 };
 
+// On the GPU the table is read from LDS: a lookup in global memory is one more dependent round trip per call (two or three calls per
+// bounce; the shading kernels are bound by exactly such chains). Every kernel that shades calls stageSinCosTab() before its first
+// barrier; the 3520 bytes are static LDS of those kernels only (kShadeStaticLds, taken off their dynamic LDS budget by the host).
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ unsigned long long ldsSinCosTab[440];
+__device__ inline void stageSinCosTab() {
+    for (uint32_t i = threadIdx.x; i < 440u; i += blockDim.x) ldsSinCosTab[i] = kSinCosTab[i];
+}
+// kLds = false: from memory (the kernels whose whole scene is LDS-resident: their LDS pipe is the busy one; measured on the C2
+// frame 446.5 ms against 448.5 with the table in LDS, the lane state machine 329 -> 317 ms the other way round)
+__device__ inline void ldsTabStore(uint32_t i, unsigned long long v) { ldsSinCosTab[i] = v; }  // (for kernels that stage by hand)
+template <bool kLds = true>
+MCRT_HD double tabAt(int i) { return bitsD(kLds ? ldsSinCosTab[i] : kSinCosTab[i]); }
+#else
+inline void stageSinCosTab() {}
+inline void ldsTabStore(uint32_t, unsigned long long) {}
+template <bool kLds = true>
 MCRT_HD double tabAt(int i) { return bitsD(kSinCosTab[i]); }
+#endif
+constexpr uint32_t kShadeStaticLds = 440u * 8u;
 // a*b + c: one rounding where the FMA build of glibc fused it (kFused), two as the source is written otherwise
 template <bool kFused>
 MCRT_HD double fmaD(double a, double b, double c) {
@@ -171,6 +190,7 @@ MCRT_HD double refCos(double x) {
 // ONE do_sin and ONE do_cos of the same reduced argument (X, DX) - (x, 0) below 0.855469, (a, da) = hp0 - |x| in two pieces up
 // to 2.426265, the Cody-Waite remainder beyond - and hands them out with the quadrant's signs; both kernels look up the same
 // table entry. Written that way here (one table read, no branch repeated), every operation as in the source.
+template <bool kLdsTab = true>
 MCRT_HD void refSinCos(double x, double& sn_out, double& cs_out) {
     using namespace glibc235;
     constexpr bool kFused = false;
@@ -208,7 +228,7 @@ MCRT_HD void refSinCos(double x, double& sn_out, double& cs_out) {
     const double u = kBig + ax;
     const double xr = ax - (u - kBig);
     const int ti = (int)(unsigned)(dBits(u) & 0xFFFFFFFFull) * 4;
-    const double sn = tabAt(ti), ssn = tabAt(ti + 1), cs = tabAt(ti + 2), ccs = tabAt(ti + 3);
+    const double sn = tabAt<kLdsTab>(ti), ssn = tabAt<kLdsTab>(ti + 1), cs = tabAt<kLdsTab>(ti + 2), ccs = tabAt<kLdsTab>(ti + 3);
     double S;
     if (ax < 0.126) {
         S = taylorSin<kFused>(X * X, X, DX);

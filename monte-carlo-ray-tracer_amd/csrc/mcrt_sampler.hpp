@@ -89,6 +89,16 @@ struct Sampler {
         seed = hashCombine(base_seed, hash32(++sequence));
         shuffled_index = owenScramble(bit_reversed_index, seed);
     }
+    // The state after initiate(global_seed, start_seed), setIndex(index) and `shuffles` calls of shuffle(): every word is a
+    // function of those four numbers, so a parked path keeps them instead of the sampler (mcrt_wavefront.hpp).
+    MCRT_HD void restore(uint32_t global_seed, uint32_t start_seed, uint32_t index, uint32_t shuffles) {
+        initiate(global_seed, start_seed);
+        setIndex(index);
+        if (shuffles != 0u) {
+            sequence = shuffles - 1u;
+            shuffle();
+        }
+    }
     // get<DIM>() (sampler.hpp:20-30). `tab` = byte tables (LDS on the GPU).
     MCRT_HD double get(int dim, MCRT_LDS_AS const uint32_t* tab) const {
         uint32_t x = shuffled_index;

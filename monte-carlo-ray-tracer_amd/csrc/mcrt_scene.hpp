@@ -485,6 +485,12 @@ struct ShadowQuery {
     uint32_t light;  // surface the shadow ray was aimed at
     double t_near;   // d (1 - 1e-9): a closer hit of another surface decides the query
     double t_far;    // d (1 + 1e-9): nothing farther can matter
+    double dist;     // d, the distance to the light point (what the wavefront pipeline queues: WfRayQueue)
+    MCRT_HD void setRange(double d) {
+        dist = d;
+        t_near = d * (1.0 - 1e-9);
+        t_far = d * (1.0 + 1e-9);
+    }
 };
 
 // kFlat: the caller knows the scene is in flat mode (a kernel instance for such scenes only): the BVH walk is not compiled in.

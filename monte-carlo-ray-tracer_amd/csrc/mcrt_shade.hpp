@@ -83,6 +83,7 @@ MCRT_HD double ggxTransmission(d3 wi, d3 wo, double n1, double n2, double ax, do
     pdf = ggxDV(m, wo, ax, ay) * dm_dwi;
     return fabs(ggxG2(wi, wo, ax, ay) * ggxD(m, ax, ay) * dot(wo, m) * dm_dwi / (wo.z * wi.z));
 }
+template <bool kLdsTab = true>
 MCRT_HD d3 ggxVisibleMicrofacet(double u, double v, d3 wo, double ax, double ay) {  // :67-88 (Heitz 2018)
     d3 Vh = normalize(d3{ax * wo.x, ay * wo.y, wo.z});
     double len2 = sq(Vh.x) + sq(Vh.y);
@@ -91,7 +92,7 @@ MCRT_HD d3 ggxVisibleMicrofacet(double u, double v, d3 wo, double ax, double ay)
     double r = sqrt(u);
     double phi = v * kTwoPi;
     double sin_phi, cos_phi;
-    refSinCos(phi, sin_phi, cos_phi);  // glibc's sincos, bit for bit (mcrt_libm.hpp)
+    refSinCos<kLdsTab>(phi, sin_phi, cos_phi);  // glibc's sincos, bit for bit (mcrt_libm.hpp)
     double t1 = r * cos_phi;
     double t2 = r * sin_phi;
     double s = 0.5 * (1.0 + Vh.z);
@@ -173,11 +174,52 @@ MCRT_HD d3 surfSample(const ShadeViewT<L>& sh, uint32_t i, double u, double v) {
         double r = sqrt(1.0 - sq(z));
         double phi = kTwoPi * v;
         double sin_phi, cos_phi;
-        refSinCos(phi, sin_phi, cos_phi);
+        refSinCos<!L>(phi, sin_phi, cos_phi);
         return ld3(p) + p[3] * d3{r * cos_phi, r * sin_phi, z};
     }
     double su = sqrt(u);
     return (1 - su) * ld3(p) + ((1 - v) * su) * ld3(p + 3) + (v * su) * ld3(p + 6);
+}
+
+// A surface's record asked for in ONE round trip (kind, the nine vertex words, the face normal, the area) - the kernels that read
+// the scene from memory are bound by the number of dependent trips a bounce makes, and kind -> vertices -> normal -> area one after
+// the other is four of them. Same arithmetic on the fetched values as surfSample / surfNormal (a triangle pays 32 bytes it does not use
+// in surfNormalOf, a sphere 64).
+struct SurfRec {
+    uint32_t kind;
+    double v[9];
+    d3 normal;
+};
+template <bool L>
+MCRT_HD SurfRec surfFetch(const ShadeViewT<L>& sh, uint32_t i, bool vertices) {
+    SurfRec r;
+    r.kind = sh.surf_kind[i];
+    cptr<double, L> p = sh.surf_v + (size_t)i * 9;
+    for (int k = 0; k < 4; k++) r.v[k] = p[k];
+    for (int k = 4; k < 9; k++) r.v[k] = vertices ? p[k] : 0.0;
+    r.normal = ld3(sh.surf_normal + (size_t)i * 3);
+    return r;
+}
+template <bool L>
+MCRT_HD d3 surfNormalOf(const SurfRec& r, d3 pos) {
+    if (r.kind == MCRT_SURF_SPHERE) return (pos - d3{r.v[0], r.v[1], r.v[2]}) / r.v[3];
+    if constexpr (QuadricsIn<L>::value) {
+        if (r.kind == MCRT_SURF_QUADRIC) return quadricNormal(quadricPtr(r.v[0]), pos);
+    }
+    return r.normal;
+}
+template <bool L>
+MCRT_HD d3 surfSampleOf(const SurfRec& r, double u, double v) {
+    if (r.kind == MCRT_SURF_SPHERE) {
+        double z = 1.0 - 2.0 * u;
+        double rr = sqrt(1.0 - sq(z));
+        double phi = kTwoPi * v;
+        double sin_phi, cos_phi;
+        refSinCos<!L>(phi, sin_phi, cos_phi);
+        return d3{r.v[0], r.v[1], r.v[2]} + r.v[3] * d3{rr * cos_phi, rr * sin_phi, z};
+    }
+    double su = sqrt(u);
+    return (1 - su) * d3{r.v[0], r.v[1], r.v[2]} + ((1 - v) * su) * d3{r.v[3], r.v[4], r.v[5]} + (v * su) * d3{r.v[6], r.v[7], r.v[8]};
 }
 
 // ------------------------------------------------------------------ RefractionHistory (ray/ray.cpp:74-98)
@@ -259,7 +301,19 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
     ia.ray_diffuse_depth = ray.diffuse_depth;
     ia.ray_dirac_delta = ray.dirac_delta;
     ia.position = ray.start + ray.direction * ia.t;  // Ray::operator() ray.cpp:69-72
-    ia.normal = surfNormal(sh, isect.surface, ia.position);
+    d3 vn0 = splat(0.0), vn1 = splat(0.0), vn2 = splat(0.0);
+    if constexpr (L) {
+        ia.normal = surfNormal(sh, isect.surface, ia.position);
+    } else {  // scene in memory: everything the hit needs in one round trip
+        const SurfRec rec = surfFetch(sh, isect.surface, false);
+        if (isect.interpolate) {
+            cptr<double, L> n = sh.surf_vn + (size_t)isect.surface * 9;
+            vn0 = ld3(n);
+            vn1 = ld3(n + 3);
+            vn2 = ld3(n + 6);
+        }
+        ia.normal = surfNormalOf<L>(rec, ia.position);
+    }
     const uint32_t flags = ia.material->flags;
 
     double cos_theta = dot(ray.direction, ia.normal);
@@ -268,7 +322,8 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
 
     d3 shading_normal = ia.normal;
     if (isect.interpolate) {
-        shading_normal = surfInterpolatedNormal(sh, isect.surface, isect.u, isect.v);
+        if constexpr (L) shading_normal = surfInterpolatedNormal(sh, isect.surface, isect.u, isect.v);
+        else shading_normal = normalize((1.0 - isect.u - isect.v) * vn0 + isect.u * vn1 + isect.v * vn2);  // (surfInterpolatedNormal)
         if ((cos_theta < 0.0) != (dot(ray.direction, shading_normal) < 0.0)) shading_normal = ia.normal;
     }
     if (cos_theta > 0.0) {
@@ -351,11 +406,12 @@ MCRT_HD bool interactionBSDF(const InteractionT<L>& ia, d3& bsdf_absIdotN, d3 wo
     return pdf > 0.0;
 }
 
+template <bool kLdsTab = true>
 MCRT_HD d3 cosWeightedHemi(double u, double v) {  // sampling/sampling.hpp:35-44
     double r = sqrt(u);
     double azimuth = v * kTwoPi;
     double sin_a, cos_a;
-    refSinCos(azimuth, sin_a, cos_a);
+    refSinCos<kLdsTab>(azimuth, sin_a, cos_a);
     return d3{r * cos_a, r * sin_a, sqrt(1 - u)};
 }
 
@@ -363,7 +419,7 @@ template <bool L>
 MCRT_HD d3 interactionSpecularNormal(const InteractionT<L>& ia, const Sampler& smp, SobolTab tab) {  // interaction.cpp:185-193
     if (ia.material->flags & MCRT_MAT_ROUGH_SPECULAR) {
         double u0 = smp.get(kDimBsdf, tab), u1 = smp.get(kDimBsdf + 1, tab);
-        return csFrom(ia.shading_cs, ggxVisibleMicrofacet(u0, u1, csTo(ia.shading_cs, ia.out), ia.material->a[0], ia.material->a[1]));
+        return csFrom(ia.shading_cs, ggxVisibleMicrofacet<!L>(u0, u1, csTo(ia.shading_cs, ia.out), ia.material->a[0], ia.material->a[1]));
     }
     return ia.shading_cs.c2;
 }
@@ -404,7 +460,7 @@ MCRT_HD Ray rayFromInteraction(const InteractionT<L>& ia, const Sampler& smp, So
     } else {
         r.diffuse_depth++;
         double u0 = smp.get(kDimBsdf, tab), u1 = smp.get(kDimBsdf + 1, tab);
-        r.direction = csFrom(ia.shading_cs, cosWeightedHemi(u0, u1));
+        r.direction = csFrom(ia.shading_cs, cosWeightedHemi<!L>(u0, u1));
         r.medium_ior = ia.n1;
         r.start = r.start + ia.normal * kEpsilon;
     }
@@ -455,6 +511,7 @@ MCRT_HD uint32_t selectLight(const ShadeViewT<L>& sh, double u, double& select_p
 struct DirectQuery {
     Ray shadow_ray;
     double cos_light_theta;
+    double light_area;  // surf_area of the chosen light (scenes in memory: fetched with the light's record)
     ShadowQuery sq;  // bounds for the shadow traversal (mcrt_scene.hpp)
 };
 template <bool L>
@@ -466,10 +523,21 @@ MCRT_HD bool sampleDirectSetup(const ShadeViewT<L>& sh, const InteractionT<L>& i
     }
     double u0 = smp.get(kDimLight, tab), u1 = smp.get(kDimLight + 1, tab), u2 = smp.get(kDimLight + 2, tab);
     ls.light = selectLight(sh, u2, ls.select_probability);
-    d3 light_pos = surfSample(sh, ls.light, u0, u1);
+    d3 light_pos, light_normal;
     d3 shadow_start = ia.position + ia.normal * kEpsilon;
-    q.shadow_ray = makeRayTo(shadow_start, light_pos);
-    q.cos_light_theta = dot(-q.shadow_ray.direction, surfNormal(sh, ls.light, light_pos));
+    if constexpr (L) {
+        light_pos = surfSample(sh, ls.light, u0, u1);
+        q.shadow_ray = makeRayTo(shadow_start, light_pos);
+        light_normal = surfNormal(sh, ls.light, light_pos);
+        q.light_area = 0.0;  // (read where it is used: one value less to keep across the shadow ray's trace)
+    } else {  // scene in memory: the light's record and its area in one round trip
+        const SurfRec rec = surfFetch(sh, ls.light, true);
+        q.light_area = sh.surf_area[ls.light];
+        light_pos = surfSampleOf<L>(rec, u0, u1);
+        q.shadow_ray = makeRayTo(shadow_start, light_pos);
+        light_normal = surfNormalOf<L>(rec, light_pos);
+    }
+    q.cos_light_theta = dot(-q.shadow_ray.direction, light_normal);
     if (q.cos_light_theta <= 0.0) return false;
     double cos_theta = dot(q.shadow_ray.direction, ia.normal);
     if (cos_theta <= 0.0) {
@@ -480,8 +548,7 @@ MCRT_HD bool sampleDirectSetup(const ShadeViewT<L>& sh, const InteractionT<L>& i
     const d3 to_light = light_pos - shadow_start;
     const double dist = sqrt(dot(to_light, to_light));
     q.sq.light = ls.light;
-    q.sq.t_near = dist * (1.0 - 1e-9);
-    q.sq.t_far = dist * (1.0 + 1e-9);
+    q.sq.setRange(dist);
     return true;
 }
 // Second half (integrator.cpp:68-86), given the shadow ray's closest hit.
@@ -489,7 +556,7 @@ template <bool L>
 MCRT_HD d3 sampleDirectFinish(const ShadeViewT<L>& sh, const InteractionT<L>& ia, const LightSample& ls, const DirectQuery& q,
                               const Hit& shadow_hit) {
     if (shadow_hit.surface == kNoSurface || shadow_hit.surface != ls.light) return splat(0.0);
-    double light_pdf = sq(shadow_hit.t) / (sh.surf_area[ls.light] * q.cos_light_theta);
+    double light_pdf = sq(shadow_hit.t) / ((L ? sh.surf_area[ls.light] : q.light_area) * q.cos_light_theta);
     double bsdf_pdf;
     d3 bsdf_absIdotN;
     if (!interactionBSDF(ia, bsdf_absIdotN, q.shadow_ray.direction, bsdf_pdf)) return splat(0.0);
@@ -532,6 +599,7 @@ MCRT_HD d3 skyColor(const Ray& ray) {
 }
 
 // Camera::samplePixel ray generation, camera/camera.cpp:79-95 (sampler already at setIndex(i)).
+template <bool kLdsTab = true>
 MCRT_HD Ray cameraRay(const mcrt_camera_desc& cam, double scene_ior, uint32_t x, uint32_t y, const Sampler& smp,
                       SobolTab tab) {
     double pixel_size = cam.sensor_width / (double)cam.width;
@@ -546,7 +614,7 @@ MCRT_HD Ray cameraRay(const mcrt_camera_desc& cam, double scene_ior, uint32_t x,
         double azimuth = u1 * kTwoPi;  // Sampling::uniformDisk, sampling.hpp:29-33
         double su = sqrt(u0);
         double sin_a, cos_a;
-        refSinCos(azimuth, sin_a, cos_a);
+        refSinCos<kLdsTab>(azimuth, sin_a, cos_a);
         double ax = cos_a * su * cam.aperture_radius, ay = sin_a * su * cam.aperture_radius;
         d3 focus_point = ray.start + ray.direction * (cam.focus_distance / dot(ray.direction, forward));
         d3 start = eye + left * ax + up * ay;

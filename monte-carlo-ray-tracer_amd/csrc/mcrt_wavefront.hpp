@@ -38,8 +38,8 @@ MCRT_HD uint32_t localToGlobalRow(const mcrt_camera_desc& cam, uint32_t ly) {
 
 // ---- slot layout: 8-byte words, word w of slot s at pool[w * n + s]
 enum : uint32_t {
-    kWfRayO = 0,         // 3  st.ray.start
-    kWfRayD = 3,         // 3  st.ray.direction (inv_direction = rcp3(direction), as in makeRay)
+    kWfRayO = 0,         // 3  st.ray.start      } photon mapper only: the path tracer reads the bounce ray back from the
+    kWfRayD = 3,         // 3  st.ray.direction  } entry it queued for the trace launch (kWfSeq, WfRayQueue::prev_ray)
     kWfMediumIor = 6,
     kWfRefrScale = 7,
     kWfRayBits = 8,      // refraction_level (i32) | depth << 32 | diffuse_depth << 48
@@ -48,28 +48,22 @@ enum : uint32_t {
     kWfThroughput = 13,  // 3
     kWfBsdfPdf = 16,
     kWfSelectProb = 17,
-    kWfSmp0 = 18,        // base_seed | seed << 32
-    kWfSmp1 = 19,        // sequence | bit_reversed_index << 32
-    kWfSmp2 = 20,        // shuffled_index | sample index of the pixel << 32
-    kWfPixel = 21,       // px | local row << 32
-    kWfSampleEnd = 22,   // the slot's work unit: samples [.., end) of the pixel (the running index is in kWfSmp2)
-    kWfIors = 23,        // 8  RefractionHistory
-    kWfNeeBsdf = 31,     // 3  NeePending
-    kWfNeePdf = 34,
-    kWfNeeAreaCos = 35,
-    kWfNeeThroughput = 36,  // 3
-    kWfNeeLight = 39,
-    kWfShO = 40,         // 3  shadow ray
-    kWfShD = 43,         // 3
-    kWfShNear = 46,
-    kWfShFar = 47,
-    kWfHit0T = 48,       // closest hit of the bounce ray
-    kWfHit0U = 49,
-    kWfHit0V = 50,
-    kWfHit0S = 51,       // surface | interpolate << 32
-    kWfHit1T = 52,       // shadow-ray result
-    kWfHit1S = 53,
-    kWfWords = 54
+    // The sampler is a function of (pixel, sample index, number of shuffles) — Sampler::restore — so those three travel,
+    // not its five words; the unit's last sample follows from the sample index (units are chunk-aligned: wfUnitEnds).
+    kWfUnit = 18,        // px (16 bits) | local row (16 bits) << 16 | sample index of the pixel << 32
+    kWfSeq = 19,         // st.smp.sequence | queue entry of the slot's bounce ray << 32
+    kWfIors = 20,        // 8  RefractionHistory
+    kWfNeeBsdf = 28,     // 3  NeePending (its light is st.ls.light: sampleDirectSetup sets both)
+    kWfNeePdf = 31,
+    kWfNeeAreaCos = 32,
+    kWfNeeThroughput = 33,  // 3
+    kWfHit0T = 36,       // closest hit of the bounce ray
+    kWfHit0U = 37,
+    kWfHit0V = 38,
+    kWfHit0S = 39,       // surface | interpolate << 32
+    kWfHit1T = 40,       // shadow-ray result
+    kWfHit1S = 41,
+    kWfWords = 42
 };
 enum : uint32_t {
     kWfAlive = 1u,        // the bounce ray in the slot was traced for this iteration
@@ -114,6 +108,9 @@ struct WfFrame {
     FilmView film;                  // type != MCRT_FILM_BOX: samples are splatted into film.blob instead (mcrt_film.hpp)
 };
 
+// A unit is the samples [c * chunk, min((c + 1) * chunk, spp)) of a pixel: `sample`, just incremented, is past its unit's end
+MCRT_HD bool wfUnitEnds(const WfFrame& fr, uint32_t sample) { return sample >= fr.spp || sample % fr.chunk == 0u; }
+
 // ---- trace side: work item = slot * 2 + port (0 = bounce ray, closest hit; 1 = shadow ray, bounded any-hit).
 // The rays themselves travel in QUEUE order (WfRayQueue: eight planes of doubles + the light of a shadow ray, entry w
 // next to entry w + 1), so a refill of the trace kernel — the idle lanes of a wave take consecutive entries — reads
@@ -121,23 +118,38 @@ struct WfFrame {
 struct WfRayQueue {
     uint32_t* item;    // [cap] slot * 2 + port
     uint32_t* light;   // [cap] shadow ray: the surface aimed at
-    double* ray;       // [8][cap] o.xyz, d.xyz, t_near, t_far
+    double* ray;       // [8][cap] o.xyz, d.xyz, shadow ray: distance to the light point (a bounce ray's range is [0, max): not stored)
+    const double* prev_ray;  // the planes the previous shade launch filled (the two sets alternate): a slot's bounce ray is
+                             // read back from its entry there instead of being kept a second time in the pool
     uint64_t cap;
-    MCRT_HD void put(uint64_t w, uint32_t it, d3 o, d3 d, double t_near, double t_far, uint32_t l) const {
+    MCRT_HD void prevRay(uint32_t w, d3& o, d3& d) const {
+        o = d3{prev_ray[0 * cap + w], prev_ray[1 * cap + w], prev_ray[2 * cap + w]};
+        d = d3{prev_ray[3 * cap + w], prev_ray[4 * cap + w], prev_ray[5 * cap + w]};
+    }
+    MCRT_HD void put(uint64_t w, uint32_t it, d3 o, d3 d, double dist, uint32_t l) const {
         item[w] = it;
-        light[w] = l;
         ray[0 * cap + w] = o.x; ray[1 * cap + w] = o.y; ray[2 * cap + w] = o.z;
         ray[3 * cap + w] = d.x; ray[4 * cap + w] = d.y; ray[5 * cap + w] = d.z;
-        ray[6 * cap + w] = t_near; ray[7 * cap + w] = t_far;
+        if (it & 1u) {
+            light[w] = l;
+            ray[6 * cap + w] = dist;
+        }
     }
     MCRT_HD uint32_t get(uint64_t w, d3& o, d3& d, bool& shadow, ShadowQuery& sq) const {
         const uint32_t it = item[w];
         o = d3{ray[0 * cap + w], ray[1 * cap + w], ray[2 * cap + w]};
         d = d3{ray[3 * cap + w], ray[4 * cap + w], ray[5 * cap + w]};
-        sq.t_near = ray[6 * cap + w];
-        sq.t_far = ray[7 * cap + w];
-        sq.light = light[w];
+        // (read for every entry, used by shadow rays: a load that waited for the item word would be a second round trip per refill)
+        const double dist = ray[6 * cap + w];
+        const uint32_t l = light[w];
         shadow = (it & 1u) != 0u;
+        sq.setRange(dist);  // sampleDirectSetup's bounds, from the same distance
+        sq.light = l;
+        if (!shadow) {
+            sq.t_near = 0.0;
+            sq.t_far = kDblMax;
+            sq.light = kNoSurface;
+        }
         return it;
     }
 };
@@ -200,14 +212,18 @@ MCRT_HD d3 wfPhotonEstimate(const WfPmView& pm, uint32_t n_slots, uint32_t slot,
 // ---- shade side. Env supplies the three places where lanes cooperate:
 //   bool any(bool)                      true if the predicate holds for any lane of the wave (host: identity)
 //   unsigned long long pop(bool need)   next index of the frame's pixel work counter for the lanes that need one
-//   void push(slot, p0, p1, rays...)    queue the slot's bounce ray / shadow ray (given: origin, direction, shadow range, light) for the next trace launch
+//   uint32_t push(slot, p0, p1, rays...)  queue the slot's bounce ray / shadow ray (given: origin, direction, shadow ray: distance and light) for the next
+//                                       trace launch; returns the entry the bounce ray went to
+//   void prevRay(entry, o, d)           the bounce ray the previous shade launch queued at `entry`
 //   void filmAdd(double*, double)       accumulate into a film splat (any lane, any time; atomic on the GPU)
 //   void request(slot, want, global)    photon mapper: queue the slot's caustic (and global) search for the next kNN launch
 // All but filmAdd are called by every lane of the wave, at the same place.
+MCRT_HD unsigned long long wfSlotFlags(const WfPool& P, uint32_t slot, bool valid) { return valid ? P.getu(kWfFlags, slot) : (unsigned long long)kWfDone; }
+
+// fw: wfSlotFlags(P, slot, valid), read by the caller (the kernel asks for it together with its staging loads)
 template <bool L, bool kPhoton, class Env>
-MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, const WfFrame& fr, const ShadeViewT<L>& sh,
+MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long long fw, const WfFrame& fr, const ShadeViewT<L>& sh,
                          RefractionHistory& rh, SobolTab tab, uint32_t& paths, const WfPmView* pm = nullptr) {
-    const unsigned long long fw = valid ? P.getu(kWfFlags, slot) : (unsigned long long)kWfDone;
     const uint32_t flags = (uint32_t)fw;
     const bool was_done = (flags & kWfDone) != 0u;
     bool done = was_done;
@@ -217,12 +233,12 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
     PathState st;
     NeePending nee;
     nee.pending = false;
-    uint32_t px = 0, ly = 0, sample = 0, sample_end = 0;
+    uint32_t px = 0, ly = 0, sample = 0;
     bool need_pixel = false;
     bool want_estimate = false, need_g = false;  // photon mapper: this hit needs its radiance estimates first
     // the shadow ray this call may queue (written into the ray queue by env.push, in queue order)
     d3 sh_o = splat(0.0), sh_d = splat(0.0);
-    double sh_near = 0.0, sh_far = 0.0;
+    double sh_dist = 0.0;
     auto loadHit0 = [&]() {
         Hit h;
         h.t = P.getd(kWfHit0T, slot);
@@ -234,53 +250,67 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         return h;
     };
 
+    Hit hit0;
+    hit0.t = hit0.u = hit0.v = 0.0;
+    hit0.surface = kNoSurface;
+    hit0.interpolate = false;
     if (!was_done) {
-        // ---- load the slot
-        st.ray.start = P.get3(kWfRayO, slot);
-        st.ray.direction = P.get3(kWfRayD, slot);
-        st.ray.inv_direction = rcp3(st.ray.direction);
+        // ---- load the slot. The launch is bound by the length of its chain of dependent round trips to memory, not by bytes or
+        // arithmetic: every word the slot may need is asked for here, before the first of them is used.
+        const unsigned long long sq_w = P.getu(kWfSeq, slot);
+        const unsigned long long uw = P.getu(kWfUnit, slot);
+        const unsigned long long rb = P.getu(kWfRayBits, slot);
         st.ray.medium_ior = P.getd(kWfMediumIor, slot);
         st.ray.refraction_scale = P.getd(kWfRefrScale, slot);
-        const unsigned long long rb = P.getu(kWfRayBits, slot);
-        st.ray.refraction_level = (int)(uint32_t)rb;
-        st.ray.depth = (uint16_t)(rb >> 32);
-        st.ray.diffuse_depth = (uint16_t)(rb >> 48);
-        st.ray.dirac_delta = (flags & kWfDirac) != 0u;
-        st.ray.refraction = (flags & kWfRefraction) != 0u;
         st.radiance = P.get3(kWfRadiance, slot);
         st.throughput = P.get3(kWfThroughput, slot);
         st.ls.bsdf_pdf = P.getd(kWfBsdfPdf, slot);
         st.ls.select_probability = P.getd(kWfSelectProb, slot);
         st.ls.light = (uint32_t)(fw >> 32);
-        const unsigned long long s0 = P.getu(kWfSmp0, slot), s1 = P.getu(kWfSmp1, slot), s2 = P.getu(kWfSmp2, slot);
-        st.smp.base_seed = (uint32_t)s0;
-        st.smp.seed = (uint32_t)(s0 >> 32);
-        st.smp.sequence = (uint32_t)s1;
-        st.smp.bit_reversed_index = (uint32_t)(s1 >> 32);
-        st.smp.shuffled_index = (uint32_t)s2;
-        sample = (uint32_t)(s2 >> 32);
-        const unsigned long long pw = P.getu(kWfPixel, slot);
-        px = (uint32_t)pw;
-        ly = (uint32_t)(pw >> 32);
-        sample_end = (uint32_t)P.getu(kWfSampleEnd, slot);
-        rh.size = (int)((flags >> kWfRhShift) & 15u);
-        for (int i = 0; i < kMaxIors; i++)
-            if (i < rh.size) rh.put(i, P.getd(kWfIors + (uint32_t)i, slot));
-
-        // ---- second half of the previous bounce's Integrator::sampleDirect, now that its shadow ray is back
+        const double ior0 = P.getd(kWfIors, slot), ior1 = P.getd(kWfIors + 1u, slot);  // (deeper histories: below)
+        hit0 = loadHit0();
+        Hit sh_hit;
+        sh_hit.t = 0.0;
+        sh_hit.u = sh_hit.v = 0.0;
+        sh_hit.surface = kNoSurface;
+        sh_hit.interpolate = false;
+        uint32_t light_material = 0u;
         if (nee_was_pending) {
-            nee.light = (uint32_t)P.getu(kWfNeeLight, slot);
+            nee.light = st.ls.light;
             nee.bsdf_absIdotN = P.get3(kWfNeeBsdf, slot);
             nee.bsdf_pdf = P.getd(kWfNeePdf, slot);
             nee.area_cos = P.getd(kWfNeeAreaCos, slot);
             nee.throughput = P.get3(kWfNeeThroughput, slot);
-            Hit sh_hit;
             sh_hit.t = P.getd(kWfHit1T, slot);
-            sh_hit.u = sh_hit.v = 0.0;
             sh_hit.surface = (uint32_t)P.getu(kWfHit1S, slot);
-            sh_hit.interpolate = false;
-            smNeeFinish(st, sh, nee, sh_hit);
+            light_material = sh.surf_material[st.ls.light];
         }
+        if constexpr (kPhoton) {  // a hit that waits for its estimates is not re-queued: the ray stays in the pool
+            st.ray.start = P.get3(kWfRayO, slot);
+            st.ray.direction = P.get3(kWfRayD, slot);
+        } else {
+            st.ray.start = st.ray.direction = splat(0.0);
+            if (alive) env.prevRay((uint32_t)(sq_w >> 32), st.ray.start, st.ray.direction);
+        }
+        st.ray.inv_direction = rcp3(st.ray.direction);
+        st.ray.refraction_level = (int)(uint32_t)rb;
+        st.ray.depth = (uint16_t)(rb >> 32);
+        st.ray.diffuse_depth = (uint16_t)(rb >> 48);
+        st.ray.dirac_delta = (flags & kWfDirac) != 0u;
+        st.ray.refraction = (flags & kWfRefraction) != 0u;
+        px = (uint32_t)uw & 0xFFFFu;
+        ly = ((uint32_t)uw >> 16) & 0xFFFFu;
+        sample = (uint32_t)(uw >> 32);
+        st.smp.restore(fr.global_seed, localToGlobalRow(fr.cam, ly) * fr.cam.width + px, sample, (uint32_t)sq_w);
+        rh.size = (int)((flags >> kWfRhShift) & 15u);
+        rh.put(0, ior0);
+        rh.put(1, ior1);
+        if (env.any(rh.size > 2))
+            for (int i = 2; i < kMaxIors; i++)
+                if (i < rh.size) rh.put(i, P.getd(kWfIors + (uint32_t)i, slot));
+
+        // ---- second half of the previous bounce's Integrator::sampleDirect, now that its shadow ray is back
+        if (nee_was_pending) smNeeFinish(st, sh, nee, sh_hit, light_material);
 
         // ---- this bounce (path-tracer.cpp:27-49 / photon-mapper.cpp:288-340)
         bool ended;
@@ -288,7 +318,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         ShadowQuery shadow_q;
         if constexpr (!kPhoton) {
             if (alive) {
-                const Hit h = loadHit0();
+                const Hit h = hit0;
                 alive = smShade(st, rh, sh, h, nee, shadow_ray, shadow_q, tab);
                 if (alive) st.smp.shuffle();  // top of the next while(true) iteration (path-tracer.cpp:23)
                 ended = !alive && !nee.pending;
@@ -299,7 +329,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         } else {
             const bool waiting = (flags & kWfEstWait) != 0u;
             if (alive) {
-                const Hit h = loadHit0();
+                const Hit h = hit0;
                 bool go_on = false;  // finish the bounce with `ia` (sampling, russian roulette)
                 InteractionT<L> ia;
                 if (h.surface == kNoSurface) {
@@ -339,9 +369,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         if (nee.pending) {
             sh_o = shadow_ray.start;
             sh_d = shadow_ray.direction;
-            sh_near = shadow_q.t_near;
-            sh_far = shadow_q.t_far;
-            P.setu(kWfNeeLight, slot, nee.light);
+            sh_dist = shadow_q.dist;
             P.set3(kWfNeeBsdf, slot, nee.bsdf_absIdotN);
             P.setd(kWfNeePdf, slot, nee.bsdf_pdf);
             P.setd(kWfNeeAreaCos, slot, nee.area_cos);
@@ -353,13 +381,13 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             const double fx = (double)px + at_start.get(kDimPixel, tab);
             const double fy = (double)localToGlobalRow(fr.cam, ly) + at_start.get(kDimPixel + 1, tab);  // splats land in any shard's rows
             filmDeposit(fr.film, fx, fy, st.radiance, [&](double* a, double v) { env.filmAdd(a, v); });
-            if (++sample == sample_end) have_pixel = false;
+            if (wfUnitEnds(fr, ++sample)) have_pixel = false;
         } else if (ended) {  // Film::deposit with the box filter (own pixel, weight 1): the addend, kept per sample
             double* o = fr.samples + ((size_t)sample * fr.pass_pixels + ((size_t)(ly - fr.row_base) * fr.cam.width + px)) * 3;
             o[0] = st.radiance.x * 1.0;
             o[1] = st.radiance.y * 1.0;
             o[2] = st.radiance.z * 1.0;
-            if (++sample == sample_end) have_pixel = false;
+            if (wfUnitEnds(fr, ++sample)) have_pixel = false;
         }
         need_pixel = !alive && !nee.pending && !have_pixel;
     }
@@ -384,7 +412,6 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
                     have_pixel = true;
                     need_pixel = false;
                     sample = first;
-                    sample_end = first + fr.chunk < fr.spp ? first + fr.chunk : fr.spp;
                     st.smp.initiate(fr.global_seed, localToGlobalRow(fr.cam, ly) * fr.cam.width + px);  // camera.cpp:73
                 }
             }
@@ -400,6 +427,9 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
         alive = true;
     }
 
+    const uint32_t entry = env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending, st.ray.start, st.ray.direction,
+                                    sh_o, sh_d, sh_dist, nee.pending ? nee.light : kNoSurface);
+
     // ---- store the slot
     if (!was_done) {
         uint32_t nf = (alive ? kWfAlive : 0u) | (have_pixel ? kWfHavePixel : 0u) | (nee.pending ? kWfNeePending : 0u) | (done ? kWfDone : 0u) |
@@ -407,8 +437,10 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
                       (want_estimate ? kWfEstWait : 0u) | (want_estimate && need_g ? kWfEstNeedG : 0u);
         P.setu(kWfFlags, slot, (unsigned long long)nf | ((unsigned long long)st.ls.light << 32));
         if (!done) {
-            P.set3(kWfRayO, slot, st.ray.start);
-            P.set3(kWfRayD, slot, st.ray.direction);
+            if constexpr (kPhoton) {
+                P.set3(kWfRayO, slot, st.ray.start);
+                P.set3(kWfRayD, slot, st.ray.direction);
+            }
             P.setd(kWfMediumIor, slot, st.ray.medium_ior);
             P.setd(kWfRefrScale, slot, st.ray.refraction_scale);
             P.setu(kWfRayBits, slot, (unsigned long long)(uint32_t)st.ray.refraction_level | ((unsigned long long)st.ray.depth << 32) |
@@ -417,17 +449,12 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, bool valid, c
             P.set3(kWfThroughput, slot, st.throughput);
             P.setd(kWfBsdfPdf, slot, st.ls.bsdf_pdf);
             P.setd(kWfSelectProb, slot, st.ls.select_probability);
-            P.setu(kWfSmp0, slot, (unsigned long long)st.smp.base_seed | ((unsigned long long)st.smp.seed << 32));
-            P.setu(kWfSmp1, slot, (unsigned long long)st.smp.sequence | ((unsigned long long)st.smp.bit_reversed_index << 32));
-            P.setu(kWfSmp2, slot, (unsigned long long)st.smp.shuffled_index | ((unsigned long long)sample << 32));
-            P.setu(kWfPixel, slot, (unsigned long long)px | ((unsigned long long)ly << 32));
-            P.setu(kWfSampleEnd, slot, sample_end);
+            P.setu(kWfUnit, slot, (unsigned long long)(px | (ly << 16)) | ((unsigned long long)sample << 32));
+            P.setu(kWfSeq, slot, (unsigned long long)st.smp.sequence | ((unsigned long long)entry << 32));
             for (int i = 0; i < kMaxIors; i++)
                 if (i < rh.size) P.setd(kWfIors + (uint32_t)i, slot, rh.at(i));
         }
     }
-    env.push(slot, !was_done && !done && alive && !want_estimate, !was_done && nee.pending, st.ray.start, st.ray.direction, sh_o, sh_d, sh_near, sh_far,
-             nee.pending ? nee.light : kNoSurface);
     if constexpr (kPhoton) env.request(slot, want_estimate, need_g);
 }
 

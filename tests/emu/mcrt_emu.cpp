@@ -483,11 +483,16 @@ namespace {
 struct HostRayRec {  // one entry of the ray queue (the device keeps these as planes: WfRayQueue)
     uint32_t item, light;
     d3 o, d;
-    double t_near, t_far;
+    double dist;
 };
 struct HostWfEnv {
     unsigned long long* work;
     std::vector<HostRayRec>* queue;
+    std::vector<HostRayRec>* prev;  // the queue of the previous shade pass
+    void prevRay(uint32_t entry, d3& o, d3& d) const {
+        o = (*prev)[entry].o;
+        d = (*prev)[entry].d;
+    }
     bool any(bool b) const { return b; }
     unsigned long long pop(bool need) const { return need ? (*work)++ : 0ull; }
     void filmAdd(double* a, double v) const { *a += v; }
@@ -495,9 +500,11 @@ struct HostWfEnv {
     void request(uint32_t slot, bool want, bool global) const {
         if (want) requests->push_back(slot | (global ? 0x80000000u : 0u));
     }
-    void push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double near1, double far1, uint32_t light1) const {
-        if (p0) queue->push_back(HostRayRec{slot * 2u, kNoSurface, o0, d0, 0.0, kDblMax});
-        if (p1) queue->push_back(HostRayRec{slot * 2u + 1u, light1, o1, d1, near1, far1});
+    uint32_t push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double dist1, uint32_t light1) const {
+        const uint32_t e0 = (uint32_t)queue->size();
+        if (p0) queue->push_back(HostRayRec{slot * 2u, kNoSurface, o0, d0, 0.0});
+        if (p1) queue->push_back(HostRayRec{slot * 2u + 1u, light1, o1, d1, dist1});
+        return e0;
     }
 };
 }  // namespace
@@ -607,18 +614,19 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
         fr.samples = samples.data();
     }
     unsigned long long work = 0;
-    std::vector<HostRayRec> queue;
+    std::vector<HostRayRec> queue, prev_queue;
     std::vector<uint32_t> requests;
-    HostWfEnv env{&work, &queue, &requests};
+    HostWfEnv env{&work, &queue, &prev_queue, &requests};
     TraceCounters cnt = {0, 0, 0, 0};
     uint32_t paths = 0;
     uint64_t iterations = 0, searches = 0;
     for (;;) {
+        queue.swap(prev_queue);
         queue.clear();
         requests.clear();
         for (uint32_t s = 0; s < slots; s++) {
-            if (photon) wfShadeSlot<false, true>(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths, &pm);
-            else wfShadeSlot<false, false>(env, P, s, true, fr, E.sh_top, E.rh, E.tab.data(), paths);
+            if (photon) wfShadeSlot<false, true>(env, P, s, wfSlotFlags(P, s, true), fr, E.sh_top, E.rh, E.tab.data(), paths, &pm);
+            else wfShadeSlot<false, false>(env, P, s, wfSlotFlags(P, s, true), fr, E.sh_top, E.rh, E.tab.data(), paths);
         }
         iterations++;
         if (queue.empty() && requests.empty()) break;
@@ -640,8 +648,9 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
         }
         for (const HostRayRec& r : queue) {
             ShadowQuery sq;
-            sq.t_near = r.t_near;
-            sq.t_far = r.t_far;
+            sq.t_near = 0.0;
+            sq.t_far = kDblMax;
+            if (r.item & 1u) sq.setRange(r.dist);
             sq.light = r.light;
             const Hit h = qt.run(r.o, r.d, (r.item & 1u) != 0u, &sq, cnt);
             wfStoreHit(P, r.item, h);
