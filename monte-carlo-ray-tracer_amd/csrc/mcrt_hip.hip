@@ -86,7 +86,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_rec, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -1123,6 +1123,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     else if (int rc = uploadArray(ctx, ctx->flat_pre, L.flat_pre.data(), L.flat_pre.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_v, L.num_quadric_surfaces ? L.surf_v_patched.data() : s->surf_v, ns * 9)) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_normal, normal.data(), normal.size())) return rc;
+    if (int rc = uploadArray(ctx, ctx->surf_rec, L.shade_rec.data(), L.shade_rec.size())) return rc;
     if (any_vn) {
         if (int rc = uploadArray(ctx, ctx->surf_vn, s->surf_vn, ns * 9)) return rc;
     } else {
@@ -1167,6 +1168,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.pre_bound = L.pre_bound;
     d.surf_v = ctx->surf_v.as<double>();
     d.surf_normal = ctx->surf_normal.as<double>();
+    d.surf_rec = ctx->surf_rec.as<double>();
     d.surf_vn = any_vn ? ctx->surf_vn.as<double>() : nullptr;
     d.surf_area = ctx->surf_area.as<double>();
     d.surf_material = ctx->surf_material.as<uint32_t>();

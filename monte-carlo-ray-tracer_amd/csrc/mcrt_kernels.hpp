@@ -41,6 +41,7 @@ struct DeviceScene {
     double pre_centre[3], pre_bound;
     const double* surf_v;
     const double* surf_normal;
+    const double* surf_rec;  // [n][4] normal + material | kind << 32 (ShadeViewT::surf_rec)
     const double* surf_vn;  // may be null
     const double* surf_area;
     const uint32_t* surf_material;
@@ -253,6 +254,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
         stageCopy(ln, s.surf_normal, ns * 3);
         sh.surf_normal = ln;
+        sh.surf_rec = nullptr;
         MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
         if (s.surf_vn) stageCopy(lvn, s.surf_vn, ns * 9);
         sh.surf_vn = lvn;
@@ -286,6 +288,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         sv.pre_cx = sv.pre_cy = sv.pre_cz = sv.pre_bound = 0.0;
         sh.surf_v = s.surf_v;
         sh.surf_normal = s.surf_normal;
+        sh.surf_rec = s.surf_rec;
         sh.surf_vn = s.surf_vn;
         sh.surf_area = s.surf_area;
         sh.surf_material = s.surf_material;
@@ -534,6 +537,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
         MCRT_LDS_AS double* ln = ldsAt<double>(lds, p.surf_normal);
         stageCopy(ln, scene.surf_normal, ns * 3);
         sh.surf_normal = ln;
+        sh.surf_rec = nullptr;
         MCRT_LDS_AS double* lvn = ldsAt<double>(lds, p.surf_vn);
         if (scene.surf_vn) stageCopy(lvn, scene.surf_vn, ns * 9);
         sh.surf_vn = lvn;
@@ -561,6 +565,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
         setLeafCull(sv, scene.leaf_pre, scene.leaf_cx, scene.leaf_cy, scene.leaf_cz, scene.leaf_bound);
         sh.surf_v = scene.surf_v;
         sh.surf_normal = scene.surf_normal;
+        sh.surf_rec = scene.surf_rec;
         sh.surf_vn = scene.surf_vn;
         sh.surf_area = scene.surf_area;
         sh.surf_material = scene.surf_material;
@@ -1378,6 +1383,7 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
     sh.scene_ior = scene.scene_ior;
     sh.surf_v = scene.surf_v;
     sh.surf_normal = scene.surf_normal;
+    sh.surf_rec = scene.surf_rec;
     sh.surf_vn = scene.surf_vn;
     sh.surf_area = scene.surf_area;
     sh.surf_material = scene.surf_material;

@@ -24,6 +24,8 @@ struct HostLayout {
     std::vector<NodeMeta> node_meta;   // [n]
     std::vector<double> prim;          // [n][kPrimStride]
     std::vector<double> normal;        // [n][3] Triangle::normal_
+    std::vector<double> shade_rec;     // [n][16] what a hit needs, ONE 128-byte line per surface: the face normal, material | kind << 32 as the fourth
+                                       // word's bits, the three vertex normals (interpolating triangles), padding (mcrt_shade.hpp: kSurfRecWords)
     bool any_vn = false;
     // kind-sorted copy for the flat (tiny-scene) loop: triangles first, then spheres
     std::vector<double> flat_prim;     // [n][kPrimStride]
@@ -593,6 +595,13 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             err = "unsupported surface kind";
             return MCRT_ERR_UNSUPPORTED;
         }
+    }
+    L.shade_rec.assign(ns * 16, 0.0);
+    for (size_t i = 0; i < ns; i++) {
+        memcpy(&L.shade_rec[i * 16], &L.normal[i * 3], 3 * sizeof(double));
+        const unsigned long long w = (unsigned long long)s->surf_material[i] | ((unsigned long long)s->surf_kind[i] << 32);
+        memcpy(&L.shade_rec[i * 16 + 3], &w, 8);
+        if (s->surf_kind[i] == MCRT_SURF_TRIANGLE && s->surf_interpolate[i] && s->surf_vn) memcpy(&L.shade_rec[i * 16 + 4], s->surf_vn + i * 9, 9 * sizeof(double));
     }
     for (uint32_t i = 0; i < s->num_lights; i++)
         if (s->light_surface[i] >= s->num_surfaces) {

@@ -21,6 +21,8 @@ struct ShadeViewT {
     cptr<double, L> surf_area;        // [n]
     cptr<uint32_t, L> surf_material;  // [n]
     cptr<uint8_t, L> surf_kind;       // [n]
+    const double* surf_rec;           // [n][16] scenes in memory: normal, material | kind << 32, vertex normals in ONE 128-byte line
+                                      // (HostLayout::shade_rec); from the five arrays a hit moves four to six lines
     cptr<mcrt_material, L> materials;
     uint32_t num_lights;
     cptr<uint32_t, L> light_surface;
@@ -293,7 +295,6 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
     ia.out = -ray.direction;
     ia.n1 = ray.medium_ior;
     ia.surface = isect.surface;
-    ia.material = &sh.materials[sh.surf_material[isect.surface]];
     ia.ray_direction = ray.direction;
     ia.ray_refraction_scale = ray.refraction_scale;
     ia.ray_refraction_level = ray.refraction_level;
@@ -303,16 +304,29 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
     ia.position = ray.start + ray.direction * ia.t;  // Ray::operator() ray.cpp:69-72
     d3 vn0 = splat(0.0), vn1 = splat(0.0), vn2 = splat(0.0);
     if constexpr (L) {
+        ia.material = &sh.materials[sh.surf_material[isect.surface]];
         ia.normal = surfNormal(sh, isect.surface, ia.position);
-    } else {  // scene in memory: everything the hit needs in one round trip
-        const SurfRec rec = surfFetch(sh, isect.surface, false);
+    } else {  // scene in memory: everything the hit needs in one round trip, the record and (interpolating triangles) the vertex normals
+        const double* rp = sh.surf_rec + (size_t)isect.surface * 16;
+        const d3 face_normal = ld3(rp);
+        const unsigned long long w = dBits(rp[3]);
         if (isect.interpolate) {
-            cptr<double, L> n = sh.surf_vn + (size_t)isect.surface * 9;
-            vn0 = ld3(n);
-            vn1 = ld3(n + 3);
-            vn2 = ld3(n + 6);
+            vn0 = ld3(rp + 4);
+            vn1 = ld3(rp + 7);
+            vn2 = ld3(rp + 10);
         }
-        ia.normal = surfNormalOf<L>(rec, ia.position);
+        ia.material = &sh.materials[(uint32_t)w];
+        const uint32_t kind = (uint32_t)(w >> 32);
+        ia.normal = face_normal;
+        if (kind != MCRT_SURF_TRIANGLE) {  // (spheres and quadrics read their own data: a second trip for those lanes)
+            SurfRec rec;
+            rec.kind = kind;
+            cptr<double, L> p = sh.surf_v + (size_t)isect.surface * 9;
+            for (int k = 0; k < 4; k++) rec.v[k] = p[k];
+            for (int k = 4; k < 9; k++) rec.v[k] = 0.0;
+            rec.normal = face_normal;
+            ia.normal = surfNormalOf<L>(rec, ia.position);
+        }
     }
     const uint32_t flags = ia.material->flags;
 

@@ -84,6 +84,7 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     auto fillShade = [&](auto& sh) {
         sh.surf_v = E.L.num_quadric_surfaces ? E.L.surf_v_patched.data() : s->surf_v;
         sh.surf_normal = E.L.normal.data();
+        sh.surf_rec = E.L.shade_rec.data();
         sh.surf_vn = s->surf_vn;
         sh.surf_area = s->surf_area;
         sh.surf_material = s->surf_material;
