@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -637,8 +638,40 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     return MCRT_OK;
 }
 
-int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out,
-                 hipStream_t stream, double* film_out = nullptr) {
+// Frames of DIFFERENT contexts on ONE device never overlap on the GPU: a launch waits (on the GPU, hipStreamWaitEvent) for the
+// frame the device's previous launcher queued, and the host side of a launch — the whole frame for the wavefront pipeline — runs
+// under the device's mutex. Why: kernels that use scratch memory gave wrong frames when two contexts of one process rendered on
+// the same GPU at the same time (two host threads, one stream each: ray counts identical, radiance a few per cent off, different
+// from run to run; the same kernels without scratch — the shade kernel compiled for 2 waves per SIMD — were right).
+// One context per device, the production shape, never waits here.
+struct DeviceOrder {
+    std::mutex m;
+    hipEvent_t last = nullptr;
+    mcrt_ctx* owner = nullptr;
+};
+DeviceOrder g_device_order[64];
+
+int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out, hipStream_t stream,
+                     double* film_out);
+int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out, hipStream_t stream,
+                 double* film_out = nullptr) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    DeviceOrder& o = g_device_order[(unsigned)ctx->device & 63u];
+    std::lock_guard<std::mutex> guard(o.m);
+    if (o.owner && o.owner != ctx) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, o.last, 0));
+    }
+    const int rc = launchRenderImpl(ctx, cam, global_seed, integrator, d_out, stream, film_out);
+    if (rc == MCRT_OK && ctx->pending) {
+        o.last = ctx->ev1;
+        o.owner = ctx;
+    }
+    return rc;
+}
+
+int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out, hipStream_t stream,
+                     double* film_out) {
     if (!ctx) return MCRT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, MCRT_ERR_NO_SCENE, "mcrt_render before mcrt_upload_scene");
     if (int rc = validateCamera(ctx, cam)) return rc;
@@ -1036,6 +1069,15 @@ int mcrt_create(mcrt_ctx** out, int device_id) {
 void mcrt_destroy(mcrt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    {
+        DeviceOrder& o = g_device_order[(unsigned)ctx->device & 63u];
+        std::lock_guard<std::mutex> guard(o.m);
+        if (o.owner == ctx) {  // nobody may wait on an event that is about to go
+            (void)hipEventSynchronize(o.last);
+            o.owner = nullptr;
+            o.last = nullptr;
+        }
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);

@@ -37,6 +37,24 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _dirty_device_memory(request):
+    """GPU tests run on memory that is NOT zero: before each of them a few GB are filled with 0xFF bytes (NaN as doubles, ~4e9 as
+    indices) and handed back, so that whatever the library allocates next is dirty — as it is on a GPU that other processes or
+    contexts use too. A result that depends on fresh memory being zero (an unwritten word read as 0) then fails here, on the
+    single-process box, instead of only when the device is shared."""
+    if "gpu" in request.keywords and _has_gpu():
+        import torch
+        try:
+            junk = [torch.full((1 << 30,), 0xFF, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+            torch.cuda.synchronize()
+            del junk
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def pkg():
     """The product binding. The shared library must already be built (python __graft_entry__.py build)."""
