@@ -119,7 +119,7 @@ struct mcrt_ctx {
     std::vector<uint64_t> host_keys[2];
 
     // wavefront path tracer: slot pool, ray queue, control words {count[2], pop}, pinned read-back word
-    DevBuf wf_pool, wf_queue, wf_ctrl, wf_film, wf_film_cache, wf_requests, wf_res_n, wf_res_r2, wf_res_idx, wf_res_d2;
+    DevBuf wf_pool, wf_queue, wf_ctrl, wf_film, wf_film_cache, wf_requests, wf_res_n, wf_res_r2, wf_res_idx, wf_res_d2, wf_stage, wf_est;
     uint32_t wf_res_slots = 0, wf_res_k = 0;
     uint32_t wf_slots = 0;
     unsigned long long* wf_host = nullptr;   // pinned: one read-back word per half
@@ -521,14 +521,23 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     WfKnnArgs ka;
     memset(&ka, 0, sizeof(ka));
     uint32_t knn_grid = 0;
+    bool knn_eval = false;
     if (photon) {
         const uint32_t k = ctx->k_nearest;
-        if (ctx->wf_res_slots != slots || ctx->wf_res_k != k) {
+        // MCRT_WF_PM_EVAL (default 1): the kNN launch evaluates the estimates from staged Interactions; 0: it hands the k photons
+        // back and the shade launch sums them per lane (round 2's form)
+        knn_eval = ctxOptL(ctx, "MCRT_WF_PM_EVAL", 1) != 0;
+        if (ctx->wf_res_slots != slots || ctx->wf_res_k != k || (knn_eval ? !ctx->wf_stage.p : !ctx->wf_res_idx.p)) {
             HIP_TRY(ctx, ctx->wf_requests.alloc((size_t)slots * sizeof(uint32_t)));
-            HIP_TRY(ctx, ctx->wf_res_n.alloc((size_t)2 * slots * sizeof(uint32_t)));
-            HIP_TRY(ctx, ctx->wf_res_r2.alloc((size_t)2 * slots * sizeof(double)));
-            HIP_TRY(ctx, ctx->wf_res_idx.alloc((size_t)2 * k * slots * sizeof(uint32_t)));
-            HIP_TRY(ctx, ctx->wf_res_d2.alloc((size_t)2 * k * slots * sizeof(double)));
+            if (knn_eval) {
+                HIP_TRY(ctx, ctx->wf_stage.alloc((size_t)slots * kStageDoubles * sizeof(double)));
+                HIP_TRY(ctx, ctx->wf_est.alloc((size_t)slots * 6 * sizeof(double)));
+            } else {
+                HIP_TRY(ctx, ctx->wf_res_n.alloc((size_t)2 * slots * sizeof(uint32_t)));
+                HIP_TRY(ctx, ctx->wf_res_r2.alloc((size_t)2 * slots * sizeof(double)));
+                HIP_TRY(ctx, ctx->wf_res_idx.alloc((size_t)2 * k * slots * sizeof(uint32_t)));
+                HIP_TRY(ctx, ctx->wf_res_d2.alloc((size_t)2 * k * slots * sizeof(double)));
+            }
             ctx->wf_res_slots = (uint32_t)slots;
             ctx->wf_res_k = k;
         }
@@ -543,6 +552,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         ka.res_r2 = ctx->wf_res_r2.as<double>();
         ka.res_idx = ctx->wf_res_idx.as<uint32_t>();
         ka.res_d2 = ctx->wf_res_d2.as<double>();
+        ka.stage = knn_eval ? ctx->wf_stage.as<double>() : nullptr;
+        ka.est = knn_eval ? ctx->wf_est.as<double>() : nullptr;
         knn_grid = (uint32_t)ctx->num_cus * 8u;
         WfShadeArgs& s0 = sa[0];
         s0.requests = ctx->wf_requests.as<uint32_t>();
@@ -555,6 +566,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         s0.pm.res_d2 = ka.res_d2;
         s0.pm.k = k;
         s0.pm.direct_visualization = ctx->direct_visualization != 0;
+        s0.pm.est = ka.est;
+        s0.stage = knn_eval ? ctx->wf_stage.as<double>() : nullptr;
     }
 
     const uint64_t check_every = (uint64_t)std::max<long>(2, envi("MCRT_WF_CHECK", 16));
@@ -601,7 +614,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             ctx->launches++;
             if (photon) {
                 ka.count = ctrl + 4 + (it & 1);
-                hipLaunchKernelGGL(wfKnnKernel, dim3(knn_grid), dim3(256), 0, hs[h], ka);
+                if (knn_eval) hipLaunchKernelGGL(wfKnnKernel<true>, dim3(knn_grid), dim3(256), 0, hs[h], ka);
+                else hipLaunchKernelGGL(wfKnnKernel<false>, dim3(knn_grid), dim3(256), 0, hs[h], ka);
                 ctx->launches++;
             }
         }

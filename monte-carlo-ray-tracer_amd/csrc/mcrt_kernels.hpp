@@ -1298,6 +1298,7 @@ struct WfShadeArgs {
     unsigned long long* rcount_reset;
     unsigned long long* rpop_reset;
     WfPmView pm;
+    double* stage;                    // photon mapper: staged Interactions for the kNN launch (DevWfEnv::stage), or null
     uint32_t lds_tables;              // bytes of LDS after the refraction histories for the materials and the light tables (0: read from memory)
 };
 
@@ -1315,6 +1316,17 @@ struct DevWfEnv {
     unsigned long long* count;
     uint32_t* requests;
     unsigned long long* rcount;
+    double* stage_buf;                   // [slots][kStageDoubles] staged Interactions of the estimate requests (null: searches only)
+    const mcrt_material* mat_view;       // the shade launch's materials (its LDS copy) and the array in memory, for the staged pointer
+    const mcrt_material* mat_global;
+    __device__ void stage_(uint32_t slot, const InteractionT<false>& ia) const {
+        InteractionT<false> q = ia;
+        q.material = mat_global + (ia.material - mat_view);
+        stageInteraction(stage_buf + (size_t)slot * kStageDoubles, q);
+    }
+    __device__ void stage(uint32_t slot, const InteractionT<false>& ia) const {
+        if (stage_buf) stage_(slot, ia);
+    }
     __device__ void request(uint32_t slot, bool want, bool global) const {
         const unsigned long long m = waveBallot(want);
         if (!m) return;
@@ -1427,7 +1439,7 @@ __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3
         }
     }
     __syncthreads();
-    DevWfEnv env{a.work, a.queue, a.count_out, a.requests, a.rcount_out};
+    DevWfEnv env{a.work, a.queue, a.count_out, a.requests, a.rcount_out, a.stage, sh.materials, scene.materials};
     uint32_t paths = 0;
     wfShadeSlot<false, kPhoton>(env, a.pool, slot, fw, a.fr, sh, rh, (SobolTab)ltab, paths, &a.pm);
     waveAccumulate(a.stats + 0, paths);
@@ -1473,8 +1485,14 @@ struct WfKnnArgs {
     double* res_r2;
     uint32_t* res_idx;
     double* res_d2;
+    const double* stage;  // [slots][kStageDoubles] the requests' Interactions (written by the shade launch); null: write the photons out
+    double* est;          // [slots][6] the estimates, caustic rgb then global rgb
 };
 
+// kEval: the launch evaluates the estimate itself — the k photons' BSDF terms by k lanes at once, a wave reduction
+// (waveEvalPhotons, as in renderKernelPM) — from the Interaction the shade launch staged, instead of handing the k photons
+// back for a per-lane loop in the next shade launch (2 x k x 12 B per slot written and read, k divergent BSDF evaluations).
+template <bool kEval>
 __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     __shared__ double s_d2[4 * kWaveCand];
     __shared__ uint32_t s_idx[4 * kWaveCand];
@@ -1500,6 +1518,21 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
             double r2;
             const uint32_t c = waveKnnSearch(a.maps[map], p, a.k, W, r2, overflow, visits);
             searches++;
+            if constexpr (kEval) {
+                d3 sum = splat(0.0);
+                if (c) {  // else photons.empty(): the estimate is zero (photon-mapper.cpp:347, :374)
+                    InteractionT<false> q;
+                    loadStagedInteraction(a.stage + (size_t)slot * kStageDoubles, q);
+                    sum = waveEvalPhotons(q, a.maps[map], map == 1, W.d2, W.idx, c, r2);
+                }
+                if (lane == 0) {
+                    double* o = a.est + (size_t)slot * 6 + (map == 1 ? 0 : 3);
+                    o[0] = sum.x;
+                    o[1] = sum.y;
+                    o[2] = sum.z;
+                }
+                continue;
+            }
             if (lane == 0) {
                 a.res_n[(size_t)map * slots + slot] = c;
                 a.res_r2[(size_t)map * slots + slot] = r2;

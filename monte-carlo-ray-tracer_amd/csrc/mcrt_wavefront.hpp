@@ -181,6 +181,9 @@ struct WfPmView {
     const double* res_d2;        // [2][k][slots]
     uint32_t k;
     bool direct_visualization;
+    // estimates evaluated by the kNN launch itself (wfKnnKernel with staged Interactions, the wave-cooperative evaluation of
+    // mcrt_waveknn.hpp): [slots][6] caustic rgb, global rgb; null: the k photons come back and the shade launch sums them per lane
+    const double* est;
 };
 
 template <bool L>
@@ -217,6 +220,7 @@ MCRT_HD d3 wfPhotonEstimate(const WfPmView& pm, uint32_t n_slots, uint32_t slot,
 //   void prevRay(entry, o, d)           the bounce ray the previous shade launch queued at `entry`
 //   void filmAdd(double*, double)       accumulate into a film splat (any lane, any time; atomic on the GPU)
 //   void request(slot, want, global)    photon mapper: queue the slot's caustic (and global) search for the next kNN launch
+//   void stage(slot, ia)                photon mapper: leave the hit's Interaction where the kNN launch finds it (any lane; no-op when that launch only searches)
 // All but filmAdd are called by every lane of the wave, at the same place.
 MCRT_HD unsigned long long wfSlotFlags(const WfPool& P, uint32_t slot, bool valid) { return valid ? P.getu(kWfFlags, slot) : (unsigned long long)kWfDone; }
 
@@ -345,11 +349,14 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long
                         } else {
                             want_estimate = true;                                                    // :315 (+ :327-330)
                             need_g = !(!pm->direct_visualization && (st.ray.dirac_delta || st.ray.depth == 0));
+                            env.stage(slot, ia);
                         }
                     } else {
-                        st.radiance = st.radiance + wfPhotonEstimate(*pm, P.n, slot, 1, ia) * st.throughput;  // :315
+                        const d3 est_c = pm->est ? ld3(pm->est + (size_t)slot * 6) : wfPhotonEstimate(*pm, P.n, slot, 1, ia);
+                        st.radiance = st.radiance + est_c * st.throughput;  // :315
                         if (flags & kWfEstNeedG) {
-                            st.radiance = st.radiance + wfPhotonEstimate(*pm, P.n, slot, 0, ia) * st.throughput;  // :330: the path ends here
+                            const d3 est_g = pm->est ? ld3(pm->est + (size_t)slot * 6 + 3) : wfPhotonEstimate(*pm, P.n, slot, 0, ia);
+                            st.radiance = st.radiance + est_g * st.throughput;  // :330: the path ends here
                             alive = false;
                         } else {
                             go_on = true;

@@ -501,6 +501,7 @@ struct HostWfEnv {
     void request(uint32_t slot, bool want, bool global) const {
         if (want) requests->push_back(slot | (global ? 0x80000000u : 0u));
     }
+    void stage(uint32_t, const InteractionT<false>&) const {}  // (the host stand-in of the kNN launch only searches)
     uint32_t push(uint32_t slot, bool p0, bool p1, d3 o0, d3 d0, d3 o1, d3 d1, double dist1, uint32_t light1) const {
         const uint32_t e0 = (uint32_t)queue->size();
         if (p0) queue->push_back(HostRayRec{slot * 2u, kNoSurface, o0, d0, 0.0});
