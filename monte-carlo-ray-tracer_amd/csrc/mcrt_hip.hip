@@ -885,7 +885,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
     {
         // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
-        // store holds (MCRT_SAMPLE_STORE_GB, default 16: the whole 1080p @ 256 spp frame is 12.7 GB), each pass = one
+        // store holds (MCRT_SAMPLE_STORE_GB, default 64: mcrt_plan.hpp), each pass = one
         // integrator launch + the in-order resolve.
         const PassPlan pp = planPasses(cam->width, prm.owned_rows, prm.spp, sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB")));
         const uint64_t pass_rows = pp.pass_rows;
