@@ -106,6 +106,9 @@ def load_emu():
     L.emu_octree_desc.restype = vp
     L.emu_octree_free.argtypes = [vp]
     L.emu_sampler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_sampler_restore.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.emu_shade_rec.argtypes = [vp, vp]
+    L.emu_shade_rec.restype = C.c_int
     L.emu_render_wf_film.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.emu_film_resolve.argtypes = [vp, C.c_uint64, vp]
     L.emu_film_resolve.restype = None

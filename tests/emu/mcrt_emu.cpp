@@ -923,6 +923,29 @@ void emu_sampler(uint32_t global_seed, uint32_t pixel, uint32_t index, uint32_t 
     for (int d = 0; d < 7; d++) out[d] = s.get(d, tab.data());
 }
 
+// The same numbers from Sampler::restore — what the wavefront pool keeps of a sampler is (pixel, sample index, number of shuffles)
+void emu_sampler_restore(uint32_t global_seed, uint32_t pixel, uint32_t index, uint32_t shuffles, double* out) {
+    static std::vector<uint32_t> tab;
+    if (tab.empty()) {
+        tab.resize(kSobolTableWords);
+        buildSobolByteTables(tab.data());
+    }
+    Sampler s;
+    s.base_seed = s.seed = s.sequence = s.bit_reversed_index = s.shuffled_index = 0xDEADBEEFu;
+    s.restore(global_seed, pixel, index, shuffles);
+    for (int d = 0; d < 7; d++) out[d] = s.get(d, tab.data());
+    out[7] = (double)s.sequence;
+}
+
+// HostLayout::shade_rec of a scene: [num_surfaces][16] doubles (the bits of word 3 = material | kind << 32)
+int emu_shade_rec(const mcrt_scene_desc* scene, double* out) {
+    HostLayout L;
+    std::string err;
+    if (int rc = buildLayout(scene, L, err)) return rc;
+    memcpy(out, L.shade_rec.data(), L.shade_rec.size() * sizeof(double));
+    return 0;
+}
+
 int emu_knn(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count, uint32_t* out_index,
             double* out_d2) {
     Emu E;

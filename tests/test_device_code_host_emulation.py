@@ -165,6 +165,43 @@ def test_sampler_byte_tables_equal_reference(emu, manifest):
         np.testing.assert_array_equal(out, want)
 
 
+def test_sampler_restored_from_three_numbers_equals_reference(emu, manifest):
+    """What a parked path keeps of its sampler (mcrt_wavefront.hpp: pixel, sample index, number of shuffles) gives the reference's numbers."""
+    d = golden_path(manifest["cases"]["hexagon_room"]["kat"])
+    inp = np.fromfile(os.path.join(d, "sampler_in.u32"), dtype=np.uint32).reshape(-1, 3)
+    ref = np.fromfile(os.path.join(d, "sampler_out.f64")).reshape(-1, 7)
+    out = np.empty(8)
+    for (pixel, index, shuffles), want in zip(inp, ref):
+        emu.emu_sampler_restore(manifest["seed"], int(pixel), int(index), int(shuffles), out.ctypes.data)
+        np.testing.assert_array_equal(out[:7], want)
+        assert out[7] == shuffles
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "quadric", "dragon_room"])
+def test_shading_record_holds_what_the_arrays_hold(pkg, emu, manifest, name):
+    """HostLayout::shade_rec (one 128-byte line per surface) against the per-field arrays it replaces for scenes in memory."""
+    img = pkg.SceneImage(golden_path(manifest["cases"][name]["image"]))
+    sc = img.scene
+    n = sc.num_surfaces
+    rec = np.zeros((n, 16))
+    assert emu.emu_shade_rec(C.addressof(sc), rec.ctypes.data) == 0
+    kind = np.ctypeslib.as_array(sc.surf_kind, (n,))
+    mat = np.ctypeslib.as_array(sc.surf_material, (n,))
+    e = np.ctypeslib.as_array(sc.surf_e, (n, 9))
+    interp = np.ctypeslib.as_array(sc.surf_interpolate, (n,))
+    w = rec[:, 3].copy().view(np.uint64)
+    np.testing.assert_array_equal(w & 0xFFFFFFFF, mat.astype(np.uint64))
+    np.testing.assert_array_equal(w >> np.uint64(32), kind.astype(np.uint64))
+    tri = kind == 0
+    np.testing.assert_array_equal(rec[tri, 0:3], e[tri, 6:9])
+    smooth = tri & (interp != 0)
+    if smooth.any():
+        vn = np.ctypeslib.as_array(sc.surf_vn, (n, 9))
+        np.testing.assert_array_equal(rec[smooth, 4:13], vn[smooth])
+    np.testing.assert_array_equal(rec[~smooth, 4:13], 0.0)
+    np.testing.assert_array_equal(rec[:, 13:], 0.0)
+
+
 @pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "ior_test", "quadric"])
 def test_traversal_device_code_kat(pkg, emu, oracle, manifest, name):
     case = manifest["cases"][name]
