@@ -230,3 +230,45 @@ def test_gpu_render_multi_film(pkg, manifest):
     assert (rel > 1e-4).sum() <= max(2, int(0.002 * rel.size)) and np.quantile(rel, 0.99) < 1e-9
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_contexts_sharing_the_device_from_two_threads(pkg, manifest):
+    """Two contexts on one GPU, each rendering its shard's splats from its own host thread at the same time: the buffers are the
+    ones the shards give one after the other (frames of contexts that share a device are ordered: DESIGN.md section 5)."""
+    import threading
+    import torch
+    img, cam, _ = _case(pkg, manifest, "film_mitchell")
+    n = 2
+    ctxs = [pkg.Context(0) for _ in range(n)]
+    for c in ctxs:
+        c.upload_image(img)
+
+    def shard(i):
+        sh = cam.copy()
+        sh.shard_count, sh.shard_index, sh.shard_rows = n, i, 8
+        return sh
+
+    def render(i, buf, stats):
+        ctxs[i].render_film_device(shard(i), manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, buf.data_ptr())
+        stats[i] = ctxs[i].render_finish()
+
+    def buffers():
+        return [torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(n)]
+
+    one_by_one, st0 = buffers(), [None] * n
+    for i in range(n):
+        render(i, one_by_one[i], st0)
+    for _ in range(3):
+        at_once, st1 = buffers(), [None] * n
+        threads = [threading.Thread(target=render, args=(i, at_once[i], st1)) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for i in range(n):
+            assert st1[i]["rays"] == st0[i]["rays"]
+            # (splats are atomic adds: their order, and so the last bits of a sum, differ from run to run)
+            np.testing.assert_allclose(at_once[i].cpu().numpy(), one_by_one[i].cpu().numpy(), rtol=1e-11, atol=1e-11)
+    for c in ctxs:
+        c.close()
