@@ -446,8 +446,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     auto runPass = [&]() -> int {  // the rows [fr.row_base, fr.row_end): shade / trace launches until nothing is queued
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_ctrl.p, 0, kWfCtrlWords * sizeof(unsigned long long), stream));
-    // a fresh slot is all-zero flags (no path, no pixel); nothing else is read before it is written
+    // a fresh slot is all-zero flags (no path, no pixel); nothing else is used before it is written (kWfSeq is cleared too: the
+    // sampler is rebuilt from it before the flags are looked at; tests/emu runs the same code on a pool of garbage)
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfSeq * slots, 0, (size_t)slots * 8, stream));
 
     const bool wide = useWideNodes(ctx);
     // MCRT_WF_SCHED=1: the slot-scheduled trace kernel (ray state in LDS, steps issued for 64 rays that want the same step)

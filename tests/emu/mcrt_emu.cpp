@@ -571,7 +571,10 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     QTrace qt;
     qt.init(E, scene);
 
-    std::vector<unsigned long long> pool((size_t)kWfWords * slots, 0ull);
+    // as on the device, where only the flags and the kWfSeq planes of a fresh pool are cleared: every other word starts as garbage
+    // (all ones = NaN as a double, 4e9 as an index), so a word that is read before it is written shows in the frame
+    std::vector<unsigned long long> pool((size_t)kWfWords * slots, ~0ull);
+    for (uint32_t i = 0; i < slots; i++) pool[(size_t)kWfFlags * slots + i] = pool[(size_t)kWfSeq * slots + i] = 0ull;
     WfPool P;
     P.w = pool.data();
     P.n = slots;
