@@ -656,10 +656,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
 
 // Frames of DIFFERENT contexts on ONE device never overlap on the GPU: a launch waits (on the GPU, hipStreamWaitEvent) for the
 // frame the device's previous launcher queued, and the host side of a launch — the whole frame for the wavefront pipeline — runs
-// under the device's mutex. Why: kernels that use scratch memory gave wrong frames when two contexts of one process rendered on
-// the same GPU at the same time (two host threads, one stream each: ray counts identical, radiance a few per cent off, different
-// from run to run; the same kernels without scratch — the shade kernel compiled for 2 waves per SIMD — were right).
-// One context per device, the production shape, never waits here.
+// under the device's mutex. Why: an experimental build (hit records as one record per slot) gave wrong frames when two contexts of
+// one process rendered on the same GPU at the same time (two host threads, one stream each: ray counts identical, radiance a few
+// per cent low, different from run to run) and was never understood. The committed kernels have not shown it,
+// but nothing relies on concurrent frames of one device. One context per device, the production shape, never waits here.
 struct DeviceOrder {
     std::mutex m;
     hipEvent_t last = nullptr;
