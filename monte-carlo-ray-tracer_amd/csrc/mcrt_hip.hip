@@ -108,6 +108,14 @@ struct mcrt_ctx {
     DevBuf op_buf[6];
     std::map<std::string, std::string> options;  // mcrt_set_option; seeded from the MCRT_* environment variables at mcrt_create
     DevBuf pm_iors;  // refraction histories of the 1024-lane photon-mapping kernel
+    // the frame in flight, kept so that mcrt_render_finish can run it again through the wavefront pipeline (deep refraction histories)
+    mcrt_camera_desc last_cam;
+    uint32_t last_seed = 0;
+    int last_integrator = 0;
+    double* last_out = nullptr;
+    double* last_film = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool force_wf = false;
     DevBuf wf_ray_scratch;  // slot-scheduled trace kernel: the FP64 rays of the slots, [workgroup][slot][8]
     DevPool pass_pool;  // work buffers of the device photon pass (mcrt_photon_device.hpp)
     DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
@@ -682,6 +690,12 @@ int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_see
     if (rc == MCRT_OK && ctx->pending) {
         o.last = ctx->ev1;
         o.owner = ctx;
+        if (cam != &ctx->last_cam) ctx->last_cam = *cam;
+        ctx->last_seed = global_seed;
+        ctx->last_integrator = integrator;
+        ctx->last_out = d_out;
+        ctx->last_film = film_out;
+        ctx->last_stream = stream;
     }
     return rc;
 }
@@ -737,7 +751,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // is not built, so it is refused rather than rendered as the default box
     if (filtered && photon && ctx->k_nearest > 128)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters on photon-mapped frames need k_nearest_photons <= 128 (wavefront pipeline)");
-    const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0);
+    const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0) || ctx->force_wf;
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
     const char* mn = ctxOpt(ctx, "MCRT_WF_MIN_NODES");
@@ -1363,7 +1377,21 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_id = ctx->kernel_id;
     }
     if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
-    if (h[7]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "a path entered more than 8 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to 8 entries per lane)");
+    if (h[7]) {
+        // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
+        // (32). A frame that nested deeper than 8 media is rendered AGAIN through the pipeline: slower for the scenes the megakernels
+        // are chosen for, and correct. (The reference's vector is unbounded; no scene of it nests deeper than 4.)
+        const bool was_pipeline = ctx->kernel_id == MCRT_KERNEL_WAVEFRONT || ctx->kernel_id == MCRT_KERNEL_WAVEFRONT_PM;
+        const bool photon = ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER;
+        if (!was_pipeline && !ctx->force_wf && ctx->scene.q_nodes > 0 && (!photon || ctx->k_nearest <= 128)) {
+            ctx->force_wf = true;
+            const int rc = launchRender(ctx, &ctx->last_cam, ctx->last_seed, ctx->last_integrator, ctx->last_out, ctx->last_stream, ctx->last_film);
+            ctx->force_wf = false;
+            if (rc != MCRT_OK) return rc;
+            return mcrt_render_finish(ctx, stats);
+        }
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "a path entered more than 32 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to kMaxIorsDeep entries per slot)");
+    }
     return MCRT_OK;
 }
 

@@ -189,7 +189,8 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
                                   SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes,
                                   uint32_t stack_depth = kLdsStackDepth, double* iors_global = nullptr) {
     const LdsPlan p = planLds(s, blockDim.x, !kFlat, stack_depth, iors_global ? kPmLdsIors : (uint32_t)kMaxIors);
-    rh.giors = iors_global ? iors_global + (size_t)blockIdx.x * blockDim.x + threadIdx.x : nullptr;
+    rh.giors = iors_global;
+    rh.glane = blockIdx.x * blockDim.x + threadIdx.x;
     rh.gstride = total_lanes;
     rh.lds_depth = iors_global ? (int)kPmLdsIors : kMaxIors;
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;

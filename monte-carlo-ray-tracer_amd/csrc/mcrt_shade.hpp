@@ -228,8 +228,11 @@ MCRT_HD d3 surfSampleOf(const SurfRec& r, double u, double v) {
 // The reference keeps a std::vector<double> of medium IORs (reserve(8)). Here it is a per-lane stack of
 // kMaxIors doubles in LDS ([entry][lane]); it is a separate object, not a member of the path state,
 // so that the dynamically indexed array does not force the whole path state out of registers.
-// Documented cap: nesting deeper than kMaxIors dielectrics keeps the top entry.
+// kMaxIors entries per lane live in LDS; nesting deeper than that (no scene of the reference comes near it) continues in memory up to
+// kMaxIorsDeep — the wavefront pool's own words, a per-lane region for the megakernels — and beyond THAT a frame ends with
+// MCRT_ERR_UNSUPPORTED instead of a wrong medium (the reference's vector is unbounded).
 constexpr int kMaxIors = 8;
+constexpr int kMaxIorsDeep = 32;
 struct RefractionHistory {
     MCRT_LDS_AS double* iors;  // &lds_iors[lane]; stride = block size
     uint32_t stride;
@@ -237,14 +240,18 @@ struct RefractionHistory {
     // The 1024-lane photon-mapping kernel keeps only the first two entries in LDS and the rest in global memory
     // ([kMaxIors - 2][lanes], interleaved by lane): 48 KB of LDS go to the traversal stacks and the estimates' buffers.
     // Everywhere else all kMaxIors entries are in LDS and giors is null.
-    double* giors = nullptr;
+    // (base and stride are the same for every lane — scalar registers on the GPU — and the lane's column is one 32-bit register: a
+    // per-lane pointer cost the lane state machine 3 % of a frame in spilled registers)
+    double* giors = nullptr;   // base of the entries in memory, [max_depth - lds_depth][gstride]
     uint32_t gstride = 0;
+    uint32_t glane = 0;        // this lane's column
     int lds_depth = kMaxIors;  // entries [0, lds_depth) in LDS, the rest (nesting deeper than that: rare) in giors
-    bool overflow = false;     // a medium was entered at nesting depth kMaxIors: reported by mcrt_render_finish (the reference's vector is unbounded)
-    MCRT_HD double at(int i) const { return i < lds_depth ? iors[(uint32_t)i * stride] : giors[(size_t)(i - lds_depth) * gstride]; }
+    int max_depth = kMaxIors;  // entries in all: lds_depth + the rows giors has
+    bool overflow = false;     // a medium was entered at nesting depth max_depth: reported by mcrt_render_finish
+    MCRT_HD double at(int i) const { return i < lds_depth ? iors[(uint32_t)i * stride] : giors[(size_t)(i - lds_depth) * gstride + glane]; }
     MCRT_HD void put(int i, double v) {
         if (i < lds_depth) iors[(uint32_t)i * stride] = v;
-        else giors[(size_t)(i - lds_depth) * gstride] = v;
+        else giors[(size_t)(i - lds_depth) * gstride + glane] = v;
     }
     MCRT_HD void init(const Ray& ray) {
         put(0, ray.medium_ior);
@@ -253,7 +260,7 @@ struct RefractionHistory {
     MCRT_HD void update(const Ray& ray) {
         if (ray.refraction_level > 0) {
             if (ray.refraction_level == size) {
-                if (size < kMaxIors) put(size++, ray.medium_ior);
+                if (size < max_depth) put(size++, ray.medium_ior);
                 else overflow = true;
             } else if (ray.refraction_level < size - 1) {
                 size--;

@@ -63,7 +63,8 @@ enum : uint32_t {
     kWfHit0S = 39,       // surface | interpolate << 32
     kWfHit1T = 40,       // shadow-ray result
     kWfHit1S = 41,
-    kWfWords = 42
+    kWfIorsDeep = 42,    // 24  RefractionHistory entries kMaxIors .. kMaxIorsDeep - 1: read and written in place (rh.giors), never copied
+    kWfWords = 66
 };
 enum : uint32_t {
     kWfAlive = 1u,        // the bounce ray in the slot was traced for this iteration
@@ -72,9 +73,9 @@ enum : uint32_t {
     kWfDone = 8u,         // no pixels left for this slot
     kWfDirac = 16u,
     kWfRefraction = 32u,
-    kWfRhShift = 8,       // RefractionHistory::size in bits 8..11
-    kWfEstWait = 1u << 12,  // photon mapper: the hit in the slot waits for its radiance estimates
-    kWfEstNeedG = 1u << 13  // ... the global estimate too (the path ends with it)
+    kWfRhShift = 8,       // RefractionHistory::size in bits 8..13
+    kWfEstWait = 1u << 14,  // photon mapper: the hit in the slot waits for its radiance estimates
+    kWfEstNeedG = 1u << 15  // ... the global estimate too (the path ends with it)
 };
 
 struct WfPool {
@@ -234,6 +235,13 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long
     bool alive = (flags & kWfAlive) != 0u, have_pixel = (flags & kWfHavePixel) != 0u;
     const bool nee_was_pending = (flags & kWfNeePending) != 0u;
 
+    // histories deeper than the kMaxIors entries a lane has in LDS go on in the slot's own pool words
+    rh.giors = reinterpret_cast<double*>(P.w + (size_t)kWfIorsDeep * P.n);
+    rh.glane = slot;
+    rh.gstride = P.n;
+    rh.lds_depth = kMaxIors;
+    rh.max_depth = kMaxIorsDeep;
+
     PathState st;
     NeePending nee;
     nee.pending = false;
@@ -306,7 +314,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long
         ly = ((uint32_t)uw >> 16) & 0xFFFFu;
         sample = (uint32_t)(uw >> 32);
         st.smp.restore(fr.global_seed, localToGlobalRow(fr.cam, ly) * fr.cam.width + px, sample, (uint32_t)sq_w);
-        rh.size = (int)((flags >> kWfRhShift) & 15u);
+        rh.size = (int)((flags >> kWfRhShift) & 63u);
         rh.put(0, ior0);
         rh.put(1, ior1);
         if (env.any(rh.size > 2))

@@ -59,7 +59,7 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     E.stk.lds_stride = 1;
     E.stk.spill = E.stack_spill.data();
     E.stk.spill_stride = 1;
-    E.iors.assign(kMaxIors, 0.0);
+    E.iors.assign(kMaxIors, 0.0);  // (the wavefront integrator continues deeper histories in the slot's own pool words: wfShadeSlot)
     E.rh.iors = E.iors.data();
     E.rh.stride = 1;
     E.rh.size = 0;
