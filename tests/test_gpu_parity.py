@@ -174,10 +174,8 @@ def test_passes_and_chunks_do_not_change_the_frame(pkg, ctx, manifest, kernel_en
         assert st["paths"] == st0["paths"] and st["kernel_id"] == st0["kernel_id"]
         if store:
             assert st["kernel_launches"] > st0["kernel_launches"]   # several passes
-        if integrator == "pm":   # the k photons of an estimate are summed in heap order, which depends on the search's timing
-            assert rel_error(out, base).max() < 1e-12
-        else:
-            np.testing.assert_array_equal(out, base)
+        # (photon-mapped frames too: an estimate's photons are found and summed in an order that depends on the query alone)
+        np.testing.assert_array_equal(out, base)
 
 
 def test_photon_mapper_matches_reference(pkg, ctx, manifest):
