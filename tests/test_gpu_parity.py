@@ -9,7 +9,8 @@ Round 3: the device computes the reference's sin / cos pairs with glibc's own si
 the last arithmetic difference on the path: path-traced frames of scenes WITHOUT a sky are now required to be the reference's
 bits (EXACT below), no pixel of any path-traced frame may be off by more than 1e-12 (scenes with a sky go through asin, where
 ocml and glibc differ in the last bit of a smooth term: measured <= 4e-16), and the outlier allowance is gone. Photon-mapped
-frames keep their own bar (the k photons of an estimate are summed by a wave reduction, not in heap order: 1e-12)."""
+frames keep their own bar AGAINST THE REFERENCE (the k photons of an estimate are summed by a wave reduction, not in heap order:
+1e-12); among themselves — passes, chunking, shards, contexts, megakernel against pipeline — they are bit-equal."""
 import ctypes as C
 import os
 
@@ -203,7 +204,7 @@ def test_photon_mapper_wavefront_pipeline(pkg, ctx, manifest, kernel_env):
     _check(out, load_radiance(r), "hexagon_room_pm wavefront")
     assert st["paths"] == st0["paths"] and st["knn_searches"] == st0["knn_searches"] and st["kernel_launches"] > 3
     assert st0["kernel_id"] == pkg.KERNEL_PM_WAVE and st["kernel_id"] == pkg.KERNEL_WAVEFRONT_PM
-    assert rel_error(out, base).max() < 1e-12
+    np.testing.assert_array_equal(out, base)  # the pipeline's kNN launch evaluates an estimate exactly as renderKernelPM does
 
 
 def test_rays_equal_oracle_count(pkg, ctx, oracle, manifest):
@@ -480,9 +481,6 @@ def test_render_multi_equals_one_context(pkg, manifest, name, count, integrator)
     out, st = pkg.render_multi(ctxs, cam, manifest["seed"], mode)
     _check(out, load_radiance(r), name + " multi")
     assert st["paths"] == st0["paths"] and st["rays"] == st0["rays"] and st["kernel_id"] == st0["kernel_id"] == expected_kernel(pkg, img, mode)
-    if integrator == "pm":
-        assert rel_error(out, base).max() < 1e-12
-    else:
-        np.testing.assert_array_equal(out, base)
+    np.testing.assert_array_equal(out, base)  # (photon-mapped frames too)
     for c in ctxs:
         c.close()
