@@ -41,7 +41,7 @@ struct DeviceScene {
     double pre_centre[3], pre_bound;
     const double* surf_v;
     const double* surf_normal;
-    const double* surf_rec;  // [n][4] normal + material | kind << 32 (ShadeViewT::surf_rec)
+    const double* surf_rec;  // [n][16] one 128-byte shading record per surface: normal, material | kind << 32, vertex normals (ShadeViewT::surf_rec)
     const double* surf_vn;  // may be null
     const double* surf_area;
     const uint32_t* surf_material;
