@@ -133,7 +133,7 @@ def test_gpu_builder_on_emitted_photons(pkg, manifest):
 
 
 @pytest.mark.gpu
-def test_device_resident_photon_pass(pkg, manifest):
+def test_device_resident_photon_pass(pkg, oracle, manifest):
     """mcrt_photon_pass_device: emission, sort, octants, boxes and record lists without leaving the device. The installed
     maps, read back, are the trees the host builder makes from the same photon set (octants, boxes, photons per leaf), the
     photon sets are the emission pass's, a k-NN search on them returns what it returns on host-built maps, and a
@@ -163,6 +163,24 @@ def test_device_resident_photon_pass(pkg, manifest):
         cam = img.camera.copy()
         cam.width, cam.height, cam.sqrtspp = 96, 72, 2
         frame_dev, st_dev = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        # the composition the bench times — maps emitted and built on the GPU, then the eye pass — against the oracle's eye pass on
+        # those very maps (read back): the goldens check the eye pass on the REFERENCE's maps only
+        gpu_maps = [ctx.download_map(w) for w in (0, 1)]
+
+        class _GpuMaps:
+            scene = img.scene
+
+            def photons(self, which):
+                return gpu_maps[which].desc
+
+            def param(self, key):
+                return {"k_nearest_photons": 50, "direct_visualization": 0}.get(key, 0)
+
+        frame_oracle, _ = oracle.render(_GpuMaps(), cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        rel = np.abs(frame_dev - frame_oracle) / np.maximum(np.abs(frame_oracle), 1e-3)
+        assert rel.max() < 1e-9, rel.max()
+        for m in gpu_maps:
+            m.close()
         ctx.upload_photons(host_maps[0].desc, host_maps[1].desc, 50, False)
         host_knn = [ctx.knn(w, pts, 50) for w in (0, 1)]
         frame_host, st_host = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
