@@ -13,23 +13,24 @@ Headline workload (BASELINE.json configs[1], the config the metric is quoted on)
 Inputs (scene arrays, Sobol tables, photon maps) are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement). At N = 1 it also carries
-  roofline      of the headline kernel. hexagon_room lives in LDS, so its bound is the vector ALU, not HBM: `frac` =
-                FP64-rate lane-slots doing work / lane-slots the chip has (SQ_THREAD_CYCLES_VALU against 1024 SIMDs x 16
-                lanes x 2.4 GHz), read from rocprofv3 PMC passes of ONE frame of the same workload made inside this run
-                (child processes of this script under `rocprofv3 --pmc`); `traffic` = HBM bytes of that frame from the
-                FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-                `algorithmic_GBs` = reference-equivalent bytes (B_ray = n_node*64 + n_tri*72 +
-                n_sphere*32 + 300, per-ray counts of the reference's best-first traversal measured by the oracle) per
-                second of kernel time — a work rate, reported beside the bound, never as its fraction;
-  cpu_baseline  the reference's own integrator (oracle/_ref/mcrt_ref, kind "reference") on this box's host cores, on rows
-                of the SAME frame, at all hardware threads and at the thread count where it runs best (its shared_ptr
-                reference counts contend), and the C restatement ("port_value");
-  parity        the frame's rows 536-540 against the reference's radiance for those rows (tests/golden, made by the
-                reference itself): max relative error and the number of pixels beyond 1e-4;
-  secondary     driver-timed legs on the kernels that DO walk trees in HBM and search photon maps — spaceship cockpit
-                (renderKernelSM), photon-mapped hexagon_room (renderKernelPM, kNN) and metal_bunnies C3 (wavefront
-                pipeline) — each with its own HBM roofline (algorithmic bytes / kernel time / 8 TB/s; measured traffic
-                beside it) and cpu_baseline.
+  roofline      of the frame's kernels, the SAME block for the headline and every secondary leg (leg_roofline): three fractions of
+                physical peaks - `hbm_frac_measured` (fabric bytes of one frame from rocprofv3 PMC passes made inside this run - child
+                processes of this script - / kernel time / 8 TB/s), `valu_issue_frac` (SQ_THREAD_CYCLES_VALU / kernel time / 1024 SIMDs x
+                16 lanes x 2.4 GHz = VALU busy x lane utilisation) and `frac_necessary` (FP64 lane-ops of the REFERENCE's algorithm on the
+                same rays / that peak); `frac` = the larger of the two measured ones, `bound` names it. `algorithmic_GBs` /
+                `algorithmic_frac` = reference-equivalent bytes (B_ray = n_node*64 + n_tri*72 + n_sphere*32 + 300,
+                per-ray counts of the reference's best-first traversal measured by the oracle) per second of kernel time - a work
+                rate that caches serve, reported beside the bound and never as `frac`; `traffic` = the measured fabric bytes of a frame
+                (integrator kernels + sampleResolveKernel);
+  cpu_baseline  the reference's own integrator (oracle/_ref/mcrt_ref, kind "reference") on this box's host cores, on rows of the
+                SAME frame, at all hardware threads and at the thread count where it runs best (its shared_ptr reference counts
+                contend: `best_value` at `best_cores` is the baseline to quote), and the C restatement ("port_value");
+  parity        c2 and c2_ggx: the frame's rows 536-540 against the reference's radiance for those rows (tests/golden, made by the
+                reference itself): max relative error, the number of pixels beyond 1e-4, bit_identical;
+  secondary     driver-timed legs: c2_ggx (the "GGX + Fresnel" reading of BASELINE configs[1]), spaceship cockpit (renderKernelSM),
+                photon-mapped hexagon_room (renderKernelPM, kNN), metal_bunnies C3 and spaceship C4 (wavefront pipeline), water_caustics
+                C5 (photon mapper; `frame_with_photon_pass_ms` adds the device photon pass of 1e8 emission paths to the eye pass) -
+                each with its own roofline block and cpu_baseline.
 """
 import argparse
 import glob
@@ -76,17 +77,20 @@ WORKLOADS = {
 # integration/large_scenes/make_large.py in the build container; they travel to the GPU box with the snapshot)
 REF_SCENES = {
     "hexagon_room.mcrt": ("hexagon_room.json", []),
+    "hexagon_room_ggx.mcrt": ("hexagon_room.json", ["--specular-roughness", "green", "0.1", "--specular-roughness", "crystal", "0.05"]),
     "metal_bunnies_c3.mcrt": ("metal_bunnies.json", ["--bvh", "quaternary_sah", "--bins", "8"]),
     "spaceship_c4.mcrt": ("spaceship.json", []),
     "spaceship.mcrt": ("spaceship_cockpit.json", []),
     "hexagon_room_pm.mcrt": ("hexagon_room.json", []),
     "water_caustics_c5.mcrt": ("water_caustics.json", []),
 }
-SECONDARY = ("spaceship", "pm", "c3", "c4", "c5")
+# c2_ggx: the "GGX + Fresnel" reading of BASELINE configs[1] (hexagon_room.json with specular_roughness 0.1 on
+# `green` and 0.05 on `crystal`, "report both"): same frame size as the headline, its own parity block against reference-made rows
+SECONDARY = ("c2_ggx", "spaceship", "pm", "c3", "c4", "c5")
 # per leg: timed steps (None = --secondary-steps), spp of the untimed warm-up frame (None = the leg's own), spp of the frame the PMC
 # child passes count (None = the leg's own; per-sample work is the same at any spp, the scale is stated in frame_scale)
 LEG_PLAN = {"c3": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=8),
-            "c4": dict(steps=1, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~35 s: one timed frame after a 16 spp warm-up frame
+            "c4": dict(steps=2, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~30 s: two timed frames after a 16 spp warm-up frame
             "c5": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=4)}
 # photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths): BASELINE configs[4] says 1e8 emission paths for C5
 EMISSIONS = {"pm": 1e6, "c5": 1e7}
@@ -236,7 +240,8 @@ SQ_SET = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_C
 PMC_PASSES = (("read+sq", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"] + SQ_SET),
               ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]))
 PMC_FALLBACK = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET))  # round 2's passes, if a combined pass is refused
-INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKernel")
+# every kernel between the HIP events that time a frame: the integrator kernels and the in-order resolve of the per-sample store
+INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKernel", "sampleResolveKernel")
 PROFILE_DIR = os.path.join(ROOT, "gpurun_out", "bench_profiles")  # per-leg counter summaries of THIS run (copied to profiles/ when committed)
 
 
@@ -271,7 +276,7 @@ def _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out):
             def bucket(kname):
                 key = next((k for k in INTEGRATOR_KERNELS if k in kname), None)
                 if key is None:
-                    return None  # sampleResolveKernel, memsets, torch kernels, the photon pass
+                    return None  # memsets, torch kernels, the photon pass
                 if "renderKernelSM" in kname:
                     return "renderKernelSM"
                 if "renderKernelPM" in kname:
@@ -382,9 +387,11 @@ def write_leg_profile(name, desc, pmc_raw, summary, roofline):
                     f.write("| `%s` | %s | %.6g |\n" % (k, cn, v))
             f.write("\n## derived (frame_scale = timed frame / counted frame)\n\n```json\n%s\n```\n" % json.dumps(summary, indent=1))
             f.write("\n## roofline block of the bench line\n\n```json\n%s\n```\n" % json.dumps(roofline, indent=1))
-            f.write("\nRecompute: read bytes = 32 n32 + 128 n128 + 64 (RDREQ - n32 - n128); write bytes = WRITE_SIZE x 1024; traffic = (read + write) x frame_scale; "
-                    "traffic_GBs = traffic / kernel_ms of the timed frame; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x counted kernel time x 2.4 GHz); "
-                    "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU).\n")
+            f.write("\nRecompute: read bytes = 32 n32 + 128 n128 + 64 (RDREQ - n32 - n128); write bytes = WRITE_SIZE x 1024; traffic = (read + write) x frame_scale "
+                    "(all kernels between the frame's HIP events: integrator kernels + sampleResolveKernel); hbm_frac_measured = traffic / kernel_ms of the timed "
+                    "frame / 8 TB/s; valu_issue_frac = SQ_THREAD_CYCLES_VALU x frame_scale / kernel_ms / (1024 SIMDs x 16 lanes x 2.4 GHz); valu_busy = "
+                    "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x counted kernel time x 2.4 GHz); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
+                    "frac = max(hbm_frac_measured, valu_issue_frac).\n")
     except OSError:
         pass
 
@@ -435,9 +442,14 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
         sc = img.scene
         t_pass = time.perf_counter()
         ps = wl.ctx.photon_pass_device(wl.emissions, 10.0, SEED, sc.bb_min[:], sc.bb_max[:], 200, 50, False)
+        cold_s = time.perf_counter() - t_pass
+        # once more: the pass as it costs per frame of an animation (work buffers pooled in the context, DevPool); same maps
+        if not getattr(args, "child_frame", False):
+            t_pass = time.perf_counter()
+            ps = wl.ctx.photon_pass_device(wl.emissions, 10.0, SEED, sc.bb_min[:], sc.bb_max[:], 200, 50, False)
         wl.emit_info = dict(paths=ps["emission_paths"], rays=ps["rays"], kernel_ms=ps["emission_ms"], global_photons=int(ps["global_count"]),
                             caustic_photons=int(ps["caustic_count"]), octree_build_s=(ps["total_ms"] - ps["emission_ms"]) * 1e-3,
-                            octree_builder="device (mcrt_photon_pass_device)", photon_pass_s=time.perf_counter() - t_pass,
+                            octree_builder="device (mcrt_photon_pass_device)", photon_pass_s=time.perf_counter() - t_pass, photon_pass_first_call_s=cold_s,
                             map_ms=dict(sort=ps["sort_ms"], octants=ps["octant_ms"], boxes_and_lists=ps["finish_ms"]),
                             octants=[int(ps["global_octants"]), int(ps["caustic_octants"])],
                             emission_Mray_per_s=ps["rays"] / max(ps["emission_ms"], 1e-9) / 1e3)
@@ -469,6 +481,9 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
             dist.all_gather(parts, pad)
             lists.append(torch.cat([parts[r][: counts[r]] for r in range(world)]).contiguous())
         sc = img.scene
+        # the lists were produced on torch's streams (all_gather on RCCL's, cat / contiguous on the current one); the library builds the
+        # maps on the context's own stream and include/mcrt.h requires device inputs to be COMPLETE when the call is made
+        torch.cuda.synchronize(dev)
         t_build = time.perf_counter()
         ps = wl.ctx.upload_photons_device(lists[0].data_ptr(), lists[0].shape[0], lists[1].data_ptr(), lists[1].shape[0], sc.bb_min[:], sc.bb_max[:],
                                           200, 50, False)
@@ -541,85 +556,106 @@ def run_steps(wl, steps, warmup, world, dist, warm_sqrtspp=None):
     return time.perf_counter() - t0, stats
 
 
-def hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, knn_per_launch, pmc):
-    """Trees that stay in HBM: algorithmic bytes per launch / kernel time against the 8 TB/s peak; the
-    measured HBM traffic of a frame beside it."""
+# Necessary work of the REFERENCE's algorithm on the same rays, in FP64 lane-ops (one +, -, x, /, sqrt, min, max or compare = 1): the
+# oracle's per-ray test counts (best-first traversal of the reference's tree) x the operation count of each test as the reference
+# writes it - BoundingBox::intersect 24 (bounding-box.cpp:9-17), Triangle::intersect 28 at the u exit ... 54 accepted, priced 41
+# (triangle.cpp:23-63), Sphere::intersect 21 at the discriminant exit ... 31 accepted, priced 26 (sphere.cpp:13-26) - plus shading:
+# ~640 per path vertex (Interaction, emissive, light sample + BSDF value/pdf, BSDF sample, roulette, next ray; static FP64 count of
+# the shading code's common path) / 1.6 rays per vertex = 400 per ray. Photon-mapped legs add per kNN search (linear-octree.cpp:25-117,
+# photon-mapper.cpp:343-391): 20 per octant visited (BoundingBox::distance2 / max_distance2, bounding-box.cpp:43-54), 9 per photon
+# scanned (distance2 + compare) and 100 per photon of the estimate (Photon::dir's sincosf pair, Interaction::BSDF, the weighted sum).
+NECESSARY_OPS = {"box_test": 24.0, "triangle_test": 41.0, "sphere_test": 26.0, "shading_per_ray": 400.0,
+                 "knn_octant_test": 20.0, "knn_photon_test": 9.0, "knn_estimate_per_photon": 100.0, "knn_k": 50.0}
+
+
+def add_physical_fractions(r, counts, kernel_ms, rays_per_launch, knn_per_launch, pmc):
+    """Every leg's roofline block carries the same three fractions, each a share of a PHYSICAL peak of the chip:
+      hbm_frac_measured  bytes the L2s moved over the fabric (rocprofv3 counters of one frame, made in this run) / kernel time / 8 TB/s
+      valu_issue_frac    lane-slots that executed a vector instruction (SQ_THREAD_CYCLES_VALU) / kernel time / 39.3 T lane-op/s
+                         (= VALU busy x lane utilisation; integer, move and FP32 cull instructions count: occupancy, not useful work)
+      frac_necessary     FP64 lane-ops the REFERENCE's algorithm needs for the same rays (NECESSARY_OPS) / kernel time / 39.3 T lane-op/s
+    `frac` = the larger of the two measured ones and `bound` / `achieved` / `peak` / `unit` name it. The algorithmic-bytes rate
+     stays beside them as `algorithmic_GBs` / `algorithmic_frac`: a work rate in the reference's units - caches and
+    LDS serve most of those bytes, so it can exceed 1 and is never `frac`."""
+    sec = kernel_ms * 1e-3
+    o = NECESSARY_OPS
+    per_ray = counts["node_per_ray"] * o["box_test"] + counts["tri_per_ray"] * o["triangle_test"] + counts["sphere_per_ray"] * o["sphere_test"] + o["shading_per_ray"]
+    necessary = per_ray * rays_per_launch
+    r["necessary_lane_ops_per_ray"] = per_ray
+    if counts.get("knn_photons_per_search") and knn_per_launch:
+        per_search = counts["knn_octants_per_search"] * o["knn_octant_test"] + counts["knn_photons_per_search"] * o["knn_photon_test"] + o["knn_k"] * o["knn_estimate_per_photon"]
+        r["necessary_lane_ops_per_search"] = per_search
+        necessary += per_search * knn_per_launch
+    r["necessary_lane_ops_prices"] = o
+    r["frac_necessary"] = necessary / sec / 1e9 / VALU_PEAK_GLANEOPS
+    r["hbm_frac_measured"] = r["valu_issue_frac"] = None
+    if pmc and pmc.get("traffic_bytes"):
+        r["traffic_GBs"] = pmc["traffic_bytes"] / sec / 1e9
+        r["hbm_frac_measured"] = r["traffic_GBs"] / HBM_PEAK_GBS
+        r["traffic_over_algorithmic"] = pmc["traffic_bytes"] / (r["algorithmic_GBs"] * 1e9 * sec)
+    if pmc and pmc.get("valu_lane_ops"):
+        r["valu_G_lane_ops_per_s"] = pmc["valu_lane_ops"] / sec / 1e9
+        r["valu_issue_frac"] = r["valu_G_lane_ops_per_s"] / VALU_PEAK_GLANEOPS
+    if pmc:
+        keep = ("valu_busy", "lane_utilisation", "waves_waiting", "valu_insts", "measured_clock_GHz", "fetch_bytes", "write_bytes", "l2_hit_rate", "frame_scale",
+                "pass_wall_s", "errors")
+        r["counters"] = {k: pmc[k] for k in keep if k in pmc}
+        if pmc.get("valu_lane_ops"):
+            r["counters"]["lane_ops_per_ray"] = pmc["valu_lane_ops"] / rays_per_launch
+            r["counters"]["valu_insts_per_ray"] = pmc["valu_insts"] * 64.0 / rays_per_launch  # wave instructions x 64 lanes
+    hbm, valu = r["hbm_frac_measured"], r["valu_issue_frac"]
+    if hbm is None and valu is None:
+        r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"] = "hbm", None, None, HBM_PEAK_GBS, "GB/s"
+        r["note"] += "; counters unavailable in this run (%s): no measured fraction" % ((pmc or {}).get("errors") or "rocprofv3 passes skipped")
+    elif valu is None or (hbm is not None and hbm >= valu):
+        r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"] = "hbm", hbm, r["traffic_GBs"], HBM_PEAK_GBS, "GB/s"
+    else:
+        r["bound"], r["frac"], r["achieved"], r["peak"] = "valu", valu, r["valu_G_lane_ops_per_s"], VALU_PEAK_GLANEOPS
+        r["unit"] = "G lane-op/s (FP64 rate: 1024 SIMDs x 16 lanes x 2.4 GHz)"
+    return r
+
+
+def leg_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, knn_per_launch, pmc):
+    """The roofline block of one leg (headline included). Algorithmic bytes: B_ray = n_node*64 + n_tri*72 +
+    n_sphere*32 + 300 with the per-ray counts of the reference-equivalent best-first traversal (oracle, rows of this frame) and
+    B_knn = n_octant*128 + n_photon_scanned*32 + k*32 per search; the measured fractions: add_physical_fractions."""
     b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
-    achieved = rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    sec = kernel_ms * 1e-3
+    alg = rays_per_launch * b_ray / sec / 1e9
+    r = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
          "traffic": pmc.get("traffic_bytes") if pmc else None,
          "kernel": m.KERNEL_NAMES.get(kernel_id, "?") + (" (all launches of the frame)" if kernel_id in (m.KERNEL_WAVEFRONT, m.KERNEL_WAVEFRONT_PM) else ""),
          "kernel_id": kernel_id, "kernel_ms": kernel_ms, "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
          "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")},
-         "note": "achieved = reference-equivalent algorithmic bytes (SURVEY.md 8(d)) / kernel time (HIP events around the frame's launches); "
-                 "traffic = HBM bytes of one frame measured in this run (rocprofv3 PMC)"}
+         "note": "frac = the larger of hbm_frac_measured and valu_issue_frac (both from rocprofv3 PMC passes of one frame made in this run, priced over the "
+                 "HIP-event kernel time of the timed steps); algorithmic_GBs = reference-equivalent bytes (SURVEY.md 8(d)) per second of kernel time: a work "
+                 "rate, served mostly by LDS / L2 / Infinity Cache, reported beside the bound and never as its fraction; traffic = measured fabric bytes of one frame"}
     if counts.get("knn_photons_per_search") and knn_per_launch:
-        # SURVEY.md §8(d): B_knn = n_octant*128 + n_photon_scanned*32 + k*32 per search (reference-equivalent counts)
         b_knn = counts["knn_octants_per_search"] * 128 + counts["knn_photons_per_search"] * 32 + 50 * 32
-        knn_rate = knn_per_launch / (kernel_ms * 1e-3)
+        knn_rate = knn_per_launch / sec
         r["knn"] = {"bytes_per_search": b_knn, "searches_per_s_in_kernel": knn_rate}
-        r["achieved"] = achieved + knn_rate * b_knn / 1e9
-        r["frac"] = r["achieved"] / HBM_PEAK_GBS
-        r["achieved_rays_only"] = achieved
-    if pmc:
-        if pmc.get("traffic_bytes"):
-            r["traffic_GBs"] = pmc["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9
-            r["traffic_frac"] = r["traffic_GBs"] / HBM_PEAK_GBS
-            r["traffic_over_algorithmic"] = pmc["traffic_bytes"] / (r["achieved"] * 1e9 * kernel_ms * 1e-3)
-        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "fetch_bytes", "write_bytes", "l2_hit_rate", "frame_scale", "pass_wall_s", "errors") if k in pmc}
-    if r["frac"] > 1.0:  # more algorithmic bytes than HBM could move: the caches serve them; not an HBM fraction
-        r["note"] += "; algorithmic rate above the HBM peak (cache-served): frac withheld"
-        r["algorithmic_frac"] = r["frac"]
-        r["frac"] = None
-    return r
+        r["algorithmic_GBs_rays_only"] = alg
+        alg += knn_rate * b_knn / 1e9
+    r["algorithmic_GBs"] = alg
+    r["algorithmic_frac"] = alg / HBM_PEAK_GBS
+    return add_physical_fractions(r, counts, kernel_ms, rays_per_launch, knn_per_launch, pmc)
 
 
-def valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc):
-    """Scenes that live in LDS (flat kernel): the bound is the vector ALU. frac = FP64-rate lane slots that did work
-    (SQ_THREAD_CYCLES_VALU of one frame, measured in this run) per second of kernel time against the chip's 39.3e12/s."""
-    b_ray = counts["node_per_ray"] * 64 + counts["tri_per_ray"] * 72 + counts["sphere_per_ray"] * 32 + 300
-    r = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GLANEOPS, "unit": "G lane-op/s (FP64 rate: 1024 SIMDs x 16 lanes x 2.4 GHz)", "frac": None,
-         "traffic": pmc.get("traffic_bytes") if pmc else None,
-         "kernel": m.KERNEL_NAMES.get(kernel_id, "?"), "kernel_id": kernel_id, "kernel_ms": kernel_ms,
-         "algorithmic_GBs": rays_per_launch * b_ray / (kernel_ms * 1e-3) / 1e9, "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch,
-         "per_ray_counts": {k: counts[k] for k in ("node_per_ray", "tri_per_ray", "sphere_per_ray")},
-         "note": "scene resident in LDS: bound = vector ALU. achieved = lane-slots executing VALU work per second (SQ_THREAD_CYCLES_VALU of one frame, "
-                 "rocprofv3 PMC pass made in this run, / kernel time of the timed steps); frac = achieved / peak = VALU busy x lane utilisation (SIMD time priced at the 2.4 GHz spec clock). "
-                 "algorithmic_GBs = reference-equivalent bytes (SURVEY.md 8(d)) per second: a work rate, not HBM traffic; traffic = measured HBM bytes of one frame"}
-    # Necessary work of the REFERENCE's algorithm on the same rays, in FP64 lane-ops (one +, -, x, /, sqrt, min, max or compare = 1): the
-    # oracle's per-ray test counts (best-first traversal of the reference's tree) x the operation count of each test as the reference
-    # writes it - BoundingBox::intersect 24 (bounding-box.cpp:9-17), Triangle::intersect 28 at the u exit ... 54 accepted, priced 41
-    # (triangle.cpp:23-63), Sphere::intersect 21 at the discriminant exit ... 31 accepted, priced 26 (sphere.cpp:13-26) - plus shading:
-    # ~640 per path vertex (Interaction, emissive, light sample + BSDF value/pdf, BSDF sample, roulette, next ray; static FP64 count of
-    # the shading code's common path) / 1.6 rays per vertex = 400 per ray. frac_necessary = that rate / the chip's FP64-rate lane slots.
-    ops = {"box_test": 24.0, "triangle_test": 41.0, "sphere_test": 26.0, "shading_per_ray": 400.0}
-    necessary = counts["node_per_ray"] * ops["box_test"] + counts["tri_per_ray"] * ops["triangle_test"] + counts["sphere_per_ray"] * ops["sphere_test"] + ops["shading_per_ray"]
-    r["necessary_lane_ops_per_ray"] = necessary
-    r["necessary_lane_ops_prices"] = ops
-    r["frac_necessary"] = necessary * rays_per_launch / (kernel_ms * 1e-3) / 1e9 / VALU_PEAK_GLANEOPS
-    if pmc and pmc.get("valu_lane_ops"):
-        r["achieved"] = pmc["valu_lane_ops"] / (kernel_ms * 1e-3) / 1e9
-        r["frac"] = r["achieved"] / VALU_PEAK_GLANEOPS
-        r["counters"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "waves_waiting", "valu_insts", "measured_clock_GHz", "fetch_bytes", "write_bytes", "errors") if k in pmc}
-        r["counters"]["lane_ops_per_ray"] = pmc["valu_lane_ops"] / rays_per_launch
-        r["counters"]["valu_insts_per_ray"] = pmc["valu_insts"] * 64.0 / rays_per_launch  # wave instructions x 64 lanes
-        if pmc.get("traffic_bytes"):
-            r["traffic_GBs"] = pmc["traffic_bytes"] / (kernel_ms * 1e-3) / 1e9
-    else:
-        r["note"] += "; counters unavailable in this run (%s)" % ((pmc or {}).get("errors") or "rocprofv3 pass skipped")
-    return r
+PARITY_ROWS = {"c2": "hexagon_room.c2_1920x1080_s16_rows536_540.f64", "c2_ggx": "hexagon_room_ggx.c2ggx_1920x1080_s16_rows536_540.f64"}
 
 
 def c2_parity(wl, frame):
-    """Rows 536-540 of the full-size C2 frame against the reference's own radiance (tests/golden fixture)."""
-    g = os.path.join(ROOT, "tests", "golden", "hexagon_room.c2_1920x1080_s16_rows536_540.f64")
-    if wl.name != "c2" or wl.sqrtspp != 16 or not os.path.exists(g):
+    """Rows 536-540 of the full-size C2 / C2-GGX frame against the reference's own radiance (tests/golden fixtures, made by
+    tests/golden/make_golden.py with the reference itself)."""
+    g = os.path.join(ROOT, "tests", "golden", PARITY_ROWS.get(wl.name, "-"))
+    if wl.sqrtspp != 16 or not os.path.exists(g):
         return None
     ref = np.fromfile(g, dtype=np.float64).reshape(4, 1920, 3)
     out = frame[536:540].cpu().numpy()
     rel = (np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)).max(axis=2)
     return {"rows": [536, 540], "pixels": int(rel.size), "max_rel": float(rel.max()), "p999_rel": float(np.quantile(rel, 0.999)),
-            "outliers_gt_1e-4": int((rel > 1e-4).sum()), "tolerance": 1e-4, "reference": "tests/golden/hexagon_room.c2_1920x1080_s16_rows536_540.f64 (rendered by the reference)"}
+            "outliers_gt_1e-4": int((rel > 1e-4).sum()), "bit_identical": bool(np.array_equal(out, ref)), "tolerance": 1e-4,
+            "reference": "tests/golden/%s (rendered by the reference)" % PARITY_ROWS[wl.name]}
 
 
 def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup, want_cpu, want_counters, headline, ref_threads=None):
@@ -665,6 +701,12 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
                        "knn_searches_per_s": total_knn / elapsed if total_knn else None,
                        "photon_pass": wl.emit_info if wl.photon else None},
         }
+        if wl.photon and wl.emit_info and wl.emit_info.get("photon_pass_s") is not None:
+            # PhotonMapper's constructor (photon-mapper.cpp:24-223) is part of what BASELINE configs[4] names: the frame with its photon
+            # pass (emission + both maps, on the device) beside the eye-pass figure the step times
+            pp_ms = wl.emit_info["photon_pass_s"] * 1e3
+            result["frame_with_photon_pass_ms"] = result["ms_per_step"] + pp_ms
+            result["value_with_photon_pass"] = (total_rays / steps + wl.emit_info["rays"]) / (result["frame_with_photon_pass_ms"] * 1e-3) / 1e6
         par = c2_parity(wl, frame) if world == 1 else None
         if par:
             result["parity"] = par
@@ -697,10 +739,7 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
         launches = steps
         kernel_ms = kernel_ms_sum / launches
         rays_per_launch = total_rays / steps / world
-        if kernel_id == m.KERNEL_FLAT:
-            result["roofline"] = valu_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, pmc)
-        else:
-            result["roofline"] = hbm_roofline(m, name, counts, kernel_id, kernel_ms, rays_per_launch, total_knn / steps / world, pmc)
+        result["roofline"] = leg_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, total_knn / steps / world, pmc)
         result["roofline"]["per_ray_counts_source"] = counts_source
         if world == 1 and want_counters:
             write_leg_profile(name, wl.desc, raw, pmc, result["roofline"])

@@ -313,7 +313,11 @@ typedef struct mcrt_photon_emission_device {
 } mcrt_photon_emission_device;
 int mcrt_emit_photons_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, uint32_t shard_index,
                              uint32_t shard_count, mcrt_photon_emission_device* out);
-/* Both maps from photon lists in device memory (not modified), installed like mcrt_upload_photons. */
+/* Both maps from photon lists in device memory (not modified), installed like mcrt_upload_photons.
+ * STREAM CONTRACT for every device-pointer INPUT of this header (these lists; mcrt_film_resolve_device's blob): the library reads them
+ * on the context's own non-blocking stream, which is not ordered after any stream of the caller - the data must be COMPLETE
+ * (producing stream synchronised, e.g. hipStreamSynchronize / torch.cuda.synchronize) when the call is made. Device OUTPUTS
+ * (mcrt_render_device's d_out) are written on the stream the caller passes and are ordered like any work on that stream. */
 int mcrt_upload_photons_device(mcrt_ctx* ctx, const float* d_global_photons, uint64_t global_count, const float* d_caustic_photons,
                                uint64_t caustic_count, const double bb_min[3], const double bb_max[3], uint32_t max_photons_per_leaf,
                                uint32_t k_nearest_photons, int direct_visualization, mcrt_photon_pass_stats* stats);

@@ -156,6 +156,8 @@ int fail(mcrt_ctx* ctx, int code, const std::string& msg) {
             return fail(ctx, MCRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
+int planSampleStore(mcrt_ctx* ctx, uint32_t width, uint32_t owned_rows, uint32_t spp, PassPlan& pp);  // below
+
 template <class T>
 int uploadArray(mcrt_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
     HIP_TRY(ctx, buf.alloc(count * sizeof(T)));
@@ -282,7 +284,7 @@ bool useWideNodes(const mcrt_ctx* ctx) {
 long halvesWanted(const mcrt_ctx* ctx) { return ctxOptL(ctx, "MCRT_WF_HALVES", 1); }
 
 template <class K>
-int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false, bool sched = false) {
+int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false, bool sched = false, bool share_leaves = false) {
     if (sched) {  // slot-scheduled kernel: one 1024-lane workgroup per CU, all of its LDS for the ray slots
         tp.block = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_SCHED_WAVES", 16), 1), kTraceMaxBlock / 64) * 64u;
         tp.lds_bytes = (uint32_t)sizeof(SchedLds);
@@ -321,9 +323,9 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds_trace, envi("MCRT_TRACE_LDS", (long)ctx->max_lds_trace));
-    if ((long)stack_bytes + 64 > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
-    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u) / 64u);
-    tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u;  // + the workgroup's queue cursor
+    if ((long)stack_bytes + 64 + (long)(waves * kShareMapBytes) > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
+    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u - waves * kShareMapBytes) / 64u);
+    tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u + waves * kShareMapBytes;  // + the workgroup's queue cursor + the waves' shared-leaf maps
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)tp.block, tp.lds_bytes));
@@ -354,7 +356,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     ta.spill = ctx->spill.as<SmStackEntry>();
     ta.total_lanes = total_lanes;
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
-    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 24);
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 12 : 24);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 6), 6), 20);
@@ -425,9 +427,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool splats = fr.film.type != MCRT_FILM_BOX;
     uint64_t pass_rows = owned_rows;
     if (!splats) {
-        const PassPlan pp = planPasses(cam->width, owned_rows, fr.spp, sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB")));
+        PassPlan pp;
+        if (int rc = planSampleStore(ctx, cam->width, (uint32_t)owned_rows, fr.spp, pp)) return rc;
         pass_rows = pp.pass_rows;
-        if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         fr.samples = ctx->samples.as<double>();
     }
     // Pool size: up to 8 M slots (3.6 GB) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
@@ -463,7 +465,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     // MCRT_WF_SCHED=1: the slot-scheduled trace kernel (ray state in LDS, steps issued for 64 rays that want the same step)
     const bool sched = ctxOptOn(ctx, "MCRT_WF_SCHED") && halvesWanted(ctx) < 2;
     const bool defer = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0;  // deferred leaves: the default since round 3 (C3 / C4 -1.3 %)
+    const bool share = defer && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // ... tested by the whole wave (travSharedLeafStep): round 4
     void (*trace)(WfTraceArgs, PoolRays) = wide    ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
+                                           : share ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)
                                            : defer ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
                                                    : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
     void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
@@ -472,7 +476,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     if (shade_tables > kWfShadeTableMax || ctxOptL(ctx, "MCRT_WF_LDS_TABLES", 1) == 0) shade_tables = 0;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u + shade_tables;
     TracePlan tp;
-    if (int rc = sched ? planTrace(ctx, trace_sched, slots * 2, tp, false, true) : planTrace(ctx, trace, slots * 2, tp, wide, false)) return rc;
+    if (int rc = sched ? planTrace(ctx, trace_sched, slots * 2, tp, false, true) : planTrace(ctx, trace, slots * 2, tp, wide, false, share)) return rc;
 
     // MCRT_WF_HALVES=2 (experiment, off by default): two halves of the pool on two streams, so that while one half's trace
     // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
@@ -903,9 +907,9 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         // Sample-chunked work units (RenderParams): the frame goes through in passes of as many rows as the per-sample
         // store holds (MCRT_SAMPLE_STORE_GB, default 64: mcrt_plan.hpp), each pass = one
         // integrator launch + the in-order resolve.
-        const PassPlan pp = planPasses(cam->width, prm.owned_rows, prm.spp, sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB")));
+        PassPlan pp;
+        if (int rc = planSampleStore(ctx, cam->width, prm.owned_rows, prm.spp, pp)) return rc;
         const uint64_t pass_rows = pp.pass_rows;
-        if (ctx->samples.bytes < pp.store_bytes) HIP_TRY(ctx, ctx->samples.alloc(pp.store_bytes));
         prm.samples = ctx->samples.as<double>();
         PmExtra pmx;
         if (use_pm_wave) {
@@ -947,6 +951,27 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->pending = true;
     return MCRT_OK;
+}
+
+
+// The per-sample store of a frame (mcrt_plan.hpp): MCRT_SAMPLE_STORE_GB (default 64) is an upper bound, the device decides how much of
+// it exists - at most 40 % of the memory that is free now plus what this context's store already holds (hipMemGetInfo), so that a
+// 1080p @ 1024 spp frame (51 GB in one pass on a 288 GB MI355X) goes through in more passes on a smaller or shared device instead of
+// failing with out-of-memory; if the allocation still fails (fragmentation, another process grew meanwhile) the store is halved
+// until it fits or one 8-row pass does not. Returns the plan through `pp`.
+int planSampleStore(mcrt_ctx* ctx, uint32_t width, uint32_t owned_rows, uint32_t spp, PassPlan& pp) {
+    double gb = sampleStoreGb(ctxOpt(ctx, "MCRT_SAMPLE_STORE_GB"));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) gb = std::min(gb, 0.4 * (double)(free_b + ctx->samples.bytes) / 1e9);
+    else (void)hipGetLastError();
+    for (;;) {
+        pp = planPasses(width, owned_rows, spp, gb);
+        if (ctx->samples.bytes >= pp.store_bytes) return MCRT_OK;
+        if (ctx->samples.alloc(pp.store_bytes) == hipSuccess) return MCRT_OK;
+        (void)hipGetLastError();
+        if (pp.pass_rows <= 8) return fail(ctx, MCRT_ERR_HIP, "out of device memory for the per-sample store of one 8-row pass");
+        gb = std::min(gb, (double)pp.store_bytes / 1e9) * 0.5;
+    }
 }
 
 int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
@@ -1661,9 +1686,10 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFF00000ull) {  // (32-bit queue cursors with room for the waves' overshoot)
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
         const bool wide = useWideNodes(ctx);
-        auto trace = wide ? wfTraceKernel<ArrayRays, false, 1> : wfTraceKernel<ArrayRays, false>;
+        const bool share = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0 && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // the pipeline's default form
+        auto trace = wide ? wfTraceKernel<ArrayRays, false, 1> : share ? wfTraceKernel<ArrayRays, false, 3> : wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
-        if (int rc = planTrace(ctx, trace, n, tp, wide)) return rc;
+        if (int rc = planTrace(ctx, trace, n, tp, wide, false, share)) return rc;
         DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
         if (int rc = uploadInto(ctx, ds, start, n * 3)) return rc;
         if (int rc = uploadInto(ctx, dd, direction, n * 3)) return rc;

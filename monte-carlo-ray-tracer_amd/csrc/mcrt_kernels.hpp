@@ -774,15 +774,109 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
     }
 };
 
+// ---- Shared leaf step (round 4): the wave's pending leaves tested by ALL of its lanes ----------------------------------------
+// What the counters said about the leaf step (C3, round 3): it runs with ~23 of a wave's 64 lanes, every one of them testing TWO
+// primitives in sequence (two 80-byte records, ~300 instructions with the hit updates) - 35 % of the kernel's wave cycles at a
+// third of the lanes. Here the work items of a leaf step are (pending lane, primitive) PAIRS and they are dealt over all 64 lanes:
+// with n lanes holding a pending leaf every one of them gets 2^sh = 4 / 2 / 1 item lanes (n <= 16 / <= 32 / more), item lane
+// k = (rank of the pending lane << sh) + j tests that lane's j-th primitive with that lane's ray - the ray (start, direction: twelve
+// 32-bit words) and the leaf range are PULLED from the owner with ds_bpermute, no LDS is written except a 64-byte rank -> lane map
+// per wave. The owner then pulls the entry distances of its item lanes back, keeps the FIRST minimum (items are in ascending
+// primitive order, so ties go to the lowest index: the tie rule of `closer`), pulls that item's u / v and updates its hit exactly as
+// travPendStep does. Same tests (primTestRec: the reference's FP64 arithmetic), same minimum, same tie rule: the hit is the one
+// every other form returns. A leaf of up to four primitives is one step instead of two, a step costs one primitive test instead of
+// two, and it is worth issuing with far fewer pending lanes (the gate MCRT_WF_LEAF drops from 24 to 12), so lanes wait less at
+// their leaves. Shadow queries: the winner is the closest accepted item, so "an occluder closer than t_near" is seen on the winner
+// (an occluder that is not the winner has a closer one in front of it).
+constexpr uint32_t kShareMapBytes = 64;  // per wave
+__device__ __forceinline__ uint32_t wavePull(uint32_t v, uint32_t src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+__device__ __forceinline__ double wavePullD(double v, uint32_t src_lane) {
+    const unsigned long long b = dBits(v);
+    const uint32_t lo = wavePull((uint32_t)b, src_lane), hi = wavePull((uint32_t)(b >> 32), src_lane);
+    return bitsD(((unsigned long long)hi << 32) | lo);
+}
+template <bool kCount>
+__device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv, Trav& T, PendLeaf& P, bool pend, unsigned long long m_pend,
+                                                    MCRT_LDS_AS uint8_t* map, TraceCounters& cnt) {
+    const uint32_t lane = laneId();
+    const uint32_t n = (uint32_t)__popcll(m_pend);  // >= 1 (the caller's gate)
+    const uint32_t sh = n <= 16u ? 2u : n <= 32u ? 1u : 0u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_pend, 0u));
+    if (pend) map[rank] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t grp = lane >> sh, j = lane & ((1u << sh) - 1u);
+    const uint32_t src = grp < n ? (uint32_t)map[grp] : lane;
+    __builtin_amdgcn_wave_barrier();  // (the next step's writes stay behind these reads)
+    const uint32_t pa = wavePull(P.a, src), pn = wavePull(P.n, src);
+    d3 o, d;
+    o.x = wavePullD(T.o.x, src); o.y = wavePullD(T.o.y, src); o.z = wavePullD(T.o.z, src);
+    d.x = wavePullD(T.d.x, src); d.y = wavePullD(T.d.y, src); d.z = wavePullD(T.d.z, src);
+    const bool item = grp < n && j < pn;
+    Hit h;
+    h.t = 0.0; h.u = 0.0; h.v = 0.0; h.surface = kNoSurface; h.interpolate = false;
+    bool ok = false;
+    if (item) {
+        const PrimRec rec = loadPrim(sv.prim + (size_t)(pa + j) * kPrimStride);
+        Ray r;
+        r.start = o;
+        r.direction = d;
+        r.inv_direction = d3{0.0, 0.0, 0.0};
+        if (rec.v[9] == 3.0) r.inv_direction = rcp3(d);  // Quadric::intersect clips to its box first (the same rcp3 the owner's travBegin took)
+        r.medium_ior = 1.0; r.refraction_scale = 1.0; r.refraction_level = 0; r.depth = 0; r.diffuse_depth = 0; r.dirac_delta = false; r.refraction = false;
+        if (kCount) cnt.prim_tests++;
+        ok = primTestRec<true>(rec, r, h);
+    }
+    const double key = ok ? h.t : INFINITY;
+    // owner side: the first minimum over its item lanes
+    const uint32_t base = rank << sh;
+    double win_t = INFINITY;
+    uint32_t win_j = 0u;
+    for (uint32_t jj = 0u; jj < (1u << sh); jj++) {  // wave-uniform trip count (1, 2 or 4)
+        const double tj = wavePullD(key, (base + jj) & 63u);
+        if (tj < win_t) {
+            win_t = tj;
+            win_j = jj;
+        }
+    }
+    const uint32_t wl = (base + win_j) & 63u;
+    const double win_u = wavePullD(h.u, wl), win_v = wavePullD(h.v, wl);
+    const uint32_t win_i = wavePull(h.interpolate ? 1u : 0u, wl);
+    if (pend) {
+        const uint32_t used = P.n < (1u << sh) ? P.n : (1u << sh);
+        bool decided = false;
+        const uint32_t idx = P.a + win_j;
+        if (win_t < INFINITY && closer(win_t, idx, T.best)) {
+            T.best.t = win_t;
+            T.best.u = win_u;
+            T.best.v = win_v;
+            T.best.interpolate = win_i != 0u;
+            T.best.surface = idx;
+            if (T.shadow && idx != T.light && win_t < T.t_near) decided = true;  // occluded for sure
+        }
+        if (decided) {
+            T.sp = 0;
+            T.active = false;
+            P.n = 0u;
+        } else {
+            P.a += used;
+            P.n -= used;
+        }
+    }
+}
+
 // Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
 // traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
 // are visited through quantised child blocks, the top of the tree from LDS.
-// kForm: 0 = the default walk (4-wide quantised blocks, a lane waits at its leaf), 1 = eight-wide nodes (mcrt_wbvh.hpp), 2 = deferred
-// leaves (mcrt_lanesm.hpp). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
+// kForm: 0 = the first walk (4-wide quantised blocks, a lane waits at its leaf), 1 = eight-wide nodes (mcrt_wbvh.hpp), 2 = deferred
+// leaves (mcrt_lanesm.hpp), 3 = deferred leaves tested by the whole wave (travSharedLeafStep above; the default since round 4). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
 // default form a register spill and ~1 % of a frame.
 template <class Rays, bool kCount, int kForm = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
-    constexpr bool kWide = kForm == 1, kDefer = kForm == 2;
+    constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
     extern __shared__ __align__(64) unsigned char lds[];
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
     if constexpr (!kWide)
@@ -817,6 +911,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     // Interleaved blocks keep a refill's reads consecutive and give every workgroup a sample of the whole queue.)
     const unsigned long long n = *a.count;
     MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
+    // (behind the cursor's 64 bytes: the rank -> lane map of every wave's shared leaf steps)
+    MCRT_LDS_AS uint8_t* share_map = reinterpret_cast<MCRT_LDS_AS uint8_t*>(cursor) + 64u + (threadIdx.x >> 6) * kShareMapBytes;
     const uint32_t deal_shift = a.deal_shift, deal_mask = (1u << deal_shift) - 1u;
     if (threadIdx.x == 0) *cursor = 0u;
     __syncthreads();
@@ -915,14 +1011,34 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             // a lane standing at a leaf (new ray whose root is a leaf, pending slot freed by the last leaf step) parks it and moves on
             if (have) travParkLeaf(T, P, stk);
             const bool inner = have && T.active && (T.node_m & kSmInner);
+            unsigned long long ti = 0ull;
+            if (kCount) {
+                const unsigned long long mi = waveBallot(inner);
+                ph_iter++;
+                ph_have += __popcll(waveBallot(have));
+                ph_in_steps += mi ? 1u : 0u;
+                ph_in_lanes += __popcll(mi);
+                ti = clock64();
+            }
             if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
             if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
+            if (kCount) ph_in_cyc += clock64() - ti;
             if (inner) travParkLeaf(T, P, stk);  // landed on a leaf: it joins this iteration's leaf step
             const bool pend = have && P.n != 0u;
             const unsigned long long m_pend = waveBallot(pend);
             const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
             if (m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
-                if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
+                unsigned long long tc = 0ull;
+                if (kCount) {
+                    ph_lf_steps++;
+                    ph_lf_lanes += __popcll(m_pend);
+                    tc = clock64();
+                }
+                if constexpr (kShare) travSharedLeafStep<kCount>(sv, T, P, pend, m_pend, share_map, cnt);
+                else if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
+                if (kCount) ph_lf_cyc += clock64() - tc;
+            } else if (kCount) {
+                ph_lf_wait += __popcll(m_pend);
             }
             continue;
         }

@@ -257,4 +257,107 @@ MCRT_HD void refSinCos(double x, double& sn_out, double& cs_out) {
     cs_out = rc;
 }
 
+// ---- asin as the reference computes it (Scene::skyColor, scene/scene.cpp:219-223: the one libm call of a sky scene's miss) ----
+// glibc 2.35 __ieee754_asin (sysdeps/ieee754/dbl-64/e_asin.c, IBM Accurate Mathematical Library; the version without the
+// multi-precision fall-backs): |x| < 2^-26: x; < 0.125: an odd polynomial; [0.125, 0.96875): per interval of width 2^-8 the Taylor
+// expansion of asin around the interval's centre, coefficients from the table `asncs` (asincos.tbl); [0.96875, 1): pi/2 - 2 asin(sqrt
+// ((1 - |x|) / 2)) with the root from a table seed, one Newton step and a double-double correction. std::asin is an IFUNC like sin
+// (sysdeps/x86_64/fpu/multiarch/e_asin.c): on a CPU with FMA and AVX2 - the build container's and the GPU box's - the dynamic linker
+// picks __ieee754_asin_fma, the same source compiled with -mfma. refAsin restates THAT instruction sequence (Ubuntu glibc
+// 2.35-0ubuntu3.11, every a*b + c below is one vfmadd there); kFused = false evaluates the same expression tree with every operation
+// rounded (not what any build of glibc computes bit for bit - its sse2 variant is compiled from the same source but this tree is the
+// FMA build's; kept for the emulation's A/B counts, not used by the product). Tables:
+// mcrt_glibc_asintab.inc (tools/make_glibc_asin_table.py). tests/test_libm.py: bit-equal to the host's asin on millions of arguments
+// in every interval and across every interval boundary.
+namespace glibc235 {
+MCRT_LIBM_TABLE unsigned long long kAsinTab[2568 + 128] = {
+#include "mcrt_glibc_asintab.inc"
+};
+MCRT_HD double asinTab(int i) { return bitsD(kAsinTab[i]); }
+constexpr double kAf1 = 0x1.55555555554f9p-3, kAf2 = 0x1.333333336127dp-4, kAf3 = 0x1.6db6dae42c0e4p-5, kAf4 = 0x1.f1c7e04f4ad99p-6,
+                 kAf5 = 0x1.6e442c822d419p-6, kAf6 = 0x1.292d80f453c72p-6;
+constexpr double kRt0 = 0x1.fffffffecc1ddp-1, kRt1 = 0x1.fffffff757304p-2, kRt2 = 0x1.800496769c91ap-2, kRt3 = 0x1.4006318d1dab9p-2;
+constexpr double kT24 = 16777216.0;
+
+// one table interval: record at n, Taylor coefficients x[n+2 .. n+top], then x[n+top+1] (the low word of asin(x0)), the first-order
+// term x[n+1] * xx, and x[n+top+2] (the high word) last
+template <bool kFused>
+MCRT_HD double asinInterval(double ax, int n, int top) {
+    const double xx = ax - asinTab(n);
+    double p = asinTab(n + top);
+    for (int j = top - 1; j >= 2; j--) p = fmaD<kFused>(xx, p, asinTab(n + j));
+    const double xx2 = xx * xx;
+    p = fmaD<kFused>(xx2, p, asinTab(n + top + 1));
+    const double r = fmaD<kFused>(xx, asinTab(n + 1), p);
+    return r + asinTab(n + top + 2);
+}
+}  // namespace glibc235
+
+template <bool kFused = true>
+MCRT_HD double refAsinT(double x) {
+    using namespace glibc235;
+    const unsigned long long bits = dBits(x);
+    const int m = (int)(uint32_t)(bits >> 32);
+    const int k = m & 0x7fffffff;
+    if (k < 0x3e500000) return x;                       // |x| < 2^-26
+    if (k < 0x3fc00000) {                               // |x| < 0.125
+        const double x2 = x * x;
+        double p = fmaD<kFused>(x2, kAf6, kAf5);
+        p = fmaD<kFused>(x2, p, kAf4);
+        p = fmaD<kFused>(x2, p, kAf3);
+        p = fmaD<kFused>(x2, p, kAf2);
+        p = fmaD<kFused>(x2, p, kAf1);
+        return fmaD<kFused>(p, x * x2, x);              // x + p * (x2 * x)
+    }
+    const double ax = m > 0 ? x : -x;
+    double res;
+    if (k < 0x3fe00000) {                               // [0.125, 0.5): 11-word records
+        const int n = k < 0x3fd00000 ? 11 * ((k >> 15) & 0x1f) : 11 * ((k >> 14) & 0x3f) + 352;
+        res = asinInterval<kFused>(ax, n, 6);
+    } else if (k < 0x3fe80000) {                        // [0.5, 0.75): 12-word records
+        res = asinInterval<kFused>(ax, 1056 + 3 * ((k >> 11) & 0x1fc), 7);
+    } else if (k < 0x3fed8000) {                        // [0.75, 0.921875): 13-word records
+        res = asinInterval<kFused>(ax, 992 + 13 * ((k >> 13) & 0x7f), 8);
+    } else if (k < 0x3fee8000) {                        // [0.921875, 0.953125): 14-word records
+        res = asinInterval<kFused>(ax, 884 + 14 * ((k >> 13) & 0x7f), 9);
+    } else if (k < 0x3fef0000) {                        // [0.953125, 0.96875): 15-word records
+        res = asinInterval<kFused>(ax, 768 + 15 * ((k >> 13) & 0x7f), 10);
+    } else if (k < 0x3ff00000) {                        // [0.96875, 1)
+        const double z = (1.0 - ax) * 0.5;
+        const unsigned long long v = dBits(z);
+        double t = asinTab(2568 + (int)((v >> 46) & 0x7f)) * bitsD((unsigned long long)(1023 + 0x1ff - (int)(v >> 53)) << 52);  // inroot[] * powtwo[]
+        const double r = fmaD<kFused>(-(t * t), z, 1.0);
+        double q = fmaD<kFused>(r, kRt3, kRt2);
+        q = fmaD<kFused>(r, q, kRt1);
+        q = fmaD<kFused>(r, q, kRt0);
+        t = t * q;
+        const double c = t * z;
+        const double e = fmaD<kFused>(-c, t * 0.5, 1.5);
+        const double y = (c + kT24) - kT24;
+        const double tpy = fmaD<kFused>(e, c, y);
+        const double cc = fmaD<kFused>(-y, y, z) / tpy;
+        double p = fmaD<kFused>(z, kAf6, kAf5);
+        p = fmaD<kFused>(z, p, kAf4);
+        p = fmaD<kFused>(z, p, kAf3);
+        p = fmaD<kFused>(z, p, kAf2);
+        p = fmaD<kFused>(z, p, kAf1);
+        p = p * z;
+        const double ypc = y + cc;
+        const double cor1 = fmaD<kFused>(-2.0, cc, kHp1);
+        const double res1 = fmaD<kFused>(-2.0, y, kHp0);
+        const double s2 = ypc + ypc;
+        const double cor = fmaD<kFused>(-s2, p, cor1);
+        res = cor + res1;
+    } else if (k == 0x3ff00000 && (uint32_t)bits == 0u) {
+        res = kHp0;                                     // |x| = 1
+    } else if (k > 0x7ff00000 || (k == 0x7ff00000 && (uint32_t)bits != 0u)) {
+        return x + x;                                   // NaN
+    } else {
+        const double d = x - x;                         // |x| > 1 (or infinite): invalid
+        return d / d;
+    }
+    return m > 0 ? res : -res;
+}
+MCRT_HD double refAsin(double x) { return refAsinT<true>(x); }
+
 }  // namespace mcrt

@@ -615,7 +615,7 @@ MCRT_HD bool absorb(const Ray& ray, d3& throughput, const Sampler& smp, SobolTab
 
 // Scene::skyColor, scene.cpp:219-223
 MCRT_HD d3 skyColor(const Ray& ray) {
-    double fy = (1.0 + asin(dot(d3{0.0, 1.0, 0.0}, ray.direction)) / kPi) / 2.0;
+    double fy = (1.0 + refAsin(dot(d3{0.0, 1.0, 0.0}, ray.direction)) / kPi) / 2.0;  // glibc's asin, bit for bit (mcrt_libm.hpp)
     return mix(d3{1.0, 0.5, 0.0}, d3{0.0, 0.5, 1.0}, fy);
 }
 

@@ -775,6 +775,46 @@ void emu_libm_check(uint64_t n, uint64_t seed, double lo, double hi, int edges, 
     }
 }
 
+// refAsin (mcrt_libm.hpp) against this host's asin: n arguments uniform in [lo, hi], then - edges != 0 - n more within a few thousand
+// ulps of every interval boundary of e_asin.c (multiples of 2^-8 in [0.125, 1], 2^-26, 1). out[0] = arguments on which the FMA-form
+// restatement differs (bitwise) from libm, out[1] = the first of them (bit pattern); out[2], out[3]: the same for the all-operations-
+// rounded form (kFused = false; informational: libm's IFUNC picks ONE variant per machine).
+void emu_asin_check(uint64_t n, uint64_t seed, double lo, double hi, int edges, uint64_t* out) {
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    double (*volatile libm_asin)(double) = ::asin;
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    auto check = [&](double x) {
+        const double want = libm_asin(x), a = refAsinT<true>(x), b = refAsinT<false>(x);
+        const bool nan_ok = want != want;
+        if (nan_ok ? (a == a) : memcmp(&a, &want, 8) != 0) {
+            if (!out[0]) memcpy(&out[1], &x, 8);
+            out[0]++;
+        }
+        if (nan_ok ? (b == b) : memcmp(&b, &want, 8) != 0) {
+            if (!out[2]) memcpy(&out[3], &x, 8);
+            out[2]++;
+        }
+    };
+    for (uint64_t i = 0; i < n; i++) check(lo + (hi - lo) * ((double)(next() >> 11) * 0x1.0p-53));
+    if (edges) {
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t r = next();
+            double m = (r % 227u) == 0u ? 0x1.0p-26 : (double)(32u + (r % 225u)) / 256.0;  // 0.125 .. 1.0 in steps of 2^-8
+            long long b;
+            memcpy(&b, &m, 8);
+            b += (long long)(next() % 8192) - 4096;
+            memcpy(&m, &b, 8);
+            check((next() & 1) ? m : -m);
+        }
+    }
+}
+
 void emu_set_wide(int on) { g_wide = on; }
 void emu_set_leaf_cull(int on) { g_leaf_cull = on; }
 uint64_t emu_wide_nodes(const mcrt_scene_desc* scene) {

@@ -38,7 +38,9 @@ CASES = [
     dict(name="hexagon_room_ggx", scene="hexagon_room.json",
          args=["--specular-roughness", "green", "0.1", "--specular-roughness", "crystal", "0.05"],
          image=dict(width=1920, height=1080, sqrtspp=16),
-         renders=[dict(tag="c2ggx_192x108_s4", width=192, height=108, sqrtspp=4)]),
+         renders=[dict(tag="c2ggx_192x108_s4", width=192, height=108, sqrtspp=4),
+                  # rows of the full-size frame bench.py's c2_ggx leg times ("report both")
+                  dict(tag="c2ggx_1920x1080_s16_rows536_540", width=1920, height=1080, sqrtspp=16, rows=[536, 540])]),
     dict(name="hexagon_room_dof", scene="hexagon_room.json", args=["--f-stop", "1.8", "--focus-distance", "8"],
          image=dict(width=96, height=54, sqrtspp=3),
          renders=[dict(tag="dof_96x54_s3", width=96, height=54, sqrtspp=3)]),

@@ -5,10 +5,9 @@ Tolerance (BASELINE.json north_star): per-pixel radiance within 1e-4 relative of
 fixed seed, measured as |gpu-ref| / max(|ref|, 1e-3) per channel. Integer/index work (sampler bits,
 hit surface indices, kNN photon indices) must be exact.
 
-Round 3: the device computes the reference's sin / cos pairs with glibc's own sincos algorithm (csrc/mcrt_libm.hpp), which was
-the last arithmetic difference on the path: path-traced frames of scenes WITHOUT a sky are now required to be the reference's
-bits (EXACT below), no pixel of any path-traced frame may be off by more than 1e-12 (scenes with a sky go through asin, where
-ocml and glibc differ in the last bit of a smooth term: measured <= 4e-16), and the outlier allowance is gone. Photon-mapped
+Round 3: the device computes the reference's sin / cos pairs with glibc's own sincos algorithm (csrc/mcrt_libm.hpp); round 4: and
+Scene::skyColor's asin with glibc's own asin (refAsin) - the last libm call of the path-traced path. EVERY path-traced golden frame
+is now required to be the reference's bits (EXACT below = all of them), and the outlier allowance is gone. Photon-mapped
 frames keep their own bar AGAINST THE REFERENCE (the k photons of an estimate are summed by a wave reduction, not in heap order:
 1e-12); among themselves — passes, chunking, shards, contexts, megakernel against pipeline — they are bit-equal."""
 import ctypes as C
@@ -21,10 +20,10 @@ from conftest import camera_for, check_hits_against_reference, golden_path, load
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-SMOOTH_TOL = 1e-12  # path-traced frames whose only non-identical operation is asin in Scene::skyColor
-# scenes without a sky: every operation of a path is reproduced bit for bit
+SMOOTH_TOL = 1e-12  # (photon-mapped frames and film-filter frames: sums in another order)
+# every operation of a path is reproduced bit for bit - with or without a sky (refAsin, round 4)
 EXACT = {"hexagon_room_diffuse", "hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah", "coffee_maker_bsah", "shell_room",
-         "dragon_room"}
+         "dragon_room", "ior_test", "veach_mis", "metals", "oren_nayar_test", "ggx_test", "quadric"}
 
 
 @pytest.fixture(scope="module")
@@ -125,8 +124,10 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
 @pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "quadric"])
 def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name, monkeypatch):
     """The wavefront pipeline's optional trace kernels - slot-scheduled (MCRT_WF_SCHED: ray state in LDS, steps issued for 64 rays
-    that want the same step), eight-wide nodes (MCRT_WF_WIDE), lanes waiting at their leaves (MCRT_WF_DEFER=0, the round-2 form) -
-    give the default kernel's frame, bit for bit."""
+    that want the same step), eight-wide nodes (MCRT_WF_WIDE), lanes waiting at their leaves (MCRT_WF_DEFER=0, the round-2 form), a
+    pending leaf tested by its own lane (MCRT_WF_SHARE=0, round 3's default), and the default's leaf gate at both extremes (a shared
+    leaf step for every single pending lane: four item lanes per leaf; only when 40 lanes wait: one item lane per leaf) - give the
+    default kernel's frame, bit for bit."""
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
     r = case["renders"][0]
@@ -135,7 +136,9 @@ def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name,
     ctx.upload_image(img)
     base, st0 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     assert st0["kernel_id"] == pkg.KERNEL_WAVEFRONT
-    for key, value in (("MCRT_WF_SCHED", "1"), ("MCRT_WF_WIDE", "1"), ("MCRT_WF_DEFER", "0")):
+    # (MCRT_WF_SHARE=0: round 3's default - a pending leaf tested by its own lane, two primitives per step; the default since round 4
+    # deals the wave's pending (leaf, primitive) pairs over all 64 lanes, travSharedLeafStep)
+    for key, value in (("MCRT_WF_SCHED", "1"), ("MCRT_WF_WIDE", "1"), ("MCRT_WF_DEFER", "0"), ("MCRT_WF_SHARE", "0"), ("MCRT_WF_LEAF", "1"), ("MCRT_WF_LEAF", "40")):
         monkeypatch.setenv(key, value)
         out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
         monkeypatch.delenv(key)

@@ -42,6 +42,21 @@ def test_restated_sincos_sin_cos_equal_glibc(emu, n, lo, hi, edges):
     assert out[2] == 0 and out[3] == 0, "sin / cos differ, first at %r / %r" % (first[2], first[3])
 
 
+@pytest.mark.parametrize("n,lo,hi,edges", [(3000000, -1.0, 1.0, 1), (500000, 0.96, 1.0, 0), (500000, -0.13, 0.13, 0), (200000, -1e-7, 1e-7, 0),
+                                           (100000, -1.5, 1.5, 0)])
+def test_restated_asin_equals_glibc(emu, n, lo, hi, edges):
+    """refAsin (Scene::skyColor's one libm call, scene.cpp:219-223) = the FMA variant of glibc 2.35's __ieee754_asin, bit for bit:
+    dense over [-1, 1], the |x| >= 0.96875 branch, the polynomial branch, the tiny branch, every interval boundary, |x| > 1 (NaN)."""
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the restatement is of x86-64 glibc")
+    if not (_has("fma") and _has("avx2")):
+        pytest.skip("this CPU has no FMA/AVX2: libm's asin is another IFUNC variant than the one restated")
+    emu.emu_asin_check.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    out = np.zeros(4, dtype=np.uint64)
+    emu.emu_asin_check(n, 20260926, lo, hi, edges, out.ctypes.data)
+    assert out[0] == 0, "asin differs on %d arguments, first at %r" % (out[0], out[1:2].view(np.float64)[0])
+
+
 def test_sincos_table_is_glibcs():
     """The committed table against an independent evaluation of sin / cos at k/128 (high words must be the correctly rounded
     values; glibc's low words are within 2^-40 of the exact remainders, 17 of them not the nearest double)."""
