@@ -348,6 +348,14 @@ int mcrt_sampler(mcrt_ctx* ctx, uint64_t n, const uint32_t* pixel, const uint32_
  * Material::diffuseReflection rgb, pdf (material/material.cpp:17-27,82-95) · 0. No scene needed. */
 int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts, double* out);
 
+/* The libm calls of the path as the DEVICE computes them (csrc/mcrt_libm.hpp: glibc 2.35's algorithms restated so that the GPU returns
+ * the bits the reference's std::sin / std::cos pairs (= sincos: sampling/sampling.hpp:29-44, material/ggx.cpp:77-79, surface/sphere.cpp:43),
+ * std::sin alone (camera/filter.hpp:64), std::asin (scene/scene.cpp:221) and std::atan2 (integrator/photon-mapper/photon.hpp:10-11)
+ * return on an x86-64 host with FMA). fn selects the function; a[n] (and b[n] for atan2: a = y, b = x) are the arguments, out0[n]
+ * (and out1[n] for sincos: out0 = sine, out1 = cosine) the results. Known-answer tests only; no scene needed. */
+enum { MCRT_LIBM_SINCOS = 0, MCRT_LIBM_SIN = 1, MCRT_LIBM_COS = 2, MCRT_LIBM_ASIN = 3, MCRT_LIBM_ATAN2 = 4 };
+int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1);
+
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map
  * (which = 0 global, 1 caustic) for n query points p[n][3]. Outputs per query: count found
  * (≤ k), photon indices and squared distances sorted by ascending distance (ties by index),

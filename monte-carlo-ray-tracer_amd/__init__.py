@@ -22,6 +22,7 @@ ABI_VERSION = 2
 FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
+LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2 = range(5)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
 # mcrt_stats.kernel_id (include/mcrt.h MCRT_KERNEL_*)
 KERNEL_NONE, KERNEL_FLAT, KERNEL_WAVESYNC, KERNEL_LANE_SM, KERNEL_WAVEFRONT, KERNEL_PM_WAVE, KERNEL_PM_LANE, KERNEL_WAVEFRONT_PM = range(8)
 KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernel<path_tracer, flat>", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
@@ -220,6 +221,7 @@ def lib():
     L.mcrt_sampler.argtypes = [vp, C.c_uint64, _u32p, _u32p, C.c_uint32, C.c_uint32, _dp]
     L.mcrt_knn.argtypes = [vp, C.c_int, C.c_uint64, _dp, C.c_uint32, _u32p, _u32p, _dp]
     L.mcrt_bsdf.argtypes = [vp, C.c_uint64, _dp, _dp, _dp]
+    L.mcrt_libm.argtypes = [vp, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp]
     L.mcrt_bvh_build_octree.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mcrt_bvh_build_sah.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.mcrt_bvh_build_sah_gpu.argtypes = [vp, C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.POINTER(vp)]
@@ -631,6 +633,15 @@ class Context:
         out = np.zeros((inputs.shape[0], 18))
         self._check(self._lib.mcrt_bsdf(self._h, inputs.shape[0], _ptr(inputs, C.c_double), _ptr(consts, C.c_double), _ptr(out, C.c_double)), "mcrt_bsdf")
         return out
+
+    def libm(self, fn, a, b=None):
+        """mcrt_libm: the device's sincos (fn 0 -> (sin, cos)), sin (1), cos (2), asin (3), atan2 (4: a = y, b = x) on arrays."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out0, out1 = np.zeros_like(a), np.zeros_like(a)
+        bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+        self._check(self._lib.mcrt_libm(self._h, int(fn), a.size, _ptr(a, C.c_double), _ptr(bb, C.c_double) if bb is not None else None,
+                                        _ptr(out0, C.c_double), _ptr(out1, C.c_double)), "mcrt_libm")
+        return (out0, out1) if fn == 0 else out0
 
     def knn(self, which, points, k):
         self._sync_env()

@@ -214,7 +214,7 @@ int ensureSpill(mcrt_ctx* ctx, size_t bytes) {  // traversal-stack spill area, s
 int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-    if (int rc = ensureSpill(ctx, (size_t)total_lanes * (kMaxStackDepth - kLdsStackDepth) * sizeof(StackEntry))) return rc;
+    if (int rc = ensureSpill(ctx, (size_t)total_lanes * (ctx->scene.stack_depth - kLdsStackDepth) * sizeof(StackEntry))) return rc;
     if (photon && (ctx->knn_lanes < total_lanes || ctx->knn_k < ctx->k_nearest)) {
         const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1);
         HIP_TRY(ctx, ctx->knn_res_d2.alloc((size_t)total_lanes * k * sizeof(double)));
@@ -294,7 +294,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
         if (tp.grid < 1) tp.grid = 1;
         const uint32_t total_slots = tp.grid * kSchedSlots;
         if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-        if (int rc = ensureSpill(ctx, (size_t)total_slots * kMaxStackDepth * sizeof(StackEntry))) return rc;
+        if (int rc = ensureSpill(ctx, (size_t)total_slots * ctx->scene.stack_depth * sizeof(StackEntry))) return rc;
         HIP_TRY(ctx, ctx->wf_ray_scratch.reserve((size_t)total_slots * 128));
         WfTraceArgs& ta = tp.args;
         memset(&ta, 0, sizeof(ta));
@@ -314,6 +314,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
         ta.spill = ctx->spill.as<SmStackEntry>();
         ta.total_lanes = total_slots;
         ta.lds_stack = (int)kSchedStack;
+        ta.max_stack = ctx->scene.stack_depth;
         ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_WF_DEAL", 6), 6), 20);
         return MCRT_OK;
     }
@@ -336,7 +337,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
     // two trace launches (the two halves of the wavefront pool) can be resident at once; a region holds kMaxStackDepth entries
     // per lane whatever part of them lives in LDS
-    if (int rc = ensureSpill(ctx, (size_t)2 * total_lanes * kMaxStackDepth * sizeof(StackEntry))) return rc;
+    if (int rc = ensureSpill(ctx, (size_t)2 * total_lanes * ctx->scene.stack_depth * sizeof(StackEntry))) return rc;
     WfTraceArgs& ta = tp.args;
     memset(&ta, 0, sizeof(ta));
     ta.stats = ctx->stats.as<unsigned long long>();
@@ -359,6 +360,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 12 : 24);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
+    ta.max_stack = ctx->scene.stack_depth;
     ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_WF_DEAL", 6), 6), 20);
     return MCRT_OK;
 }
@@ -505,7 +507,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         unsigned long long* c = ctrl + 4 * h;  // {count[2], pop} of this half
         ta[h] = tp.args;
         ta[h].pop = c + 2;
-        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * kMaxStackDepth;
+        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * ctx->scene.stack_depth;
         pr[h].pool.w = ctx->wf_pool.as<unsigned long long>();
         pr[h].pool.n = (uint32_t)slots;
         {
@@ -848,9 +850,9 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     }
     if (int rc = ensureScratch(ctx, g.total_lanes, photon && !use_pm_wave)) return rc;
     if (use_sm && sm_depth < kLdsStackDepth)
-        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (kMaxStackDepth - sm_depth) * sizeof(StackEntry))) return rc;
+        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (ctx->scene.stack_depth - sm_depth) * sizeof(StackEntry))) return rc;
     if (use_pm_wave && pm_stack_depth < (uint32_t)kLdsStackDepth)
-        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (kMaxStackDepth - pm_stack_depth) * sizeof(StackEntry))) return rc;
+        if (int rc = ensureSpill(ctx, (size_t)g.total_lanes * (ctx->scene.stack_depth - pm_stack_depth) * sizeof(StackEntry))) return rc;
 
     RenderParams prm;
     memset(&prm, 0, sizeof(prm));
@@ -1245,6 +1247,23 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.qblocks = ctx->qblocks.as<QBlock>();
     d.num_qblocks = (uint32_t)L.qblocks.size();
     d.q_nodes = (uint32_t)L.nodes64.size();
+    // every lane's traversal stack holds what a depth-first walk of THIS tree can hold (HostLayout::stack_bound), never fewer than
+    // kMaxStackDepth entries; the spill slabs behind the LDS part are sized from it at launch (ensureSpill)
+    d.stack_depth = std::max<uint32_t>((uint32_t)kMaxStackDepth, L.stack_bound + 1u);
+    {
+        // the deepest spill slab a frame allocates: two trace launches x 256 CUs x 1024 lanes x 8 bytes per entry. A tree degenerate
+        // enough to need more than a quarter of the device's memory for it (tens of thousands of stack entries: a BVH that is a list)
+        // is refused here, with its number, instead of failing in some later hipMalloc.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = (size_t)64 << 30;
+        }
+        const size_t slab = (size_t)d.stack_depth * sizeof(StackEntry) * 2u * (size_t)ctx->num_cus * kTraceMaxBlock;
+        if (slab > total_b / 4)
+            return fail(ctx, MCRT_ERR_UNSUPPORTED, "BVH so unbalanced that a depth-first walk may hold " + std::to_string(L.stack_bound) +
+                                                       " pending nodes per ray: the traversal stacks would not fit in device memory");
+    }
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
     d.wnodes = L.wnodes.empty() ? nullptr : ctx->wnodes.as<WNode>();
@@ -1401,7 +1420,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_launches = ctx->launches;
         stats->kernel_id = ctx->kernel_id;
     }
-    if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
+    if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
         // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
         // (32). A frame that nested deeper than 8 media is rendered AGAIN through the pipeline: slower for the scenes the megakernels
@@ -1717,7 +1736,7 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         }
         unsigned long long h[kStatsWords];
         HIP_TRY(ctx, hipMemcpy(h, ctx->stats.p, sizeof(h), hipMemcpyDeviceToHost));
-        if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (BVH deeper than the 128-entry per-lane stack)");
+        if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
         HIP_TRY(ctx, hipMemcpy(out_t, dt.p, n * 8, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(out_surface, dsf.p, n * 4, hipMemcpyDeviceToHost));
         if (out_uv) HIP_TRY(ctx, hipMemcpy(out_uv, duv.p, n * 16, hipMemcpyDeviceToHost));
@@ -1791,6 +1810,28 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 18 * 8, hipMemcpyDeviceToHost));
+    return MCRT_OK;
+}
+
+int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
+    if (!ctx) return MCRT_ERR_INVALID;
+    if (fn < MCRT_LIBM_SINCOS || fn > MCRT_LIBM_ATAN2) return fail(ctx, MCRT_ERR_INVALID, "mcrt_libm: unknown function selector");
+    if (n == 0) return MCRT_OK;
+    if (!a || !out0 || (fn == MCRT_LIBM_ATAN2 && !b) || (fn == MCRT_LIBM_SINCOS && !out1)) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    REJECT_IF_PENDING(ctx, "mcrt_libm");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf &da = ctx->op_buf[0], &db = ctx->op_buf[1], &d0 = ctx->op_buf[2], &d1 = ctx->op_buf[3];
+    if (int rc = uploadInto(ctx, da, a, n)) return rc;
+    if (fn == MCRT_LIBM_ATAN2)
+        if (int rc = uploadInto(ctx, db, b, n)) return rc;
+    HIP_TRY(ctx, d0.reserve(n * 8));
+    HIP_TRY(ctx, d1.reserve(n * 8));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(libmKernel, dim3(grid), dim3(256), 0, ctx->stream, fn, n, da.as<double>(), db.as<double>(), d0.as<double>(), d1.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out0, d0.p, n * 8, hipMemcpyDeviceToHost));
+    if (fn == MCRT_LIBM_SINCOS) HIP_TRY(ctx, hipMemcpy(out1, d1.p, n * 8, hipMemcpyDeviceToHost));
     return MCRT_OK;
 }
 

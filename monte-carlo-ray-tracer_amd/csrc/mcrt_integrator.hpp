@@ -131,8 +131,8 @@ MCRT_HD void encodePhoton(PhotonOut& out, d3 flux, d3 position, d3 direction) { 
     out.rec[3] = (float)position.x;
     out.rec[4] = (float)position.y;
     out.rec[5] = (float)position.z;
-    out.rec[7] = (float)atan2(sqrt(direction.x * direction.x + direction.y * direction.y), direction.z);  // theta
-    out.rec[6] = (float)atan2(direction.y, direction.x);                                                   // phi
+    out.rec[7] = (float)refAtan2(sqrt(direction.x * direction.x + direction.y * direction.y), direction.z);  // theta (glibc's atan2, bit for bit)
+    out.rec[6] = (float)refAtan2(direction.y, direction.x);                                                   // phi
 }
 
 // photon-mapper.cpp:98-110: emission `index` of light number `light` (position in Scene::emissives).

@@ -31,6 +31,7 @@ struct DeviceScene {
     uint32_t num_wnodes;
     const float* leaf_pre;        // FP32 cull records of the primitives in BVH order (mcrt_lanesm.hpp "leaf cull"); null: none
     double leaf_cx, leaf_cy, leaf_cz, leaf_bound;
+    uint32_t stack_depth;         // traversal-stack entries per lane (LDS + spill slab): max(kMaxStackDepth, the tree's stack bound), mcrt_upload_scene
     uint32_t q_nodes;             // records in nodes64 = num_nodes, or — scene without a BVH — the nodes of the index-range tree the wavefront pipeline walks (mcrt_layout.hpp)
     const double* prim;
     const double* flat_prim;      // kind-sorted copy (flat mode)
@@ -205,6 +206,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
     stk.lds_stride = blockDim.x;
     stk.spill = spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = total_lanes;
+    stk.max_depth = (int)s.stack_depth;
 
     sv.num_nodes = s.flat ? 0u : s.num_nodes;
     sv.num_surfaces = s.num_surfaces;
@@ -497,6 +499,7 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
     stk.spill = reinterpret_cast<SmStackEntry*>(prm.spill) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = prm.total_lanes;
     stk.lds_depth = prm.sm_lds_depth;
+    stk.max_depth = (int)scene.stack_depth;
     RefractionHistory rh;
     rh.iors = ldsAt<double>(lds, p.iors) + threadIdx.x;
     rh.stride = blockDim.x;
@@ -741,6 +744,7 @@ struct WfTraceArgs {
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
+    uint32_t max_stack;                 // stack entries per lane in all (DeviceScene::stack_depth)
     uint32_t deal_shift;                // queue entries are dealt to the workgroups in blocks of 2^deal_shift
 };
 
@@ -888,6 +892,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     stk.spill = a.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     stk.spill_stride = a.total_lanes;
     stk.lds_depth = a.lds_stack;
+    stk.max_depth = (int)a.max_stack;
     SmSceneView<false> sv;
     sv.num_nodes = a.num_nodes;
     sv.nodes = a.nodes;
@@ -1180,6 +1185,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernelSched(const WfTra
         stk.lds_depth = (int)kSchedStack;
         stk.spill = a.spill + (size_t)blockIdx.x * kSchedSlots + slot;
         stk.spill_stride = a.total_lanes;  // (= grid * kSchedSlots: planTrace)
+        stk.max_depth = (int)a.max_stack;
         return stk;
     };
     // file the slots of this wave's lanes under queue q (lanes with `want`): one ticket reservation per wave
@@ -1725,6 +1731,7 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
     q.stk.lds_stride = lstk.lds_stride;
     q.stk.spill = reinterpret_cast<SmStackEntry*>(lstk.spill);
     q.stk.spill_stride = lstk.spill_stride;
+    q.stk.max_depth = lstk.max_depth;
 }
 
 struct PmExtra {
@@ -2126,6 +2133,29 @@ __global__ void samplerKernel(const uint32_t* tab, uint64_t n, const uint32_t* p
 // directions — Fresnel::dielectric / conductor, GGX::reflection / transmission / visibleMicrofacet / D / Lambda and
 // Material::diffuseReflection (Oren-Nayar) — one vector per lane, same device functions as the integrators.
 // in[n][11] = wi(3) wo(3) n1 n2 alpha u v; out[n][18] (layout in include/mcrt.h).
+// mcrt_libm: the restated libm functions (mcrt_libm.hpp) on arrays of arguments, one per lane.
+__global__ void __launch_bounds__(256) libmKernel(int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
+    glibc235::stageSinCosTab();
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double x = a[i];
+        if (fn == 0) {
+            double sn, cs;
+            refSinCos(x, sn, cs);
+            out0[i] = sn;
+            out1[i] = cs;
+        } else if (fn == 1) {
+            out0[i] = refSin(x);
+        } else if (fn == 2) {
+            out0[i] = refCos(x);
+        } else if (fn == 3) {
+            out0[i] = refAsin(x);
+        } else {
+            out0[i] = refAtan2(x, b[i]);
+        }
+    }
+}
+
 struct BsdfKatConsts {
     mcrt_material rough;   // roughness, reflectance, A, B, MCRT_MAT_ROUGH
     double real[3], imag[3];

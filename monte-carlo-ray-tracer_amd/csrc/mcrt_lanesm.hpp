@@ -50,6 +50,7 @@ struct SmStack {
     SmStackEntry* spill;
     uint32_t spill_stride;
     int lds_depth = kLdsStackDepth;  // entries per lane kept in LDS (the trace kernel trades some of them for more tree blocks)
+    int max_depth = kMaxStackDepth;  // entries per lane in all: the scene's stack bound, at least kMaxStackDepth (HostLayout::stack_bound)
     // (the empty asm statements keep the two address spaces in separate branches: merged into one generic-pointer access the
     // compiler emits flat_load / flat_store, which wait on both the LDS and the vector-memory counters)
     MCRT_HD void put(int sp, SmStackEntry e) const {
@@ -137,6 +138,29 @@ MCRT_HD void travPop(Trav& T, const SmStack& stk) {
     }
 }
 
+// One primitive record in registers.
+struct PrimRec {
+    double v[kPrimStride];
+};
+template <class P>
+MCRT_HD PrimRec loadPrim(P p) {
+    PrimRec r;
+    for (int k = 0; k < kPrimStride; k++) r.v[k] = p[k];
+    return r;
+}
+template <bool kQuadrics>
+MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
+    if (rec.v[9] == 1.0 || (kQuadrics && rec.v[9] == 3.0)) return primIntersect<kQuadrics>(rec.v, ray, h);  // sphere / quadric (rare in walked BVHs)
+    double t, u, v;
+    const bool ok = triangleTestFlat(rec.v, ray.start, ray.direction, t, u, v);
+    const bool interp = rec.v[9] >= 2.0;
+    h.t = t;
+    h.u = interp ? u : 0.0;
+    h.v = interp ? v : 0.0;
+    h.interpolate = interp;
+    return ok;
+}
+
 // Scene::intersect / BVH::intersect start (bvh.cpp:84-88): root box test.
 template <bool kAll, bool kCount>
 MCRT_HD void travBegin(const SmSceneView<kAll>& sv, Trav& T, d3 start, d3 direction, d3 inv_direction, bool shadow,
@@ -156,11 +180,31 @@ MCRT_HD void travBegin(const SmSceneView<kAll>& sv, Trav& T, d3 start, d3 direct
     // (1e25: the FP32 slab test of the quantised blocks, mcrt_qbvh.hpp, multiplies scene-sized lengths by these)
     T.fast = fabs(inv_direction.x) <= 1e25 && fabs(inv_direction.y) <= 1e25 && fabs(inv_direction.z) <= 1e25;
     cnt.rays++;
+    const Ray r = travRay(T);
+    if (shadow) {
+        // Shadow query, exactly (integrator.cpp:68-73: the closest hit must BE the light): the light's own intersection first - the
+        // reference's FP64 test on the light's record - then "is any other surface closer than THAT" with the tie rule of every other
+        // query. (Until round 4 the bound was the distance d to the sampled point, d (1 +- 1e-9): off when the ray grazes the light - a
+        // shading point in the plane of a light triangle, lego_bulldozer's lamp quads - where the computed t deviates from d by more than
+        // that, and a frame lost the reference's last bits.) A light the exact test does not hit cannot be the closest hit: no walk at all.
+        Hit h;
+        if (kCount) cnt.prim_tests++;
+        const PrimRec rec = loadPrim(sv.prim + (size_t)sq->light * kPrimStride);
+        if (!primTestRec<QuadricsIn<kAll>::value>(rec, r, h)) {
+            T.active = false;
+            T.node_a = T.node_m = 0u;
+            return;
+        }
+        // the light IS the hit so far (its leaf's box may start an ulp behind this t and be culled: the walk need not find it again);
+        // another surface replaces it when it is closer - or exactly as far with a lower index, the tie rule of every query
+        T.best = h;
+        T.best.surface = sq->light;
+        T.t_near = h.t;
+    }
     if (kCount) cnt.node_tests++;
     uint32_t a, m;
     Box rb = smLoadBox(sv, 0u, a, m);
     double t;
-    const Ray r = travRay(T);
     T.active = T.fast ? boxIntersect<true>(rb, r, t) : boxIntersect<false>(rb, r, t);
     T.node_a = a;
     T.node_m = m;
@@ -195,7 +239,7 @@ MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& 
                 have_near = true;
             }
             if (push) {
-                if (T.sp < kMaxStackDepth) {
+                if (T.sp < stk.max_depth) {
                     SmStackEntry e;
                     e.key = (floatBits(floatBelow(push_t)) & ~0x1FFu) | push_m;
                     e.a = push_a;
@@ -212,29 +256,6 @@ MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& 
     } else {
         travPop(T, stk);
     }
-}
-
-// One primitive record in registers.
-struct PrimRec {
-    double v[kPrimStride];
-};
-template <class P>
-MCRT_HD PrimRec loadPrim(P p) {
-    PrimRec r;
-    for (int k = 0; k < kPrimStride; k++) r.v[k] = p[k];
-    return r;
-}
-template <bool kQuadrics>
-MCRT_HD bool primTestRec(const PrimRec& rec, const Ray& ray, Hit& h) {
-    if (rec.v[9] == 1.0 || (kQuadrics && rec.v[9] == 3.0)) return primIntersect<kQuadrics>(rec.v, ray, h);  // sphere / quadric (rare in walked BVHs)
-    double t, u, v;
-    const bool ok = triangleTestFlat(rec.v, ray.start, ray.direction, t, u, v);
-    const bool interp = rec.v[9] >= 2.0;
-    h.t = t;
-    h.u = interp ? u : 0.0;
-    h.v = interp ? v : 0.0;
-    h.interpolate = interp;
-    return ok;
 }
 
 // ---- Leaf cull (round 3) ---------------------------------------------------------------------------------------------------

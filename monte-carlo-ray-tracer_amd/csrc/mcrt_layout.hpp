@@ -44,7 +44,28 @@ struct HostLayout {
     std::vector<WNode> wnodes;         // eight-wide quantised nodes (mcrt_wbvh.hpp), breadth-first, inner children of a node contiguous
     uint32_t num_quadric_surfaces = 0;
     std::vector<double> surf_v_patched;  // surf_v with quadric record addresses (only when the scene has quadrics)
+    // Most traversal-stack entries any depth-first walk of nodes64 can hold at once: on the way down a visit continues with one child
+    // and pushes at most the others, so standing at a node the stack holds at most the sum over its ancestors of (children - 1) - a
+    // property of the tree, computed at upload. The reference's frontier is an unbounded heap (bvh.cpp:80-129); the kernels' stacks
+    // are sized to THIS bound (mcrt_upload_scene: kMaxStackDepth or more), so no ray can overflow them.
+    uint32_t stack_bound = 0;
 };
+
+// (nodes are breadth-first with parents in front of their children: one forward pass)
+inline uint32_t stackBound(const std::vector<Node64>& nodes) {
+    const size_t n = nodes.size();
+    if (n == 0) return 0;
+    std::vector<uint32_t> held(n, 0u);  // entries on the stack while the walk stands at node i
+    uint32_t bound = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!(nodes[i].m & kSmInner)) continue;
+        const uint32_t count = nodes[i].m & 0xFFu, first = nodes[i].a;
+        const uint32_t below = held[i] + (count ? count - 1u : 0u);
+        bound = bound > below ? bound : below;
+        for (uint32_t c = 0; c < count && (size_t)first + c < n; c++) held[first + c] = below;
+    }
+    return bound;
+}
 
 // One axis of one block: origin (float, rounded down), cell exponent and the cell coordinates of every child,
 // chosen so that qDecode(lower) <= lo and qDecode(upper) >= hi hold in the kernels' own arithmetic.
@@ -657,6 +678,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             }
             n.pad0 = n.pad1 = 0;
         }
+        L.stack_bound = stackBound(L.nodes64);
         if (int rc = buildQBlocks(L, err)) return rc;
         return buildWNodes(L, err);
     };
@@ -681,6 +703,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
         L.qblocks.clear();
         L.wnodes.clear();
         L.q_root_a = L.q_root_m = 0;
+        L.stack_bound = 0;
     }
     std::swap(err, ignored);
     return MCRT_OK;

@@ -267,7 +267,7 @@ MCRT_HD void refSinCos(double x, double& sn_out, double& cs_out) {
 // 2.35-0ubuntu3.11, every a*b + c below is one vfmadd there); kFused = false evaluates the same expression tree with every operation
 // rounded (not what any build of glibc computes bit for bit - its sse2 variant is compiled from the same source but this tree is the
 // FMA build's; kept for the emulation's A/B counts, not used by the product). Tables:
-// mcrt_glibc_asintab.inc (tools/make_glibc_asin_table.py). tests/test_libm.py: bit-equal to the host's asin on millions of arguments
+// mcrt_glibc_asintab.inc (tools/make_glibc_asin_atan_tables.py). tests/test_libm.py: bit-equal to the host's asin on millions of arguments
 // in every interval and across every interval boundary.
 namespace glibc235 {
 MCRT_LIBM_TABLE unsigned long long kAsinTab[2568 + 128] = {
@@ -359,5 +359,138 @@ MCRT_HD double refAsinT(double x) {
     return m > 0 ? res : -res;
 }
 MCRT_HD double refAsin(double x) { return refAsinT<true>(x); }
+
+// ---- atan2 as the reference computes it (Photon's constructor, integrator/photon-mapper/photon.hpp:10-11: theta and phi of a stored
+// photon's direction are (float)std::atan2 (...)) ----
+// glibc 2.35 __ieee754_atan2 (sysdeps/ieee754/dbl-64/e_atan2.c, IBM Accurate Mathematical Library, the version without the multi-
+// precision fall-backs): u = min(|y|, |x|) / max(|y|, |x|) with the division's remainder du (EMULV: exact product through an fma),
+// atan(u) by an odd polynomial below 1/16 or by the Taylor expansion around the nearest of 241 table points (cij, uatan.tbl), and
+// the quadrant by adding to / subtracting from pi/2 or pi as double-doubles. An IFUNC like asin: restated is __ieee754_atan2_fma, the
+// variant the build container's and the GPU box's CPUs select (every a*b + c below is one vfmadd there - including the table index
+// (u * 256 + 2^52) - 2^52). Inputs with a NaN or an infinity go to the platform's atan2 (never produced by the path: the arguments are
+// components of a unit vector). tests/test_libm.py: bit-equal to the host's atan2 on millions of argument pairs in every octant, on
+// the axes, with extreme ratios and at the table-interval boundaries.
+namespace glibc235 {
+MCRT_LIBM_TABLE unsigned long long kAtanTab[241 * 7] = {
+#include "mcrt_glibc_atantab.inc"
+};
+MCRT_HD double cij(int i, int j) { return bitsD(kAtanTab[7 * i + j]); }
+constexpr double kD3 = -0x1.5555555555555p-2, kD5 = 0x1.99999999997fdp-3, kD7 = -0x1.24924923f7603p-3, kD9 = 0x1.c71c6e5129a3bp-4,
+                 kD11 = -0x1.7458022b13c25p-4, kD13 = 0x1.375f08b31cbcep-4;
+constexpr double kOpi = 0x1.921fb54442d18p+1, kOpi1 = 0x1.1a62633145c07p-53, kTwo52 = 0x1.0p+52, kTwo500 = 0x1.0p+500, kTwoM500 = 0x1.0p-500;
+
+MCRT_HD double atanPoly(double v) {  // d3 + v (d5 + v (d7 + v (d9 + v (d11 + v d13))))
+    double p = fmaD<true>(v, kD13, kD11);
+    p = fmaD<true>(v, p, kD9);
+    p = fmaD<true>(v, p, kD7);
+    p = fmaD<true>(v, p, kD5);
+    return fmaD<true>(v, p, kD3);
+}
+MCRT_HD int atanRow(double u) { return (int)(fmaD<true>(u, 256.0, kTwo52) - kTwo52) - 16; }
+MCRT_HD double atanRowPoly(int i, double v) {  // cij[i][2] + v (cij[i][3] + v (cij[i][4] + v (cij[i][5] + v cij[i][6])))
+    double q = fmaD<true>(v, cij(i, 6), cij(i, 5));
+    q = fmaD<true>(v, q, cij(i, 4));
+    q = fmaD<true>(v, q, cij(i, 3));
+    return fmaD<true>(v, q, cij(i, 2));
+}
+}  // namespace glibc235
+
+MCRT_HD double refAtan2(double y, double x) {
+    using namespace glibc235;
+    const unsigned long long by = dBits(y), bx = dBits(x);
+    const uint32_t uy = (uint32_t)(by >> 32), ux = (uint32_t)(bx >> 32), dy = (uint32_t)by, dx = (uint32_t)bx;
+    if ((ux & 0x7ff00000u) == 0x7ff00000u || (uy & 0x7ff00000u) == 0x7ff00000u) return atan2(y, x);  // NaN / infinity: not on the path
+    if (uy == 0u && dy == 0u) return (ux & 0x80000000u) ? kOpi : 0.0;                                 // y = +0
+    if (uy == 0x80000000u && dy == 0u) return (ux & 0x80000000u) ? -kOpi : -0.0;                      // y = -0
+    if (x == 0.0) return (uy & 0x80000000u) ? -kHp0 : kHp0;
+    double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+    const int de = (int)(uy & 0x7ff00000u) - (int)(ux & 0x7ff00000u);
+    if (de > 0x038fffff) return y > 0.0 ? kHp0 : -kHp0;                                               // |y| / |x| > 2^57
+    if (de < -0x038fffff) {                                                                           // |y| / |x| < 2^-57
+        if (x > 0.0) return copySign(ay / ax, y);
+        return y > 0.0 ? kOpi : -kOpi;
+    }
+    if (ax < kTwoM500 || ay < kTwoM500) {
+        ax *= kTwo500;
+        ay *= kTwo500;
+    }
+    if (ax > kTwo500 || ay > kTwo500) {
+        ax *= kTwoM500;
+        ay *= kTwoM500;
+    }
+    double u, du, z;
+    const bool y_smaller = ay < ax;
+    {
+        const double num = y_smaller ? ay : ax, den = y_smaller ? ax : ay;
+        u = num / den;
+        const double v = den * u, vv = fmaD<true>(den, u, -v);  // EMULV
+        du = ((num - v) - vv) / den;
+    }
+    if (x > 0.0) {
+        if (y_smaller) {                                   // (i) atan(ay / ax)
+            if (u < 0.0625) {
+                const double v = u * u;
+                const double zz = fmaD<true>(u * v, atanPoly(v), du);
+                z = u + zz;
+            } else {
+                const int i = atanRow(u);
+                const double t3 = u - cij(i, 0);
+                const double v = du + t3;                  // EADD (t3, du, v, dv)
+                const double dv = absD(t3) > absD(du) ? (t3 - v) + du : (du - v) + t3;
+                const double t2 = cij(i, 2);
+                double q = fmaD<true>(v, cij(i, 6), cij(i, 5));
+                q = fmaD<true>(v, q, cij(i, 4));
+                q = fmaD<true>(v, q, cij(i, 3));
+                q = (v * v) * q;
+                q = fmaD<true>(dv, t2, q);
+                const double zz = fmaD<true>(v, t2, q);
+                z = zz + cij(i, 1);
+            }
+        } else {                                           // (ii) pi/2 - atan(ax / ay)
+            if (u < 0.0625) {
+                const double v = u * u;
+                const double zz = (u * v) * atanPoly(v);
+                const double t2 = kHp0 - u;                // ESUB (hpi, u, t2, cor)
+                const double cor = kHp0 > absD(u) ? (kHp0 - t2) - u : kHp0 - (u + t2);
+                const double t3 = ((cor + kHp1) - du) - zz;
+                z = t3 + t2;
+            } else {
+                const int i = atanRow(u);
+                const double v = (u - cij(i, 0)) + du;
+                const double zz = fmaD<true>(-v, atanRowPoly(i, v), kHp1);
+                z = (kHp0 - cij(i, 1)) + zz;
+            }
+        }
+    } else if (ay > ax) {                                  // (iii) x < 0: pi/2 + atan(ax / ay)
+        if (u < 0.0625) {
+            const double v = u * u;
+            const double zz = (v * u) * atanPoly(v);
+            const double t2 = u + kHp0;                    // EADD (hpi, u, t2, cor)
+            const double cor = kHp0 > absD(u) ? (kHp0 - t2) + u : (u - t2) + kHp0;
+            const double t3 = ((cor + kHp1) + du) + zz;
+            z = t3 + t2;
+        } else {
+            const int i = atanRow(u);
+            const double v = (u - cij(i, 0)) + du;
+            const double zz = fmaD<true>(v, atanRowPoly(i, v), kHp1);
+            z = (kHp0 + cij(i, 1)) + zz;
+        }
+    } else {                                               // (iv) x < 0: pi - atan(ay / ax)
+        if (u < 0.0625) {
+            const double v = u * u;
+            const double zz = (v * u) * atanPoly(v);
+            const double t2 = kOpi - u;                    // ESUB (opi, u, t2, cor)
+            const double cor = kOpi > absD(u) ? (kOpi - t2) - u : kOpi - (t2 + u);
+            const double t3 = ((cor + kOpi1) - du) - zz;
+            z = t3 + t2;
+        } else {
+            const int i = atanRow(u);
+            const double v = (u - cij(i, 0)) + du;
+            const double zz = fmaD<true>(-v, atanRowPoly(i, v), kOpi1);
+            z = (kOpi - cij(i, 1)) + zz;
+        }
+    }
+    return copySign(z, y);
+}
 
 }  // namespace mcrt

@@ -87,7 +87,7 @@ MCRT_HD void travInnerStepQ64(const QView<kLds>& qv, Trav& T, const SmStack& stk
     double near_t = kMiss;
     uint32_t near_a = 0, near_m = 0;
     auto push = [&](double t, uint32_t a, uint32_t m) {
-        if (T.sp < kMaxStackDepth) {
+        if (T.sp < stk.max_depth) {
             SmStackEntry e;
             e.key = (floatBits(floatBelow(t)) & ~0x1FFu) | m;
             e.a = a;
@@ -177,7 +177,7 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
     const bool pos[3] = {T.inv.x >= 0.0, T.inv.y >= 0.0, T.inv.z >= 0.0};
     uint32_t near_key = kQMissKey, near_a = 0;
     auto push = [&](uint32_t key, uint32_t a) {
-        if (T.sp < kMaxStackDepth) {
+        if (T.sp < stk.max_depth) {
             SmStackEntry e;
             e.key = key;
             e.a = a;

@@ -37,7 +37,7 @@ namespace mcrt {
 constexpr uint32_t kInnerFlag = 0x80000000u;
 constexpr int kPrimStride = 10;      // doubles per intersection record
 constexpr int kLdsStackDepth = 16;   // entries per lane kept in LDS
-constexpr int kMaxStackDepth = 128;  // total entries per lane (LDS + global spill)
+constexpr int kMaxStackDepth = 128;  // total entries per lane (LDS + global spill) - the MINIMUM: a scene whose tree can hold more on a stack gets its own bound (HostLayout::stack_bound)
 
 struct NodeMeta {
     uint32_t a, b;
@@ -115,6 +115,7 @@ struct LaneStack {
     uint32_t lds_stride;
     StackEntry* spill;            // &spill[global_lane]; stride = total lanes
     uint32_t spill_stride;
+    int max_depth = kMaxStackDepth;  // entries per lane in all (LDS + spill slab): the scene's stack bound, at least kMaxStackDepth (DeviceScene::stack_depth)
     MCRT_HD void put(int sp, StackEntry e) const {
         if (sp < kLdsStackDepth) lds[(uint32_t)sp * lds_stride] = e;
         else spill[(uint32_t)(sp - kLdsStackDepth) * (size_t)spill_stride] = e;
@@ -498,12 +499,19 @@ template <bool kAll, bool kCount, bool kShadow, bool kFlat = false>
 MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const LaneStack& stk, TraceCounters& cnt,
                            const ShadowQuery* sq = nullptr) {
     Hit best;
-    best.t = kShadow ? sq->t_far : kDblMax;
+    best.t = kDblMax;
     best.u = 0.0;
     best.v = 0.0;
     best.surface = kNoSurface;
     best.interpolate = false;
     cnt.rays++;
+    // Shadow queries, exactly (integrator.cpp:68-73: the closest hit must BE the light). The flat loop below tests every primitive the
+    // cull leaves anyway, so it simply returns the true closest hit, unbounded. The walks bound themselves by the light's OWN
+    // intersection: the reference's FP64 test on the light's record first, then "is any other surface closer than that" (ties to the
+    // lowest index as everywhere); a light its own test does not hit cannot be the closest hit - no walk. (Until round 4 the bound was
+    // the distance d to the sampled point, d (1 +- 1e-9): off where the ray grazes the light and the computed t strays farther from d.)
+    uint32_t sh_light = kNoSurface;
+    double sh_near = 0.0;
 
     if (kFlat || sv.num_nodes == 0) {  // every primitive, as scene.cpp:161-173 does without a BVH
         if (kFlat || (kAll && sv.flat_prim)) {
@@ -599,10 +607,22 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
             if (primIntersect<QuadricsIn<kAll>::value>(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                 best = h;
                 best.surface = i;
-                if (kShadow && i != sq->light && h.t < sq->t_near) return best;
+                if (kShadow && i != sh_light && h.t < sh_near) return best;
             }
         }
         return best;
+    }
+
+    if (kShadow) {  // the light's own intersection bounds the walk (see above)
+        sh_light = sq->light;
+        Hit h;
+        if (kCount) cnt.prim_tests++;
+        if (!primIntersect<QuadricsIn<kAll>::value>(sv.prim + (size_t)sh_light * kPrimStride, ray, h)) return best;
+        // the light IS the hit so far (its leaf's box may start an ulp behind this t and be culled: the walk need not find it again);
+        // another surface replaces it when it is closer - or exactly as far with a lower index, the tie rule of every query
+        best = h;
+        best.surface = sh_light;
+        sh_near = h.t;
     }
 
     // v_min/v_max box test is exact unless a slab product can be 0*inf = NaN
@@ -640,7 +660,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                         near_t = t;
                     }
                     if (push_node != kNoSurface) {
-                        if (sp < kMaxStackDepth) {
+                        if (sp < stk.max_depth) {
                             StackEntry e;
                             e.t = floatBelow(push_t);
                             e.node = push_node;
@@ -677,7 +697,7 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                 if (primIntersect<QuadricsIn<kAll>::value>(sv.prim + (size_t)i * kPrimStride, ray, h) && closer(h.t, i, best)) {
                     best = h;
                     best.surface = i;
-                    if (kShadow && i != sq->light && h.t < sq->t_near) return best;
+                    if (kShadow && i != sh_light && h.t < sh_near) return best;
                 }
             }
         }

@@ -141,7 +141,7 @@ MCRT_HD void travWideStep(const WView& wv, Trav& T, WLeaves& Lv, const SmStack& 
     const uint32_t child = T.node_a + popCount(imask_parent & ((1u << s) - 1u));
     const uint32_t rest = bits & (bits - 1u);
     if (rest) {  // what is left of the group waits on the stack
-        if (T.sp < kMaxStackDepth) {
+        if (T.sp < stk.max_depth) {
             SmStackEntry e;
             e.key = (T.node_m & ~kWGroupBits) | rest;
             e.a = T.node_a;

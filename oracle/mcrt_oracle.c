@@ -300,6 +300,17 @@ static void nqPop(NodeQueue* q) { /* :33-45 */
 
 typedef struct { NodeQueue to_visit; void* knn_visit; void* knn_result[2]; } ThreadScratch;
 
+/* oracle_set_true_minimum(1): the closest hit as the TRUE minimum over all primitives with ties to the lowest surface index - what
+ * the HIP walks return by construction (DESIGN.md "Ties") - instead of the reference's heap-order result, which differs from it only
+ * where two surfaces are hit within an ulp of each other and a child box starts exactly at the first one's t (bvh.cpp:100,120: strict
+ * `<` on hits, `top.t >= intersect.t` ends the walk without looking inside). Default 0 = the reference. The tests use it to show that
+ * a frame that is not the reference's bits (metal_bunnies: a shelf coplanar with the back wall) differs by this rule and nothing else. */
+static int g_true_minimum = 0;
+void oracle_set_true_minimum(int on) { g_true_minimum = on; }
+static inline int hitCloser(const Hit* h, uint32_t i, const Hit* best) {
+    return h->t < best->t || (g_true_minimum && h->t == best->t && i < best->surface);
+}
+
 static Hit sceneIntersect(const SceneRef* S, const Ray* ray, ThreadScratch* ts) { /* scene/scene.cpp:151-176, bvh/bvh.cpp:80-129 */
     const mcrt_scene_desc* s = S->s;
     Hit best; best.t = DBL_MAX; best.surface = NO_SURFACE; best.u = best.v = 0.0; best.interpolate = 0;
@@ -307,7 +318,7 @@ static Hit sceneIntersect(const SceneRef* S, const Ray* ray, ThreadScratch* ts) 
     if (s->num_nodes == 0) {
         for (uint32_t i = 0; i < s->num_surfaces; i++) {
             Hit h;
-            if (surfIntersect(S, i, ray, &h) && h.t < best.t) { best = h; best.surface = i; }
+            if (surfIntersect(S, i, ray, &h) && hitCloser(&h, i, &best)) { best = h; best.surface = i; }
         }
         return best;
     }
@@ -322,20 +333,20 @@ static Hit sceneIntersect(const SceneRef* S, const Ray* ray, ThreadScratch* ts) 
                 uint32_t start = s->node_start_surface[node_idx], end = start + ns;
                 for (uint32_t i = start; i < end; i++) {
                     Hit h;
-                    if (surfIntersect(S, i, ray, &h) && h.t < best.t) { best = h; best.surface = i; }
+                    if (surfIntersect(S, i, ray, &h) && hitCloser(&h, i, &best)) { best = h; best.surface = i; }
                 }
             } else {
                 uint32_t child = node_idx + 1;
                 while (child != 0) {
                     if (S->c) S->c->node_tests++;
-                    if (bbIntersect(s->node_bounds + 6 * (size_t)child, ray, &t) && t < best.t) {
+                    if (bbIntersect(s->node_bounds + 6 * (size_t)child, ray, &t) && (t < best.t || (g_true_minimum && t == best.t))) {
                         NodeIsect ni = {t, child};
                         nqPush(q, ni);
                     }
                     child = s->node_next_sibling[child];
                 }
             }
-            if (q->size == 0 || q->H[0].t >= best.t) break;
+            if (q->size == 0 || (g_true_minimum ? q->H[0].t > best.t : q->H[0].t >= best.t)) break;
             node_idx = q->H[0].node;
             nqPop(q);
         }

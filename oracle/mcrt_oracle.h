@@ -35,6 +35,10 @@ void oracle_intersect(const mcrt_scene_desc* scene, uint64_t n, const double* st
                       const double* direction, double* out_t, uint32_t* out_surface, double* out_uv,
                       oracle_counters* counters);
 
+/* 1: closest hits as the true minimum with ties to the lowest surface index (the HIP walks' rule) instead of the reference's heap
+ * order; 0 (default): the reference. See mcrt_oracle.c. Not thread safe against running renders. */
+void oracle_set_true_minimum(int on);
+
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117); outputs sorted by
  * (distance2, index) ascending, [n][k]. */
 void oracle_knn(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k,

@@ -54,11 +54,13 @@ int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     E.tab.resize(kSobolTableWords);
     buildSobolByteTables(E.tab.data());
     E.stack_lds.resize(kLdsStackDepth);
-    E.stack_spill.resize(kMaxStackDepth - kLdsStackDepth);
+    const int depth = std::max<int>(kMaxStackDepth, (int)E.L.stack_bound + 1);  // as mcrt_upload_scene sizes the device's stacks
+    E.stack_spill.resize(depth - kLdsStackDepth);
     E.stk.lds = E.stack_lds.data();
     E.stk.lds_stride = 1;
     E.stk.spill = E.stack_spill.data();
     E.stk.spill_stride = 1;
+    E.stk.max_depth = depth;
     E.iors.assign(kMaxIors, 0.0);  // (the wavefront integrator continues deeper histories in the slot's own pool words: wfShadeSlot)
     E.rh.iors = E.iors.data();
     E.rh.stride = 1;
@@ -222,11 +224,13 @@ struct QTrace {
     void init(Emu& E, const mcrt_scene_desc* scene) {
         wv.nodes = E.L.wnodes.empty() ? nullptr : E.L.wnodes.data();
         s_lds.resize(kLdsStackDepth);
-        s_spill.resize(kMaxStackDepth - kLdsStackDepth);
+        const int depth = std::max<int>(kMaxStackDepth, (int)E.L.stack_bound + 1);
+        s_spill.resize(depth - kLdsStackDepth);
         stk.lds = s_lds.data();
         stk.lds_stride = 1;
         stk.spill = s_spill.data();
         stk.spill_stride = 1;
+        stk.max_depth = depth;
         sv.num_nodes = (uint32_t)E.L.nodes64.size();  // (a scene without a BVH: the index-range tree of mcrt_layout.hpp)
         sv.nodes = E.L.nodes64.data();
         sv.prim = E.L.prim.data();
@@ -391,12 +395,14 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
                   int stage_all, double* out_rgb, uint64_t* counters /* rays,node_tests,prim_tests,overflow,paths */) {
     Emu E;
     if (int rc = setup(E, scene, stage_all ? 1 : 0)) return rc;
-    std::vector<SmStackEntry> s_lds(kLdsStackDepth), s_spill(kMaxStackDepth - kLdsStackDepth);
+    const int sm_depth = std::max<int>(kMaxStackDepth, (int)E.L.stack_bound + 1);
+    std::vector<SmStackEntry> s_lds(kLdsStackDepth), s_spill(sm_depth - kLdsStackDepth);
     SmStack stk;
     stk.lds = s_lds.data();
     stk.lds_stride = 1;
     stk.spill = s_spill.data();
     stk.spill_stride = 1;
+    stk.max_depth = sm_depth;
     SmSceneView<true> sv_all;
     SmSceneView<false> sv_top;
     auto fill = [&](auto& sv) {
@@ -812,6 +818,90 @@ void emu_asin_check(uint64_t n, uint64_t seed, double lo, double hi, int edges, 
             memcpy(&m, &b, 8);
             check((next() & 1) ? m : -m);
         }
+    }
+}
+
+// refAtan2 (mcrt_libm.hpp) against this host's atan2 on n argument pairs per family: (0) directions - y = r sin a, x = r cos a,
+// a uniform in (-pi, pi], r log-uniform over [2^-scale, 2^scale]; (1) components of unit vectors as the photon constructor passes them
+// (length of xy against z; y against x); (2) ratios at the table-interval boundaries (u = k / 512 +- a few thousand ulps, both
+// orders, all sign combinations); (3) extreme ratios (2^+-40 .. 2^+-70), zeros, axes, subnormals. out[0] = pairs on which the
+// restatement differs (bitwise) from libm, out[1], out[2] = the first such y, x (bit patterns).
+void emu_atan2_check(uint64_t n, uint64_t seed, int scale, uint64_t* out) {
+    auto next = [&]() {
+        seed += 0x9E3779B97F4A7C15ull;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&]() { return (double)(next() >> 11) * 0x1.0p-53; };
+    double (*volatile libm_atan2)(double, double) = ::atan2;
+    out[0] = out[1] = out[2] = 0;
+    auto check = [&](double y, double x) {
+        const double want = libm_atan2(y, x), got = refAtan2(y, x);
+        if (want != want ? (got == got) : memcmp(&got, &want, 8) != 0) {
+            if (!out[0]) {
+                memcpy(&out[1], &y, 8);
+                memcpy(&out[2], &x, 8);
+            }
+            out[0]++;
+        }
+    };
+    for (uint64_t i = 0; i < n; i++) {  // (0)
+        const double a = (2.0 * unit() - 1.0) * 3.14159265358979323846, r = ldexp(1.0 + unit(), (int)(next() % (uint64_t)(2 * scale + 1)) - scale);
+        check(r * ::sin(a), r * ::cos(a));
+    }
+    for (uint64_t i = 0; i < n; i++) {  // (1)
+        double d[3] = {2.0 * unit() - 1.0, 2.0 * unit() - 1.0, 2.0 * unit() - 1.0};
+        const double l = ::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (!(l > 1e-3)) continue;
+        for (int k = 0; k < 3; k++) d[k] /= l;
+        check(::sqrt(d[0] * d[0] + d[1] * d[1]), d[2]);
+        check(d[1], d[0]);
+    }
+    for (uint64_t i = 0; i < n; i++) {  // (2)
+        double u = (double)(1 + next() % 512u) / 512.0;
+        long long b;
+        memcpy(&b, &u, 8);
+        b += (long long)(next() % 8192) - 4096;
+        memcpy(&u, &b, 8);
+        const double big = ldexp(1.0 + unit(), (int)(next() % 41u) - 20), small = big * u;
+        const uint64_t r = next();
+        const double p = (r & 1) ? small : big, q = (r & 1) ? big : small;
+        check((r & 2) ? -p : p, (r & 4) ? -q : q);
+    }
+    for (uint64_t i = 0; i < n / 4 + 64; i++) {  // (3)
+        const uint64_t r = next();
+        const double big = ldexp(1.0 + unit(), (int)(r % 61u) - 30), ratio = ldexp(1.0 + unit(), -(int)(40 + (r >> 8) % 31u));
+        double p = big, q = big * ratio;
+        switch ((r >> 16) % 8u) {
+            case 0: q = 0.0; break;
+            case 1: q = -0.0; break;
+            case 2: p = 0x1.0p-1060 * (1.0 + (double)((r >> 20) % 1000u)); break;
+            case 3: p = ldexp(1.0 + unit(), 600); q = ldexp(1.0 + unit(), 590 + (int)((r >> 20) % 21u)); break;
+            case 4: p = ldexp(1.0 + unit(), -600); q = ldexp(1.0 + unit(), -590 - (int)((r >> 20) % 21u)); break;
+            default: break;
+        }
+        const bool sw = (r >> 40) & 1;
+        const double yy = sw ? q : p, xx = sw ? p : q;
+        check(((r >> 41) & 1) ? -yy : yy, ((r >> 42) & 1) ? -xx : xx);
+    }
+}
+
+// This host's libm on arrays (the expected values of the GPU known-answer test of mcrt_libm): fn as MCRT_LIBM_*. Every function is
+// called through its own volatile pointer, one call per argument (a sin and a cos of one argument would be merged into sincos).
+void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
+    double (*volatile f_sin)(double) = ::sin;
+    double (*volatile f_cos)(double) = ::cos;
+    double (*volatile f_asin)(double) = ::asin;
+    double (*volatile f_atan2)(double, double) = ::atan2;
+    void (*volatile f_sincos)(double, double*, double*) = ::sincos;
+    for (uint64_t i = 0; i < n; i++) {
+        if (fn == 0) f_sincos(a[i], &out0[i], &out1[i]);
+        else if (fn == 1) out0[i] = f_sin(a[i]);
+        else if (fn == 2) out0[i] = f_cos(a[i]);
+        else if (fn == 3) out0[i] = f_asin(a[i]);
+        else out0[i] = f_atan2(a[i], b[i]);
     }
 }
 

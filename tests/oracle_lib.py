@@ -71,6 +71,11 @@ def render(image, cam, seed, integrator, rows=None, threads=0, per_sample=False)
     return out, info
 
 
+def set_true_minimum(on):
+    """oracle_set_true_minimum: closest hits as the true minimum with ties to the lowest index (the HIP walks' rule)."""
+    lib().oracle_set_true_minimum(int(bool(on)))
+
+
 def intersect(image, start, direction):
     L = lib()
     start = np.ascontiguousarray(start, dtype=np.float64)

@@ -28,10 +28,8 @@ def test_spaceship_matches_reference(pkg, spaceship):
     out, st = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PATH_TRACER)
     ref = np.fromfile(os.path.join(IMAGES, "spaceship.480x270_s2.f64")).reshape(270, 480, 3)
     rel = rel_error(out, ref).max(axis=2)
-    bad = int((rel > 1e-4).sum())
-    print("spaceship: max rel %.3e, outliers %d / %d, %.1f Mray/s, %.2f rays/path" %
-          (rel.max(), bad, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
-    assert bad <= int(0.002 * rel.size)
+    print("spaceship: max rel %.3e, %.1f Mray/s, %.2f rays/path" % (rel.max(), st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
+    np.testing.assert_array_equal(out, ref, err_msg="spaceship: not the reference's bits")  # every operation of the path is reproduced (round 4: asin too)
     assert st["kernel_id"] == pkg.KERNEL_LANE_SM  # 23 187 nodes: the state-machine megakernel walks the tree
     ctx.close()
 
@@ -104,11 +102,30 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
         ctx.upload_photons(img.photons(0), img.photons(1), int(img.param("k_nearest_photons")), bool(img.param("direct_visualization")))
     out, st = ctx.sample_image(cam, 0x12345678, integ)
     ref = np.fromfile(golden).reshape(r1 - r0, c["width"], 3)
-    rel = rel_error(out[r0:r1], ref).max(axis=2)  # mcrt_render writes owned rows in place
-    bad = int((rel > 1e-4).sum())
-    print("%s rows %d-%d: max rel %.3e, outliers %d / %d, %.1f Mray/s, %.2f rays/path" %
-          (name, r0, r1, rel.max(), bad, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
-    assert bad <= max(4, int(0.002 * rel.size))
+    got = out[r0:r1]  # mcrt_render writes owned rows in place
+    rel = rel_error(got, ref).max(axis=2)
+    differing = int((got != ref).any(axis=2).sum())
+    print("%s rows %d-%d: max rel %.3e, pixels that are not the reference's bits %d / %d, %.1f Mray/s, %.2f rays/path" %
+          (name, r0, r1, rel.max(), differing, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
+    if c["photon"]:
+        # photon-mapped rows: the k photons of an estimate are summed by a wave reduction, not in the reference's heap order
+        assert rel.max() <= 1e-10
+    elif differing:
+        # Not the reference's bits: then the ONLY admissible reason is the closest-hit tie rule (DESIGN.md "Ties": the HIP walks return the
+        # true minimum with ties to the lowest index; the reference's heap stops at `top.t >= t` and keeps the first-tested hit - they
+        # part only where two surfaces are hit within an ulp, metal_bunnies' shelf against the back wall). Shown, not assumed: the
+        # oracle - bit-equal to the reference on these very rows, tests/test_oracle_large.py - with THAT rule switched on
+        # (oracle_set_true_minimum) must give the GPU's rows bit for bit; and the rule may only touch a few pixels, by little.
+        import oracle_lib
+        oracle_lib.set_true_minimum(True)
+        try:
+            want, _ = oracle_lib.render(img, cam, 0x12345678, integ, rows=(r0, r1))
+        finally:
+            oracle_lib.set_true_minimum(False)
+        np.testing.assert_array_equal(got, want, err_msg="%s: neither the reference's rows nor the oracle's under the true-minimum tie rule" % name)
+        assert differing <= 0.02 * rel.size and rel.max() <= 1e-4
+        # (round 4, first run with every libm call restated and the exact shadow query: no frame needs this branch - C3, C4, baroque_table,
+        # lego_bulldozer, pipes and the spaceship cockpit are all the reference's bits; the branch stays as the only admissible way out)
     # (the pipeline is the default for trees of 65 536 nodes or more: baroque_table and lego_bulldozer stay with the lane state machine)
     want = pkg.KERNEL_PM_WAVE if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" or c["nodes"] < 65536 else pkg.KERNEL_WAVEFRONT
     assert st["kernel_id"] == want, pkg.KERNEL_NAMES.get(st["kernel_id"])
@@ -154,7 +171,8 @@ def test_full_size_traversal_equals_oracle(pkg, oracle, name, env, monkeypatch):
 
 def test_c5_emission_matches_oracle(pkg, oracle):
     """Photon emission through the 6.9 M-triangle octree BVH (emitKernel walking the quantised child blocks) against the
-    oracle's emission pass: photons matched by (light, emission, bounce) key, fields within 2e-6 (ocml vs glibc trig)."""
+    oracle's emission pass: the same photons bit for bit, matched by (light, emission, bounce) key (sincos and atan2 are glibc's on
+    the device, csrc/mcrt_libm.hpp: no tolerance, no unmatched keys)."""
     from conftest import sort_by_key
     img, _, _ = _config(pkg, "c5")
     want = oracle.emit_photons(img, 2000, 10.0, 0x12345678)
@@ -162,15 +180,11 @@ def test_c5_emission_matches_oracle(pkg, oracle):
     ctx.upload_image(img)
     got = ctx.emit_photons(2000, 10.0, 0x12345678)
     assert got["paths"] == want["paths"] == 20000
-    assert abs(got["rays"] - want["rays"]) <= 0.002 * want["rays"] + 2
+    assert got["rays"] == want["rays"]
     for name in ("global_", "caustic"):
         a, ak = sort_by_key(*got[name])
         b, bk = want[name]
-        common, ia, ib = np.intersect1d(ak, bk, return_indices=True)
-        unmatched = (len(ak) - len(common)) + (len(bk) - len(common))
-        assert unmatched <= 0.002 * len(bk) + 2
-        x, y = a[ia].astype(np.float64), b[ib].astype(np.float64)
-        err = np.abs(x - y) / np.maximum(np.abs(y), 1e-3)
-        assert int((err.max(axis=1) > 2e-6).sum()) <= 0.002 * len(common) + 2
-        print("c5 %s: %d photons, %d unmatched keys, max field error %.2e" % (name, len(bk), unmatched, err.max() if len(common) else 0.0))
+        np.testing.assert_array_equal(ak, bk, err_msg="c5 %s: photon keys" % name)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg="c5 %s: photon records" % name)
+        print("c5 %s: %d photons, identical" % (name, len(bk)))
     ctx.close()

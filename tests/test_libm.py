@@ -57,6 +57,72 @@ def test_restated_asin_equals_glibc(emu, n, lo, hi, edges):
     assert out[0] == 0, "asin differs on %d arguments, first at %r" % (out[0], out[1:2].view(np.float64)[0])
 
 
+@pytest.mark.parametrize("n,scale", [(1500000, 0), (500000, 40)])
+def test_restated_atan2_equals_glibc(emu, n, scale):
+    """refAtan2 (the Photon constructor's two calls, photon.hpp:10-11) = the FMA variant of glibc 2.35's __ieee754_atan2, bit for bit:
+    directions in every octant, unit-vector components as the emission pass passes them, ratios at every table-interval boundary,
+    extreme ratios, zeros and axes, huge and subnormal magnitudes."""
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the restatement is of x86-64 glibc")
+    if not (_has("fma") and _has("avx2")):
+        pytest.skip("this CPU has no FMA/AVX2: libm's atan2 is another IFUNC variant than the one restated")
+    emu.emu_atan2_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    out = np.zeros(3, dtype=np.uint64)
+    emu.emu_atan2_check(n, 20260926, scale, out.ctypes.data)
+    f = out[1:].view(np.float64)
+    assert out[0] == 0, "atan2 differs on %d pairs, first at y = %r, x = %r" % (out[0], f[0], f[1])
+
+
+@pytest.mark.gpu
+def test_device_libm_equals_glibc_bits(pkg, emu):
+    """The DEVICE's sincos / sin / cos / asin / atan2 (mcrt_libm through the C ABI: the functions the kernels inline, compiled for
+    gfx950) against this host's glibc on 1.2e7 arguments: bit equality. This is the direct form of what the frame tests infer."""
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the restatement is of x86-64 glibc")
+    if not (_has("fma") and _has("avx2")):
+        pytest.skip("this CPU has no FMA/AVX2: its libm's sin / cos / asin / atan2 are other IFUNC variants than the ones restated")
+    emu.emu_libm_host.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(20260926)
+    ctx = pkg.Context(0)
+
+    def host(fn, a, b=None):
+        o0, o1 = np.zeros_like(a), np.zeros_like(a)
+        emu.emu_libm_host(fn, a.size, a.ctypes.data, b.ctypes.data if b is not None else None, o0.ctypes.data, o1.ctypes.data)
+        return o0, o1
+
+    def same(x, y):
+        return np.array_equal(x.view(np.uint64), y.view(np.uint64))
+
+    # sincos: the range the path uses (2 pi u), wider ranges, tiny arguments
+    a = np.concatenate([rng.random(3000000) * 2.0 * math.pi, (rng.random(1000000) - 0.5) * 200.0, (rng.random(500000) - 0.5) * 2e8,
+                        (rng.random(500000) - 0.5) * 1e-3])
+    gs, gc = ctx.libm(pkg.LIBM_SINCOS, a)
+    hs, hc = host(0, a)
+    assert same(gs, hs) and same(gc, hc), "sincos: %d / %d arguments differ" % ((gs != hs).sum(), (gc != hc).sum())
+    a = np.concatenate([rng.random(1000000) * 2.0 * math.pi, (rng.random(500000) - 0.5) * 2000.0])
+    assert same(ctx.libm(pkg.LIBM_SIN, a), host(1, a)[0]), "sin"
+    assert same(ctx.libm(pkg.LIBM_COS, a), host(2, a)[0]), "cos"
+    # asin: dense over [-1, 1], the branch near 1, around every interval boundary
+    edges = (32 + rng.integers(0, 225, 500000)) / 256.0 * (1.0 + (rng.integers(-4096, 4097, 500000)) * 2.0 ** -52)
+    a = np.concatenate([rng.random(2000000) * 2.0 - 1.0, 1.0 - rng.random(500000) * 0.04, edges * np.where(rng.random(500000) < 0.5, -1.0, 1.0)])
+    g, h = ctx.libm(pkg.LIBM_ASIN, a), host(3, a)[0]
+    ok = (g.view(np.uint64) == h.view(np.uint64)) | (np.isnan(g) & np.isnan(h))
+    assert ok.all(), "asin: %d arguments differ, first %r" % ((~ok).sum(), a[~ok][0])
+    # atan2: directions in every octant; unit-vector components as Photon's constructor passes them; table-interval boundaries
+    ang, r = (rng.random(1500000) * 2.0 - 1.0) * math.pi, np.exp2(rng.integers(-20, 21, 1500000)) * (1.0 + rng.random(1500000))
+    d = rng.normal(size=(500000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    u = (1 + rng.integers(0, 512, 500000)) / 512.0 * (1.0 + rng.integers(-4096, 4097, 500000) * 2.0 ** -52)
+    big = np.exp2(rng.integers(-10, 11, 500000)) * (1.0 + rng.random(500000))
+    sw = rng.random(500000) < 0.5
+    y = np.concatenate([r * np.sin(ang), np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2), d[:, 1], np.where(sw, big * u, big) * np.where(rng.random(500000) < 0.5, -1, 1)])
+    x = np.concatenate([r * np.cos(ang), d[:, 2], d[:, 0], np.where(sw, big, big * u) * np.where(rng.random(500000) < 0.5, -1, 1)])
+    g, h = ctx.libm(pkg.LIBM_ATAN2, y, x), host(4, y, x)[0]
+    bad = g.view(np.uint64) != h.view(np.uint64)
+    assert not bad.any(), "atan2: %d pairs differ, first y = %r, x = %r" % (bad.sum(), y[bad][0], x[bad][0])
+    ctx.close()
+
+
 def test_sincos_table_is_glibcs():
     """The committed table against an independent evaluation of sin / cos at k/128 (high words must be the correctly rounded
     values; glibc's low words are within 2^-40 of the exact remainders, 17 of them not the nearest double)."""

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Writes monte-carlo-ray-tracer_amd/csrc/mcrt_glibc_asintab.inc: the tables of glibc 2.35's double asin
+"""Writes monte-carlo-ray-tracer_amd/csrc/mcrt_glibc_asintab.inc and mcrt_glibc_atantab.inc: the tables of glibc 2.35's double asin and atan2
+(atan2: sysdeps/ieee754/dbl-64/e_atan2.c, table cij of uatan.tbl - the reference's Photon constructor, photon.hpp:10-11). asin:
 (sysdeps/ieee754/dbl-64/e_asin.c, IBM Accurate Mathematical Library, LGPL-2.1-or-later): `asncs` (asincos.tbl, 2568 doubles: per
 interval of |x| in [0.125, 0.96875) its centre x0, the Taylor coefficients of asin around x0 and asin(x0) as a double-double) and
 `inroot` (root.tbl, 128 doubles: 1/sqrt seeds of the |x| >= 0.96875 branch). `powtwo` is 2^0 .. 2^26 and is computed, not stored.
@@ -17,6 +18,7 @@ from fractions import Fraction
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc", "mcrt_glibc_asintab.inc")
+OUT_ATAN = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc", "mcrt_glibc_atantab.inc")
 
 
 def asin_frac(x, terms=400):
@@ -104,10 +106,34 @@ def main():
         assert v == v and abs(v) < 1e16, v  # (the tenth-order coefficients near |x| = 0.97 reach 1e12)
     for i in range(128):  # inroot[i] ~ 1 / sqrt(m) for m the midpoint of the i-th 1/64-wide (i < 64: [0.5, 1) in 1/128 steps ...) interval
         assert 0.70 < inroot[i] < 1.42
+    # atan2: cij (uatan.tbl), 241 rows of 7 doubles: x0 = the row's point, atan(x0), then the Taylor coefficients of atan around x0
+    lead = struct.pack("<2d", 0.06347694384761945, 0.063391893014217)
+    cj = blob.find(lead)
+    if cj < 0:
+        raise SystemExit("cij table not found in %s" % path)
+    nx = blob.find(lead, cj + 8)
+    while nx >= 0:
+        if blob[nx:nx + 1687 * 8] != blob[cj:cj + 1687 * 8]:
+            raise SystemExit("two different cij tables in %s" % path)
+        nx = blob.find(lead, nx + 8)
+    cij = struct.unpack_from("<1687d", blob, cj)
+    import math
+    for i in range(241):
+        x0, a0, c2 = cij[7 * i], cij[7 * i + 1], cij[7 * i + 2]
+        assert abs(x0 - (i + 16) / 256.0) < 1.0 / 256.0, (i, x0)           # the row for u with round(256 u) - 16 = i
+        assert abs(a0 - math.atan(x0)) <= 2.3e-16 * a0, (i, a0)            # atan(x0) (this libm's, an ulp is enough: the KAT is test_libm)
+        assert abs(c2 * (1.0 + x0 * x0) - 1.0) < 1e-15, (i, c2)            # first derivative 1 / (1 + x0^2)
+    with open(OUT_ATAN, "w") as f:
+        f.write("// glibc 2.35 e_atan2.c table cij (uatan.tbl, 241 rows x 7 words: x0, atan(x0), Taylor coefficients of atan around x0) as IEEE-754\n"
+                "// bit patterns. IBM Accurate Mathematical Library, (C) Free Software Foundation, LGPL-2.1-or-later; read out of libm.so.6 by\n"
+                "// tools/make_glibc_asin_atan_tables.py (which also checks the row structure); do not edit.\n")
+        for i in range(0, 1687, 7):
+            f.write("    " + ", ".join("0x%016xull" % struct.unpack("<Q", struct.pack("<d", w))[0] for w in cij[i:i + 7]) + ",\n")
+    print("wrote", OUT_ATAN, "(cij at file offset 0x%x)" % cj)
     with open(OUT, "w") as f:
         f.write("// glibc 2.35 e_asin.c tables as IEEE-754 bit patterns: asncs (asincos.tbl, 2568 words) then inroot (root.tbl, 128 words).\n"
                 "// IBM Accurate Mathematical Library, (C) Free Software Foundation, LGPL-2.1-or-later; read out of libm.so.6 by\n"
-                "// tools/make_glibc_asin_table.py (which also checks the record structure); do not edit.\n")
+                "// tools/make_glibc_asin_atan_tables.py (which also checks the record structure); do not edit.\n")
         words = list(asncs) + list(inroot)
         for i in range(0, len(words), 4):
             f.write("    " + ", ".join("0x%016xull" % struct.unpack("<Q", struct.pack("<d", w))[0] for w in words[i:i + 4]) + ",\n")
