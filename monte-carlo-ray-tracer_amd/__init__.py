@@ -312,10 +312,10 @@ class Bvh:
         self._lib = lib()
         self._h = C.c_void_p()
         bins = int(bins_per_axis) if bins_per_axis else (8 if kind == "quaternary_sah" else 16)
-        if kind in ("binary_sah", "quaternary_sah") and (ctx is not None or levels) and bins <= 16:
-            # level-synchronous build: on the GPU of ctx, or (levels=True, no ctx) the same passes as host loops. It takes at most 16
-            # bins per axis (the reference's defaults are 16 and 8): a caller that asks for more gets the recursive host build
-            # below, which has no limit, instead of an error.
+        if kind in ("binary_sah", "quaternary_sah") and (ctx is not None or levels):
+            # level-synchronous build: on the GPU of ctx, or (levels=True, no ctx) the same passes as host loops. Its per-node bin tables
+            # hold at most 16 bins per axis (the reference's defaults are 16 and 8); for more the C entry point itself hands the scene to
+            # the recursive host builder, which has no limit and builds the same tree.
             rc = self._lib.mcrt_bvh_build_sah_gpu(ctx._h if ctx is not None else None, C.byref(scene_desc), 2 if kind == "binary_sah" else 4,
                                                   int(bins_per_axis), C.byref(self._h))
             if rc != 0:

@@ -372,8 +372,15 @@ int mcrt_bvh_build_sah_gpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, int arit
     const uint32_t bins = bins_per_axis ? bins_per_axis : (arity == 4 ? 8u : 16u);  // bvh.cpp:29,36
     if (!out || !sceneUsable(scene) || (arity != 2 && arity != 4) || bins < 2)
         return ctx ? ctxFail(ctx, MCRT_ERR_INVALID, "mcrt_bvh_build_sah_gpu: bad scene descriptor, arity or bin count") : MCRT_ERR_INVALID;
-    if (bins > kSahMaxBins)
-        return ctx ? ctxFail(ctx, MCRT_ERR_UNSUPPORTED, "mcrt_bvh_build_sah_gpu: more than 16 bins per axis (mcrt_bvh_build_sah has no limit)") : MCRT_ERR_UNSUPPORTED;
+    if (bins > kSahMaxBins) {
+        // The level loop keeps a table of bins (binary) or bins x bins (quaternary) counters and boxes per open node, sized for the
+        // reference's defaults (16 and 8 x 8, bvh.cpp:29,36) and up to 16. The reference takes any "bins_per_axis" (bvh.cpp:24-40): more
+        // than 16 goes to the recursive builder on all host threads, which has no limit and builds the same tree (same split rule, same
+        // order) - the caller gets its hierarchy either way (until round 4: MCRT_ERR_UNSUPPORTED).
+        if (bins > 1024) return ctx ? ctxFail(ctx, MCRT_ERR_INVALID, "mcrt_bvh_build_sah_gpu: more than 1024 bins per axis") : MCRT_ERR_INVALID;
+        const int rc = mcrt_bvh_build_sah(scene, arity, bins, 0, out);
+        return (rc != MCRT_OK && ctx) ? ctxFail(ctx, rc, "mcrt_bvh_build_sah_gpu: host build with more than 16 bins per axis failed") : rc;
+    }
     mcrt_bvh* B = nullptr;
     try {  // (no exception may cross the C boundary: an allocation failure in the level loop is an error code, and B is freed)
         B = new mcrt_bvh();

@@ -434,11 +434,23 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         pass_rows = pp.pass_rows;
         fr.samples = ctx->samples.as<double>();
     }
-    // Pool size: up to 8 M slots (3.6 GB) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
+    // Pool size: up to 16 M slots (5.6 GB of pool, 4.6 GB of queue) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
     // 1447 / 1492 / 1507 Mray/s with 4 / 8 / 16 M) — but no more
     // than gives every slot 16 work units of at least 4 samples; units per pixel: the power of two that reaches 16 per slot.
     const uint64_t pixels = (uint64_t)cam->width * std::min<uint64_t>(pass_rows, owned_rows);
-    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 23);
+    // (round 4: 16 M by default - C3 at 1024 spp 2024 / 2068 / 2072 Mray/s with 8 / 16 / 32 M; 10 GB of pool and queue - but never more
+    // than an eighth of the memory that is free on this device)
+    uint64_t slots = (uint64_t)envi("MCRT_WF_SLOTS", 1l << 24);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t per_slot = (uint64_t)kWfWords * 8u + 2u * (2u * sizeof(uint32_t) + 2u * 8u * sizeof(double));
+            const uint64_t have = (uint64_t)ctx->wf_slots * per_slot;  // what this context's pool and queue already hold
+            slots = std::min<uint64_t>(slots, std::max<uint64_t>(((uint64_t)free_b + have) / 8u / per_slot, (uint64_t)kWfBlock));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     slots = std::min<uint64_t>(slots, (std::max<uint64_t>(pixels * fr.spp / 64, 1) + kWfBlock - 1) / kWfBlock * kWfBlock);
     slots = std::max<uint64_t>(slots, kWfBlock);
     {
@@ -1305,7 +1317,10 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.stage_all = 1;
     d.stage_nodes = 0;
     const uint32_t fixed = planLds(DeviceScene{}, kBlock).total;
-    if (planLds(d, kBlock).total - fixed > 48u * 1024u || L.num_quadric_surfaces) {  // quadric code lives in the kAll == false kernels
+    // (... and only when the plan of the 512-lane kernels - tables, stacks, histories AND the image - fits the device's LDS: an image of
+    // 40-48 KiB did not, and its mcrt_intersect / legacy frames failed with "LDS plan exceeds the device limit" until round 4)
+    if (planLds(d, kBlock).total - fixed > 48u * 1024u || planLds(d, kBlock).total > ctx->max_lds ||
+        L.num_quadric_surfaces) {  // quadric code lives in the kAll == false kernels
         d.stage_all = 0;
         d.stage_nodes = std::min<uint32_t>(d.num_nodes, 512u);
     }
@@ -1549,6 +1564,9 @@ int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_
         HIP_TRY(ctx, hipMemcpy(h, ctx->emit_counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow in the emission pass");
+        // RefractionHistory (ray.cpp:74-98) is unbounded in the reference; the emission kernel keeps kMaxIors (8) entries per lane. The eye
+        // pass of such a scene retries through the 32-entry pool or fails (mcrt_render_finish); the photon pass must not be the silent one.
+        if (h[6]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "a photon path entered more than 8 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to 8 entries per lane in the emission pass)");
         if (h[1] <= cap[0] && h[2] <= cap[1]) break;
         cap[0] = std::max(cap[0], h[1]);  // a list was too small: size it exactly and emit again
         cap[1] = std::max(cap[1], h[2]);

@@ -2088,6 +2088,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     waveAccumulate(prm.counters + 3, paths);
     waveAccumulate(prm.counters + 4, cnt.rays);
     waveAccumulate(prm.counters + 5, cnt.overflow);
+    waveAccumulate(prm.counters + 6, rh.overflow ? 1u : 0u);  // a photon path nested deeper than the kMaxIors media a lane keeps (mcrt_emit_photons*: an error, not a silent wrong medium)
 }
 
 // ------------------------------------------------------------------------------------------------

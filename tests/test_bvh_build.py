@@ -288,3 +288,30 @@ def test_rebuilt_scene_renders_like_the_original(pkg, oracle, manifest):
             return 0
     out, _ = oracle.render(_Img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, rows=r["rows"])
     np.testing.assert_array_equal(out, load_radiance(r))
+
+
+def _same_arrays(a, b):
+    A, B = a.arrays(), b.arrays()
+    for k in ("bounds", "start", "count", "next", "order"):
+        np.testing.assert_array_equal(A[k], B[k], err_msg=k)
+
+
+@pytest.mark.parametrize("kind,bins", [("quaternary_sah", 24), ("binary_sah", 64)])
+def test_level_entry_point_takes_any_bin_count(pkg, manifest, kind, bins):
+    """The reference takes any "bins_per_axis" (bvh.cpp:24-40). mcrt_bvh_build_sah_gpu's level loop keeps bin tables for at most 16;
+    beyond that the entry point builds through the recursive builder instead of refusing (until round 4: MCRT_ERR_UNSUPPORTED) - same
+    tree as asking the recursive builder directly, and a different one from the 16-bin tree (the bins do matter)."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["coffee_maker_qsah"]["image"]))
+    via_levels = pkg.Bvh(img.scene, kind=kind, bins_per_axis=bins, levels=True)
+    direct = pkg.Bvh(img.scene, kind=kind, bins_per_axis=bins)
+    _same_arrays(via_levels, direct)
+    coarse = pkg.Bvh(img.scene, kind=kind, bins_per_axis=16, levels=True)
+    assert not np.array_equal(coarse.arrays()["bounds"], direct.arrays()["bounds"]) or coarse.arrays()["bounds"].shape != direct.arrays()["bounds"].shape
+
+
+@pytest.mark.gpu
+def test_gpu_entry_point_takes_any_bin_count(pkg, manifest):
+    img = pkg.SceneImage(golden_path(manifest["cases"]["coffee_maker_qsah"]["image"]))
+    ctx = pkg.Context(0)
+    _same_arrays(pkg.Bvh(img.scene, ctx=ctx, kind="quaternary_sah", bins_per_axis=24), pkg.Bvh(img.scene, kind="quaternary_sah", bins_per_axis=24))
+    ctx.close()

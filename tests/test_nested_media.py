@@ -142,8 +142,8 @@ def test_gpu_keeps_deep_histories(pkg, oracle, manifest, kernel):
         if old is not None:
             os.environ["MCRT_KERNEL"] = old
     assert st["kernel_id"] == 4  # whatever was asked for, the frame that holds comes from the pipeline
-    # (the scene has a sky: asin / atan2 of the device differ from glibc's in the last bits, as for every sky scene: test_gpu_parity.py)
-    assert rel_error(out, ref).max() < 1e-12
+    # (the scene has a sky; since round 4 the device's asin is glibc's too, csrc/mcrt_libm.hpp: the oracle's bits)
+    np.testing.assert_array_equal(out, ref)
     ctx.close()
 
 
@@ -155,4 +155,30 @@ def test_gpu_reports_histories_beyond_the_limit(pkg, manifest):
     with pytest.raises(pkg.McrtError) as e:
         ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     assert "dielectric" in str(e.value) or "refraction" in str(e.value).lower()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_emission_reports_histories_beyond_its_limit(pkg, oracle, manifest):
+    """The photon emission pass keeps 8 refraction-history entries per lane: photon paths through the twelve shells nest deeper.
+    Until round 4 the kernel dropped the overflow (a photon then carried a wrong external IOR, silently); now the call fails. With
+    four shells - the reference's own ior_test - the lists are the oracle's."""
+    s12, _ = _setup(pkg, manifest, 12)
+    ctx = pkg.Context(0)
+    ctx.upload_scene(s12.scene)
+    with pytest.raises(pkg.McrtError) as e:
+        ctx.emit_photons(500000, 10.0, manifest["seed"])  # (the shells fill 0.08 % of the lamp's sphere of directions: a few thousand of the 5 M paths enter them)
+    assert "nested dielectric" in str(e.value)
+    ctx.close()
+    from conftest import sort_by_key
+    s4, _ = _setup(pkg, manifest, 4)
+    want = oracle.emit_photons(s4, 2000, 10.0, manifest["seed"])
+    ctx = pkg.Context(0)
+    ctx.upload_scene(s4.scene)
+    got = ctx.emit_photons(2000, 10.0, manifest["seed"])
+    for name in ("global_", "caustic"):
+        a, ak = sort_by_key(*got[name])
+        b, bk = want[name]
+        np.testing.assert_array_equal(ak, bk)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     ctx.close()
