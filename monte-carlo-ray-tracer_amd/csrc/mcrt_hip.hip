@@ -139,6 +139,7 @@ struct mcrt_ctx {
     std::chrono::steady_clock::time_point t_begin;
     uint32_t launches = 0;
     uint32_t kernel_id = MCRT_KERNEL_NONE;  // kernel form of the last render (mcrt_stats.kernel_id)
+    bool dense_cell_refused = false;        // buildMapOnDevice: the 21-level cell codes could not separate a leaf's worth of photons
 };
 
 namespace {
@@ -1435,7 +1436,11 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_launches = ctx->launches;
         stats->kernel_id = ctx->kernel_id;
     }
-    if (h[5]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
+    if (h[5])
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER
+                                                   ? "kNN frontier overflow: the wave search keeps 128 pending octants, a photon octree whose leaves hold far fewer photons than "
+                                                     "k_nearest_photons can need more (or, internal error, a traversal stack overflowed: they are sized to the tree's own bound)"
+                                                   : "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
         // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
         // (32). A frame that nested deeper than 8 media is rendered AGAIN through the pipeline: slower for the scenes the megakernels
@@ -1625,6 +1630,30 @@ int mcrt_emit_photons_device(mcrt_ctx* ctx, double emissions, double caustic_fac
     return MCRT_OK;
 }
 
+// buildMapOnDevice, or - when more than a leaf's worth of photons share one cell of its 21-level codes (2^-21 of the map's cube: the
+// focus of a sharp caustic can do that) - the same map from the recursive host builder, which splits as deep as the reference's Octree
+// does (octree.cpp:35-80): the list goes to the host once, the finished map comes back (mcrt_upload_photons' path). Slower, and what the
+// call used to refuse with MCRT_ERR_UNSUPPORTED until round 4.
+int buildMapAnyDepth(mcrt_ctx* ctx, int which, const float* d_photons, uint64_t n, const double bb_min[3], const double bb_max[3],
+                     uint32_t max_node_data, double* timing) {
+    ctx->dense_cell_refused = false;
+    const int rc = buildMapOnDevice(ctx, which, d_photons, n, bb_min, bb_max, max_node_data, timing);
+    if (rc != MCRT_ERR_UNSUPPORTED || !ctx->dense_cell_refused) return rc;
+    ctx->dense_cell_refused = false;
+    std::vector<float> host;
+    try {
+        host.resize((size_t)n * 8);
+    } catch (...) {
+        return fail(ctx, MCRT_ERR_HIP, "photon map: out of host memory for the recursive builder's copy of the list");
+    }
+    HIP_TRY(ctx, hipMemcpy(host.data(), d_photons, (size_t)n * 32, hipMemcpyDeviceToHost));
+    mcrt_photon_map* M = nullptr;
+    if (int rc2 = mcrt_photon_map_build(host.data(), n, bb_min, bb_max, max_node_data, &M)) return fail(ctx, rc2, "photon map: the recursive host builder failed");
+    const int rc3 = uploadMap(ctx, which, mcrt_photon_map_get(M));
+    mcrt_photon_map_free(M);
+    return rc3;
+}
+
 int mcrt_upload_photons_device(mcrt_ctx* ctx, const float* d_global_photons, uint64_t global_count, const float* d_caustic_photons,
                                uint64_t caustic_count, const double bb_min[3], const double bb_max[3], uint32_t max_photons_per_leaf,
                                uint32_t k_nearest_photons, int direct_visualization, mcrt_photon_pass_stats* stats) {
@@ -1637,8 +1666,8 @@ int mcrt_upload_photons_device(mcrt_ctx* ctx, const float* d_global_photons, uin
     ctx->has_photons = false;
     ctx->k_nearest = k_nearest_photons;  // before the maps: the record lists expand octants with more than k photons
     double timing[3] = {0.0, 0.0, 0.0};
-    if (int rc = buildMapOnDevice(ctx, 0, d_global_photons, global_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
-    if (int rc = buildMapOnDevice(ctx, 1, d_caustic_photons, caustic_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
+    if (int rc = buildMapAnyDepth(ctx, 0, d_global_photons, global_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
+    if (int rc = buildMapAnyDepth(ctx, 1, d_caustic_photons, caustic_count, bb_min, bb_max, max_photons_per_leaf, timing)) return rc;
     ctx->direct_visualization = direct_visualization ? 1 : 0;
     ctx->has_photons = true;
     if (stats) {

@@ -291,7 +291,10 @@ int buildMapOnDevice(mcrt_ctx* ctx, int which, const float* d_photons, uint64_t 
             HIP_TRY(ctx, hipMemcpyAsync(h, counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
             if (h[0] > cap) return fail(ctx, MCRT_ERR_HIP, "photon octree: octant capacity exceeded");
-            if (h[2]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon octree: more than max_photons_per_leaf photons in one 2^-21 cell (use mcrt_photon_map_build)");
+            if (h[2]) {  // (buildMapAnyDepth, mcrt_hip.hip, takes it from here: the recursive host builder has no level limit)
+                ctx->dense_cell_refused = true;
+                return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon octree: more than max_photons_per_leaf photons in one 2^-21 cell of the map's cube");
+            }
             level_count = h[1];
             if (level_count > list_cap) return fail(ctx, MCRT_ERR_HIP, "photon octree: level list capacity exceeded");
             HIP_TRY(ctx, hipMemsetAsync(counters.as<unsigned int>() + 1, 0, 4, st));  // (no host source that could leave scope before the copy runs)

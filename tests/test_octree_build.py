@@ -192,13 +192,28 @@ def test_device_resident_photon_pass(pkg, oracle, manifest):
         assert rel.max() < 1e-9, rel.max()
         for h in host_maps:
             h.close()
-    # one cell deeper than the codes: refused, the recursive host builder is the one for that
-    ph = np.zeros((300, 8), dtype=np.float32)
-    ph[:, 3:6] = 0.25
+    # More than a leaf's worth of photons inside one cell of the 21-level codes (the focus of a sharp caustic): the device build cannot
+    # separate them; until round 4 the call was refused, now the list goes through the recursive host builder, which splits as deep as
+    # the reference's Octree does - the host builder's own trees, whatever the mix (a tight cluster inside a cloud; nothing but the cluster)
     import torch
-    t = torch.from_numpy(ph).to("cuda:0")
-    with pytest.raises(pkg.McrtError):
-        ctx.upload_photons_device(t.data_ptr(), 300, t.data_ptr(), 300, [0, 0, 0], [1, 1, 1], 200, 50, False)
+    rng = np.random.default_rng(9)
+    cluster = np.zeros((300, 8), dtype=np.float32)
+    cluster[:, 3:6] = 0.25 + (rng.random((300, 3)) * 1e-7).astype(np.float32)
+    cloud = rng.random((20000, 8)).astype(np.float32)
+    for ph in (np.concatenate([cloud, cluster]), cluster):
+        t = torch.from_numpy(np.ascontiguousarray(ph)).to("cuda:0")
+        torch.cuda.synchronize()
+        ctx.upload_photons_device(t.data_ptr(), len(ph), t.data_ptr(), 300, [0, 0, 0], [1, 1, 1], 200, 50, False)
+        dev = ctx.download_map(0)
+        host = pkg.PhotonMap(ph, [0, 0, 0], [1, 1, 1], 200)
+        assert_same_octree(host.arrays(), dev.arrays())
+        pts = ph[::37, 3:6].astype(np.float64) + 1e-4
+        cnt, idx, d2 = ctx.knn(0, pts, 50)
+        ocnt, oidx, od2 = oracle.knn(host.desc, pts, 50)
+        np.testing.assert_array_equal(cnt, ocnt)
+        np.testing.assert_array_equal(d2, od2)
+        dev.close()
+        host.close()
     # ... while lists in device memory that do fit give the host builder's trees
     rng = np.random.default_rng(5)
     ph = rng.random((50000, 8)).astype(np.float32)
