@@ -224,7 +224,11 @@ int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed
  * d_out_rgb holds owned rows only, packed in ascending row order: mcrt_shard_rows() rows of
  * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. (Scenes whose tree is walked by the
  * wavefront pipeline — BVHs of 65 536 nodes or more — run as a host-driven sequence of launches on `stream`; for them
- * the call returns when the frame is complete and mcrt_render_finish() only collects the statistics.) */
+ * the call returns when the frame is complete and mcrt_render_finish() only collects the statistics.)
+ * ORDERING: queue consumers of d_out_rgb (copies, reductions, the gather) AFTER mcrt_render_finish() has returned MCRT_OK, not right
+ * after this call: a megakernel frame in which a path nests deeper than the eight dielectric media a lane keeps in LDS is rendered
+ * AGAIN by mcrt_render_finish through the wavefront pipeline (32 media; mcrt_stats.kernel_id then says MCRT_KERNEL_WAVEFRONT[_PM] and
+ * kernel_ms / kernel_launches describe that second run), into the same d_out_rgb on the same stream. */
 int mcrt_render_device(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed,
                        int integrator, double* d_out_rgb, void* stream);
 int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats /* may be NULL */);
