@@ -198,10 +198,14 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
                 q0 = max(r0, mid - n_rows // 2)
                 r = _run_reference(img.path, cam, q0, q0 + n_rows, best_t)
                 sample_rays = rays_per_row * n_rows
-                base = dict(value=cal[threads] / 1e6, unit="Mray/s", cores=threads, kind="reference",
-                            sample="reference Camera::samplePixel, row %d of %dx%d @ %d spp at %d threads; best thread count: rows %d-%d (%d paths, %.1f s)"
-                                   % (mid, cam.width, cam.height, spp, threads, q0, q0 + n_rows, r["paths"], r["seconds"]),
+                # `value` / `cores`: the reference at the thread count where it runs BEST on this host - the baseline to quote. With every
+                # hardware thread it is slower (all_threads_value): BVH::intersect copies a shared_ptr per visited node (bvh.cpp:80-129)
+                # and the reference counts contend across sockets - an artefact of the reference's host code, not of the hardware.
+                base = dict(value=sample_rays / r["seconds"] / 1e6, unit="Mray/s", cores=best_t, kind="reference",
+                            sample="reference Camera::samplePixel at its best thread count (%d of %d hardware threads): rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s); "
+                                   "thread scan on row %d" % (best_t, threads, q0, q0 + n_rows, cam.width, cam.height, spp, r["paths"], r["seconds"], mid),
                             best_value=sample_rays / r["seconds"] / 1e6, best_cores=best_t,
+                            all_threads_value=cal[threads] / 1e6, all_threads_cores=threads,
                             by_threads={str(k): v / 1e6 for k, v in sorted(cal.items())},
                             port_value=port["value"], port_cores=threads)
         except Exception as ex:  # keep the port numbers
