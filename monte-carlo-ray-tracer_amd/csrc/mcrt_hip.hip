@@ -325,9 +325,9 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     const uint32_t lds_stack = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_STACK", kLdsStackDepth), 4), kLdsStackDepth);
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds_trace, envi("MCRT_TRACE_LDS", (long)ctx->max_lds_trace));
-    if ((long)stack_bytes + 64 + (long)(waves * kShareMapBytes) > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
-    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 64u - waves * kShareMapBytes) / 64u);
-    tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u + waves * kShareMapBytes;  // + the workgroup's queue cursor + the waves' shared-leaf maps
+    if ((long)stack_bytes + 128 + (long)(waves * kShareMapBytes) > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
+    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 128u - waves * kShareMapBytes) / 64u);
+    tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u + waves * kShareMapBytes + 64u;  // + the workgroup's queue cursor + the waves' shared-leaf maps + the root's record
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)tp.block, tp.lds_bytes));
@@ -359,6 +359,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     ta.total_lanes = total_lanes;
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
     ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 12 : 24);
+    ta.leaf_items = (int)envi("MCRT_WF_LEAF_ITEMS", 1 << 20);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
     ta.max_stack = ctx->scene.stack_depth;
@@ -1415,9 +1416,10 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
                 100.0 * (h[8] - h[10] - h[12]) / h[8], (double)h[14] / h[8]);
     else if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt trace] per wave iteration: %.1f lanes hold a ray; inner step in %.1f%% of the iterations with %.1f lanes, leaf step in %.1f%% with %.1f lanes, "
-                        "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%%; per ray: %.2f inner steps, %.2f leaf steps\n",
+                        "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%% (of the kernel: refills %.1f%%, pop site %.1f%%); per ray: %.2f inner steps, %.2f leaf steps\n",
                 (double)h[9] / h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
                 (double)h[14] / h[8], 100.0 * h[15] / (double)h[17], 100.0 * h[16] / (double)h[17], 100.0 * (h[17] - h[15] - h[16]) / (double)h[17],
+                100.0 * h[18] / (double)h[17], 100.0 * h[19] / (double)h[17],
                 (double)h[11] / (double)(h[1] ? h[1] : 1), (double)h[13] / (double)(h[1] ? h[1] : 1));
     if (ctx->kernel_id == MCRT_KERNEL_PM_WAVE && h[9] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt pm] wave cycles inside the radiance estimates: %.1f%% of the kernel (%llu searches, %.1f octants per search)\n",

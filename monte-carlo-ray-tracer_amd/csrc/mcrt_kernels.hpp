@@ -744,6 +744,7 @@ struct WfTraceArgs {
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
+    int leaf_items;                     // shared leaf step: offered primitives from which a step is issued (MCRT_WF_LEAF_ITEMS)
     uint32_t max_stack;                 // stack entries per lane in all (DeviceScene::stack_depth)
     uint32_t deal_shift;                // queue entries are dealt to the workgroups in blocks of 2^deal_shift
 };
@@ -782,8 +783,8 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // What the counters said about the leaf step (C3, round 3): it runs with ~23 of a wave's 64 lanes, every one of them testing TWO
 // primitives in sequence (two 80-byte records, ~300 instructions with the hit updates) - 35 % of the kernel's wave cycles at a
 // third of the lanes. Here the work items of a leaf step are (pending lane, primitive) PAIRS and they are dealt over all 64 lanes:
-// with n lanes holding a pending leaf every one of them gets 2^sh = 4 / 2 / 1 item lanes (n <= 16 / <= 32 / more), item lane
-// k = (rank of the pending lane << sh) + j tests that lane's j-th primitive with that lane's ray - the ray (start, direction: twelve
+// every pending lane offers up to four primitives of its leaf, the offers are numbered by a prefix sum over the lanes and the first 64
+// are the step's items: item lane k tests the j-th offered primitive of its owner with the owner's ray - the ray (start, direction: twelve
 // 32-bit words) and the leaf range are PULLED from the owner with ds_bpermute, no LDS is written except a 64-byte rank -> lane map
 // per wave. The owner then pulls the entry distances of its item lanes back, keeps the FIRST minimum (items are in ascending
 // primitive order, so ties go to the lowest index: the tie rule of `closer`), pulls that item's u / v and updates its hit exactly as
@@ -801,30 +802,50 @@ __device__ __forceinline__ double wavePullD(double v, uint32_t src_lane) {
     const uint32_t lo = wavePull((uint32_t)b, src_lane), hi = wavePull((uint32_t)(b >> 32), src_lane);
     return bitsD(((unsigned long long)hi << 32) | lo);
 }
+// Items: every pending lane offers up to kShareCap primitives of its leaf; the offers are numbered by an exclusive prefix sum over the
+// lanes (the counts are 0 .. 4: three bit planes, one ballot and one mbcnt each) and the first 64 are a step's. The kernel's gate looks
+// at the TOTAL (a step is worth issuing when it fills the wave), so the offers are made before the gate.
+constexpr uint32_t kShareCap = 4u;
+struct ShareOffer {
+    uint32_t want;                    // this lane's offer (0: no pending leaf)
+    unsigned long long b0, b1, b2;    // bit planes of the offers over the wave
+    uint32_t total;                   // sum of the offers
+};
+__device__ __forceinline__ ShareOffer shareOffer(bool pend, const PendLeaf& P) {
+    ShareOffer s;
+    s.want = pend ? (P.n < kShareCap ? P.n : kShareCap) : 0u;
+    s.b0 = waveBallot((s.want & 1u) != 0u);
+    s.b1 = waveBallot((s.want & 2u) != 0u);
+    s.b2 = waveBallot((s.want & 4u) != 0u);
+    s.total = (uint32_t)__popcll(s.b0) + 2u * (uint32_t)__popcll(s.b1) + 4u * (uint32_t)__popcll(s.b2);
+    return s;
+}
 template <bool kCount>
-__device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv, Trav& T, PendLeaf& P, bool pend, unsigned long long m_pend,
+__device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv, Trav& T, PendLeaf& P, const ShareOffer& so,
                                                     MCRT_LDS_AS uint8_t* map, TraceCounters& cnt) {
     const uint32_t lane = laneId();
-    const uint32_t n = (uint32_t)__popcll(m_pend);  // >= 1 (the caller's gate)
-    const uint32_t sh = n <= 16u ? 2u : n <= 32u ? 1u : 0u;
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_pend, 0u));
-    if (pend) map[rank] = (uint8_t)lane;
+    const uint32_t want = so.want, total = so.total;
+    auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    const uint32_t pre = below(so.b0) + 2u * below(so.b1) + 4u * below(so.b2);
+    const uint32_t take = pre >= 64u ? 0u : (want < 64u - pre ? want : 64u - pre);  // what of this lane's offer fits
+#pragma unroll
+    for (uint32_t jj = 0u; jj < kShareCap; jj++)
+        if (jj < take) map[pre + jj] = (uint8_t)lane;  // item -> owner
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t grp = lane >> sh, j = lane & ((1u << sh) - 1u);
-    const uint32_t src = grp < n ? (uint32_t)map[grp] : lane;
+    const bool item = lane < (total < 64u ? total : 64u);
+    const uint32_t src = item ? (uint32_t)map[lane] : lane;
     __builtin_amdgcn_wave_barrier();  // (the next step's writes stay behind these reads)
-    const uint32_t pa = wavePull(P.a, src), pn = wavePull(P.n, src);
+    const uint32_t pa = wavePull(P.a, src), pre_src = wavePull(pre, src);
     d3 o, d;
     o.x = wavePullD(T.o.x, src); o.y = wavePullD(T.o.y, src); o.z = wavePullD(T.o.z, src);
     d.x = wavePullD(T.d.x, src); d.y = wavePullD(T.d.y, src); d.z = wavePullD(T.d.z, src);
-    const bool item = grp < n && j < pn;
     Hit h;
     h.t = 0.0; h.u = 0.0; h.v = 0.0; h.surface = kNoSurface; h.interpolate = false;
     bool ok = false;
     if (item) {
-        const PrimRec rec = loadPrim(sv.prim + (size_t)(pa + j) * kPrimStride);
+        const PrimRec rec = loadPrim(sv.prim + (size_t)(pa + (lane - pre_src)) * kPrimStride);
         Ray r;
         r.start = o;
         r.direction = d;
@@ -835,22 +856,21 @@ __device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv,
         ok = primTestRec<true>(rec, r, h);
     }
     const double key = ok ? h.t : INFINITY;
-    // owner side: the first minimum over its item lanes
-    const uint32_t base = rank << sh;
+    // owner side: the first minimum over its item lanes (ascending primitive index: ties go to the lowest)
     double win_t = INFINITY;
     uint32_t win_j = 0u;
-    for (uint32_t jj = 0u; jj < (1u << sh); jj++) {  // wave-uniform trip count (1, 2 or 4)
-        const double tj = wavePullD(key, (base + jj) & 63u);
-        if (tj < win_t) {
+#pragma unroll
+    for (uint32_t jj = 0u; jj < kShareCap; jj++) {
+        const double tj = wavePullD(key, (pre + jj) & 63u);
+        if (jj < take && tj < win_t) {
             win_t = tj;
             win_j = jj;
         }
     }
-    const uint32_t wl = (base + win_j) & 63u;
+    const uint32_t wl = (pre + win_j) & 63u;
     const double win_u = wavePullD(h.u, wl), win_v = wavePullD(h.v, wl);
     const uint32_t win_i = wavePull(h.interpolate ? 1u : 0u, wl);
-    if (pend) {
-        const uint32_t used = P.n < (1u << sh) ? P.n : (1u << sh);
+    if (take != 0u) {
         bool decided = false;
         const uint32_t idx = P.a + win_j;
         if (win_t < INFINITY && closer(win_t, idx, T.best)) {
@@ -864,10 +884,11 @@ __device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv,
         if (decided) {
             T.sp = 0;
             T.active = false;
+            T.need_pop = false;
             P.n = 0u;
         } else {
-            P.a += used;
-            P.n -= used;
+            P.a += take;
+            P.n -= take;
         }
     }
 }
@@ -897,8 +918,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     sv.num_nodes = a.num_nodes;
     sv.nodes = a.nodes;
     sv.prim = a.prim;
-    sv.lds_nodes = 0;
-    sv.lds_node_ptr = nullptr;
+    sv.lds_nodes = 1;            // the root (below)
+    sv.lds_node_ptr = nullptr;   // set once the root is staged
     setLeafCull(sv, a.leaf_pre, a.leaf_cx, a.leaf_cy, a.leaf_cz, a.leaf_bound);
     QView<true> qv;
     qv.blocks = a.qblocks;
@@ -918,8 +939,12 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
     // (behind the cursor's 64 bytes: the rank -> lane map of every wave's shared leaf steps)
     MCRT_LDS_AS uint8_t* share_map = reinterpret_cast<MCRT_LDS_AS uint8_t*>(cursor) + 64u + (threadIdx.x >> 6) * kShareMapBytes;
+    // (... and behind the maps the root's exact record: every refill tests it - an LDS read instead of a memory round trip per refill)
+    MCRT_LDS_AS Node64* lds_root = reinterpret_cast<MCRT_LDS_AS Node64*>(reinterpret_cast<MCRT_LDS_AS uint8_t*>(cursor) + 64u + (blockDim.x >> 6) * kShareMapBytes);
+    if (threadIdx.x < 16u) reinterpret_cast<MCRT_LDS_AS uint32_t*>(lds_root)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.nodes)[threadIdx.x];
     const uint32_t deal_shift = a.deal_shift, deal_mask = (1u << deal_shift) - 1u;
     if (threadIdx.x == 0) *cursor = 0u;
+    sv.lds_node_ptr = lds_root;
     __syncthreads();
     auto dealt = [&](uint32_t v) -> unsigned long long {  // the v-th entry of this workgroup
         return ((((unsigned long long)(v >> deal_shift) * gridDim.x + blockIdx.x) << deal_shift) | (v & deal_mask));
@@ -938,16 +963,27 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     // MCRT_COUNT_TESTS: where the wave's issue slots go (per wave: iterations, lanes holding a ray, inner / leaf steps and the lanes
     // that took part, leaf lanes kept waiting by the gate, wave cycles inside the two steps and in all)
     unsigned long long ph_iter = 0, ph_have = 0, ph_in_steps = 0, ph_in_lanes = 0, ph_lf_steps = 0, ph_lf_lanes = 0, ph_lf_wait = 0, ph_in_cyc = 0, ph_lf_cyc = 0;
+    unsigned long long ph_refill_cyc = 0, ph_pop_cyc = 0;  // (what "rest" is made of: the refill blocks, the loop's pop site)
     const unsigned long long ph_begin = kCount ? clock64() : 0ull;
     bool have = false, exhausted = dealt(0u) >= n;
     uint32_t item = 0;
     for (;;) {
-        if (have && !T.active && (!kDefer || P.n == 0u)) {  // finished since the last look: hand the hit back (deferred leaves: none pending either)
-            rays.store(item, T.best);
-            have = false;
+        // Finished rays (deferred leaves: none pending, nothing left to pop) hand their hits back in BATCHES - together with the refill
+        // that replaces them (a store per iteration for the three rays that finish in it cost the whole wave ~30 instructions each time)
+        const bool done = have && !T.active && (!kDefer || (P.n == 0u && !T.need_pop));
+        const unsigned long long m_done = waveBallot(done);
+        unsigned long long m_have = waveBallot(have) & ~m_done;
+        const bool want_refill = !exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull);
+        if (m_done && (want_refill || exhausted)) {
+            if (done) {
+                rays.store(item, T.best);
+                have = false;
+            }
+        } else {
+            m_have |= m_done;  // (they keep their lanes until the next batch)
         }
-        const unsigned long long m_have = waveBallot(have);
-        if (!exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull)) {
+        if (want_refill) {
+            const unsigned long long t_refill = kCount ? clock64() : 0ull;
             unsigned long long w = n;
             {
                 const unsigned long long need = waveBallot(!have);  // (not empty here)
@@ -968,6 +1004,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 have = true;
             }
             exhausted = waveBallot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
+            if (kCount) ph_refill_cyc += clock64() - t_refill;
         }
         if (!waveBallot(have)) {
             if (exhausted) break;
@@ -1013,8 +1050,24 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             continue;
         }
         if constexpr (kDefer) {
-            // a lane standing at a leaf (new ray whose root is a leaf, pending slot freed by the last leaf step) parks it and moves on
-            if (have) travParkLeaf(T, P, stk);
+            // A lane standing at a leaf whose pending slot is free parks the leaf; it and every lane whose last visit kept no child take
+            // their next node from the stack HERE - the loop's one pop site (round 4; the walk used to pop in three places per
+            // iteration - after each of two parking sites and at the end of the inner step - each a chain of dependent LDS reads the
+            // whole wave waits for). A lane that pops a leaf while its slot is taken waits; with a free slot it parks it next time round.
+            if (have && T.active && !(T.node_m & kSmInner) && P.n == 0u) {
+                P.a = T.node_a;
+                P.n = T.node_m;
+                T.active = false;
+                T.need_pop = true;
+            }
+            if (waveBallot(have && T.need_pop)) {
+                const unsigned long long t_pop = kCount ? clock64() : 0ull;
+                if (have && T.need_pop) {
+                    travPopCached(T, stk);
+                    T.need_pop = false;
+                }
+                if (kCount) ph_pop_cyc += clock64() - t_pop;
+            }
             const bool inner = have && T.active && (T.node_m & kSmInner);
             unsigned long long ti = 0ull;
             if (kCount) {
@@ -1025,21 +1078,26 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 ph_in_lanes += __popcll(mi);
                 ti = clock64();
             }
-            if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
-            if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
+            if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
+            if (inner && !T.fast) travInnerStep<false, kCount, true>(sv, T, stk, cnt);  // zero direction component: exact records
             if (kCount) ph_in_cyc += clock64() - ti;
-            if (inner) travParkLeaf(T, P, stk);  // landed on a leaf: it joins this iteration's leaf step
             const bool pend = have && P.n != 0u;
             const unsigned long long m_pend = waveBallot(pend);
-            const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
-            if (m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+            const unsigned long long m_inner = waveBallot(have && (T.need_pop || (T.active && (T.node_m & kSmInner))));
+            ShareOffer so;
+            bool go = m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner);
+            if constexpr (kShare) {  // the shared step is gated by what it would TEST: enough offered primitives to fill the wave
+                so = shareOffer(pend, P);
+                go = go || (int)so.total >= a.leaf_items;
+            }
+            if (go) {
                 unsigned long long tc = 0ull;
                 if (kCount) {
                     ph_lf_steps++;
                     ph_lf_lanes += __popcll(m_pend);
                     tc = clock64();
                 }
-                if constexpr (kShare) travSharedLeafStep<kCount>(sv, T, P, pend, m_pend, share_map, cnt);
+                if constexpr (kShare) travSharedLeafStep<kCount>(sv, T, P, so, share_map, cnt);
                 else if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
                 if (kCount) ph_lf_cyc += clock64() - tc;
             } else if (kCount) {
@@ -1086,6 +1144,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
         atomicAdd(a.stats + 15, ph_in_cyc);
         atomicAdd(a.stats + 16, ph_lf_cyc);
         atomicAdd(a.stats + 17, (unsigned long long)(clock64() - ph_begin));
+        atomicAdd(a.stats + 18, ph_refill_cyc);
+        atomicAdd(a.stats + 19, ph_pop_cyc);
     }
     waveAccumulate(a.stats + 1, cnt.rays);
     if (kCount) {

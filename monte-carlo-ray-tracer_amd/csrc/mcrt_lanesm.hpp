@@ -44,6 +44,16 @@ struct SmStackEntry {
     uint32_t a;
 };
 
+// sp * stride of a stack slot: both are far below 2^24, and the 24-bit multiply issues at full rate where v_mul_lo_u32 takes four
+// slots (a block visit pushes up to four entries and the loop pops one: five multiplies per iteration of the trace kernel)
+MCRT_HD uint32_t stackSlot(int sp, uint32_t stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24((uint32_t)sp, stride);
+#else
+    return (uint32_t)sp * stride;
+#endif
+}
+
 struct SmStack {
     MCRT_LDS_AS SmStackEntry* lds;
     uint32_t lds_stride;
@@ -55,7 +65,7 @@ struct SmStack {
     // compiler emits flat_load / flat_store, which wait on both the LDS and the vector-memory counters)
     MCRT_HD void put(int sp, SmStackEntry e) const {
         if (sp < lds_depth) {
-            lds[(uint32_t)sp * lds_stride] = e;
+            lds[stackSlot(sp, lds_stride)] = e;
         } else {
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::: "memory");
@@ -66,7 +76,7 @@ struct SmStack {
     MCRT_HD SmStackEntry get(int sp) const {
         SmStackEntry e;
         if (sp < lds_depth) {
-            e = lds[(uint32_t)sp * lds_stride];
+            e = lds[stackSlot(sp, lds_stride)];
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(e.key), "+v"(e.a));  // the value exists HERE: the load cannot sink below the join
 #endif
@@ -87,6 +97,11 @@ struct Trav {
     uint32_t node_a, node_m;  // meta of the node to visit next
     int sp;
     bool active;       // a node is waiting to be visited
+    bool need_pop = false;  // (lazy-pop walks, wfTraceKernel forms 2 / 3) the next node is still on the stack: popped at the loop's one pop site
+    // (same walks) the stack's TOP entry, also held in registers: every push leaves the entry it wrote last here (write-through: it
+    // is in the stack's memory too), a pop takes it without waiting for an LDS read and asks for the entry below at once - that read
+    // lands while the wave runs its next step. top_key == kTopNone: not cached, read the stack.
+    uint32_t top_key = 0xFFFFFFFFu, top_a = 0u;
     bool fast;         // v_min/v_max box test allowed (no NaN slab products possible)
     bool shadow;
     uint32_t light;    // shadow query: surface aimed at
@@ -123,6 +138,59 @@ MCRT_HD Ray travRay(const Trav& T) {  // only start/direction/inv_direction are 
     r.dirac_delta = false;
     r.refraction = false;
     return r;
+}
+
+constexpr uint32_t kTopNone = 0xFFFFFFFFu;  // (never a stack key: the block visit's "miss" sentinel is not pushed)
+// The pop of the lazy-pop walks: top entry from registers, the next one requested before the popped one is looked at. Written as a
+// straight-line first attempt (the popped entry is visited nine times in ten) so that the request for the entry below goes into the
+// lane's own top registers with nothing waiting for it here; only a culled entry falls into the loop, which does wait.
+MCRT_HD void travTopRequest(Trav& T, const SmStack& stk) {  // T.sp > 0: ask for stack[sp - 1]
+    const int below = T.sp - 1;
+    if (below < stk.lds_depth) {
+        const SmStackEntry n = stk.lds[stackSlot(below, stk.lds_stride)];
+        T.top_key = n.key;
+        T.top_a = n.a;
+    } else {
+        const SmStackEntry n = stk.get(below);
+        T.top_key = n.key;
+        T.top_a = n.a;
+    }
+}
+MCRT_HD void travPopCached(Trav& T, const SmStack& stk) {
+    T.active = false;
+    if (T.sp <= 0) return;
+    SmStackEntry e;
+    if (T.top_key != kTopNone) {
+        e.key = T.top_key;
+        e.a = T.top_a;
+    } else {
+        e = stk.get(T.sp - 1);
+    }
+    --T.sp;
+    T.top_key = kTopNone;
+    if (T.sp > 0) travTopRequest(T, stk);
+    if ((double)bitsFloat(e.key & ~0x1FFu) <= T.best.t) {
+        T.node_a = e.a;
+        T.node_m = e.key & 0x1FFu;
+        T.active = true;
+        return;
+    }
+    // The popped entry was culled (a hit since it was pushed): work down the stack, one entry per round trip. (Four entries per trip -
+    // a lane's entries at consecutive depths are independent LDS reads - was measured SLOWER, C3 393.9 -> 400.3 ms: culled runs are
+    // short, and the extra reads and selects cost every pop that reaches this loop.)
+    while (T.sp > 0) {
+        e.key = T.top_key;
+        e.a = T.top_a;
+        --T.sp;
+        T.top_key = kTopNone;
+        if (T.sp > 0) travTopRequest(T, stk);
+        if ((double)bitsFloat(e.key & ~0x1FFu) <= T.best.t) {
+            T.node_a = e.a;
+            T.node_m = e.key & 0x1FFu;
+            T.active = true;
+            break;
+        }
+    }
 }
 
 MCRT_HD void travPop(Trav& T, const SmStack& stk) {
@@ -177,6 +245,8 @@ MCRT_HD void travBegin(const SmSceneView<kAll>& sv, Trav& T, d3 start, d3 direct
     T.light = shadow ? sq->light : kNoSurface;
     T.t_near = shadow ? sq->t_near : 0.0;
     T.sp = 0;
+    T.need_pop = false;
+    T.top_key = kTopNone;
     // (1e25: the FP32 slab test of the quantised blocks, mcrt_qbvh.hpp, multiplies scene-sized lengths by these)
     T.fast = fabs(inv_direction.x) <= 1e25 && fabs(inv_direction.y) <= 1e25 && fabs(inv_direction.z) <= 1e25;
     cnt.rays++;
@@ -211,7 +281,7 @@ MCRT_HD void travBegin(const SmSceneView<kAll>& sv, Trav& T, d3 start, d3 direct
 }
 
 // Visit one INNER node: test its children (bvh.cpp:108-119), continue with the nearest hit child, push the rest.
-template <bool kAll, bool kCount>
+template <bool kAll, bool kCount, bool kLazyPop = false>
 MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const uint32_t first = T.node_a, count = T.node_m & 0xFFu;
     const Ray r = travRay(T);
@@ -244,6 +314,8 @@ MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& 
                     e.key = (floatBits(floatBelow(push_t)) & ~0x1FFu) | push_m;
                     e.a = push_a;
                     stk.put(T.sp++, e);
+                    T.top_key = e.key;  // (the stack's top, cached: travPopCached)
+                    T.top_a = e.a;
                 } else {
                     cnt.overflow = 1;
                 }
@@ -253,6 +325,9 @@ MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& 
     if (have_near) {
         T.node_a = near_a;
         T.node_m = near_m;
+    } else if (kLazyPop) {
+        T.active = false;
+        T.need_pop = true;
     } else {
         travPop(T, stk);
     }
@@ -368,6 +443,7 @@ MCRT_HD void travPendStep(const SmSceneView<kAll>& sv, Trav& T, PendLeaf& P, Tra
     if (decided) {
         T.sp = 0;
         T.active = false;
+        T.need_pop = false;
         P.n = 0u;
     } else {
         P.a = i + used;

@@ -92,6 +92,8 @@ MCRT_HD void travInnerStepQ64(const QView<kLds>& qv, Trav& T, const SmStack& stk
             e.key = (floatBits(floatBelow(t)) & ~0x1FFu) | m;
             e.a = a;
             stk.put(T.sp++, e);
+            T.top_key = e.key;
+            T.top_a = e.a;
         } else {
             cnt.overflow = 1;
         }
@@ -169,7 +171,7 @@ MCRT_HD void travInnerStepQ64(const QView<kLds>& qv, Trav& T, const SmStack& stk
 // children are ordered with integer min / max and pushed as they are. (Round 2, second pass: A and C themselves in FP32 —
 // six conversions of the ray per visit instead of nine FP64 operations and six conversions per block.)
 constexpr uint32_t kQMissKey = 0xFFFFFFFFu;
-template <bool kLds, bool kCount>
+template <bool kLds, bool kCount, bool kLazyPop = false>
 MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const float best_up = floatAbove(T.best.t);  // smallest float >= best.t
     // the ray in FP32, rounded to nearest: |of - o| <= u |o|, invf = inv (1 + e), |e| <= u = 2^-24 (|inv| <= 1e25: T.fast)
@@ -182,6 +184,8 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
             e.key = key;
             e.a = a;
             stk.put(T.sp++, e);
+            T.top_key = key;  // (the stack's top, cached: travPopCached, mcrt_lanesm.hpp)
+            T.top_a = a;
         } else {
             cnt.overflow = 1;
         }
@@ -255,6 +259,9 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
     if (near_key != kQMissKey) {
         T.node_a = near_a;
         T.node_m = near_key & 0x1FFu;
+    } else if (kLazyPop) {  // (the trace kernel's deferred-leaf forms pop at ONE site per loop iteration: mcrt_kernels.hpp)
+        T.active = false;
+        T.need_pop = true;
     } else {
         travPop(T, stk);
     }
