@@ -358,7 +358,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     ta.spill = ctx->spill.as<SmStackEntry>();
     ta.total_lanes = total_lanes;
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
-    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 12 : 24);
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 16 : 24);  // (shared step, C3 64 spp: 8 / 12 / 16 / 20 pending lanes 412.7 / 402.1 / 398.1 / 402.3 ms; gating on 48-56 offered primitives instead: 398.4-399.0)
     ta.leaf_items = (int)envi("MCRT_WF_LEAF_ITEMS", 1 << 20);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;

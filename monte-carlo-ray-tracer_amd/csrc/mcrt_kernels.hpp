@@ -1759,6 +1759,53 @@ __device__ inline Hit traceWalkQ(const SmSceneView<false>& sv, const QView<true>
     return T.best;
 }
 
+// The same walk with the trace kernel's round-4 machinery (deferred leaves tested by the whole wave, one pop site, the stack's top in
+// registers): EVERY lane of the wave calls it - `valid` says whether the lane has a ray - because the shared leaf step deals its
+// primitive tests over all 64 lanes. `map`: 64 bytes of this wave's LDS that nothing else uses during the walk.
+template <bool kCount>
+__device__ inline Hit traceWalkShared(const SmSceneView<false>& sv, const QView<true>& qv, const SmStack& stk, bool valid, const Ray& ray, bool shadow,
+                                      const ShadowQuery* sq, TraceCounters& cnt, MCRT_LDS_AS uint8_t* map) {
+    Trav T;
+    PendLeaf P;
+    T.active = false;
+    T.need_pop = false;
+    T.sp = 0;
+    T.shadow = false;
+    T.fast = true;
+    T.light = kNoSurface;
+    T.t_near = 0.0;
+    T.node_a = T.node_m = 0u;
+    hitInit(T.best, kDblMax);
+    T.o = T.d = T.inv = d3{0.0, 0.0, 0.0};
+    if (valid) travBeginQ<false, true, kCount>(sv, qv, T, ray.start, ray.direction, ray.inv_direction, shadow, sq, cnt);
+    for (;;) {
+        if (T.active && !(T.node_m & kSmInner) && P.n == 0u) {
+            P.a = T.node_a;
+            P.n = T.node_m;
+            T.active = false;
+            T.need_pop = true;
+        }
+        if (waveBallot(T.need_pop)) {
+            if (T.need_pop) {
+                travPopCached(T, stk);
+                T.need_pop = false;
+            }
+        }
+        const bool inner = T.active && (T.node_m & kSmInner);
+        if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
+        if (inner && !T.fast) travInnerStep<false, kCount, true>(sv, T, stk, cnt);
+        const bool pend = P.n != 0u;
+        const unsigned long long m_pend = waveBallot(pend);
+        if (!(m_pend | waveBallot(T.need_pop || T.active))) break;
+        if (m_pend) {
+            const unsigned long long m_inner = waveBallot(T.need_pop || (T.active && (T.node_m & kSmInner)));
+            const ShareOffer so = shareOffer(pend, P);
+            if (so.total >= 48u || __popcll(m_inner) < 8) travSharedLeafStep<kCount>(sv, T, P, so, map, cnt);
+        }
+    }
+    return T.best;
+}
+
 // What traceWalkQ needs, carved out of the LDS plan of the wave-synchronous kernels (planLds): the top child blocks take
 // the place of the staged node records, the traversal stack region is used with the state machine's 8-byte entries.
 struct QWalk {
@@ -1888,9 +1935,13 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         ia.inside = false;
         ia.dirac_delta = false;
         bool ended = false, needC = false, needG = false;
+        Hit walked;  // (tree in memory: the walk is a whole-wave affair, traceWalkShared - every lane calls it)
+        if constexpr (!kAll) walked = traceWalkShared<kCount>(qw.sv, qw.qv, qw.stk, path_active, st.ray, false, nullptr, cnt, reinterpret_cast<MCRT_LDS_AS uint8_t*>(W.hist));
         if (path_active) {
             st.smp.shuffle();
-            Hit isect = intersect(st.ray, false, nullptr);
+            Hit isect;
+            if constexpr (kAll) isect = intersect(st.ray, false, nullptr);
+            else isect = walked;
             if (isect.surface == kNoSurface) {
                 ended = true;  // no sky in photon mode (:292-295)
             } else {
@@ -1917,14 +1968,19 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         }
         if (kCount) cyc_est += clock64() - t_est;
         // ---- part 3 (per lane): next-event estimate, BSDF sampling, russian roulette (:308-311, :319-325, :334-339)
-        if (path_active && !ended) {
-            if (!ia.dirac_delta) {
-                DirectQuery dq;
-                if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
-                    Hit shadow = intersect(dq.shadow_ray, true, &dq.sq);
-                    st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
-                }
+        DirectQuery dq;
+        bool want_shadow = false;
+        if (path_active && !ended && !ia.dirac_delta) want_shadow = sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab);
+        if constexpr (kAll) {
+            if (want_shadow) {
+                Hit shadow = intersect(dq.shadow_ray, true, &dq.sq);
+                st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
             }
+        } else {
+            const Hit shadow = traceWalkShared<kCount>(qw.sv, qw.qv, qw.stk, want_shadow, dq.shadow_ray, true, &dq.sq, cnt, reinterpret_cast<MCRT_LDS_AS uint8_t*>(W.hist));
+            if (want_shadow) st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
+        }
+        if (path_active && !ended) {
             d3 bsdf_absIdotN;
             if (!interactionSampleBSDF(ia, bsdf_absIdotN, st.ls.bsdf_pdf, st.ray, false, st.smp, tab)) {
                 ended = true;
