@@ -92,7 +92,7 @@ struct mcrt_ctx {
 
     bool has_photons = false;
     PhotonMapView maps[2]{};
-    DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2];
+    DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2], map_pos[2];
     const WideRec* map_children_ptr[2] = {nullptr, nullptr};
     uint32_t map_root_a[2] = {0, 0}, map_root_m[2] = {0, 0};
     uint32_t k_nearest = 50;
@@ -234,7 +234,25 @@ PhotonMapViewW waveMapView(const mcrt_ctx* ctx, int which) {
     v.wide = ctx->map_children_ptr[which];
     v.root_a = ctx->map_root_a[which];
     v.root_m = ctx->map_root_m[which];
+    v.pos = ctx->map_pos[which].as<PhotonPos>();
     return v;
+}
+
+// The positions of a map's photons by themselves (PhotonPos, mcrt_waveknn.hpp), from the records in map order.
+__global__ void photonPosKernel(const float4* records, uint64_t n, PhotonPos* pos) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = records[2 * i], b = records[2 * i + 1];  // flux rgb, x | y, z, phi, theta
+    pos[i] = PhotonPos{a.w, b.x, b.y};
+}
+int buildMapPositions(mcrt_ctx* ctx, int which, uint64_t n) {
+    if (n == 0) return MCRT_OK;
+    HIP_TRY(ctx, ctx->map_pos[which].reserve(n * sizeof(PhotonPos)));
+    hipLaunchKernelGGL(photonPosKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->map_photons[which].as<float4>(), n,
+                       ctx->map_pos[which].as<PhotonPos>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCRT_OK;
 }
 
 int validateCamera(mcrt_ctx* ctx, const mcrt_camera_desc* cam) {
@@ -1075,7 +1093,7 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     v.octant_next = ctx->map_next[which].as<uint32_t>();
     v.octant_leaf = ctx->map_leaf[which].as<uint8_t>();
     v.photons = ctx->map_photons[which].as<float>();
-    return MCRT_OK;
+    return buildMapPositions(ctx, which, m->num_photons);
 }
 
 #include "mcrt_photon_device.hpp"

@@ -393,6 +393,7 @@ int buildMapOnDevice(mcrt_ctx* ctx, int which, const float* d_photons, uint64_t 
     v.octant_next = m_next;
     v.octant_leaf = m_leaf;
     v.photons = ctx->map_photons[which].as<float>();
+    if (int rc = buildMapPositions(ctx, which, n)) return rc;
     if (timing) {
         timing[0] += ms(t0, t1);
         timing[1] += ms(t1, t2);

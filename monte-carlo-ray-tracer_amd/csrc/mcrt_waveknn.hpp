@@ -53,10 +53,18 @@ struct WideRec {
     uint32_t pad;
 };
 
+// A photon's position alone, 12 bytes: what a leaf scan reads. The reference's 32-byte Photon (photon.hpp:36-37: flux, position,
+// two angles) is only needed of the k photons an estimate ends up with; scanning the records themselves moved 32 bytes per
+// photon for the 12 it looked at (round 4: a copy of the positions, made when a map is built or uploaded).
+struct PhotonPos {
+    float x, y, z;
+};
+
 struct PhotonMapViewW {
     PhotonMapView base;
     const WideRec* wide;
     uint32_t root_a, root_m;  // the root as an entry
+    const PhotonPos* pos;     // [num_photons], in map order
 };
 
 // Broadcast from lane `src` (wave-uniform): v_readlane, no LDS round trip.
@@ -529,10 +537,10 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                 for (int c = 0; c < 4; c++) {
                     const uint32_t i = base + 64u * c + lane;
                     const uint32_t ii = i < contained ? i : contained - 1;  // clamp: keeps the loads unconditional
-                    const float* ph = m.photons + (size_t)(start + ii) * 8;
-                    px[c] = ph[3];
-                    py[c] = ph[4];
-                    pz[c] = ph[5];
+                    const PhotonPos q = map.pos[(size_t)(start + ii)];
+                    px[c] = q.x;
+                    py[c] = q.y;
+                    pz[c] = q.z;
                 }
                 for (int c = 0; c < 4; c++) {
                     if (base + 64u * c >= contained) break;  // wave-uniform
