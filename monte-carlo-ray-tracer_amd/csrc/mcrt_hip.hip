@@ -662,8 +662,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             ctx->launches++;
             if (photon) {
                 ka.count = ctrl + 4 + (it & 1);
-                if (knn_eval) hipLaunchKernelGGL(wfKnnKernel<true>, dim3(knn_grid), dim3(256), 0, hs[h], ka);
-                else hipLaunchKernelGGL(wfKnnKernel<false>, dim3(knn_grid), dim3(256), 0, hs[h], ka);
+                const bool large_k = ctx->k_nearest > waveMaxK(kWaveRows);  // the wide candidate buffer (mcrt_waveknn.hpp)
+                if (knn_eval) hipLaunchKernelGGL((large_k ? wfKnnKernel<true, kWaveRowsLarge> : wfKnnKernel<true>), dim3(knn_grid), dim3(256), 0, hs[h], ka);
+                else hipLaunchKernelGGL((large_k ? wfKnnKernel<false, kWaveRowsLarge> : wfKnnKernel<false>), dim3(knn_grid), dim3(256), 0, hs[h], ka);
                 ctx->launches++;
             }
         }
@@ -787,8 +788,9 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters need the wavefront pipeline, and this scene has neither a BVH nor finite surface bounds to build its stand-in from");
     // Film::Film(w, h, json) with "filter": "box" and a radius other than the default 0.5 splats too (film.cpp:27-30); that case
     // is not built, so it is refused rather than rendered as the default box
-    if (filtered && photon && ctx->k_nearest > 128)
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters on photon-mapped frames need k_nearest_photons <= 128 (wavefront pipeline)");
+    constexpr uint32_t kWaveKMax = waveMaxK(kWaveRowsLarge);  // 768: what the wave-cooperative search's widest candidate buffer serves
+    if (filtered && photon && ctx->k_nearest > kWaveKMax)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "reconstruction filters on photon-mapped frames need k_nearest_photons <= 768 (wavefront pipeline)");
     const bool want_wf = filtered || (kenv && strcmp(kenv, "wf") == 0) || ctx->force_wf;
     // measured: the pipeline wins on deep trees (metal_bunnies 169 k nodes +28 %, spaceship with hulls 154 k
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
@@ -800,7 +802,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
     // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
     // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
-    if (photon && has_tree && ctx->k_nearest <= 128 && want_wf)
+    if (photon && has_tree && ctx->k_nearest <= kWaveKMax && want_wf)
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true, film_out);
     // workgroup size of the state-machine kernel for trees that stay in HBM (MCRT_SM_BLOCK: 512 / 768 / 1024 lanes) and the
     // stack entries per lane it keeps in LDS (MCRT_SM_STACK; the rest of a lane's stack is in the HBM spill area)
@@ -819,8 +821,19 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         if (ctxOpt(ctx, "MCRT_SM_STACK")) sm_depth = std::min(std::max((int)ctxOptL(ctx, "MCRT_SM_STACK", 0), 2), (int)kLdsStackDepth);
     }
 
-    // photon mapping: wave-cooperative estimates unless k is too large for the per-wave buffer
-    const bool use_pm_wave = photon && ctx->k_nearest <= 128 && !(kenv && strcmp(kenv, "legacy") == 0);
+    // photon mapping: wave-cooperative estimates unless k is too large for the widest per-wave buffer (k <= 128: 256 candidates per
+    // wave; k <= 768: 1024 candidates per wave, 512 lanes per workgroup)
+    bool use_pm_wave = photon && ctx->k_nearest <= kWaveKMax && !(kenv && strcmp(kenv, "legacy") == 0);
+    const bool pm_large_k = use_pm_wave && ctx->k_nearest > waveMaxK(kWaveRows);
+    if (pm_large_k) {
+        // the wide buffers take 100 KB of a 512-lane workgroup's LDS: a BVH staged whole with its 16 stack entries per lane may not
+        // leave that (a tree in HBM keeps as few as 2 entries per lane in LDS, a flat scene has no stack) - then the per-lane kernel
+        DeviceScene probe = ctx->scene;
+        if (!probe.stage_all) probe.stage_nodes = std::min<uint32_t>(probe.stage_nodes, 128u);
+        const uint32_t least = alignUp(planLds(probe, kBlock, true, probe.stage_all ? (uint32_t)kLdsStackDepth : 2u, (uint32_t)kMaxIors).total, 16) +
+                               (kBlock / 64) * waveKnnBytes(kWaveRowsLarge);
+        if (least > ctx->max_lds) use_pm_wave = false;
+    }
     using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
     PmKernelT pm_kernel = nullptr;
     DeviceScene launch_scene = ctx->scene;
@@ -836,12 +849,23 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         // 1024 lanes per workgroup (4 waves per SIMD) when the LDS plan allows it: flat scenes have no traversal stack; a tree in
         // HBM is walked with the state machine's stack, of which then only a few entries per lane stay in LDS (the rest
         // spills to HBM); a staged BVH walked by the wave-synchronous code needs its 16 entries (512 lanes).
-        const int want = (int)ctxOptL(ctx, "MCRT_PM_BLOCK", 1024);
+        static const PmKernelT pm_table_large[2][2] = {{renderKernelPM<false, false, (int)kBlock, kWaveRowsLarge>, renderKernelPM<false, true, (int)kBlock, kWaveRowsLarge>},
+                                                       {renderKernelPM<true, false, (int)kBlock, kWaveRowsLarge>, renderKernelPM<true, true, (int)kBlock, kWaveRowsLarge>}};
+        const int want = pm_large_k ? (int)kBlock : (int)ctxOptL(ctx, "MCRT_PM_BLOCK", 1024);
+        const uint32_t knn_bytes = waveKnnBytes(pm_large_k ? kWaveRowsLarge : kWaveRows);
         g.block = kBlock;
         // (the 1024-lane instance keeps two refraction-history entries per lane in LDS, the deeper ones in global memory)
         auto ldsBytes = [&](uint32_t block, uint32_t depth) {
-            return alignUp(planLds(launch_scene, block, true, depth, block != 1024u ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) + (block / 64) * kWaveKnnBytes;
+            return alignUp(planLds(launch_scene, block, true, depth, block != 1024u ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) + (block / 64) * knn_bytes;
         };
+        if (pm_large_k && !launch_scene.stage_all) {
+            pm_stack_depth = 2;
+            for (uint32_t depth = 16u; depth > 2u; depth -= 2)
+                if (ldsBytes(kBlock, depth) <= ctx->max_lds) {
+                    pm_stack_depth = depth;
+                    break;
+                }
+        }
         if (want == 1024) {
             if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= ctx->max_lds) {
                 g.block = 1024;
@@ -854,7 +878,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
                     }
             }
         }
-        pm_kernel = pm_table[g.block == 1024 ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
+        pm_kernel = pm_large_k ? pm_table_large[count_tests ? 1 : 0][all ? 1 : 0] : pm_table[g.block == 1024 ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
         g.lds_bytes = ldsBytes(g.block, pm_stack_depth);
         if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
@@ -1467,7 +1491,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         // are chosen for, and correct. (The reference's vector is unbounded; no scene of it nests deeper than 4.)
         const bool was_pipeline = ctx->kernel_id == MCRT_KERNEL_WAVEFRONT || ctx->kernel_id == MCRT_KERNEL_WAVEFRONT_PM;
         const bool photon = ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER;
-        if (!was_pipeline && !ctx->force_wf && ctx->scene.q_nodes > 0 && (!photon || ctx->k_nearest <= 128)) {
+        if (!was_pipeline && !ctx->force_wf && ctx->scene.q_nodes > 0 && (!photon || ctx->k_nearest <= waveMaxK(kWaveRowsLarge))) {
             ctx->force_wf = true;
             const int rc = launchRender(ctx, &ctx->last_cam, ctx->last_seed, ctx->last_integrator, ctx->last_out, ctx->last_stream, ctx->last_film);
             ctx->force_wf = false;
@@ -1912,7 +1936,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
     if (!p || !out_count || !out_index || !out_distance2) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const char* kenv = ctxOpt(ctx, "MCRT_KERNEL");
-    if (k <= 128 && !(kenv && strcmp(kenv, "legacy") == 0)) {  // wave-cooperative search (mcrt_waveknn.hpp)
+    if (k <= waveMaxK(kWaveRowsLarge) && !(kenv && strcmp(kenv, "legacy") == 0)) {  // wave-cooperative search (mcrt_waveknn.hpp)
         DevBuf &dp = ctx->op_buf[0], &dc = ctx->op_buf[1], &di = ctx->op_buf[2], &dd = ctx->op_buf[3], &flags = ctx->op_buf[4];
         if (int rc = uploadInto(ctx, dp, p, n * 3)) return rc;
         HIP_TRY(ctx, dc.reserve(n * 4));
@@ -1931,8 +1955,8 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
             hipLaunchKernelGGL(knnGroupKernel, dim3(std::min<uint32_t>(grid, (uint32_t)((n + 15) / 16))), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k,
                                dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
         else
-            hipLaunchKernelGGL(knnWaveKernel, dim3(grid), dim3(256), 0, ctx->stream, mv, n, dp.as<double>(), k, dc.as<uint32_t>(),
-                               di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
+            hipLaunchKernelGGL((k > waveMaxK(kWaveRows) ? knnWaveKernel<kWaveRowsLarge> : knnWaveKernel<kWaveRows>), dim3(grid), dim3(256), 0, ctx->stream, mv, n,
+                               dp.as<double>(), k, dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1675,15 +1675,15 @@ struct WfKnnArgs {
 // kEval: the launch evaluates the estimate itself — the k photons' BSDF terms by k lanes at once, a wave reduction
 // (waveEvalPhotons, as in renderKernelPM) — from the Interaction the shade launch staged, instead of handing the k photons
 // back for a per-lane loop in the next shade launch (2 x k x 12 B per slot written and read, k divergent BSDF evaluations).
-template <bool kEval>
+template <bool kEval, int R = kWaveRows>
 __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
-    __shared__ double s_d2[4 * kWaveCand];
-    __shared__ uint32_t s_idx[4 * kWaveCand];
+    __shared__ double s_d2[4 * waveCand(R)];
+    __shared__ uint32_t s_idx[4 * waveCand(R)];
     __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
-    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
-    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
+    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
     W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
     const unsigned long long n = *a.count;
     const uint32_t slots = a.pool.n;
@@ -1699,7 +1699,7 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
         const d3 p = a.pool.get3(kWfRayO, slot) + a.pool.get3(kWfRayD, slot) * a.pool.getd(kWfHit0T, slot);
         for (int map = 1; map >= ((req >> 31) ? 0 : 1); map--) {  // caustic map always, global map on request
             double r2;
-            const uint32_t c = waveKnnSearch(a.maps[map], p, a.k, W, r2, overflow, visits);
+            const uint32_t c = waveKnnSearch<R>(a.maps[map], p, a.k, W, r2, overflow, visits);
             searches++;
             if constexpr (kEval) {
                 d3 sum = splat(0.0);
@@ -1852,7 +1852,7 @@ struct PmExtra {
 // cycles inside the radiance estimates (measured, hexagon_room maps), whose throughput follows the resident waves
 // (knnWaveKernel alone: 61 / 112 / 172 / 188 M searches/s at 1 / 2 / 4 / 5 waves per SIMD) — the spills the narrow
 // register budget causes in the per-lane path code do not matter next to that.
-template <bool kCount, bool kAll, int kLanes = (int)kBlock>
+template <bool kCount, bool kAll, int kLanes = (int)kBlock, int R = kWaveRows>
 __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
     extern __shared__ __align__(16) unsigned char lds[];
     SceneViewT<kAll> sv;
@@ -1877,9 +1877,9 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
     {
         const uint32_t base = alignUp(planLds(scene, blockDim.x, true, pmx.stack_depth, pmx.iors_global ? kPmLdsIors : (uint32_t)kMaxIors).total, 16);
         const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-        W.d2 = ldsAt<double>(lds, base) + wave * kWaveCand;
-        W.idx = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 8u) + wave * kWaveCand;
-        W.hist = ldsAt<uint32_t>(lds, base + waves * kWaveCand * 12u) + wave * kWaveHist;
+        W.d2 = ldsAt<double>(lds, base) + wave * waveCand(R);
+        W.idx = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 8u) + wave * waveCand(R);
+        W.hist = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 12u) + wave * kWaveHist;
     }
 
     double* const stage_lane = pmx.stage + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStageDoubles;
@@ -1959,9 +1959,9 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         const unsigned long long t_est = kCount ? clock64() : 0ull;
         if (needC) stageInteraction(stage_lane, ia);  // needG implies needC
         __threadfence_block();                        // the records are read by the other lanes of the wave
-        const d3 C = waveEstimate<kAll>(needC, stage_wave, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
+        const d3 C = waveEstimate<kAll, R>(needC, stage_wave, pmx.caustic_map, prm.k_nearest, true, W, searches, octant_visits, knn_overflow);
         if (needC) st.radiance = st.radiance + C * st.throughput;
-        const d3 G = waveEstimate<kAll>(needG, stage_wave, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
+        const d3 G = waveEstimate<kAll, R>(needG, stage_wave, pmx.global_map, prm.k_nearest, false, W, searches, octant_visits, knn_overflow);
         if (needG) {
             st.radiance = st.radiance + G * st.throughput;  // :330, the path ends here
             ended = true;
@@ -2013,23 +2013,24 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
 }
 
 // LinearOctree::knnSearch operator: one query at a time per wave
+template <int R = kWaveRows>
 __global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
                                                      uint32_t* out_index, double* out_d2, unsigned long long* flags) {
-    __shared__ double s_d2[4 * kWaveCand];
-    __shared__ uint32_t s_idx[4 * kWaveCand];
+    __shared__ double s_d2[4 * waveCand(R)];
+    __shared__ uint32_t s_idx[4 * waveCand(R)];
     __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
-    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * kWaveCand;
-    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * kWaveCand;
+    W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
+    W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
     W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
     const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t overflow = 0, visits = 0;
     for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {
         const d3 pt = ld3(p + 3 * q);
         double r2;
-        const uint32_t c = waveKnnSearch(map, pt, k, W, r2, overflow, visits);
-        waveSortResult(W, c);
+        const uint32_t c = waveKnnSearch<R>(map, pt, k, W, r2, overflow, visits);
+        waveSortResult<(R <= 4 ? 2 : R - 4)>(W, c);
         if (lane == 0) out_count[q] = c;
         for (uint32_t j = lane; j < k; j += 64) {
             out_index[q * k + j] = j < c ? W.idx[j] : 0xFFFFFFFFu;

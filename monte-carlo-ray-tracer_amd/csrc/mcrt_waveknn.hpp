@@ -29,14 +29,21 @@
 
 namespace mcrt {
 
-constexpr uint32_t kWaveCand = 256;   // candidate buffer entries per wave (prune when > kWaveCand - 64)
+// The candidate buffer of a wave holds R rows of 64 entries (template parameter of everything below that keeps the buffer in
+// registers row by row). R = 4 serves k <= 128 — every scene of the reference asks for 50; R = 16 serves k <= 768 (round 4: larger k
+// used to fall to the per-lane legacy kernel); only beyond that does the per-lane kernel still run.
+constexpr int kWaveRows = 4, kWaveRowsLarge = 16;
+__host__ __device__ constexpr uint32_t waveCand(int R) { return 64u * (uint32_t)R; }  // entries per wave (pruned when > waveCand - 64)
+__host__ __device__ constexpr uint32_t waveMaxK(int R) { return R <= 4 ? 128u : waveCand(R) - 256u; }
+constexpr uint32_t kWaveCand = waveCand(kWaveRows);
 
 constexpr uint32_t kWaveHist = 128;   // bins of the per-wave distance histogram (see "Selection by histogram")
-constexpr uint32_t kWaveKnnBytes = kWaveCand * 12u + kWaveHist * 4u;  // LDS per wave: candidates + histogram
+__host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHist * 4u; }  // LDS per wave: candidates + histogram
+constexpr uint32_t kWaveKnnBytes = waveKnnBytes(kWaveRows);
 
 struct WaveKnnLds {
-    MCRT_LDS_AS double* d2;      // [kWaveCand] this wave's candidate distances
-    MCRT_LDS_AS uint32_t* idx;   // [kWaveCand] photon indices
+    MCRT_LDS_AS double* d2;      // [waveCand(R)] this wave's candidate distances
+    MCRT_LDS_AS uint32_t* idx;   // [waveCand(R)] photon indices
     MCRT_LDS_AS uint32_t* hist;  // [kWaveHist] candidates per distance2 bin
 };
 
@@ -156,13 +163,14 @@ __device__ inline uint32_t waveRead(uint32_t v, int src) { return (uint32_t)__bu
 // popcount) instead of an all-pairs ranking. Entries equal to the k-th key are kept in buffer order
 // until k are reached (the reference resolves such ties by insertion order, linear-octree.cpp:58-77).
 // All lanes must call.
+template <int R = kWaveRows>
 __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
     const uint32_t lane = __lane_id();
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
-    unsigned long long key[4];
-    uint32_t my_i[4];
-    bool valid[4];
-    for (int s = 0; s < 4; s++) {
+    unsigned long long key[R];
+    uint32_t my_i[R];
+    bool valid[R];
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         const uint32_t j = lane + 64u * s;
         valid[s] = j < count;
         union { double d; unsigned long long u; } c;
@@ -172,7 +180,7 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
     }
     if (count <= k) {  // nothing to drop: only the largest distance is needed
         double mx = 0.0;
-        for (int s = 0; s < 4; s++) {
+        _Pragma("unroll") for (int s = 0; s < R; s++) {
             union { double d; unsigned long long u; } c;
             c.u = key[s];
             if (valid[s] && c.d > mx) mx = c.d;
@@ -185,15 +193,15 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
     for (int bit = 62; bit >= 0; bit--) {  // bit 63 (sign) is clear in every key
         const unsigned long long trial = T | ((1ull << bit) - 1ull);  // all candidates with this bit clear
         uint32_t n_le = 0;
-        for (int s = 0; s < 4; s++)
+        _Pragma("unroll") for (int s = 0; s < R; s++)
             if (s < rows) n_le += __popcll(waveBallot(valid[s] && key[s] <= trial));
         if (n_le < k) T |= (1ull << bit);
     }
     uint32_t n_lt = 0;
-    for (int s = 0; s < 4; s++) n_lt += __popcll(waveBallot(valid[s] && key[s] < T));
+    _Pragma("unroll") for (int s = 0; s < R; s++) n_lt += __popcll(waveBallot(valid[s] && key[s] < T));
     // compaction: everything below T, then entries equal to T until k are kept
     uint32_t out = 0, eq_left = k - n_lt;
-    for (int s = 0; s < 4; s++) {
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         const bool lt = valid[s] && key[s] < T;
         const bool eq = valid[s] && key[s] == T;
         const unsigned long long m_lt = waveBallot(lt), m_eq = waveBallot(eq);
@@ -225,11 +233,12 @@ __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint
 // selection runs once, at the end of the search. Returns the new count; all lanes must call.
 constexpr int kCoarseBits = 20;
 // `slack`: the search for the bits stops as soon as a prefix keeps between k and k + slack entries.
+template <int R = kWaveRows>
 __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2, uint32_t slack = 0) {
     const uint32_t lane = __lane_id();
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
-    uint32_t hi[4], lo[4], my_i[4];
-    for (int s = 0; s < 4; s++) {
+    uint32_t hi[R], lo[R], my_i[R];
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         const uint32_t j = lane + 64u * s;
         const bool valid = j < count;
         union { double d; uint32_t u[2]; } c;
@@ -246,7 +255,7 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
     for (int bit = 30; bit >= 32 - kCoarseBits; bit--) {  // bit 31 of the high word (the sign) is clear in every key
         const uint32_t trial = Th | ((1u << bit) - 1u);
         uint32_t n_le = 0;
-        for (int s = 0; s < 4; s++)
+        _Pragma("unroll") for (int s = 0; s < R; s++)
             if (s < rows) n_le += __popcll(waveBallot(hi[s] <= trial));
         if (n_le < k) {
             Th |= (1u << bit);
@@ -259,7 +268,7 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
     // (two bits per step — three trial values counted side by side, half the dependent steps — measured slower: 196 -> 180 M/s)
     if (!settled) Th |= (1u << (32 - kCoarseBits)) - 1u;
     uint32_t out = 0;
-    for (int s = 0; s < 4; s++) {
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         const bool keep = hi[s] <= Th;  // (an invalid entry's high word is above every Th: bit 31 of Th is clear)
         const unsigned long long m_keep = waveBallot(keep);
         if (keep) {
@@ -319,12 +328,13 @@ __device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint
     return n;
 }
 
-// Sort the first n (<= 64 per pass) result entries ascending by (distance2, index) in place (n <= 128).
+// Sort the first n result entries ascending by (distance2, index) in place (n <= 64 S).
+template <int S = 2>
 __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
     const uint32_t lane = __lane_id();
-    double my_d[2];
-    uint32_t my_i[2], rank[2];
-    for (int s = 0; s < 2; s++) {
+    double my_d[S];
+    uint32_t my_i[S], rank[S];
+    _Pragma("unroll") for (int s = 0; s < S; s++) {
         const uint32_t j = lane + 64u * s;
         my_d[s] = j < n ? W.d2[j] : INFINITY;
         my_i[s] = j < n ? W.idx[j] : 0xFFFFFFFFu;
@@ -333,9 +343,9 @@ __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
         const double d = W.d2[i];
         const uint32_t id = W.idx[i];
-        for (int s = 0; s < 2; s++) rank[s] += (d < my_d[s] || (d == my_d[s] && id < my_i[s])) ? 1u : 0u;
+        _Pragma("unroll") for (int s = 0; s < S; s++) rank[s] += (d < my_d[s] || (d == my_d[s] && id < my_i[s])) ? 1u : 0u;
     }
-    for (int s = 0; s < 2; s++) {
+    _Pragma("unroll") for (int s = 0; s < S; s++) {
         const uint32_t j = lane + 64u * s;
         if (j < n) {
             W.d2[rank[s]] = my_d[s];
@@ -408,6 +418,7 @@ __device__ inline bool histKthBin(const WaveKnnLds& W, uint32_t k, uint32_t& bin
 // (k - below) smallest (the largest is dropped until that many are left — among equal keys the one latest in the buffer
 // first). Result compacted into slots [0, k); kth_d2 = the largest distance kept. Falls back (returns 0) when the
 // boundary bin holds too many candidates for that (the caller then runs the general selection). All lanes must call.
+template <int R = kWaveRows>
 __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, uint32_t count, uint32_t k, double& kth_d2) {
     const uint32_t lane = __lane_id();
     uint32_t bin, below, upto;
@@ -416,10 +427,10 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
     if (have > 64u || have - need > 6u) return 0u;
     const int rows = (int)((count + 63u) / 64u);
     // pass 1: entries of lower bins keep their relative order at the front; boundary entries are gathered in registers (one per lane)
-    double keep_d[4];
-    uint32_t keep_i[4];
-    bool low[4], edge[4];
-    for (int s = 0; s < 4; s++) {
+    double keep_d[R];
+    uint32_t keep_i[R];
+    bool low[R], edge[R];
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         const uint32_t j = lane + 64u * s;
         const bool valid = s < rows && j < count;
         keep_d[s] = valid ? W.d2[j] : 0.0;
@@ -431,7 +442,7 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
     // boundary entries -> lanes 0 .. have-1 (in buffer order) through LDS slots [kWaveCand - 64, kWaveCand) ... they may still hold
     // live entries, so use registers + a staging pass: first write the low entries, then stage the boundary ones behind them
     uint32_t out = 0;
-    for (int s = 0; s < 4; s++) {
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         if (s >= rows) break;
         const unsigned long long m = waveBallot(low[s]);
         if (low[s]) {
@@ -442,7 +453,7 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
         out += __popcll(m);
     }
     uint32_t eout = 0;
-    for (int s = 0; s < 4; s++) {
+    _Pragma("unroll") for (int s = 0; s < R; s++) {
         if (s >= rows) break;
         const unsigned long long m = waveBallot(edge[s]);
         if (edge[s]) {
@@ -500,6 +511,7 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
 // `bound2`: an upper bound of the k-th nearest photon's squared distance known beforehand (kDblMax: none). The search then
 // starts pruning where it would otherwise arrive after its first scans; the k-set is the same (every one of the k nearest
 // lies within ANY upper bound, and all comparisons against the bound are inclusive).
+template <int R = kWaveRows>
 __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
                                          uint32_t& overflow, uint32_t& octant_visits, double bound2 = kDblMax) {
     r2_max = 0.0;
@@ -558,10 +570,10 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         }
                         count += __popcll(mask);
                         dirty = true;
-                        if (count > kWaveCand - 64u) {  // make room: drop what cannot be among the k nearest
+                        if (count > waveCand(R) - 64u) {  // make room: drop what cannot be among the k nearest
                             double bound;
-                            count = waveSelectBound(W, count, k, bound, 4u);
-                            if (count > kWaveCand - 64u) count = waveSelectK(W, count, k, bound);  // a crowd inside 0.4 %
+                            count = waveSelectBound<R>(W, count, k, bound, 4u);
+                            if (count > waveCand(R) - 64u) count = waveSelectK<R>(W, count, k, bound);  // a crowd inside 0.4 %
                             dirty = false;
                             bounded = true;
                             max_distance2 = gmin(max_distance2, bound);
@@ -591,7 +603,7 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                 }
             } else if (dirty && count >= k && !bounded) {
                 double bound;
-                count = waveSelectBound(W, count, k, bound, 4u);
+                count = waveSelectBound<R>(W, count, k, bound, 4u);
                 dirty = false;
                 bounded = true;
                 max_distance2 = gmin(max_distance2, bound);
@@ -668,14 +680,14 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     // exact selection, once: shrink to the entries that can still matter (k of them plus the few that share the k-th key's
     // leading bits), then drop the largest until k are left — instead of a 63-step search for the exact k-th key
     if (H.on && count > k) {
-        const uint32_t n = histSelectK(W, H, count, k, r2_max);
+        const uint32_t n = histSelectK<R>(W, H, count, k, r2_max);
         if (n) return n;
     }
     if (count > k) {
         double bound;
-        count = waveSelectBound(W, count, k, bound, 2u);
+        count = waveSelectBound<R>(W, count, k, bound, 2u);
     }
-    if (count > 64u || count > k + 4u) return waveSelectK(W, count, k, r2_max);  // a crowd at the k-th distance: the general selection
+    if (count > 64u || count > k + 4u) return waveSelectK<R>(W, count, k, r2_max);  // a crowd at the k-th distance: the general selection
     return waveTrimToK(W, count, k, r2_max);
 }
 
@@ -774,7 +786,7 @@ __device__ inline d3 waveEvalPhotons(const InteractionT<L>& q, const PhotonMapVi
 // The radiance estimate for every lane of the wave that asks for one (`want`), served one query at a time by the whole
 // wave from the staged records (`stage_wave` = the record of the wave's lane 0; every asking lane has called stageInteraction
 // and the stores are visible: __threadfence_block() in between). Returns the estimate to the asking lane (zero elsewhere).
-template <bool L>
+template <bool L, int R = kWaveRows>
 __device__ inline d3 waveEstimate(bool want, double* stage_wave, const PhotonMapViewW& map, uint32_t k, bool caustic,
                                   const WaveKnnLds& W, uint32_t& searches, uint32_t& octant_visits, uint32_t& overflow) {
     const uint32_t lane = __lane_id();
@@ -792,7 +804,7 @@ __device__ inline d3 waveEstimate(bool want, double* stage_wave, const PhotonMap
         const double2 p01 = reinterpret_cast<const double2*>(rec)[0];
         const d3 qpos = d3{uniformD(p01.x), uniformD(p01.y), uniformD(rec[2])};
         double r2 = 0.0;
-        const uint32_t n = waveKnnSearch(map, qpos, k, W, r2, overflow, octant_visits);
+        const uint32_t n = waveKnnSearch<R>(map, qpos, k, W, r2, overflow, octant_visits);
         d3 sum = splat(0.0);
         if (n) {  // else photons.empty(): the estimate is zero (photon-mapper.cpp:347, :374)
             InteractionT<L> q;

@@ -50,7 +50,7 @@ def _ref(x):
     return C.byref(x) if x is not None else None
 
 
-def render(image, cam, seed, integrator, rows=None, threads=0, per_sample=False):
+def render(image, cam, seed, integrator, rows=None, threads=0, per_sample=False, k=None):
     """image: SceneImage of the product binding (only its host descriptors are used).
     Returns (rgb[rows,W,3], info dict with counters and seconds)."""
     L = lib()
@@ -59,7 +59,7 @@ def render(image, cam, seed, integrator, rows=None, threads=0, per_sample=False)
     samples = np.zeros((r1 - r0, cam.width, cam.sqrtspp ** 2, 3)) if per_sample else None
     cnt, sec = Counters(), C.c_double()
     g, c = image.photons(0), image.photons(1)
-    rc = L.oracle_render(C.byref(image.scene), _ref(g), _ref(c), image.param("k_nearest_photons") or 50,
+    rc = L.oracle_render(C.byref(image.scene), _ref(g), _ref(c), int(k or image.param("k_nearest_photons") or 50),
                          int(image.param("direct_visualization")), C.byref(cam), int(seed), int(integrator), r0, r1,
                          int(threads), out.ctypes.data, samples.ctypes.data if per_sample else None, C.byref(cnt), C.byref(sec))
     if rc != 0:
