@@ -186,7 +186,7 @@ enum {
     MCRT_KERNEL_LANE_SM = 3,       /* renderKernelSM: per-lane state machine megakernel                               */
     MCRT_KERNEL_WAVEFRONT = 4,     /* wfShadeKernel + wfTraceKernel over the slot pool                               */
     MCRT_KERNEL_PM_WAVE = 5,       /* renderKernelPM: photon mapper, wave-cooperative kNN estimates                  */
-    MCRT_KERNEL_PM_LANE = 6,       /* renderKernel<photon mapper>: per-lane kNN (k > 128, MCRT_KERNEL=legacy)        */
+    MCRT_KERNEL_PM_LANE = 6,       /* renderKernel<photon mapper>: per-lane kNN (k > 768, MCRT_KERNEL=legacy)        */
     MCRT_KERNEL_WAVEFRONT_PM = 7   /* wavefront pipeline with kNN launches (MCRT_KERNEL=wf, photon-mapped frames)    */
 };
 

@@ -92,6 +92,7 @@ struct mcrt_ctx {
 
     bool has_photons = false;
     PhotonMapView maps[2]{};
+    DevBuf knn_spill;  // frontier spill lists of the wave-cooperative searches (mcrt_waveknn.hpp)
     DevBuf map_bounds[2], map_start[2], map_contained[2], map_next[2], map_leaf[2], map_photons[2], map_children[2], map_pos[2];
     const WideRec* map_children_ptr[2] = {nullptr, nullptr};
     uint32_t map_root_a[2] = {0, 0}, map_root_m[2] = {0, 0};
@@ -603,6 +604,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         ka.stage = knn_eval ? ctx->wf_stage.as<double>() : nullptr;
         ka.est = knn_eval ? ctx->wf_est.as<double>() : nullptr;
         knn_grid = (uint32_t)ctx->num_cus * 8u;
+        HIP_TRY(ctx, ctx->knn_spill.reserve((size_t)knn_grid * 4 * kWaveSpill * 12));
+        ka.spill = ctx->knn_spill.as<uint32_t>();
         WfShadeArgs& s0 = sa[0];
         s0.requests = ctx->wf_requests.as<uint32_t>();
         s0.rpop_reset = ctrl + 6;
@@ -796,7 +799,13 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // nodes +7 %), the megakernel on small ones (spaceship cockpit 23 k nodes: 1352 vs 940 Mray/s)
     const char* mn = ctxOpt(ctx, "MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
-    if (!photon && has_tree && (want_wf || (use_sm && !all && !kenv && ctx->scene.num_nodes >= wf_min_nodes)))
+    // ... and, since round 4's trace kernel, on ANY tree in memory once the frame is large enough to amortise the pipeline's launches
+    // (spaceship cockpit, 23 k nodes, 1080p, ms per frame megakernel / pipeline: 2 M paths 9.3 / 34.6, 8 M 24.3 / 46.2, 33 M 80.9 /
+    // 85.0, 133 M 311 / 231): MCRT_WF_MIN_PATHS path samples in this call's rows, default 40 M
+    const char* mp = ctxOpt(ctx, "MCRT_WF_MIN_PATHS");
+    const uint64_t wf_min_paths = mp ? strtoull(mp, nullptr, 0) : 40000000ull;
+    const uint64_t frame_paths = (uint64_t)mcrt_shard_rows(cam, nullptr) * cam->width * cam->sqrtspp * cam->sqrtspp;
+    if (!photon && has_tree && (want_wf || (use_sm && !all && !kenv && (ctx->scene.num_nodes >= wf_min_nodes || frame_paths >= wf_min_paths))))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false, film_out);
     // photon-mapped frames go through the pipeline (trace / kNN / shade launches) on request only: measured slower than
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
@@ -830,7 +839,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         // leave that (a tree in HBM keeps as few as 2 entries per lane in LDS, a flat scene has no stack) - then the per-lane kernel
         DeviceScene probe = ctx->scene;
         if (!probe.stage_all) probe.stage_nodes = std::min<uint32_t>(probe.stage_nodes, 128u);
-        const uint32_t least = alignUp(planLds(probe, kBlock, true, probe.stage_all ? (uint32_t)kLdsStackDepth : 2u, (uint32_t)kMaxIors).total, 16) +
+        const uint32_t least = alignUp(planLds(probe, kBlock, true, probe.stage_all ? (uint32_t)kLdsStackDepth : 2u, kPmLdsIors).total, 16) +
                                (kBlock / 64) * waveKnnBytes(kWaveRowsLarge);
         if (least > ctx->max_lds) use_pm_wave = false;
     }
@@ -856,7 +865,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         g.block = kBlock;
         // (the 1024-lane instance keeps two refraction-history entries per lane in LDS, the deeper ones in global memory)
         auto ldsBytes = [&](uint32_t block, uint32_t depth) {
-            return alignUp(planLds(launch_scene, block, true, depth, block != 1024u ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) + (block / 64) * knn_bytes;
+            return alignUp(planLds(launch_scene, block, true, depth, (block != 1024u && !pm_large_k) ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) + (block / 64) * knn_bytes;
         };
         if (pm_large_k && !launch_scene.stage_all) {
             pm_stack_depth = 2;
@@ -977,7 +986,9 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
             pmx.iors_global = nullptr;
             HIP_TRY(ctx, ctx->pm_stage.reserve((size_t)kStageDoubles * g.total_lanes * sizeof(double)));
             pmx.stage = ctx->pm_stage.as<double>();
-            if (g.block == 1024u) {
+            HIP_TRY(ctx, ctx->knn_spill.reserve((size_t)(g.total_lanes / 64) * kWaveSpill * 12));
+            pmx.knn_spill = ctx->knn_spill.as<uint32_t>();
+            if (g.block == 1024u || pm_large_k) {  // (two refraction-history entries per lane in LDS, the deeper ones in memory)
                 HIP_TRY(ctx, ctx->pm_iors.reserve((size_t)kMaxIors * g.total_lanes * sizeof(double)));
                 pmx.iors_global = ctx->pm_iors.as<double>();
             }
@@ -1482,8 +1493,8 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
     }
     if (h[5])
         return fail(ctx, MCRT_ERR_UNSUPPORTED, ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER
-                                                   ? "kNN frontier overflow: the wave search keeps 128 pending octants, a photon octree whose leaves hold far fewer photons than "
-                                                     "k_nearest_photons can need more (or, internal error, a traversal stack overflowed: they are sized to the tree's own bound)"
+                                                   ? "kNN frontier overflow: a search had more than 128 + 1024 octants pending at once (registers + the wave's list in memory); a photon "
+                                                     "octree whose leaves hold far fewer photons than k_nearest_photons can do that (or, internal error, a traversal stack overflowed)"
                                                    : "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
         // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
@@ -1945,6 +1956,7 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         HIP_TRY(ctx, flags.reserve(8));
         HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 8, ctx->stream));
         const PhotonMapViewW mv = waveMapView(ctx, which);
+        HIP_TRY(ctx, ctx->knn_spill.reserve((size_t)ctx->num_cus * std::max(1, (int)ctxOptL(ctx, "MCRT_KNN_BLOCKS", 8)) * 4 * kWaveSpill * 12));
         // MCRT_KNN_BLOCKS: 256-lane workgroups per CU (occupancy experiments); MCRT_KNN_TIME=1: kernel time on stderr
         const int per_cu = std::max(1, (int)ctxOptL(ctx, "MCRT_KNN_BLOCKS", 8));
         const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu, (n + 3) / 4);
@@ -1956,7 +1968,8 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
                                dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
         else
             hipLaunchKernelGGL((k > waveMaxK(kWaveRows) ? knnWaveKernel<kWaveRowsLarge> : knnWaveKernel<kWaveRows>), dim3(grid), dim3(256), 0, ctx->stream, mv, n,
-                               dp.as<double>(), k, dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>());
+                               dp.as<double>(), k, dc.as<uint32_t>(), di.as<uint32_t>(), dd.as<double>(), flags.as<unsigned long long>(),
+                               ctx->knn_spill.as<uint32_t>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1670,6 +1670,7 @@ struct WfKnnArgs {
     double* res_d2;
     const double* stage;  // [slots][kStageDoubles] the requests' Interactions (written by the shade launch); null: write the photons out
     double* est;          // [slots][6] the estimates, caustic rgb then global rgb
+    uint32_t* spill;      // [waves][kWaveSpill][3] frontier entries beyond the registers' (mcrt_waveknn.hpp)
 };
 
 // kEval: the launch evaluates the estimate itself — the k photons' BSDF terms by k lanes at once, a wave reduction
@@ -1679,12 +1680,13 @@ template <bool kEval, int R = kWaveRows>
 __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     __shared__ double s_d2[4 * waveCand(R)];
     __shared__ uint32_t s_idx[4 * waveCand(R)];
-    __shared__ uint32_t s_hist[4 * kWaveHist];
+    __shared__ uint32_t s_hist[4 * kWaveHistWords];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
-    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHistWords;
+    waveKnnInit(W, a.spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill));
     const unsigned long long n = *a.count;
     const uint32_t slots = a.pool.n;
     uint32_t overflow = 0, visits = 0, searches = 0;
@@ -1846,6 +1848,7 @@ struct PmExtra {
     uint32_t stack_depth;  // traversal-stack entries per lane kept in LDS (tree in HBM: the state machine's stack, any depth; else kLdsStackDepth)
     double* iors_global;   // refraction-history entries beyond the first kPmLdsIors, [kMaxIors - kPmLdsIors][lanes] (1024-lane instance), or null: all in LDS
     double* stage;         // estimate requests, [lanes][kStageDoubles]: what Interaction::BSDF reads of a lane's Interaction (mcrt_waveknn.hpp)
+    uint32_t* knn_spill;   // [waves][kWaveSpill][3]: the searches' frontier entries beyond the registers' 128 (mcrt_waveknn.hpp)
 };
 
 // kLanes: 512 (2 waves per SIMD, 256 VGPRs) or 1024 (4 waves per SIMD, 128 VGPRs). The kernel spends 97.6 % of its wave
@@ -1879,7 +1882,8 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
         W.d2 = ldsAt<double>(lds, base) + wave * waveCand(R);
         W.idx = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 8u) + wave * waveCand(R);
-        W.hist = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 12u) + wave * kWaveHist;
+        W.hist = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 12u) + wave * kWaveHistWords;
+        waveKnnInit(W, pmx.knn_spill + ((size_t)blockIdx.x * waves + wave) * (3u * kWaveSpill));
     }
 
     double* const stage_lane = pmx.stage + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStageDoubles;
@@ -2015,15 +2019,16 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
 // LinearOctree::knnSearch operator: one query at a time per wave
 template <int R = kWaveRows>
 __global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
-                                                     uint32_t* out_index, double* out_d2, unsigned long long* flags) {
+                                                     uint32_t* out_index, double* out_d2, unsigned long long* flags, uint32_t* spill) {
     __shared__ double s_d2[4 * waveCand(R)];
     __shared__ uint32_t s_idx[4 * waveCand(R)];
-    __shared__ uint32_t s_hist[4 * kWaveHist];
+    __shared__ uint32_t s_hist[4 * kWaveHistWords];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
-    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHistWords;
+    waveKnnInit(W, spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill));
     const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t overflow = 0, visits = 0;
     for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {
@@ -2099,6 +2104,7 @@ __global__ void __launch_bounds__(256) knnGroupKernel(const PhotonMapViewW map, 
             const uint64_t qq = q0 + ((uint32_t)src >> 4);
             const d3 qp = waveShfl3(pt, src);
             double rr;
+            waveKnnInit(W, nullptr);  // (the rows' buffers overlay the wave search's: no spill list here, and its state words are theirs)
             const uint32_t cc = waveKnnSearch(map, qp, k, W, rr, overflow, visits);
             waveSortResult(W, cc);
             if (lane == 0) out_count[qq] = cc;

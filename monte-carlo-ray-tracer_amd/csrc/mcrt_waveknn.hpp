@@ -38,14 +38,61 @@ __host__ __device__ constexpr uint32_t waveMaxK(int R) { return R <= 4 ? 128u : 
 constexpr uint32_t kWaveCand = waveCand(kWaveRows);
 
 constexpr uint32_t kWaveHist = 128;   // bins of the per-wave distance histogram (see "Selection by histogram")
-__host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHist * 4u; }  // LDS per wave: candidates + histogram
+constexpr uint32_t kWaveHistWords = kWaveHist + 4u;  // + the state of this wave's frontier spill list: entries in it, its address ("Frontier overflow" below)
+__host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHistWords * 4u; }  // LDS per wave: candidates + histogram
 constexpr uint32_t kWaveKnnBytes = waveKnnBytes(kWaveRows);
 
 struct WaveKnnLds {
     MCRT_LDS_AS double* d2;      // [waveCand(R)] this wave's candidate distances
     MCRT_LDS_AS uint32_t* idx;   // [waveCand(R)] photon indices
-    MCRT_LDS_AS uint32_t* hist;  // [kWaveHist] candidates per distance2 bin
+    MCRT_LDS_AS uint32_t* hist;  // [kWaveHistWords] candidates per distance2 bin; then the spill list's count and address
 };
+// Frontier overflow. The reference's frontier is an unbounded priority queue (linear-octree.cpp:33); here it is 2 entries per lane in
+// registers. An octree whose leaves hold far fewer photons than k can have more octants than that within the bound at once (k = 300
+// on leaves of <= 200: seen). Entries that find no free slot go to a list in memory (lane 0 writes them); whenever the register
+// frontier runs empty - or holds only octants beyond the bound - the list is read back (entries beyond the bound dropped). Visiting
+// order only matters for speed: every octant within the final bound is visited, so the k-set is the same. A wave without a list
+// (null address), or a list that overflows too, raises the overflow flag as before. The list's count and address live in LDS behind the
+// histogram, not in registers: the search loop is short of both kinds (as a struct member the address alone cost C5's kernel 110 more
+// spilled VGPRs and 1.7 % of the frame), and they are touched once per search - when it ends - and when an entry really overflows.
+constexpr uint32_t kWaveSpill = 1024;
+// every wave, once, before its first search
+__device__ inline void waveKnnInit(const WaveKnnLds& W, uint32_t* spill) {
+    if (__lane_id() == 0) {
+        const unsigned long long u = (unsigned long long)spill;
+        W.hist[kWaveHist] = 0u;
+        W.hist[kWaveHist + 1u] = (uint32_t)u;
+        W.hist[kWaveHist + 2u] = (uint32_t)(u >> 32);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// entries in the list (wave-uniform) and its address
+__device__ inline uint32_t waveSpillState(const WaveKnnLds& W, uint32_t*& list) {
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist]);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist + 1u]);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist + 2u]);
+    list = (uint32_t*)(((unsigned long long)hi << 32) | lo);
+    return n;
+}
+__device__ inline void waveSpillSetCount(const WaveKnnLds& W, uint32_t n) {
+    if (__lane_id() == 0) W.hist[kWaveHist] = n;
+    __builtin_amdgcn_wave_barrier();
+}
+// one more entry {distance2 as float bits, a, b} (wave-uniform values); false: no list, or full. All lanes must call.
+__device__ inline bool waveSpillPush(const WaveKnnLds& W, float d, uint32_t a, uint32_t b) {
+    uint32_t* list;
+    const uint32_t n = waveSpillState(W, list);
+    if (!list || n >= kWaveSpill) return false;
+    if (__lane_id() == 0) {
+        uint32_t* e = list + 3u * n;
+        __hip_atomic_store(e + 0, __float_as_uint(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(e + 1, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(e + 2, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    waveSpillSetCount(W, n + 1u);
+    return true;
+}
 
 // What one step of the descent reads: for an inner octant, up to 64 records — its children that can be scanned right
 // away (leaves, or octants with <= k photons, linear-octree.cpp:51) and, for every other child, that child's children
@@ -656,17 +703,46 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         if ((int)lane == __ffsll((long long)free1) - 1) {
                             f_d2[1] = d; f_a[1] = a; f_b[1] = b;
                         }
-                    } else {
+                    } else if (!waveSpillPush(W, d, a, b)) {  // every register slot taken: to the list in memory
                         overflow = 1;
                     }
                 }
             }
         }
         // pop the nearest octant of the frontier
-        const float mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
-        const float best = waveMinPosF(mine);
-        if (!(best < INFINITY)) break;                // frontier empty
-        if ((double)best > max_distance2) break;      // linear-octree.cpp:113
+        float mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
+        float best = waveMinPosF(mine);
+        bool finished = false;
+        while (!(best < INFINITY) || (double)best > max_distance2) {  // frontier empty, or nothing left within the bound (linear-octree.cpp:113)
+            uint32_t* list;
+            const uint32_t sp_n = waveSpillState(W, list);
+            if (sp_n == 0u) {
+                finished = true;
+                break;
+            }
+            // what the registers hold is beyond the bound: drop it, and take the last (up to) 128 entries of the list instead
+            __threadfence();
+            const uint32_t take = sp_n < 128u ? sp_n : 128u;
+            for (int s2 = 0; s2 < 2; s2++) {
+                const uint32_t j = lane + 64u * (uint32_t)s2;
+                f_d2[s2] = INFINITY;
+                f_a[s2] = kNone;
+                f_b[s2] = 0u;
+                if (j < take) {
+                    const uint32_t* e = list + 3u * (sp_n - 1u - j);
+                    const float d = bitsFloat(__hip_atomic_load(e + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if ((double)d <= max_distance2) {
+                        f_d2[s2] = d;
+                        f_a[s2] = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        f_b[s2] = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            waveSpillSetCount(W, sp_n - take);
+            mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
+            best = waveMinPosF(mine);
+        }
+        if (finished) break;
         const unsigned long long owner = waveBallot(mine == best);
         const int ol = __ffsll((long long)owner) - 1;
         const int which = f_d2[0] <= f_d2[1] ? 0 : 1;

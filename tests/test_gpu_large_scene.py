@@ -34,6 +34,25 @@ def test_spaceship_matches_reference(pkg, spaceship):
     ctx.close()
 
 
+def test_spaceship_large_frame_goes_through_the_pipeline(pkg, spaceship):
+    """Trees in memory below 65 536 nodes: the lane-state-machine megakernel for small frames, the wavefront pipeline once the call's
+    rows hold 40 M path samples or more (MCRT_WF_MIN_PATHS; round 4: spaceship 1080p @ 64 spp 311 -> 231 ms). Same bits either way."""
+    ctx = pkg.Context(0)
+    ctx.upload_image(spaceship)
+    cam = spaceship.camera
+    cam.width, cam.height, cam.sqrtspp = 1920, 1080, 5   # 51.8 M path samples
+    full, st = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PATH_TRACER)
+    assert st["kernel_id"] == pkg.KERNEL_WAVEFRONT, pkg.KERNEL_NAMES.get(st["kernel_id"])
+    cam.shard_rows, cam.shard_count, cam.shard_index = 8, 135, 67   # rows 536-543 alone: 0.4 M path samples
+    rows = list(pkg.shard_rows(cam))
+    part, st2 = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PATH_TRACER)
+    assert st2["kernel_id"] == pkg.KERNEL_LANE_SM, pkg.KERNEL_NAMES.get(st2["kernel_id"])
+    np.testing.assert_array_equal(part[rows], full[rows])
+    print("spaceship 1080p @ 25 spp: pipeline %.1f Mray/s; rows %d-%d by the megakernel: the same bits" %
+          (st["rays"] / st["kernel_ms"] / 1e3, rows[0], rows[-1]))
+    ctx.close()
+
+
 def test_spaceship_traversal_equals_oracle(pkg, oracle, spaceship):
     rng = np.random.default_rng(7)
     s = spaceship.scene

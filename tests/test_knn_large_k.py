@@ -87,3 +87,31 @@ def test_gpu_c5_rows_large_k(pkg, oracle):
     print("c5 rows %d-%d, k = %d: max rel %.3e, %d searches" % (r0, r1, k, rel, st["knn_searches"]))
     assert rel <= 1e-10 and st["knn_searches"] > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("leaf,k", [(1, 50), (2, 128), (4, 600)])
+def test_gpu_knn_octree_with_tiny_leaves(pkg, ctx, manifest, leaf, k):
+    """Leaves far smaller than k: more octants lie within the bound at once than the 128 frontier entries the registers of a wave
+    hold (the reference's priority queue is unbounded, linear-octree.cpp:33). Until round 4: 'kNN frontier overflow'. The entries
+    beyond 128 now go through a per-wave list in memory. Against a brute-force selection with the reference's distance expression."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    ctx.upload_image(img)
+    rng = np.random.default_rng(leaf * 1000 + k)
+    count = 20000
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    ph[:, 0:3] = 1.0
+    m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), leaf)
+    ctx.upload_photons(m.desc, m.desc, k, False)
+    pts = lo + rng.random((300, 3)) * (hi - lo)
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)  # in the map's order
+    d = pts[:, None, :] - pos[None, :, :]
+    d2_all = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    want = np.sort(d2_all, axis=1)[:, :k]
+    cnt, idx, d2 = ctx.knn(0, pts, k)
+    assert np.all(cnt == k)
+    np.testing.assert_array_equal(d2, want)
+    rows = np.arange(len(pts))[:, None]
+    np.testing.assert_array_equal(d2_all[rows, idx], want)
+    m.close()
