@@ -456,8 +456,8 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         fr.samples = ctx->samples.as<double>();
     }
     // Pool size: up to 16 M slots (5.6 GB of pool, 4.6 GB of queue) — more slots = fewer, longer trace launches (their tails amortised; metal_bunnies
-    // 1447 / 1492 / 1507 Mray/s with 4 / 8 / 16 M) — but no more
-    // than gives every slot 16 work units of at least 4 samples; units per pixel: the power of two that reaches 16 per slot.
+    // 1447 / 1492 / 1507 Mray/s with 4 / 8 / 16 M) — but no more than the pass has work for (below); units per pixel: the power of two
+    // that gives a slot up to 16 work units of at least 4 samples.
     const uint64_t pixels = (uint64_t)cam->width * std::min<uint64_t>(pass_rows, owned_rows);
     // (round 4: 16 M by default - C3 at 1024 spp 2024 / 2068 / 2072 Mray/s with 8 / 16 / 32 M; 10 GB of pool and queue - but never more
     // than an eighth of the memory that is free on this device)
@@ -472,7 +472,21 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             (void)hipGetLastError();
         }
     }
-    slots = std::min<uint64_t>(slots, (std::max<uint64_t>(pixels * fr.spp / 64, 1) + kWfBlock - 1) / kWfBlock * kWfBlock);
+    // ... and no more than the pass has work for. A slot works through its path samples one after the other, so a pass takes about
+    // (samples per slot) x (bounces per path) shade + trace launches plus the tail of the longest paths; every launch costs its overhead
+    // and, in the tail, a lane per slot whether it holds a path or not. Measured (round 4, ms per 1080p frame, samples per slot 64 / 32 /
+    // 16 / 8 / 4): spaceship 8 M paths 46 / 38 / 35 / 36 / 35, 33 M 85 / 78 / 77 / 85 / 90, 133 M 228 / 229 / 243 / 286 / 288; C3 8 M
+    // 77 / 53 / 42 / 38 / 36, 33 M 141 / 119 / 111 / 113 / 116, 133 M 390 / 371 / 378 / 410 / 411 - i.e. 2-4 M slots until the frame is
+    // large enough for more: paths / 48, at least 2.5 M, never fewer than 4 samples per slot (MCRT_WF_SLOT_PATHS, MCRT_WF_SLOT_FLOOR).
+    {
+        const uint64_t pass_paths = std::max<uint64_t>(pixels * fr.spp, 1);
+        const uint64_t per_slot = (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_PATHS", 48));
+        const uint64_t floor_slots = (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_FLOOR", 2500000));
+        uint64_t want = std::max<uint64_t>(pass_paths / per_slot, floor_slots);
+        if (!ctxOpt(ctx, "MCRT_WF_SLOT_PATHS")) want = std::min<uint64_t>(want, std::max<uint64_t>(pass_paths / 4, 1));
+        else want = std::max<uint64_t>(pass_paths / per_slot, 1);  // the option alone decides (A/B runs)
+        slots = std::min<uint64_t>(slots, (want + kWfBlock - 1) / kWfBlock * kWfBlock);
+    }
     slots = std::max<uint64_t>(slots, kWfBlock);
     {
         const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
@@ -800,10 +814,10 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     const char* mn = ctxOpt(ctx, "MCRT_WF_MIN_NODES");
     const uint32_t wf_min_nodes = mn ? (uint32_t)strtoul(mn, nullptr, 0) : 65536u;
     // ... and, since round 4's trace kernel, on ANY tree in memory once the frame is large enough to amortise the pipeline's launches
-    // (spaceship cockpit, 23 k nodes, 1080p, ms per frame megakernel / pipeline: 2 M paths 9.3 / 34.6, 8 M 24.3 / 46.2, 33 M 80.9 /
-    // 85.0, 133 M 311 / 231): MCRT_WF_MIN_PATHS path samples in this call's rows, default 40 M
+    // (spaceship cockpit, 23 k nodes, 1080p, ms per frame megakernel / pipeline: 2 M paths 9.4 / 19.1, 8 M 24.5 / 35.3, 33 M 80.9 /
+    // 77.3, 133 M 311 / 228): MCRT_WF_MIN_PATHS path samples in this call's rows, default 32 M
     const char* mp = ctxOpt(ctx, "MCRT_WF_MIN_PATHS");
-    const uint64_t wf_min_paths = mp ? strtoull(mp, nullptr, 0) : 40000000ull;
+    const uint64_t wf_min_paths = mp ? strtoull(mp, nullptr, 0) : 32000000ull;
     const uint64_t frame_paths = (uint64_t)mcrt_shard_rows(cam, nullptr) * cam->width * cam->sqrtspp * cam->sqrtspp;
     if (!photon && has_tree && (want_wf || (use_sm && !all && !kenv && (ctx->scene.num_nodes >= wf_min_nodes || frame_paths >= wf_min_paths))))
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, false, film_out);

@@ -36,11 +36,11 @@ def test_spaceship_matches_reference(pkg, spaceship):
 
 def test_spaceship_large_frame_goes_through_the_pipeline(pkg, spaceship):
     """Trees in memory below 65 536 nodes: the lane-state-machine megakernel for small frames, the wavefront pipeline once the call's
-    rows hold 40 M path samples or more (MCRT_WF_MIN_PATHS; round 4: spaceship 1080p @ 64 spp 311 -> 231 ms). Same bits either way."""
+    rows hold 32 M path samples or more (MCRT_WF_MIN_PATHS; round 4: spaceship 1080p @ 64 spp 311 -> 228 ms). Same bits either way."""
     ctx = pkg.Context(0)
     ctx.upload_image(spaceship)
     cam = spaceship.camera
-    cam.width, cam.height, cam.sqrtspp = 1920, 1080, 5   # 51.8 M path samples
+    cam.width, cam.height, cam.sqrtspp = 1920, 1080, 5   # 51.8 M path samples (MCRT_WF_MIN_PATHS: 32 M)
     full, st = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PATH_TRACER)
     assert st["kernel_id"] == pkg.KERNEL_WAVEFRONT, pkg.KERNEL_NAMES.get(st["kernel_id"])
     cam.shard_rows, cam.shard_count, cam.shard_index = 8, 135, 67   # rows 536-543 alone: 0.4 M path samples
