@@ -1605,11 +1605,20 @@ int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_
     if (int rc = launchGeometry(ctx, kernel, scene, g)) return rc;
     if (int rc = ensureScratch(ctx, g.total_lanes, false)) return rc;
 
+    // List sizes. A path leaves a photon at every diffuse bounce, so the lists can hold more photons than there are paths (C5: 1.13 per
+    // path in the caustic list) or far fewer (its global list: 0.07). A launch whose lists are too small still COUNTS exactly, and the pass
+    // is repeated at the exact sizes (below) - until round 4 that was the normal case for C5, whose emission so ran twice (0.37 s each).
+    // Now a pilot launch over every 64th path of the range (capacity 0: counting only, ~1/64 of the time) sizes the lists first, with 5 %
+    // and 64 K photons to spare; lists left by an earlier call are used at their full size.
     unsigned long long cap[2] = {std::max<unsigned long long>(1ull << 16, total), std::max<unsigned long long>(1ull << 16, total)};
-    for (int attempt = 0; attempt < 3; attempt++) {
-        for (int w = 0; w < 2; w++) {
+    constexpr uint32_t kPilotStride = 64;
+    const bool pilot = total >= (4ull << 20);
+    for (int attempt = pilot ? -1 : 0; attempt < 3; attempt++) {
+        const bool counting = attempt < 0;
+        for (int w = 0; w < 2 && !counting; w++) {
             if (ctx->emit_photons[w].bytes < cap[w] * 32) HIP_TRY(ctx, ctx->emit_photons[w].alloc(cap[w] * 32));
             if (ctx->emit_keys[w].bytes < cap[w] * 8) HIP_TRY(ctx, ctx->emit_keys[w].alloc(cap[w] * 8));
+            cap[w] = std::min<unsigned long long>(ctx->emit_photons[w].bytes / 32, ctx->emit_keys[w].bytes / 8);
         }
         EmitParams prm;
         memset(&prm, 0, sizeof(prm));
@@ -1618,12 +1627,13 @@ int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_
         prm.light_photon_flux = ctx->emit_flux.as<double>();
         prm.total_emissions = shard_end;
         prm.first_emission = shard_begin;
+        prm.stride = counting ? kPilotStride : 1u;
         prm.global_seed = global_seed;
         prm.non_caustic_reject = 1.0 / caustic_factor;
         for (int w = 0; w < 2; w++) {
             prm.photons[w] = ctx->emit_photons[w].as<float>();
             prm.keys[w] = ctx->emit_keys[w].as<unsigned long long>();
-            prm.capacity[w] = cap[w];
+            prm.capacity[w] = counting ? 0ull : cap[w];
         }
         prm.counters = ctx->emit_counters.as<unsigned long long>();
         prm.spill = ctx->spill.as<StackEntry>();
@@ -1641,6 +1651,10 @@ int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_
         // RefractionHistory (ray.cpp:74-98) is unbounded in the reference; the emission kernel keeps kMaxIors (8) entries per lane. The eye
         // pass of such a scene retries through the 32-entry pool or fails (mcrt_render_finish); the photon pass must not be the silent one.
         if (h[6]) return fail(ctx, MCRT_ERR_UNSUPPORTED, "a photon path entered more than 8 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to 8 entries per lane in the emission pass)");
+        if (counting) {
+            for (int w = 0; w < 2; w++) cap[w] = (unsigned long long)((double)h[1 + w] * kPilotStride * 1.05) + (1ull << 16);
+            continue;
+        }
         if (h[1] <= cap[0] && h[2] <= cap[1]) break;
         cap[0] = std::max(cap[0], h[1]);  // a list was too small: size it exactly and emit again
         cap[1] = std::max(cap[1], h[2]);

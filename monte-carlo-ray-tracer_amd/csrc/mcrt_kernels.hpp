@@ -2127,6 +2127,7 @@ struct EmitParams {
     const double* light_photon_flux;        // [num_lights][3]
     unsigned long long total_emissions;     // this launch handles paths [first_emission, total_emissions)
     unsigned long long first_emission;
+    uint32_t stride;                        // 1; the sizing pilot takes every stride-th path of the range (capacity 0: it only counts)
     uint32_t global_seed;
     double non_caustic_reject;
     float* photons[2];                      // 0 global, 1 caustic: [capacity][8]
@@ -2159,7 +2160,7 @@ __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, co
     for (;;) {
         const bool need = !active && !exhausted;
         if (waveBallot(need)) {
-            const unsigned long long e = prm.first_emission + wavePop(need, prm.counters + 0);
+            const unsigned long long e = prm.first_emission + wavePop(need, prm.counters + 0) * prm.stride;
             if (need) {
                 if (e >= prm.total_emissions) {
                     exhausted = true;
