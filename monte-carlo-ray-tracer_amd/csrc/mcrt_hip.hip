@@ -854,7 +854,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         DeviceScene probe = ctx->scene;
         if (!probe.stage_all) probe.stage_nodes = std::min<uint32_t>(probe.stage_nodes, 128u);
         const uint32_t least = alignUp(planLds(probe, kBlock, true, probe.stage_all ? (uint32_t)kLdsStackDepth : 2u, kPmLdsIors).total, 16) +
-                               (kBlock / 64) * waveKnnBytes(kWaveRowsLarge);
+                               (kBlock / 64) * (waveKnnBytes(kWaveRowsLarge) + kWaveStateBytes);
         if (least > ctx->max_lds) use_pm_wave = false;
     }
     using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
@@ -875,7 +875,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         static const PmKernelT pm_table_large[2][2] = {{renderKernelPM<false, false, (int)kBlock, kWaveRowsLarge>, renderKernelPM<false, true, (int)kBlock, kWaveRowsLarge>},
                                                        {renderKernelPM<true, false, (int)kBlock, kWaveRowsLarge>, renderKernelPM<true, true, (int)kBlock, kWaveRowsLarge>}};
         const int want = pm_large_k ? (int)kBlock : (int)ctxOptL(ctx, "MCRT_PM_BLOCK", 1024);
-        const uint32_t knn_bytes = waveKnnBytes(pm_large_k ? kWaveRowsLarge : kWaveRows);
+        const uint32_t knn_bytes = waveKnnBytes(pm_large_k ? kWaveRowsLarge : kWaveRows) + (all ? 0u : kWaveStateBytes);
         g.block = kBlock;
         // (the 1024-lane instance keeps two refraction-history entries per lane in LDS, the deeper ones in global memory)
         auto ldsBytes = [&](uint32_t block, uint32_t depth) {
@@ -1011,10 +1011,12 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
             prm.row_base = row;
             prm.row_end = (uint32_t)std::min<uint64_t>(prm.owned_rows, row + pass_rows);
             prm.pass_pixels = (uint64_t)(prm.row_end - prm.row_base) * cam->width;
-            // units per pixel: a power of two that gives every resident lane >= 128 units, chunks of at least 4 samples
-            // (measured on the 1080p @ 256 spp frame, ms per shard for 1 / 8 shards: whole pixels 887 / 162, 2 chunks
-            // 864 / 133, 8 chunks 848 / 111, 64 chunks 844 / 107)
-            const ChunkPlan cp = planChunks(prm.spp, unitsWanted(g.total_lanes, 128, prm.pass_pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
+            // units per pixel: a power of two that gives every resident lane >= 128 units in chunks of at least 16 samples
+            // (planChunksMega, mcrt_plan.hpp: the measurements behind it)
+            // (photon-mapped frames keep the short chunks: their paths differ far more in cost - a search per diffuse hit - and the
+            // balance is worth more than the units' fixed cost: C5 at 64 spp 770 ms with 64 units of 4 samples, 791 with 16 of 16)
+            const ChunkPlan cp = photon ? planChunks(prm.spp, unitsWanted(g.total_lanes, 128, prm.pass_pixels, ctxOpt(ctx, "MCRT_CHUNKS")))
+                                        : planChunksMega(prm.spp, g.total_lanes, prm.pass_pixels, ctxOpt(ctx, "MCRT_CHUNKS"));
             const uint32_t shift = cp.shift;
             prm.chunk_shift = cp.shift;
             prm.chunk = cp.chunk;

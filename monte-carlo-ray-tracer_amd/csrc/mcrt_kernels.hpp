@@ -1680,13 +1680,13 @@ template <bool kEval, int R = kWaveRows>
 __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     __shared__ double s_d2[4 * waveCand(R)];
     __shared__ uint32_t s_idx[4 * waveCand(R)];
-    __shared__ uint32_t s_hist[4 * kWaveHistWords];
+    __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
-    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHistWords;
-    waveKnnInit(W, a.spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill));
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
+    W.spill = a.spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill);
     const unsigned long long n = *a.count;
     const uint32_t slots = a.pool.n;
     uint32_t overflow = 0, visits = 0, searches = 0;
@@ -1882,8 +1882,12 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
         W.d2 = ldsAt<double>(lds, base) + wave * waveCand(R);
         W.idx = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 8u) + wave * waveCand(R);
-        W.hist = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 12u) + wave * kWaveHistWords;
-        waveKnnInit(W, pmx.knn_spill + ((size_t)blockIdx.x * waves + wave) * (3u * kWaveSpill));
+        W.hist = ldsAt<uint32_t>(lds, base + waves * waveCand(R) * 12u) + wave * kWaveHist;
+        W.spill = pmx.knn_spill + ((size_t)blockIdx.x * waves + wave) * (3u * kWaveSpill);
+        if constexpr (!kAll) {  // (trees in memory: the list's state in LDS, behind all the waves' buffers - mcrt_waveknn.hpp)
+            W.state = ldsAt<uint32_t>(lds, base + waves * waveKnnBytes(R)) + wave * (kWaveStateBytes / 4u);
+            waveKnnInit(W, W.spill);
+        }
     }
 
     double* const stage_lane = pmx.stage + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStageDoubles;
@@ -2022,13 +2026,13 @@ __global__ void __launch_bounds__(256) knnWaveKernel(const PhotonMapViewW map, u
                                                      uint32_t* out_index, double* out_d2, unsigned long long* flags, uint32_t* spill) {
     __shared__ double s_d2[4 * waveCand(R)];
     __shared__ uint32_t s_idx[4 * waveCand(R)];
-    __shared__ uint32_t s_hist[4 * kWaveHistWords];
+    __shared__ uint32_t s_hist[4 * kWaveHist];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     WaveKnnLds W;
     W.d2 = (MCRT_LDS_AS double*)s_d2 + wave * waveCand(R);
     W.idx = (MCRT_LDS_AS uint32_t*)s_idx + wave * waveCand(R);
-    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHistWords;
-    waveKnnInit(W, spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill));
+    W.hist = (MCRT_LDS_AS uint32_t*)s_hist + wave * kWaveHist;
+    W.spill = spill + ((size_t)blockIdx.x * 4u + wave) * (3u * kWaveSpill);
     const uint64_t waves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint32_t overflow = 0, visits = 0;
     for (uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; q < n; q += waves_total) {
@@ -2104,7 +2108,6 @@ __global__ void __launch_bounds__(256) knnGroupKernel(const PhotonMapViewW map, 
             const uint64_t qq = q0 + ((uint32_t)src >> 4);
             const d3 qp = waveShfl3(pt, src);
             double rr;
-            waveKnnInit(W, nullptr);  // (the rows' buffers overlay the wave search's: no spill list here, and its state words are theirs)
             const uint32_t cc = waveKnnSearch(map, qp, k, W, rr, overflow, visits);
             waveSortResult(W, cc);
             if (lane == 0) out_count[qq] = cc;

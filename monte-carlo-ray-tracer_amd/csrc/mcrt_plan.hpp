@@ -33,12 +33,25 @@ struct ChunkPlan {
     uint32_t chunk;  // samples per unit = ceil(spp / units per pixel); the last unit(s) of a pixel may be short or empty
 };
 
-// The smallest power-of-two number of units per pixel that reaches `want`, as long as chunks keep kMinChunk samples.
-inline ChunkPlan planChunks(uint32_t spp, uint64_t want) {
+// The smallest power-of-two number of units per pixel that reaches `want`, as long as chunks keep `min_chunk` samples.
+inline ChunkPlan planChunks(uint32_t spp, uint64_t want, uint32_t min_chunk = kMinChunk) {
     ChunkPlan c;
     c.shift = 0;
-    while ((1ull << c.shift) < want && (spp >> (c.shift + 1)) >= kMinChunk) c.shift++;
+    while ((1ull << c.shift) < want && (spp >> (c.shift + 1)) >= min_chunk) c.shift++;
     c.chunk = (spp + (1u << c.shift) - 1u) >> c.shift;
+    return c;
+}
+
+// Work units of the megakernels (one launch, lanes pop units from a counter): every unit costs its pop, the sampler's start at the
+// pixel and the decode of the tile - on the hexagon_room frame about as much as three path samples. Round 4, ms per 1080p @ 256 spp
+// shard of 1 / 2 / 4 / 8 (what one rank renders) with 4 / 16 / 64 units per pixel: 446.9 / 227.1 / 116.4 / 61.5, 445.3 / 225.4 /
+// 113.2 / 57.2, - / 264.5 / 132.5 / 66.5. So: 128 units per lane for balance, but chunks of at least 16 samples; shorter chunks (down
+// to kMinChunk) only when that leaves a lane fewer than 4 units (small frames).
+inline ChunkPlan planChunksMega(uint32_t spp, uint64_t lanes, uint64_t pass_pixels, const char* chunks_override = nullptr) {
+    if (chunks_override) return planChunks(spp, strtoull(chunks_override, nullptr, 0));  // option MCRT_CHUNKS: units per pixel
+    const uint64_t pixels = std::max<uint64_t>(pass_pixels, 1);
+    ChunkPlan c = planChunks(spp, (128 * lanes + pixels - 1) / pixels, 16);
+    if ((pixels << c.shift) < 4 * lanes) c = planChunks(spp, (4 * lanes + pixels - 1) / pixels);
     return c;
 }
 

@@ -38,45 +38,50 @@ __host__ __device__ constexpr uint32_t waveMaxK(int R) { return R <= 4 ? 128u : 
 constexpr uint32_t kWaveCand = waveCand(kWaveRows);
 
 constexpr uint32_t kWaveHist = 128;   // bins of the per-wave distance histogram (see "Selection by histogram")
-constexpr uint32_t kWaveHistWords = kWaveHist + 4u;  // + the state of this wave's frontier spill list: entries in it, its address ("Frontier overflow" below)
-__host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHistWords * 4u; }  // LDS per wave: candidates + histogram
+constexpr uint32_t kWaveStateBytes = 16u;  // per wave, for the searches that keep their spill list's state in LDS ("Frontier overflow" below)
+__host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHist * 4u; }  // LDS per wave: candidates + histogram
 constexpr uint32_t kWaveKnnBytes = waveKnnBytes(kWaveRows);
 
 struct WaveKnnLds {
     MCRT_LDS_AS double* d2;      // [waveCand(R)] this wave's candidate distances
     MCRT_LDS_AS uint32_t* idx;   // [waveCand(R)] photon indices
-    MCRT_LDS_AS uint32_t* hist;  // [kWaveHistWords] candidates per distance2 bin; then the spill list's count and address
+    MCRT_LDS_AS uint32_t* hist;  // [kWaveHist] candidates per distance2 bin
+    uint32_t* spill = nullptr;   // the spill list's address for the searches that keep it in registers (kSpillRegs, below)
+    MCRT_LDS_AS uint32_t* state = nullptr;  // [4] ... or, for the others, where its count and address are kept in LDS
 };
 // Frontier overflow. The reference's frontier is an unbounded priority queue (linear-octree.cpp:33); here it is 2 entries per lane in
 // registers. An octree whose leaves hold far fewer photons than k can have more octants than that within the bound at once (k = 300
 // on leaves of <= 200: seen). Entries that find no free slot go to a list in memory (lane 0 writes them); whenever the register
 // frontier runs empty - or holds only octants beyond the bound - the list is read back (entries beyond the bound dropped). Visiting
 // order only matters for speed: every octant within the final bound is visited, so the k-set is the same. A wave without a list
-// (null address), or a list that overflows too, raises the overflow flag as before. The list's count and address live in LDS behind the
-// histogram, not in registers: the search loop is short of both kinds (as a struct member the address alone cost C5's kernel 110 more
-// spilled VGPRs and 1.7 % of the frame), and they are touched once per search - when it ends - and when an entry really overflows.
+// (null address), or a list that overflows too, raises the overflow flag as before. Where the list's count and address live is a
+// template choice (kSpillRegs), because the two eye-pass kernels answer it differently (measured, one box): in registers the kernel that
+// walks a tree in memory (C5) spills 110 more VGPRs and loses 1.7 % (788 vs 775 ms at 64 spp); in LDS behind the histogram - touched
+// only when an entry really overflows, the loop carries one flag - the kernel of LDS-resident scenes loses 8 % (hexagon_room 106 vs 98
+// ms - and so does moving the histograms of its waves 16 bytes apart to make room). So: registers for LDS-resident scenes and the
+// operator kernels; LDS, in a small array of its own behind the waves' buffers, for trees in memory.
 constexpr uint32_t kWaveSpill = 1024;
 // every wave, once, before its first search
 __device__ inline void waveKnnInit(const WaveKnnLds& W, uint32_t* spill) {
     if (__lane_id() == 0) {
         const unsigned long long u = (unsigned long long)spill;
-        W.hist[kWaveHist] = 0u;
-        W.hist[kWaveHist + 1u] = (uint32_t)u;
-        W.hist[kWaveHist + 2u] = (uint32_t)(u >> 32);
+        W.state[0] = 0u;
+        W.state[1] = (uint32_t)u;
+        W.state[2] = (uint32_t)(u >> 32);
     }
     __builtin_amdgcn_wave_barrier();
 }
 // entries in the list (wave-uniform) and its address
 __device__ inline uint32_t waveSpillState(const WaveKnnLds& W, uint32_t*& list) {
     __builtin_amdgcn_wave_barrier();
-    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist]);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist + 1u]);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.hist[kWaveHist + 2u]);
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.state[0]);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.state[1]);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.state[2]);
     list = (uint32_t*)(((unsigned long long)hi << 32) | lo);
     return n;
 }
 __device__ inline void waveSpillSetCount(const WaveKnnLds& W, uint32_t n) {
-    if (__lane_id() == 0) W.hist[kWaveHist] = n;
+    if (__lane_id() == 0) W.state[0] = n;
     __builtin_amdgcn_wave_barrier();
 }
 // one more entry {distance2 as float bits, a, b} (wave-uniform values); false: no list, or full. All lanes must call.
@@ -558,7 +563,7 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
 // `bound2`: an upper bound of the k-th nearest photon's squared distance known beforehand (kDblMax: none). The search then
 // starts pruning where it would otherwise arrive after its first scans; the k-set is the same (every one of the k nearest
 // lies within ANY upper bound, and all comparisons against the bound are inclusive).
-template <int R = kWaveRows>
+template <int R = kWaveRows, bool kSpillRegs = true>
 __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32_t k, const WaveKnnLds& W, double& r2_max,
                                          uint32_t& overflow, uint32_t& octant_visits, double bound2 = kDblMax) {
     r2_max = 0.0;
@@ -580,6 +585,8 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
     H.on = false;
     H.scale = H.inv_scale = 0.0;
     uint32_t cur_a = map.root_a, cur_b = map.root_m;  // root
+    bool spilled = false;  // wave-uniform: this search has put entries on the wave's list in memory
+    uint32_t sp_n = 0u;    // ... how many are on it now (kSpillRegs; otherwise read from LDS when `spilled`)
     for (;;) {
         octant_visits++;
         if (cur_b & kScan) {
@@ -703,7 +710,18 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                         if ((int)lane == __ffsll((long long)free1) - 1) {
                             f_d2[1] = d; f_a[1] = a; f_b[1] = b;
                         }
-                    } else if (!waveSpillPush(W, d, a, b)) {  // every register slot taken: to the list in memory
+                    } else if (kSpillRegs ? (W.spill && sp_n < kWaveSpill) : waveSpillPush(W, d, a, b)) {  // every register slot taken: to the list in memory
+                        if constexpr (kSpillRegs) {
+                            if (lane == 0) {
+                                uint32_t* e = W.spill + 3u * sp_n;
+                                __hip_atomic_store(e + 0, floatBits(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(e + 1, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(e + 2, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            sp_n++;
+                        }
+                        spilled = true;
+                    } else {
                         overflow = 1;
                     }
                 }
@@ -714,8 +732,12 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
         float best = waveMinPosF(mine);
         bool finished = false;
         while (!(best < INFINITY) || (double)best > max_distance2) {  // frontier empty, or nothing left within the bound (linear-octree.cpp:113)
-            uint32_t* list;
-            const uint32_t sp_n = waveSpillState(W, list);
+            if (!kSpillRegs && !spilled) {  // (LDS form: one flag is all the search loop carries of the list)
+                finished = true;
+                break;
+            }
+            uint32_t* list = W.spill;
+            if constexpr (!kSpillRegs) sp_n = waveSpillState(W, list);
             if (sp_n == 0u) {
                 finished = true;
                 break;
@@ -738,7 +760,8 @@ __device__ inline uint32_t waveKnnSearch(const PhotonMapViewW& map, d3 p, uint32
                     }
                 }
             }
-            waveSpillSetCount(W, sp_n - take);
+            sp_n -= take;
+            if constexpr (!kSpillRegs) waveSpillSetCount(W, sp_n);
             mine = f_d2[0] < f_d2[1] ? f_d2[0] : f_d2[1];
             best = waveMinPosF(mine);
         }
@@ -880,7 +903,7 @@ __device__ inline d3 waveEstimate(bool want, double* stage_wave, const PhotonMap
         const double2 p01 = reinterpret_cast<const double2*>(rec)[0];
         const d3 qpos = d3{uniformD(p01.x), uniformD(p01.y), uniformD(rec[2])};
         double r2 = 0.0;
-        const uint32_t n = waveKnnSearch<R>(map, qpos, k, W, r2, overflow, octant_visits);
+        const uint32_t n = waveKnnSearch<R, L>(map, qpos, k, W, r2, overflow, octant_visits);  // (L: the scene is LDS-resident)
         d3 sum = splat(0.0);
         if (n) {  // else photons.empty(): the estimate is zero (photon-mapper.cpp:347, :374)
             InteractionT<L> q;

@@ -1157,4 +1157,11 @@ void emu_plan(uint32_t width, uint32_t owned_rows, uint32_t spp, double store_gb
     out[3] = cp.chunk;
 }
 
+// planChunksMega (mcrt_plan.hpp): out = {chunk_shift, chunk}
+void emu_plan_mega(uint32_t spp, uint64_t lanes, uint64_t pass_pixels, uint64_t* out) {
+    const ChunkPlan cp = planChunksMega(spp, lanes, pass_pixels);
+    out[0] = cp.shift;
+    out[1] = cp.chunk;
+}
+
 }  // extern "C"

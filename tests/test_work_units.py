@@ -51,3 +51,25 @@ def test_chunks_cover_every_sample_once(emu, spp, want):
     # as many units as asked for (rounded up to a power of two), unless chunks would drop below 4 samples
     assert units >= min(max(want, 1), max(1, spp // 4)) or (spp >> (p["shift"] + 1)) < 4
     assert p["shift"] == 0 or chunk >= 4 or spp < 8
+
+
+@pytest.mark.parametrize("spp,lanes,pixels", list(itertools.product([1, 4, 16, 25, 64, 256, 1024], [131072, 262144], [1920 * 1080, 1920 * 136, 1000 * 1000, 192 * 108, 64])))
+def test_megakernel_units_keep_sixteen_samples_unless_lanes_would_starve(emu, spp, lanes, pixels):
+    """planChunksMega: 128 units per lane in chunks of >= 16 samples (a unit's fixed cost is about three path samples: 1/8 shards of
+    the 1080p @ 256 spp frame 66.5 -> 57.2 ms); chunks down to 4 samples only when a lane would otherwise get fewer than 4 units."""
+    out = (C.c_uint64 * 2)()
+    emu.emu_plan_mega(spp, lanes, pixels, out)
+    shift, chunk = int(out[0]), int(out[1])
+    units = 1 << shift
+    assert chunk * units >= spp and (shift == 0 or chunk * (units - 1) < spp + chunk)
+    covered = np.zeros(spp, dtype=int)
+    for c in range(units):
+        first = c * chunk
+        if first < spp:
+            covered[first:min(first + chunk, spp)] += 1
+    assert (covered == 1).all()
+    per_lane = pixels * units / lanes
+    if chunk < 16 and shift > 0:
+        assert chunk >= 4 and pixels * (units // 2) < 4 * lanes   # short chunks only where chunks of 16+ starve the lanes
+    if per_lane > 256 and shift > 0:
+        assert pixels * (units // 2) < 128 * lanes               # never more units than the balance target asks for
