@@ -472,22 +472,10 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             (void)hipGetLastError();
         }
     }
-    // ... and no more than the pass has work for. A slot works through its path samples one after the other, so a pass takes about
-    // (samples per slot) x (bounces per path) shade + trace launches plus the tail of the longest paths; every launch costs its overhead
-    // and, in the tail, a lane per slot whether it holds a path or not. Measured (round 4, ms per 1080p frame, samples per slot 64 / 32 /
-    // 16 / 8 / 4): spaceship 8 M paths 46 / 38 / 35 / 36 / 35, 33 M 85 / 78 / 77 / 85 / 90, 133 M 228 / 229 / 243 / 286 / 288; C3 8 M
-    // 77 / 53 / 42 / 38 / 36, 33 M 141 / 119 / 111 / 113 / 116, 133 M 390 / 371 / 378 / 410 / 411 - i.e. 2-4 M slots until the frame is
-    // large enough for more: paths / 48, at least 2.5 M, never fewer than 4 samples per slot (MCRT_WF_SLOT_PATHS, MCRT_WF_SLOT_FLOOR).
-    {
-        const uint64_t pass_paths = std::max<uint64_t>(pixels * fr.spp, 1);
-        const uint64_t per_slot = (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_PATHS", 48));
-        const uint64_t floor_slots = (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_FLOOR", 2500000));
-        uint64_t want = std::max<uint64_t>(pass_paths / per_slot, floor_slots);
-        if (!ctxOpt(ctx, "MCRT_WF_SLOT_PATHS")) want = std::min<uint64_t>(want, std::max<uint64_t>(pass_paths / 4, 1));
-        else want = std::max<uint64_t>(pass_paths / per_slot, 1);  // the option alone decides (A/B runs)
-        slots = std::min<uint64_t>(slots, (want + kWfBlock - 1) / kWfBlock * kWfBlock);
-    }
-    slots = std::max<uint64_t>(slots, kWfBlock);
+    // ... and no more than the pass has work for: paths / 48, at least 2.5 M, never fewer than 4 samples per slot (planPoolSlots,
+    // mcrt_plan.hpp: the measurements; options MCRT_WF_SLOT_PATHS, MCRT_WF_SLOT_FLOOR)
+    slots = planPoolSlots(pixels * fr.spp, slots, kWfBlock, (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_PATHS", 48)),
+                          (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_FLOOR", 2500000)), ctxOpt(ctx, "MCRT_WF_SLOT_PATHS") != nullptr);
     {
         const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
         fr.chunk_shift = cp.shift;

@@ -62,6 +62,24 @@ inline uint64_t unitsWanted(uint64_t consumers, uint64_t per_consumer, uint64_t 
     return (per_consumer * consumers + pass_pixels - 1) / pass_pixels;
 }
 
+// Pool slots of the wavefront pipeline for a pass of `pass_paths` path samples, at most `max_slots` (option / memory), in multiples
+// of `block` (the shade kernel's workgroup). A slot works through its path samples one after the other, so a pass takes about
+// (samples per slot) x (bounces per path) shade + trace launches plus the tail of the longest paths; every launch lasts as long as its
+// longest ray and, in the tail, pays a lane per slot whether it holds a path or not. Measured (round 4, ms per 1080p frame, samples per
+// slot 64 / 32 / 16 / 8 / 4): spaceship 8 M paths 46 / 38 / 35 / 36 / 35, 33 M 85 / 78 / 77 / 85 / 90, 133 M 228 / 229 / 243 / 286 /
+// 288; C3 8 M 77 / 53 / 42 / 38 / 36, 33 M 141 / 119 / 111 / 113 / 116, 133 M 390 / 371 / 378 / 410 / 411 - i.e. 2-4 M slots until
+// the frame is large enough for more: paths / per_slot (48), at least floor_slots (2.5 M), never fewer than 4 samples per slot.
+// per_slot_alone: the option MCRT_WF_SLOT_PATHS was given - it alone decides (A/B runs).
+inline uint64_t planPoolSlots(uint64_t pass_paths, uint64_t max_slots, uint64_t block, uint64_t per_slot = 48, uint64_t floor_slots = 2500000,
+                              bool per_slot_alone = false) {
+    pass_paths = std::max<uint64_t>(pass_paths, 1);
+    per_slot = std::max<uint64_t>(per_slot, 1);
+    uint64_t want = std::max<uint64_t>(pass_paths / per_slot, per_slot_alone ? 1 : std::max<uint64_t>(floor_slots, 1));
+    if (!per_slot_alone) want = std::min<uint64_t>(want, std::max<uint64_t>(pass_paths / 4, 1));
+    const uint64_t slots = std::min<uint64_t>(max_slots, (want + block - 1) / block * block);
+    return std::max<uint64_t>(slots, block);
+}
+
 // option MCRT_SAMPLE_STORE_GB, default 64 of the GPU's 288 GB: a 1080p @ 1024 spp frame (51 GB) is one pass (C3: 6.04 -> 5.94 s against
 // four passes through 16 GB: every pass ends with a tail in which the pool runs dry); 4K @ 1024 spp is 204 GB, four passes
 inline double sampleStoreGb(const char* option = nullptr) {

@@ -116,6 +116,8 @@ def load_emu():
     L.emu_plan.restype = None
     L.emu_plan_mega.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.emu_plan_mega.restype = None
+    L.emu_plan_pool_slots.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    L.emu_plan_pool_slots.restype = C.c_uint64
     L.emu_tonemap.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, vp, vp]
     L.emu_flat_cull.argtypes = [vp, C.c_uint64, vp, vp, vp]
     L.emu_qstep_check.argtypes = [vp, C.c_uint64, vp, vp, vp]

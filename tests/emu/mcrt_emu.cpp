@@ -1157,6 +1157,8 @@ void emu_plan(uint32_t width, uint32_t owned_rows, uint32_t spp, double store_gb
     out[3] = cp.chunk;
 }
 
+uint64_t emu_plan_pool_slots(uint64_t pass_paths, uint64_t max_slots, uint64_t block) { return planPoolSlots(pass_paths, max_slots, block); }
+
 // planChunksMega (mcrt_plan.hpp): out = {chunk_shift, chunk}
 void emu_plan_mega(uint32_t spp, uint64_t lanes, uint64_t pass_pixels, uint64_t* out) {
     const ChunkPlan cp = planChunksMega(spp, lanes, pass_pixels);

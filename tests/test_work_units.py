@@ -73,3 +73,21 @@ def test_megakernel_units_keep_sixteen_samples_unless_lanes_would_starve(emu, sp
         assert chunk >= 4 and pixels * (units // 2) < 4 * lanes   # short chunks only where chunks of 16+ starve the lanes
     if per_lane > 256 and shift > 0:
         assert pixels * (units // 2) < 128 * lanes               # never more units than the balance target asks for
+
+
+def test_pipeline_pool_follows_the_pass(emu):
+    """planPoolSlots: paths / 48 slots, at least 2.5 M, at most the cap (16 M by default), never fewer than 4 samples per slot, whole
+    workgroups of the shade kernel - the sizes the A/B runs of round 4 found (profiles/r04_ab_pipeline_slot_paths.log)."""
+    cap, block = 1 << 24, 256
+    f = lambda paths, c=cap: int(emu.emu_plan_pool_slots(int(paths), c, block))
+    assert f(1920 * 1080 * 1024) == cap                       # C3 at full size: the cap
+    assert f(1920 * 1080 * 64) == 2764800                     # 133 M path samples: paths / 48
+    assert f(1920 * 1080 * 16) == 2500096                     # 33 M: the floor (rounded up to whole workgroups)
+    assert f(1920 * 1080 * 4) == 1920 * 1080                  # 8 M: four samples per slot
+    assert f(1920 * 1080) == 1920 * 1080 // 4 + 0             # 2 M: four samples per slot
+    assert f(1) == block and f(0) == block                    # never less than one workgroup
+    assert f(10 ** 12, 1 << 20) == 1 << 20                    # a smaller cap (memory) wins
+    for paths in (1, 255, 256, 1000, 10 ** 5, 10 ** 7, 10 ** 9, 10 ** 11):
+        s = f(paths)
+        assert s % block == 0 and block <= s <= cap
+        assert s <= max(block, -(-max(paths // 4, 1) // block) * block)   # >= 4 samples per slot (up to the rounding to workgroups)
