@@ -20,6 +20,7 @@
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_groupknn.hpp"
+#include "mcrt_widerec.hpp"
 #include "mcrt_layout.hpp"
 #include "mcrt_internal.hpp"
 #include "mcrt_plan.hpp"
@@ -1069,60 +1070,16 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
     if (int rc = uploadArray(ctx, ctx->map_next[which], m->octant_next_sibling, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_leaf[which], m->octant_leaf, n)) return rc;
     if (int rc = uploadArray(ctx, ctx->map_photons[which], m->photons, (size_t)m->num_photons * 8)) return rc;
-    {   // record lists for the wave-cooperative search (mcrt_waveknn.hpp: WideRec); children of o are o+1 and its sibling chain
-        const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1u);
-        auto scannable = [&](size_t o) { return m->octant_leaf[o] != 0 || contained[o] <= k; };
-        auto forChildren = [&](size_t o, auto f) {
-            uint32_t c = (uint32_t)o + 1;
-            int count = 0;
-            while (c != 0xFFFFFFFFu && c < n) {
-                if (++count > 8) return false;
-                f((size_t)c);
-                c = m->octant_next_sibling[c];
-            }
-            return true;
-        };
-        std::vector<uint32_t> first(n, 0), count(n, 0);
-        uint64_t total = 0;
-        bool ok = true;
-        for (size_t o = 0; o < n && ok; o++) {
-            if (scannable(o)) continue;
-            uint32_t cnt = 0;
-            ok = forChildren(o, [&](size_t c) {
-                if (scannable(c)) cnt++;
-                else ok = forChildren(c, [&](size_t) { cnt++; }) && ok;
-            }) && ok;
-            first[o] = (uint32_t)total;
-            count[o] = cnt;
-            total += cnt;
-        }
-        if (!ok) return fail(ctx, MCRT_ERR_INVALID, "photon octant with more than 8 children");
-        if (total > 0xFFFFFFFFull) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon map too large for 32-bit record indices");
-        std::vector<WideRec> wide(total);
-        auto fill = [&](WideRec& r, size_t c) {
-            memset(&r, 0, sizeof(r));
-            memcpy(r.b, m->octant_bounds + c * 6, 48);
-            r.contained = contained[c];
-            if (scannable(c)) {
-                r.a = (uint32_t)m->octant_start_data[c];
-                r.m = 0x80000000u | contained[c];
-            } else {
-                r.a = first[c];
-                r.m = count[c];
-            }
-        };
-        for (size_t o = 0; o < n; o++) {
-            if (scannable(o)) continue;
-            size_t at = first[o];
-            forChildren(o, [&](size_t c) {
-                if (scannable(c)) fill(wide[at++], c);
-                else forChildren(c, [&](size_t g) { fill(wide[at++], g); });
-            });
-        }
+    {   // record lists for the wave-cooperative search (mcrt_waveknn.hpp: WideRec; built by buildWideRecords, mcrt_widerec.hpp)
+        std::vector<WideRec> wide;
+        uint32_t root_a = 0, root_m = 0;
+        const int wrc = buildWideRecords(m, contained.data(), std::max<uint32_t>(ctx->k_nearest, 1u), wide, root_a, root_m);
+        if (wrc == 1) return fail(ctx, MCRT_ERR_INVALID, "photon octant with more than 8 children");
+        if (wrc == 2) return fail(ctx, MCRT_ERR_UNSUPPORTED, "photon map too large for 32-bit record indices");
         if (int rc = uploadArray(ctx, ctx->map_children[which], wide.data(), wide.size())) return rc;
         ctx->map_children_ptr[which] = ctx->map_children[which].as<WideRec>();
-        ctx->map_root_a[which] = scannable(0) ? 0u : first[0];
-        ctx->map_root_m[which] = scannable(0) ? (0x80000000u | contained[0]) : count[0];
+        ctx->map_root_a[which] = root_a;
+        ctx->map_root_m[which] = root_m;
     }
     v.num_octants = m->num_octants;
     v.num_photons = m->num_photons;

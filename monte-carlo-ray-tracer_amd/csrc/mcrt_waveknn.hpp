@@ -25,7 +25,16 @@
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(MCRT_WAVE_EMU)  // (MCRT_WAVE_EMU: tests/emu/wave_emu.hpp runs this file on the host, 64 fibers per wave)
+
+// Where the code below leans on the lanes of a wave running in lockstep - one lane reads what another wrote a few instructions
+// earlier with no cross-lane operation in between - it says so: nothing on the device, a rendezvous of the 64 fibers when the file
+// runs on the host (tests/emu/wave_emu.hpp, where a lane runs its whole stretch between two cross-lane operations at once).
+#if defined(MCRT_WAVE_EMU)
+#define MCRT_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define MCRT_LOCKSTEP() ((void)0)
+#endif
 
 namespace mcrt {
 
@@ -218,6 +227,7 @@ __device__ inline uint32_t waveRead(uint32_t v, int src) { return (uint32_t)__bu
 template <int R = kWaveRows>
 __device__ inline uint32_t waveSelectK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
     const uint32_t lane = __lane_id();
+    MCRT_LOCKSTEP();  // (the buffer was just written by other lanes)
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
     unsigned long long key[R];
     uint32_t my_i[R];
@@ -288,6 +298,7 @@ constexpr int kCoarseBits = 20;
 template <int R = kWaveRows>
 __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, uint32_t k, double& bound_d2, uint32_t slack = 0) {
     const uint32_t lane = __lane_id();
+    MCRT_LOCKSTEP();  // (the buffer was just written by other lanes)
     const int rows = (int)((count + 63u) / 64u);  // buffer rows in use (wave-uniform)
     uint32_t hi[R], lo[R], my_i[R];
     _Pragma("unroll") for (int s = 0; s < R; s++) {
@@ -345,6 +356,7 @@ __device__ inline uint32_t waveSelectBound(const WaveKnnLds& W, uint32_t count, 
 // reached" like waveSelectK. Result compacted into slots [0, n), kth_d2 = the largest distance kept. All lanes must call.
 __device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint32_t k, double& kth_d2) {
     const uint32_t lane = __lane_id();
+    MCRT_LOCKSTEP();  // (the buffer was just written by other lanes)
     bool valid = lane < count;
     union { double d; uint32_t u[2]; } c;
     c.d = valid ? W.d2[lane] : 0.0;
@@ -384,6 +396,7 @@ __device__ inline uint32_t waveTrimToK(const WaveKnnLds& W, uint32_t count, uint
 template <int S = 2>
 __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
     const uint32_t lane = __lane_id();
+    MCRT_LOCKSTEP();  // (the buffer was just written by other lanes)
     double my_d[S];
     uint32_t my_i[S], rank[S];
     _Pragma("unroll") for (int s = 0; s < S; s++) {
@@ -397,6 +410,7 @@ __device__ inline void waveSortResult(const WaveKnnLds& W, uint32_t n) {
         const uint32_t id = W.idx[i];
         _Pragma("unroll") for (int s = 0; s < S; s++) rank[s] += (d < my_d[s] || (d == my_d[s] && id < my_i[s])) ? 1u : 0u;
     }
+    MCRT_LOCKSTEP();  // every lane has read the whole list before any lane writes
     _Pragma("unroll") for (int s = 0; s < S; s++) {
         const uint32_t j = lane + 64u * s;
         if (j < n) {
@@ -517,6 +531,7 @@ __device__ inline uint32_t histSelectK(const WaveKnnLds& W, const WaveHist& H, u
     }
     // (out == below and eout == have by construction; the boundary entries now sit in slots [below, below + have))
     // pass 2: of the boundary entries keep the `need` smallest
+    MCRT_LOCKSTEP();  // (staged by other lanes just above)
     bool valid = lane < eout;
     union { double d; uint32_t u[2]; } c;
     c.d = valid ? W.d2[out + lane] : 0.0;
@@ -858,6 +873,7 @@ template <bool L>
 __device__ inline d3 waveEvalPhotons(const InteractionT<L>& q, const PhotonMapViewW& map, bool caustic, const MCRT_LDS_AS double* d2,
                                      const MCRT_LDS_AS uint32_t* idx, uint32_t n, double r2) {
     const uint32_t lane = __lane_id();
+    MCRT_LOCKSTEP();  // (the result was compacted by other lanes)
     d3 sum = splat(0.0);
     const double inv_max_squared_radius = 1.0 / r2;
     for (uint32_t base = 0; base < n; base += 64) {

@@ -1,0 +1,260 @@
+// Host emulation of ONE gfx950 wavefront for the wave-cooperative device code (csrc/mcrt_waveknn.hpp): 64 lanes as 64 fibers
+// on one thread. A lane runs until its next cross-lane operation (ballot, readlane, DPP move, shuffle, wave barrier),
+// publishes its operand and yields; when all 64 have arrived the scheduler snapshots the operands and resumes the lanes, each of
+// which then computes its own result from the snapshot with the ISA's rule for that operation. So the code under test is the
+// product's, unchanged, and what is emulated is exactly the part of the hardware it leans on: lockstep at cross-lane operations,
+// DPP controls with their row masks and bound_ctrl, readlane / readfirstlane, LDS as ordinary memory.
+//
+// What it is NOT: a timing model, and lanes do not run in lockstep BETWEEN cross-lane operations (lane 0 runs its whole stretch
+// before lane 1 starts it). Device code that relies on lockstep without a cross-lane operation in between (all lanes read, then
+// all lanes write the same array) needs __builtin_amdgcn_wave_barrier() there - which is a rendezvous here and free on the device.
+//
+// Test infrastructure only (tests/emu): define MCRT_WAVE_EMU and include this file BEFORE any csrc header.
+#pragma once
+
+#if !defined(__x86_64__)
+#include <ucontext.h>
+#endif
+
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+namespace wemu {
+
+constexpr int kLanes = 64;
+enum Op : uint32_t { kBallot = 1, kReadlane, kReadfirst, kDpp, kShfl, kBarrier, kBpermute };
+
+// Switching fibers: swapcontext makes a system call per switch (the signal mask), and a search is a few thousand cross-lane operations
+// x 64 lanes x 2 switches - so on x86-64 the switch is six pushes, the stack pointer, six pops (callee-saved registers only: the
+// control words of the FPU / SSE unit do not change in this code).
+#if defined(__x86_64__)
+extern "C" void wemu_switch(void** save_sp, void* load_sp);
+asm(".text\n"
+    ".hidden wemu_switch\n"
+    ".globl wemu_switch\n"
+    ".type wemu_switch,@function\n"
+    "wemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size wemu_switch,.-wemu_switch\n");
+struct Context {
+    void* sp = nullptr;
+};
+inline void switchTo(Context& from, Context& to) { wemu_switch(&from.sp, to.sp); }
+inline void makeFiber(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+    void** slot = (void**)(top - 16);   // the address `ret` jumps to; 16-aligned, so the entry sees the stack as after a call
+    slot[0] = (void*)entry;
+    slot[1] = nullptr;
+    void** sp = slot - 6;               // r15, r14, r13, r12, rbx, rbp
+    for (int i = 0; i < 6; i++) sp[i] = nullptr;
+    c.sp = sp;
+}
+#else
+struct Context {
+    ucontext_t uc;
+};
+inline void switchTo(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+inline void makeFiber(Context& c, char* stack, size_t bytes, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = bytes;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
+struct Wave {
+    Context sched;
+    Context ctx[kLanes];
+    bool done[kLanes];
+    bool waiting[kLanes];
+    uint64_t pub[kLanes], snap[kLanes];
+    uint32_t op[kLanes];
+    int cur = -1;
+    std::function<void(int)> body;
+    unsigned long long collectives = 0;
+};
+
+inline Wave*& current() {
+    static thread_local Wave* w = nullptr;
+    return w;
+}
+
+inline void trampoline() {
+    Wave* w = current();
+    const int lane = w->cur;
+    w->body(lane);
+    w->done[lane] = true;
+    w->pub[lane] = 0;  // a finished lane contributes nothing to later ballots
+    switchTo(w->ctx[lane], w->sched);
+    abort();  // (a finished lane is never resumed)
+}
+
+// Runs body(lane) for the 64 lanes of one wave to completion.
+inline void run(const std::function<void(int)>& body, size_t stack_bytes = 1u << 20) {
+    static thread_local std::vector<char> stacks[kLanes];  // kept between runs (64 MB of fresh pages per search otherwise)
+    for (int l = 0; l < kLanes; l++)
+        if (stacks[l].size() < stack_bytes) stacks[l].resize(stack_bytes);
+    Wave w;
+    Wave* saved = current();
+    current() = &w;
+    w.body = body;
+    for (int l = 0; l < kLanes; l++) {
+        w.done[l] = w.waiting[l] = false;
+        w.pub[l] = w.snap[l] = 0;
+        w.op[l] = 0;
+        makeFiber(w.ctx[l], stacks[l].data(), stack_bytes, trampoline);
+    }
+    for (;;) {
+        bool any = false;
+        for (int l = 0; l < kLanes; l++) {
+            if (w.done[l]) continue;
+            any = true;
+            w.cur = l;
+            w.waiting[l] = false;
+            switchTo(w.sched, w.ctx[l]);
+        }
+        if (!any) break;
+        // every lane still alive must have stopped at the SAME kind of operation: anything else is divergence around a
+        // cross-lane operation, which the device code must not have ("all lanes must call")
+        uint32_t kind = 0;
+        for (int l = 0; l < kLanes; l++) {
+            if (w.done[l]) continue;
+            if (!w.waiting[l]) {
+                fprintf(stderr, "wave_emu: lane %d neither finished nor at a cross-lane operation\n", l);
+                abort();
+            }
+            if (kind == 0) kind = w.op[l];
+            if (w.op[l] != kind) {
+                fprintf(stderr, "wave_emu: divergence - lane %d is at operation %u, an earlier lane at %u\n", l, w.op[l], kind);
+                abort();
+            }
+        }
+        memcpy(w.snap, w.pub, sizeof(w.snap));
+        w.collectives++;
+    }
+    current() = saved;
+}
+
+inline int lane() { return current()->cur; }
+
+// publish v, wait for the wave, return the snapshot of everybody's operands (valid until this lane's next cross-lane operation)
+inline const uint64_t* exchange(Op op, uint64_t v) {
+    Wave* w = current();
+    const int l = w->cur;
+    w->pub[l] = v;
+    w->op[l] = op;
+    w->waiting[l] = true;
+    switchTo(w->ctx[l], w->sched);
+    w->cur = l;  // (the scheduler set it before resuming; restated for clarity)
+    return w->snap;
+}
+inline bool alive(int l) { return !current()->done[l]; }
+
+// v_mov_b32_dpp: the source lane of lane i under dpp_ctrl, or -1 when the control has no valid source for it
+inline int dppSource(int i, int ctrl) {
+    const int row = i & ~15, in_row = i & 15;
+    if (ctrl >= 0x000 && ctrl <= 0x0FF) return (i & ~3) | ((ctrl >> (2 * (i & 3))) & 3);                  // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10F) return in_row + (ctrl & 15) < 16 ? i + (ctrl & 15) : -1;          // row_shl:n
+    if (ctrl >= 0x111 && ctrl <= 0x11F) return in_row >= (ctrl & 15) ? i - (ctrl & 15) : -1;              // row_shr:n
+    if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((in_row - (ctrl & 15)) & 15);                       // row_ror:n
+    if (ctrl == 0x130) return i + 1 < 64 ? i + 1 : -1;                                                    // wave_shl:1
+    if (ctrl == 0x134) return (i + 1) & 63;                                                               // wave_rol:1
+    if (ctrl == 0x138) return i >= 1 ? i - 1 : -1;                                                        // wave_shr:1
+    if (ctrl == 0x13C) return (i - 1) & 63;                                                               // wave_ror:1
+    if (ctrl == 0x140) return row | (15 - in_row);                                                        // row_mirror
+    if (ctrl == 0x141) return (i & ~7) | (7 - (i & 7));                                                   // row_half_mirror
+    if (ctrl == 0x142) return row >= 16 ? row - 1 : -1;                                                   // row_bcast:15 (last lane of the row before)
+    if (ctrl == 0x143) return i >= 32 ? 31 : -1;                                                          // row_bcast:31
+    fprintf(stderr, "wave_emu: dpp_ctrl 0x%x not modelled\n", ctrl);
+    abort();
+}
+
+}  // namespace wemu
+
+// ---- what the device code sees -----------------------------------------------------------------------------------------
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+
+struct double2 {
+    double x, y;
+};
+
+inline unsigned __lane_id() { return (unsigned)wemu::lane(); }
+inline unsigned long long waveBallot(bool p) {
+    const uint64_t* s = wemu::exchange(wemu::kBallot, p ? 1u : 0u);
+    unsigned long long m = 0;
+    for (int l = 0; l < wemu::kLanes; l++)
+        if (s[l] & 1u) m |= 1ull << l;
+    return m;
+}
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return waveBallot(p); }
+inline int __builtin_amdgcn_readlane(int v, int src) {
+    const uint64_t* s = wemu::exchange(wemu::kReadlane, (uint32_t)v);
+    return (int)(uint32_t)s[src & 63];
+}
+inline int __builtin_amdgcn_readfirstlane(int v) {
+    const uint64_t* s = wemu::exchange(wemu::kReadfirst, (uint32_t)v);
+    for (int l = 0; l < wemu::kLanes; l++)
+        if (wemu::alive(l)) return (int)(uint32_t)s[l];
+    return v;
+}
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const uint64_t* s = wemu::exchange(wemu::kDpp, (uint32_t)src);
+    const int i = wemu::lane();
+    if (!((row_mask >> (i >> 4)) & 1) || !((bank_mask >> ((i & 15) >> 2)) & 1)) return old;  // this lane's row / bank is not written
+    const int j = wemu::dppSource(i, ctrl);
+    if (j < 0 || !wemu::alive(j)) return bound_ctrl ? 0 : old;
+    return (int)(uint32_t)s[j];
+}
+inline void __builtin_amdgcn_wave_barrier() { (void)wemu::exchange(wemu::kBarrier, 0); }
+inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) {
+    const uint64_t* s = wemu::exchange(wemu::kBpermute, (uint32_t)v);
+    return (int)(uint32_t)s[(byte_addr >> 2) & 63];
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const uint64_t* s = wemu::exchange(wemu::kShfl, u);
+    const uint32_t r = (uint32_t)s[(wemu::lane() ^ mask) & (width - 1) & 63];
+    T out;
+    memcpy(&out, &r, 4);
+    return out;
+}
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline double __longlong_as_double(long long v) {
+    double d;
+    memcpy(&d, &v, 8);
+    return d;
+}
+inline long long __double_as_longlong(double d) {
+    long long v;
+    memcpy(&v, &d, 8);
+    return v;
+}
+inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}

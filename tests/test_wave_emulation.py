@@ -1,0 +1,102 @@
+"""The wave-cooperative photon search of the product (csrc/mcrt_waveknn.hpp) on the HOST: the device source unchanged, one wavefront
+emulated as 64 fibers that meet at every cross-lane operation (tests/emu/wave_emu.hpp: ballots, readlane, DPP moves with their row
+masks and bound_ctrl, shuffles, wave barriers; LDS as ordinary memory). What the GPU tier checks through the C ABI
+(test_knn_exact, test_knn_large_k) is checked here without a GPU: the reference's own k-NN vectors, the oracle's search for other k,
+both widths of the candidate buffer, and the frontier's spill list in both of its forms (state in registers / in LDS)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+
+def _search(wave_emu, desc, pts, k, rows, spill_mode, upload_k=50):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    n = len(pts)
+    cnt = np.zeros(n, dtype=np.uint32)
+    idx = np.zeros((n, k), dtype=np.uint32)
+    d2 = np.zeros((n, k))
+    overflow = np.zeros(1, dtype=np.uint32)
+    rc = wave_emu.wemu_knn(C.byref(desc), upload_k, n, pts.ctypes.data, k, rows, spill_mode, cnt.ctypes.data, idx.ctypes.data, d2.ctypes.data,
+                           overflow.ctypes.data)
+    assert rc == 0
+    return cnt, idx, d2, int(overflow[0])
+
+
+def test_wave_search_on_the_host_gives_the_reference_vectors(pkg, wave_emu, manifest):
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    k = img.param("k_nearest_photons")
+    d = golden_path(case["kat"])
+    for which, tag in ((0, "g"), (1, "c")):
+        pts = np.fromfile(os.path.join(d, "knn_%s_points.f64" % tag)).reshape(-1, 3)[:400]
+        cnt, idx, d2, overflow = _search(wave_emu, img.photons(which), pts, k, 4, 1, upload_k=k)
+        assert overflow == 0
+        np.testing.assert_array_equal(cnt, np.fromfile(os.path.join(d, "knn_%s_count.u32" % tag), dtype=np.uint32)[:400])
+        np.testing.assert_array_equal(idx, np.fromfile(os.path.join(d, "knn_%s_index.u32" % tag), dtype=np.uint32).reshape(-1, k)[:400])
+        np.testing.assert_array_equal(d2, np.fromfile(os.path.join(d, "knn_%s_d2.f64" % tag)).reshape(-1, k)[:400])
+
+
+@pytest.mark.parametrize("k,rows", [(1, 4), (7, 4), (64, 4), (128, 4), (129, 16), (300, 16), (768, 16), (50, 16)])
+def test_wave_search_on_the_host_equals_the_oracle(pkg, wave_emu, oracle, manifest, k, rows):
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    d = golden_path(case["kat"])
+    for which, tag in ((0, "g"), (1, "c")):
+        pts = np.fromfile(os.path.join(d, "knn_%s_points.f64" % tag)).reshape(-1, 3)[400:440]
+        for mode in (1, 2):  # the spill list's state in registers / in LDS (unused here: same answers)
+            cnt, idx, d2, overflow = _search(wave_emu, img.photons(which), pts, k, rows, mode)
+            ocnt, oidx, od2 = oracle.knn(img.photons(which), pts, k)
+            assert overflow == 0
+            np.testing.assert_array_equal(cnt, ocnt)
+            np.testing.assert_array_equal(d2, od2)
+            np.testing.assert_array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("count", [1, 49, 50, 51, 300])
+def test_wave_search_on_the_host_small_maps(pkg, wave_emu, count):
+    rng = np.random.default_rng(count)
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), 200)
+    pts = lo + rng.random((40, 3)) * (hi - lo)
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)
+    dd = pts[:, None, :] - pos[None, :, :]
+    d2_all = (dd[:, :, 0] * dd[:, :, 0] + dd[:, :, 1] * dd[:, :, 1]) + dd[:, :, 2] * dd[:, :, 2]
+    for k in (1, 50):
+        want = np.sort(d2_all, axis=1)[:, :min(k, count)]
+        cnt, idx, d2, overflow = _search(wave_emu, m.desc, pts, k, 4, 1)
+        assert overflow == 0 and np.all(cnt == min(k, count))
+        np.testing.assert_array_equal(d2[:, :min(k, count)], want)
+        assert np.all(np.isinf(d2[:, min(k, count):])) and np.all(idx[:, min(k, count):] == 0xFFFFFFFF)
+    m.close()
+
+
+@pytest.mark.parametrize("leaf,k,rows,upload_k", [(1, 64, 4, 1), (2, 100, 4, 2), (4, 300, 16, 16)])
+def test_frontier_spill_list_on_the_host(pkg, wave_emu, leaf, k, rows, upload_k):
+    """Leaves far smaller than k, and record lists built for a far smaller k than the one asked for (upload_k: only octants of up to
+    that many photons are scanned whole): more octants lie within the bound at once than the 128 frontier entries of a wave's
+    registers. Without the list in memory the search reports an overflow; with it - its state kept in registers or in LDS - the
+    brute-force answer."""
+    rng = np.random.default_rng(leaf * 1000 + k)
+    count = 6000
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), leaf)
+    pts = lo + rng.random((24, 3)) * (hi - lo)
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)
+    dd = pts[:, None, :] - pos[None, :, :]
+    d2_all = (dd[:, :, 0] * dd[:, :, 0] + dd[:, :, 1] * dd[:, :, 1]) + dd[:, :, 2] * dd[:, :, 2]
+    want = np.sort(d2_all, axis=1)[:, :k]
+    _, _, _, overflow = _search(wave_emu, m.desc, pts, k, rows, 0, upload_k=upload_k)
+    assert overflow == 1  # the case is a real one: 128 entries do not hold this frontier
+    for mode in (1, 2):
+        cnt, idx, d2, overflow = _search(wave_emu, m.desc, pts, k, rows, mode, upload_k=upload_k)
+        assert overflow == 0 and np.all(cnt == k)
+        np.testing.assert_array_equal(d2, want)
+        np.testing.assert_array_equal(d2_all[np.arange(len(pts))[:, None], idx], want)
+    m.close()
