@@ -258,3 +258,13 @@ inline unsigned __float_as_uint(float f) {
     memcpy(&u, &f, 4);
     return u;
 }
+// v_mbcnt_lo / v_mbcnt_hi: set bits of the mask below this lane (low / high half), added to `init`
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask_lo, unsigned init) {
+    const int l = wemu::lane();
+    return init + (unsigned)__builtin_popcount(l >= 32 ? mask_lo : (mask_lo & ((1u << l) - 1u)));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask_hi, unsigned init) {
+    const int l = wemu::lane();
+    return init + (l <= 32 ? 0u : (unsigned)__builtin_popcount(mask_hi & ((1u << (l - 32)) - 1u)));
+}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)

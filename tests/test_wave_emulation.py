@@ -100,3 +100,39 @@ def test_frontier_spill_list_on_the_host(pkg, wave_emu, leaf, k, rows, upload_k)
         np.testing.assert_array_equal(d2, want)
         np.testing.assert_array_equal(d2_all[np.arange(len(pts))[:, None], idx], want)
     m.close()
+
+
+@pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "hexagon_room", "quadric", "metals"])
+def test_shared_leaf_walk_on_the_host_equals_the_oracle(pkg, wave_walk_emu, oracle, manifest, name):
+    """traceWalkShared (csrc/mcrt_sharedleaf.hpp: the trace kernel's walk - deferred leaves tested by the whole wave, items numbered by
+    a prefix sum and pulled with ds_bpermute, one pop site, the stack's top cached in registers) and traceWalkQ, 64 rays per emulated
+    wavefront, full waves and waves with lanes that carry no ray: t, surface and uv of the oracle's Scene::intersect bit for bit,
+    on the reference's KAT rays and on random rays (some with zero direction components: the exact-record walk)."""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    img = pkg.SceneImage(golden_path(case["image"]))
+    sc = img.scene
+    rng = np.random.default_rng(11)
+    lo, hi = np.array(sc.bb_min[:]), np.array(sc.bb_max[:])
+    n = 1500
+    start = lo + (hi - lo) * rng.random((n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:40, rng.integers(0, 3)] = 0.0
+    d[:40] /= np.linalg.norm(d[:40], axis=1, keepdims=True)
+    kat = os.path.join(golden_path(case["kat"]), "isect_rays.f64") if case.get("kat") else ""
+    if kat and os.path.exists(kat):
+        rays = np.fromfile(kat).reshape(-1, 6)[:1500]
+        start, d = np.vstack([start, rays[:, :3]]), np.vstack([d, rays[:, 3:]])
+    start, d = np.ascontiguousarray(start), np.ascontiguousarray(d)
+    n = start.shape[0]
+    t0, s0, uv0, _ = oracle.intersect(img, start, d)
+    for which, holes in ((0, 0), (0, 3), (1, 0)):
+        t, surf, uv = np.full(n, np.nan), np.zeros(n, dtype=np.uint32), np.zeros((n, 2))
+        rc = wave_walk_emu.wemu_intersect(C.byref(sc), n, start.ctypes.data, d.ctypes.data, which, holes, t.ctypes.data, surf.ctypes.data, uv.ctypes.data)
+        assert rc == 0
+        hit = s0 != 0xFFFFFFFF
+        np.testing.assert_array_equal(surf, s0, err_msg="walk %d holes %d" % (which, holes))
+        np.testing.assert_array_equal(t[hit], t0[hit])
+        np.testing.assert_array_equal(uv[hit], uv0[hit])
