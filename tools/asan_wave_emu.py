@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Driver of tools/asan_wave_emu.sh: the product's wave-cooperative device code (photon search, shared-leaf tree walk) on the host
+emulation of a wavefront (tests/emu/wave_emu.hpp), built with AddressSanitizer + UndefinedBehaviourSanitizer - out-of-bounds LDS /
+buffer indices, misaligned or overflowing arithmetic in code that cannot be sanitised on the device. Prints one line per case
+(... True = the oracle's answer); any sanitizer report ends the run."""
+import ctypes as C, os, sys, importlib, json
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import conftest, oracle_lib
+pkg = importlib.import_module("monte-carlo-ray-tracer_amd")
+L = C.CDLL("/tmp/mcrt_wave_asan/libwave_knn_emu.so")
+L.wemu_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+man = json.load(open("tests/golden/manifest.json"))
+case = man["cases"]["hexagon_room_pm"]
+img = pkg.SceneImage(conftest.golden_path(case["image"]))
+d = conftest.golden_path(case["kat"])
+def run(mdesc, pts, k, rows, mode, upload_k=50):
+    n = len(pts)
+    cnt = np.zeros(n, dtype=np.uint32); idx = np.zeros((n, k), dtype=np.uint32); d2 = np.zeros((n, k)); ov = np.zeros(1, dtype=np.uint32)
+    pts = np.ascontiguousarray(pts)
+    rc = L.wemu_knn(C.byref(mdesc), upload_k, n, pts.ctypes.data, k, rows, mode, cnt.ctypes.data, idx.ctypes.data, d2.ctypes.data, ov.ctypes.data)
+    return rc, cnt, idx, d2, int(ov[0])
+for which, tag in ((0, "g"), (1, "c")):
+    pts = np.fromfile(os.path.join(d, "knn_%s_points.f64" % tag)).reshape(-1, 3)[:60]
+    for k, rows, mode in ((50, 4, 1), (128, 4, 2), (300, 16, 1), (768, 16, 2), (1, 4, 1)):
+        rc, cnt, idx, d2, ov = run(img.photons(which), pts, k, rows, mode)
+        ocnt, oidx, od2 = oracle_lib.knn(img.photons(which), pts, k)
+        print(tag, k, rows, mode, rc, ov, np.array_equal(idx, oidx))
+lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+rng = np.random.default_rng(3)
+ph = np.zeros((6000, 8), dtype=np.float32); ph[:, 3:6] = (lo + rng.random((6000, 3)) * (hi - lo)).astype(np.float32)
+m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), 1)
+pts = lo + rng.random((8, 3)) * (hi - lo)
+for mode in (0, 1, 2):
+    print("tiny leaves mode", mode, run(m.desc, pts, 64, 4, mode, 1)[4])
+
+# ---- tree walks
+L = C.CDLL("/tmp/mcrt_wave_asan/libwave_walk_emu.so")
+L.wemu_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+man = json.load(open("tests/golden/manifest.json"))
+for name in ("coffee_maker_qsah", "quadric"):
+    case = man["cases"][name]
+    img = pkg.SceneImage(conftest.golden_path(case["image"]))
+    sc = img.scene
+    rng = np.random.default_rng(11)
+    lo, hi = np.array(sc.bb_min[:]), np.array(sc.bb_max[:])
+    n = 700
+    start = np.ascontiguousarray(lo + (hi - lo) * rng.random((n, 3)))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True); d = np.ascontiguousarray(d)
+    t0, s0, uv0, _ = oracle_lib.intersect(img, start, d)
+    for which, holes in ((0, 0), (0, 3), (1, 0)):
+        t, surf, uv = np.full(n, np.nan), np.zeros(n, dtype=np.uint32), np.zeros((n, 2))
+        rc = L.wemu_intersect(C.byref(sc), n, start.ctypes.data, d.ctypes.data, which, holes, t.ctypes.data, surf.ctypes.data, uv.ctypes.data)
+        print(name, which, holes, rc, np.array_equal(surf, s0))
