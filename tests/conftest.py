@@ -118,6 +118,8 @@ def wave_walk_emu():
     L = C.CDLL(out)
     L.wemu_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.wemu_intersect.restype = C.c_int
+    L.wemu_estimate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wemu_estimate.restype = C.c_int
     return L
 
 

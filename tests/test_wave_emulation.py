@@ -136,3 +136,29 @@ def test_shared_leaf_walk_on_the_host_equals_the_oracle(pkg, wave_walk_emu, orac
         np.testing.assert_array_equal(surf, s0, err_msg="walk %d holes %d" % (which, holes))
         np.testing.assert_array_equal(t[hit], t0[hit])
         np.testing.assert_array_equal(uv[hit], uv0[hit])
+
+
+@pytest.mark.parametrize("k,rows", [(50, 4), (200, 16)])
+def test_wave_radiance_estimate_on_the_host(pkg, wave_walk_emu, manifest, k, rows):
+    """renderKernelPM's part 2 on the emulated wavefront - the asking lanes' Interactions staged in memory, one search per request by
+    the whole wave, the record read back into 'scalar registers' (readfirstlane), the k photons evaluated by k lanes, the sums by the
+    DPP reduction (waveSumD) - against the per-lane estimate functions of the legacy kernel (estimateCausticRadiance /
+    estimateGlobalRadiance) at the first hits of a small frame's camera rays. Same photons, same per-photon arithmetic; only the
+    order of the FP64 sum differs: 1e-12."""
+    from conftest import camera_for
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 32, 18, 1
+    n = cam.width * cam.height
+    lane, wave = np.zeros((n, 6)), np.zeros((n, 6))
+    valid = np.zeros(n, dtype=np.uint8)
+    rc = wave_walk_emu.wemu_estimate(C.byref(img.scene), C.byref(img.photons(0)), C.byref(img.photons(1)), k, rows, C.byref(cam),
+                                     manifest["seed"], n, lane.ctypes.data, wave.ctypes.data, valid.ctypes.data)
+    assert rc == 0
+    v = valid != 0
+    assert v.sum() > n // 2 and (lane[v] != 0).any()
+    rel = np.abs(wave[v] - lane[v]) / np.maximum(np.abs(lane[v]), 1e-3)
+    print("estimates at %d hits, k = %d: max rel %.3e between the wave's and the lane's sums" % (v.sum(), k, rel.max()))
+    assert rel.max() <= 1e-12
+    assert (wave[~v] == 0).all()
