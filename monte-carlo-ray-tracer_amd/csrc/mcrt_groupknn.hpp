@@ -20,7 +20,7 @@
 #ifndef MCRT_GROUPKNN_HPP
 #define MCRT_GROUPKNN_HPP
 
-#ifdef __HIPCC__
+#if defined(__HIPCC__) || defined(MCRT_WAVE_EMU)
 
 #include "mcrt_waveknn.hpp"
 

@@ -123,6 +123,27 @@ def wave_walk_emu():
     return L
 
 
+@pytest.fixture(scope="session")
+def wave_kernel_emu():
+    """Host build of the product's KERNELS (tests/emu/wave_kernel_emu.cpp: csrc/mcrt_kernels.hpp unchanged, workgroups of emulated
+    wavefronts with __syncthreads, LDS and the launch geometry) — test harness only."""
+    src = os.path.join(TESTS, "emu", "wave_kernel_emu.cpp")
+    out = os.path.join(TESTS, "emu", "_build", "libwave_kernel_emu.so")
+    csrc = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc")
+    deps = [src, os.path.join(TESTS, "emu", "wave_emu.hpp"), os.path.join(TESTS, "emu", "mcrt_emu.cpp")] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = "%s.%d.tmp" % (out, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        os.replace(tmp, out)
+    L = C.CDLL(out)
+    vp = C.c_void_p
+    L.wemu_trace_kernel.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
+    L.wemu_trace_kernel.restype = C.c_int
+    return L
+
+
 def load_emu():
     """Host build of the product's per-lane device code (tests/emu/mcrt_emu.cpp) — test harness only."""
     src = os.path.join(TESTS, "emu", "mcrt_emu.cpp")

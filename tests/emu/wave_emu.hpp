@@ -28,7 +28,7 @@
 namespace wemu {
 
 constexpr int kLanes = 64;
-enum Op : uint32_t { kBallot = 1, kReadlane, kReadfirst, kDpp, kShfl, kBarrier, kBpermute };
+enum Op : uint32_t { kBallot = 1, kReadlane, kReadfirst, kDpp, kShfl, kBarrier, kBpermute, kSync };
 
 // Switching fibers: swapcontext makes a system call per switch (the signal mask), and a search is a few thousand cross-lane operations
 // x 64 lanes x 2 switches - so on x86-64 the switch is six pushes, the stack pointer, six pops (callee-saved registers only: the
@@ -73,14 +73,17 @@ inline void makeFiber(Context& c, char* stack, size_t bytes, void (*entry)()) {
 }
 #endif
 
-struct Wave {
+constexpr int kMaxWaves = 16;
+struct Wave {  // a workgroup of `waves` wavefronts (1 for wemu::run); lane l of wave w is fiber 64 w + l
     Context sched;
-    Context ctx[kLanes];
-    bool done[kLanes];
-    bool waiting[kLanes];
-    uint64_t pub[kLanes], snap[kLanes];
-    uint32_t op[kLanes];
-    int cur = -1;
+    Context ctx[kMaxWaves * kLanes];
+    bool done[kMaxWaves * kLanes];
+    bool waiting[kMaxWaves * kLanes];
+    uint64_t pub[kMaxWaves * kLanes], snap[kMaxWaves * kLanes];
+    uint32_t op[kMaxWaves * kLanes];
+    bool at_sync[kMaxWaves];  // the wave has arrived at __syncthreads and waits for the others
+    int waves = 1;
+    int cur = -1;             // fiber index
     std::function<void(int)> body;
     unsigned long long collectives = 0;
 };
@@ -100,53 +103,88 @@ inline void trampoline() {
     abort();  // (a finished lane is never resumed)
 }
 
-// Runs body(lane) for the 64 lanes of one wave to completion.
-inline void run(const std::function<void(int)>& body, size_t stack_bytes = 1u << 20) {
-    static thread_local std::vector<char> stacks[kLanes];  // kept between runs (64 MB of fresh pages per search otherwise)
-    for (int l = 0; l < kLanes; l++)
+// Runs body(thread) for the 64 x waves threads of one workgroup to completion (thread = 64 wave + lane). Cross-lane operations
+// synchronise the lanes of one wave; __syncthreads (kSync) all waves: a wave that arrives there is parked until every wave that still
+// has live lanes has arrived.
+inline void runGroup(int waves, const std::function<void(int)>& body, size_t stack_bytes = 1u << 20) {
+    if (waves < 1 || waves > kMaxWaves) abort();
+    static thread_local std::vector<char> stacks[kMaxWaves * kLanes];  // kept between runs (64 MB of fresh pages per search otherwise)
+    const int threads = waves * kLanes;
+    for (int l = 0; l < threads; l++)
         if (stacks[l].size() < stack_bytes) stacks[l].resize(stack_bytes);
-    Wave w;
+    static thread_local Wave* pool = nullptr;  // (half a megabyte: not on the caller's stack)
+    if (!pool) pool = new Wave();
+    Wave& w = *pool;
     Wave* saved = current();
     current() = &w;
     w.body = body;
-    for (int l = 0; l < kLanes; l++) {
+    w.waves = waves;
+    w.collectives = 0;
+    for (int l = 0; l < threads; l++) {
         w.done[l] = w.waiting[l] = false;
         w.pub[l] = w.snap[l] = 0;
         w.op[l] = 0;
         makeFiber(w.ctx[l], stacks[l].data(), stack_bytes, trampoline);
     }
+    for (int v = 0; v < waves; v++) w.at_sync[v] = false;
     for (;;) {
         bool any = false;
-        for (int l = 0; l < kLanes; l++) {
-            if (w.done[l]) continue;
-            any = true;
-            w.cur = l;
-            w.waiting[l] = false;
-            switchTo(w.sched, w.ctx[l]);
+        for (int v = 0; v < waves; v++) {
+            if (w.at_sync[v]) {
+                any = true;
+                continue;  // parked at __syncthreads
+            }
+            bool alive_wave = false;
+            for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
+                if (w.done[l]) continue;
+                alive_wave = any = true;
+                w.cur = l;
+                w.waiting[l] = false;
+                switchTo(w.sched, w.ctx[l]);
+            }
+            if (!alive_wave) continue;
+            // every lane of the wave still alive must have stopped at the SAME kind of operation: anything else is divergence
+            // around a cross-lane operation, which the device code must not have ("all lanes must call")
+            uint32_t kind = 0;
+            bool still = false;
+            for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
+                if (w.done[l]) continue;
+                still = true;
+                if (!w.waiting[l]) {
+                    fprintf(stderr, "wave_emu: thread %d neither finished nor at a cross-lane operation\n", l);
+                    abort();
+                }
+                if (kind == 0) kind = w.op[l];
+                if (w.op[l] != kind) {
+                    fprintf(stderr, "wave_emu: divergence - thread %d is at operation %u, an earlier lane of its wave at %u\n", l, w.op[l], kind);
+                    abort();
+                }
+            }
+            if (!still) continue;
+            if (kind == kSync) w.at_sync[v] = true;
+            else memcpy(w.snap + v * kLanes, w.pub + v * kLanes, sizeof(uint64_t) * kLanes);
+            w.collectives++;
         }
         if (!any) break;
-        // every lane still alive must have stopped at the SAME kind of operation: anything else is divergence around a
-        // cross-lane operation, which the device code must not have ("all lanes must call")
-        uint32_t kind = 0;
-        for (int l = 0; l < kLanes; l++) {
-            if (w.done[l]) continue;
-            if (!w.waiting[l]) {
-                fprintf(stderr, "wave_emu: lane %d neither finished nor at a cross-lane operation\n", l);
-                abort();
-            }
-            if (kind == 0) kind = w.op[l];
-            if (w.op[l] != kind) {
-                fprintf(stderr, "wave_emu: divergence - lane %d is at operation %u, an earlier lane at %u\n", l, w.op[l], kind);
-                abort();
-            }
+        // __syncthreads: released when every wave with live lanes is parked
+        bool all = true, some = false;
+        for (int v = 0; v < waves; v++) {
+            bool live = false;
+            for (int l = v * kLanes; l < (v + 1) * kLanes; l++) live = live || !w.done[l];
+            if (!live) continue;
+            some = true;
+            all = all && w.at_sync[v];
         }
-        memcpy(w.snap, w.pub, sizeof(w.snap));
-        w.collectives++;
+        if (some && all)
+            for (int v = 0; v < waves; v++) w.at_sync[v] = false;
     }
     current() = saved;
 }
+// one wavefront
+inline void run(const std::function<void(int)>& body, size_t stack_bytes = 1u << 20) { runGroup(1, body, stack_bytes); }
 
-inline int lane() { return current()->cur; }
+inline int lane() { return current()->cur & 63; }
+inline int thread() { return current()->cur; }
 
 // publish v, wait for the wave, return the snapshot of everybody's operands (valid until this lane's next cross-lane operation)
 inline const uint64_t* exchange(Op op, uint64_t v) {
@@ -157,9 +195,9 @@ inline const uint64_t* exchange(Op op, uint64_t v) {
     w->waiting[l] = true;
     switchTo(w->ctx[l], w->sched);
     w->cur = l;  // (the scheduler set it before resuming; restated for clarity)
-    return w->snap;
+    return w->snap + (l & ~63);  // this wave's operands
 }
-inline bool alive(int l) { return !current()->done[l]; }
+inline bool alive(int l) { return !current()->done[(current()->cur & ~63) + l]; }  // lane l of the caller's wave
 
 // v_mov_b32_dpp: the source lane of lane i under dpp_ctrl, or -1 when the control has no valid source for it
 inline int dppSource(int i, int ctrl) {
@@ -268,3 +306,65 @@ inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask_hi, unsigned init) {
     return init + (l <= 32 ? 0u : (unsigned)__builtin_popcount(mask_hi & ((1u << (l - 32)) - 1u)));
 }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+
+// ---- a workgroup: threadIdx / blockIdx / blockDim / gridDim, __syncthreads, LDS declarations, atomics on memory --------------------
+namespace wemu {
+struct Launch {
+    unsigned block_idx = 0, block_dim = 64, grid_dim = 1;
+};
+inline Launch& launch() {
+    static thread_local Launch l;
+    return l;
+}
+struct ThreadIdxX {
+    operator unsigned() const { return (unsigned)thread(); }
+};
+struct BlockIdxX {
+    operator unsigned() const { return launch().block_idx; }
+};
+struct BlockDimX {
+    operator unsigned() const { return launch().block_dim; }
+};
+struct GridDimX {
+    operator unsigned() const { return launch().grid_dim; }
+};
+}  // namespace wemu
+static const struct { wemu::ThreadIdxX x; } threadIdx = {};
+static const struct { wemu::BlockIdxX x; } blockIdx = {};
+static const struct { wemu::BlockDimX x; } blockDim = {};
+static const struct { wemu::GridDimX x; } gridDim = {};
+inline void __syncthreads() { (void)wemu::exchange(wemu::kSync, 0); }
+#define __shared__
+#define __align__(n) __attribute__((aligned(n)))
+#define __launch_bounds__(...)
+template <class T, class U>
+inline T atomicAdd(T* p, U v) {  // (one OS thread: fibers switch only at cross-lane operations)
+    const T old = *p;
+    *p = (T)(old + (T)v);
+    return old;
+}
+template <class T>
+inline T __shfl_down(T v, int delta, int width = 64) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const uint64_t* s = wemu::exchange(wemu::kShfl, u);
+    const int l = wemu::lane(), src = l + delta;
+    const uint32_t r = (src < 64 && (src / width) == (l / width)) ? (uint32_t)s[src] : u;
+    T out;
+    memcpy(&out, &r, 4);
+    return out;
+}
+inline long long clock64() { return 0; }
+struct uint2 {
+    unsigned x, y;
+};
+struct uint4 {
+    unsigned x, y, z, w;
+};
+struct float4 {
+    float x, y, z, w;
+};
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }

@@ -162,3 +162,54 @@ def test_wave_radiance_estimate_on_the_host(pkg, wave_walk_emu, manifest, k, row
     print("estimates at %d hits, k = %d: max rel %.3e between the wave's and the lane's sums" % (v.sum(), k, rel.max()))
     assert rel.max() <= 1e-12
     assert (wave[~v] == 0).all()
+
+
+def _random_rays(sc, n, seed, kat_dir=None):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(sc.bb_min[:]), np.array(sc.bb_max[:])
+    start = lo + (hi - lo) * rng.random((n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:40, rng.integers(0, 3)] = 0.0   # zero direction components: the exact-record walk
+    d[:40] /= np.linalg.norm(d[:40], axis=1, keepdims=True)
+    if kat_dir and os.path.exists(os.path.join(kat_dir, "isect_rays.f64")):
+        rays = np.fromfile(os.path.join(kat_dir, "isect_rays.f64")).reshape(-1, 6)[:2000]
+        start, d = np.vstack([start, rays[:, :3]]), np.vstack([d, rays[:, 3:]])
+    return np.ascontiguousarray(start), np.ascontiguousarray(d)
+
+
+# (form, workgroups, waves per workgroup, stack entries per lane in LDS, refill gate, leaf gate, log2 of the dealing block)
+TRACE_LAUNCHES = [(3, 3, 2, 16, 16, 16, 6), (3, 1, 4, 4, 16, 16, 6), (3, 2, 2, 16, 1, 1, 6), (3, 2, 3, 16, 48, 40, 7), (3, 5, 1, 8, 16, 16, 6),
+                  (2, 2, 2, 16, 16, 24, 6), (0, 2, 1, 16, 16, 24, 6), (1, 2, 2, 16, 16, 24, 6)]
+
+
+@pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "hexagon_room", "quadric", "metals", "veach_mis"])
+def test_trace_kernel_on_the_host_equals_the_oracle(pkg, wave_kernel_emu, oracle, manifest, name):
+    """wfTraceKernel - the kernel half the bench's GPU time is spent in - as it is, on emulated workgroups: every form (shared leaf
+    step = the default, deferred leaves, the first walk, eight-wide nodes), several launch shapes (one to five workgroups of one to
+    four waves, 4 to 16 stack entries per lane in LDS with the rest spilled, refill and leaf gates from 'at once' to 'almost never',
+    dealing blocks of 64 and 128): t, surface and uv of the oracle's Scene::intersect for every ray, bit for bit, and the kernel's own
+    ray count. What this covers beyond the per-wave walk test: the queue dealt in blocks, the LDS cursor, batched refills and hit
+    stores, the staging of the tree's top and root, __syncthreads."""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    img = pkg.SceneImage(golden_path(case["image"]))
+    sc = img.scene
+    start, d = _random_rays(sc, 3000, 23, golden_path(case["kat"]) if case.get("kat") else None)
+    n = len(start)
+    t0, s0, uv0, _ = oracle.intersect(img, start, d)
+    hit = s0 != 0xFFFFFFFF
+    for form, grid, waves, lds_stack, refill, leaf, deal in TRACE_LAUNCHES:
+        t, surf, uv = np.full(n, np.nan), np.full(n, 7, dtype=np.uint32), np.zeros((n, 2))
+        stats = np.zeros(64, dtype=np.uint64)
+        rc = wave_kernel_emu.wemu_trace_kernel(C.byref(sc), n, start.ctypes.data, d.ctypes.data, form, grid, waves, 0xFFFFFFFF, lds_stack, refill, leaf,
+                                               deal, t.ctypes.data, surf.ctypes.data, uv.ctypes.data, stats.ctypes.data)
+        if rc == -201:
+            continue  # (no eight-wide nodes for this tree)
+        what = "form %d, %d x %d waves, stack %d, gates %d / %d" % (form, grid, waves, lds_stack, refill, leaf)
+        assert rc == 0, what
+        assert int(stats[1]) == n, what
+        np.testing.assert_array_equal(surf, s0, err_msg=what)
+        np.testing.assert_array_equal(t[hit], t0[hit], err_msg=what)
+        np.testing.assert_array_equal(uv[hit], uv0[hit], err_msg=what)
