@@ -141,6 +141,8 @@ def wave_kernel_emu():
     vp = C.c_void_p
     L.wemu_trace_kernel.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
     L.wemu_trace_kernel.restype = C.c_int
+    L.wemu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
+    L.wemu_render.restype = C.c_int
     return L
 
 

@@ -16,6 +16,42 @@ namespace {
 alignas(64) unsigned char lds[160 * 1024];  // what `extern __shared__ unsigned char lds[]` of the kernels refers to here
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_kernels.hpp"
 
+// a map of the host desc as the wave search wants it (record lists: buildWideRecords, positions by themselves)
+struct WaveMap {
+    std::vector<uint32_t> start, contained;
+    std::vector<WideRec> wide;
+    std::vector<PhotonPos> pos;
+    PhotonMapViewW view;
+    int init(const mcrt_photon_map_desc* m, uint32_t k) {
+        memset(&view, 0, sizeof(view));
+        if (!m || m->num_octants == 0) return 0;
+        const size_t no = m->num_octants;
+        start.resize(no);
+        contained.resize(no);
+        for (size_t i = 0; i < no; i++) {
+            start[i] = (uint32_t)m->octant_start_data[i];
+            contained[i] = (uint32_t)m->octant_contained_data[i];
+        }
+        uint32_t ra = 0, rm = 0;
+        if (const int rc = buildWideRecords(m, contained.data(), k ? k : 1u, wide, ra, rm)) return rc;
+        pos.resize((size_t)m->num_photons);
+        for (size_t i = 0; i < pos.size(); i++) pos[i] = PhotonPos{m->photons[8 * i + 3], m->photons[8 * i + 4], m->photons[8 * i + 5]};
+        view.base.num_octants = m->num_octants;
+        view.base.num_photons = m->num_photons;
+        view.base.octant_bounds = m->octant_bounds;
+        view.base.octant_start = start.data();
+        view.base.octant_contained = contained.data();
+        view.base.octant_next = m->octant_next_sibling;
+        view.base.octant_leaf = m->octant_leaf;
+        view.base.photons = m->photons;
+        view.wide = wide.data();
+        view.root_a = ra;
+        view.root_m = rm;
+        view.pos = pos.data();
+        return 0;
+    }
+};
+
 template <int kForm>
 void launchTrace(const WfTraceArgs& a, const ArrayRays& rays, uint32_t grid, uint32_t waves) {
     for (uint32_t g = 0; g < grid; g++) {
@@ -81,6 +117,207 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     else launchTrace<3>(a, rays, grid, waves);
     if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
     return stats[5] ? -100 : 0;
+}
+
+// ---- whole frames ------------------------------------------------------------------------------------------------------------------
+// The frame kernels of launchRender (mcrt_hip.hip) - renderKernel<path tracer, flat>, renderKernelSM, renderKernelPM - and
+// sampleResolveKernel on emulated workgroups: DeviceScene filled from the host layout the way mcrt_upload_scene fills it (same staging
+// rule), RenderParams / PmExtra the way launchRender fills them (same LDS plans, same work units), one pass over the whole frame.
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t kEmuMaxLds = 160u * 1024u - 3520u;  // the device's LDS less the shading kernels' static table (mcrt_create)
+
+void fillDeviceScene(const mcrt_scene_desc* s, Emu& E, DeviceScene& d, uint32_t flat_max) {
+    HostLayout& L = E.L;
+    memset(&d, 0, sizeof(d));
+    d.num_nodes = s->num_nodes;
+    d.num_surfaces = s->num_surfaces;
+    d.num_materials = s->num_materials;
+    d.num_lights = s->num_lights;
+    d.node_bounds = L.node_bounds.data();
+    d.node_meta = L.node_meta.data();
+    d.nodes64 = L.nodes64.data();
+    d.qblocks = L.qblocks.data();
+    d.num_qblocks = (uint32_t)L.qblocks.size();
+    d.q_nodes = (uint32_t)L.nodes64.size();
+    d.stack_depth = std::max<uint32_t>((uint32_t)kMaxStackDepth, L.stack_bound + 1u);
+    d.q_root_a = L.q_root_a;
+    d.q_root_m = L.q_root_m;
+    d.wnodes = L.wnodes.empty() ? nullptr : L.wnodes.data();
+    d.num_wnodes = (uint32_t)L.wnodes.size();
+    d.leaf_pre = nullptr;
+    d.prim = L.prim.data();
+    d.flat_prim = L.flat_prim.data();
+    d.flat_index = L.flat_index.data();
+    d.flat_tris = L.flat_tris;
+    d.flat_pre = L.flat_pre.empty() ? nullptr : L.flat_pre.data();
+    d.pre_tri_pairs = L.pre_tri_pairs;
+    d.pre_sph_pairs = L.pre_sph_pairs;
+    for (int c = 0; c < 3; c++) d.pre_centre[c] = L.pre_centre[c];
+    d.pre_bound = L.pre_bound;
+    d.surf_v = L.num_quadric_surfaces ? L.surf_v_patched.data() : s->surf_v;
+    d.surf_normal = L.normal.data();
+    d.surf_rec = L.shade_rec.data();
+    d.surf_vn = s->surf_vn;
+    d.surf_area = s->surf_area;
+    d.surf_material = s->surf_material;
+    d.surf_kind = s->surf_kind;
+    d.materials = s->materials;
+    d.light_surface = s->light_surface;
+    d.light_cdf = s->light_cdf;
+    d.sobol_tab = E.tab.data();
+    d.scene_ior = s->scene_ior;
+    // staging plan, as mcrt_upload_scene
+    d.stage_all = 1;
+    d.stage_nodes = 0;
+    const uint32_t fixed = planLds(DeviceScene{}, kBlock).total;
+    if (planLds(d, kBlock).total - fixed > 48u * 1024u || planLds(d, kBlock).total > kEmuMaxLds || L.num_quadric_surfaces) {
+        d.stage_all = 0;
+        d.stage_nodes = std::min<uint32_t>(d.num_nodes, 512u);
+    }
+    d.flat = (d.stage_all && d.num_surfaces <= flat_max && !L.flat_prim.empty() && L.num_quadric_surfaces == 0) ? 1u : 0u;
+}
+
+template <class F>
+void launchGrid(uint32_t grid, uint32_t block, F&& kernel_call) {
+    for (uint32_t g = 0; g < grid; g++) {
+        wemu::launch().block_idx = g;
+        wemu::launch().block_dim = block;
+        wemu::launch().grid_dim = grid;
+        wemu::runGroup((int)(block / 64u), [&](int) { kernel_call(); }, 1u << 20);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// A frame by the kernel launchRender picks for it: integrator 0 path tracer / 1 photon mapper; kernel_out: 1 flat, 3 lane state machine,
+// 5 photon-mapping wave kernel, 2 wave-synchronous (MCRT_KERNEL_* of include/mcrt.h). force: 0 = launchRender's choice, 2 = the
+// wave-synchronous kernel for path-traced frames (MCRT_KERNEL=legacy). grid: workgroups launched (the first takes what work it can).
+// out_rgb [h][w][3]; stats_out [kStatsWords]. Returns 0, or a negative code (-100 stack overflow, -202 LDS plan too large, ...).
+int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, int force, uint32_t grid,
+                double* out_rgb, unsigned long long* stats_out, int* kernel_out) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return rc;
+    DeviceScene d;
+    fillDeviceScene(scene, E, d, 64u);
+    const bool photon = integrator == MCRT_INTEGRATOR_PHOTON_MAPPER, all = d.stage_all != 0;
+    const bool flat_only = !photon && d.flat && force != 2;
+    const bool use_sm = !photon && !d.flat && force != 2;
+    const bool use_pm_wave = photon && k_nearest <= waveMaxK(kWaveRows);
+    if (photon && !use_pm_wave) return -203;
+    if (grid == 0) grid = 1;
+    RenderParams prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.cam = *cam;
+    prm.global_seed = global_seed;
+    prm.spp = cam->sqrtspp * cam->sqrtspp;
+    prm.owned_rows = cam->height;
+    prm.tiles_x = (cam->width + 7) / 8;
+    prm.tiles_y = (prm.owned_rows + 7) / 8;
+    unsigned long long work_counter = 0;
+    std::vector<unsigned long long> stats(kStatsWords + 32, 0ull);
+    prm.work_counter = &work_counter;
+    prm.stats = stats.data();
+    prm.sm_shade_lanes = 40;
+    prm.sm_regen_lanes = 16;
+    prm.sm_min_trav = 20;
+    prm.sm_leaf_lanes = 32;
+    prm.sm_min_inner = 8;
+    prm.sm_lds_depth = kLdsStackDepth;
+    DeviceScene launch_scene = d;
+    uint32_t block = kBlock, lds_bytes = 0, pm_stack_depth = kLdsStackDepth;
+    WaveMap wg, wc;
+    PmExtra pmx;
+    memset(&pmx, 0, sizeof(pmx));
+    if (use_pm_wave) {
+        if (wg.init(gmap, k_nearest) || wc.init(cmap, k_nearest)) return -301;
+        if (!launch_scene.stage_all) launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, 128u);
+        auto ldsBytes = [&](uint32_t b, uint32_t depth) {
+            return alignUp(planLds(launch_scene, b, true, depth, b != 1024u ? (uint32_t)kMaxIors : kPmLdsIors).total, 16) +
+                   (b / 64) * (waveKnnBytes(kWaveRows) + (all ? 0u : kWaveStateBytes));
+        };
+        if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= kEmuMaxLds) {
+            block = 1024;
+        } else if (!launch_scene.stage_all) {
+            for (uint32_t depth = 16u; depth >= 2 && block == kBlock; depth -= 2)
+                if (ldsBytes(1024, depth) <= kEmuMaxLds) {
+                    block = 1024;
+                    pm_stack_depth = depth;
+                }
+        }
+        lds_bytes = ldsBytes(block, pm_stack_depth);
+    } else if (use_sm) {
+        const uint32_t fixed = planSmLds(DeviceScene{}, block, (uint32_t)kLdsStackDepth).total;
+        if (!launch_scene.stage_all && fixed < kEmuMaxLds) launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, (kEmuMaxLds - fixed) / 64u);
+        lds_bytes = planSmLds(launch_scene, block, (uint32_t)kLdsStackDepth).total;
+    } else {
+        lds_bytes = planLds(launch_scene, block, !flat_only).total;
+    }
+    if (lds_bytes > kEmuMaxLds || lds_bytes > sizeof(lds)) return -202;
+    const uint32_t total_lanes = grid * block;
+    prm.total_lanes = total_lanes;
+    std::vector<StackEntry> spill((size_t)total_lanes * (d.stack_depth - kLdsStackDepth) + 16);
+    prm.spill = spill.data();
+    std::vector<double> stage, pm_iors;
+    std::vector<uint32_t> knn_spill;
+    if (use_pm_wave) {
+        prm.global_map = wg.view.base;
+        prm.caustic_map = wc.view.base;
+        prm.k_nearest = k_nearest;
+        prm.direct_visualization = direct_visualization ? 1u : 0u;
+        pmx.global_map = wg.view;
+        pmx.caustic_map = wc.view;
+        pmx.stack_depth = pm_stack_depth;
+        stage.resize((size_t)kStageDoubles * total_lanes);
+        pmx.stage = stage.data();
+        knn_spill.resize((size_t)(total_lanes / 64) * kWaveSpill * 3);
+        pmx.knn_spill = knn_spill.data();
+        if (block == 1024u) {
+            pm_iors.resize((size_t)kMaxIors * total_lanes);
+            pmx.iors_global = pm_iors.data();
+        }
+    }
+    prm.row_base = 0;
+    prm.row_end = prm.owned_rows;
+    prm.pass_pixels = (uint64_t)prm.owned_rows * cam->width;
+    const ChunkPlan cp = photon ? planChunks(prm.spp, unitsWanted(total_lanes, 128, prm.pass_pixels)) : planChunksMega(prm.spp, total_lanes, prm.pass_pixels);
+    prm.chunk_shift = cp.shift;
+    prm.chunk = cp.chunk;
+    const uint64_t tiles = (uint64_t)prm.tiles_x * ((prm.row_end - prm.row_base + 7) / 8);
+    prm.work_items = (tiles * 64ull) << cp.shift;
+    std::vector<double> samples((size_t)prm.spp * prm.pass_pixels * 3, 0.0);
+    prm.samples = samples.data();
+    int kernel_id = 0;
+    if (use_pm_wave) {
+        kernel_id = 5;
+        if (block == 1024u) {
+            if (all) launchGrid(grid, block, [&] { renderKernelPM<false, true, 1024>(launch_scene, prm, pmx); });
+            else launchGrid(grid, block, [&] { renderKernelPM<false, false, 1024>(launch_scene, prm, pmx); });
+        } else {
+            if (all) launchGrid(grid, block, [&] { renderKernelPM<false, true>(launch_scene, prm, pmx); });
+            else launchGrid(grid, block, [&] { renderKernelPM<false, false>(launch_scene, prm, pmx); });
+        }
+    } else if (use_sm) {
+        kernel_id = 3;
+        if (all) launchGrid(grid, block, [&] { renderKernelSM<false, true>(launch_scene, prm); });
+        else launchGrid(grid, block, [&] { renderKernelSM<false, false>(launch_scene, prm); });
+    } else if (flat_only) {
+        kernel_id = 1;
+        launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
+    } else {
+        kernel_id = 2;
+        if (all) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true>(launch_scene, prm); });
+        else launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, false>(launch_scene, prm); });
+    }
+    launchGrid((uint32_t)((prm.pass_pixels + 255) / 256), 256, [&] { sampleResolveKernel(prm.samples, prm.pass_pixels, prm.spp, out_rgb); });
+    if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
+    if (kernel_out) *kernel_out = kernel_id;
+    return stats[5] ? -100 : stats[7] ? -101 : 0;
 }
 
 }  // extern "C"

@@ -213,3 +213,60 @@ def test_trace_kernel_on_the_host_equals_the_oracle(pkg, wave_kernel_emu, oracle
         np.testing.assert_array_equal(surf, s0, err_msg=what)
         np.testing.assert_array_equal(t[hit], t0[hit], err_msg=what)
         np.testing.assert_array_equal(uv[hit], uv0[hit], err_msg=what)
+
+
+KERNEL_NAMES = {1: "renderKernel<path tracer, flat>", 2: "renderKernel (wave-synchronous)", 3: "renderKernelSM", 5: "renderKernelPM"}
+
+
+def _emulated_frame(pkg, wave_kernel_emu, img, cam, seed, integrator, force=0, grid=1):
+    out = np.zeros((cam.height, cam.width, 3))
+    stats = np.zeros(64, dtype=np.uint64)
+    kid = C.c_int(0)
+    g, c = img.photons(0), img.photons(1)
+    rc = wave_kernel_emu.wemu_render(C.byref(img.scene), C.byref(g) if g is not None else None, C.byref(c) if c is not None else None,
+                                     img.param("k_nearest_photons") or 50, int(img.param("direct_visualization") or 0), C.byref(cam), seed, integrator,
+                                     force, grid, out.ctypes.data, stats.ctypes.data, C.byref(kid))
+    return rc, out, stats, kid.value
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_diffuse", "hexagon_room_ggx", "hexagon_room_dof", "coffee_maker_qsah", "coffee_maker_bsah",
+                                  "veach_mis", "metals", "ggx_test", "oren_nayar_test", "ior_test", "quadric", "dragon_room", "shell_room"])
+def test_frame_kernels_on_the_host_give_the_oracle_frame(pkg, wave_kernel_emu, oracle, manifest, name):
+    """The FRAME KERNELS of the product - the flat megakernel of the headline config, the lane state machine, the wave-synchronous
+    kernel - as they are, on emulated workgroups of 8 wavefronts (work units popped with wave-aggregated atomics, path regeneration,
+    LDS staging of scene / tables / stacks, the per-sample store) followed by sampleResolveKernel: a small frame of every golden scene,
+    by the kernel launchRender picks and by the wave-synchronous one, against the oracle's frame (which is the reference's, bit for
+    bit: test_oracle_vs_reference.py) - bit for bit, with the oracle's ray count. No GPU."""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    from conftest import camera_for
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 28, 16, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+    seen = set()
+    for force, grid in ((0, 1), (2, 2)):
+        rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, force, grid)
+        assert rc == 0, "%s: rc %d" % (KERNEL_NAMES.get(kid), rc)
+        seen.add(kid)
+        assert int(stats[0]) == cam.width * cam.height * 4 and int(stats[1]) == info["rays"], KERNEL_NAMES.get(kid)
+        np.testing.assert_array_equal(out, want, err_msg="%s: %s is not the oracle's frame" % (name, KERNEL_NAMES.get(kid)))
+    print("%s: %s - the oracle's bits, %d rays" % (name, " and ".join(KERNEL_NAMES[k] for k in sorted(seen)), info["rays"]))
+
+
+def test_photon_mapping_kernel_on_the_host(pkg, wave_kernel_emu, oracle, manifest):
+    """renderKernelPM (1024 lanes = 16 emulated wavefronts: per-lane bounce code, estimates served by whole waves) on hexagon_room_pm's
+    maps against the oracle's photon-mapped frame: the order of an estimate's FP64 sum is the only difference (1e-12)."""
+    from conftest import camera_for
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 24, 12, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    assert rc == 0 and kid == 5
+    assert int(stats[1]) == info["rays"] and int(stats[4]) > 0
+    rel = np.abs(out - want) / np.maximum(np.abs(want), 1e-3)
+    print("hexagon_room_pm through renderKernelPM on the host: max rel %.3e, %d searches" % (rel.max(), int(stats[4])))
+    assert rel.max() <= 1e-12
