@@ -343,7 +343,7 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
 // kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs).
 template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
 __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;
@@ -485,7 +485,7 @@ enum : int { kStRegen = 0, kStTrav = 1, kStShade = 2, kStDone = 3 };
 // fewer stack entries per lane in LDS (prm.sm_lds_depth).
 template <bool kCount, bool kAll, bool kProf = false, int kLanes = (int)kBlock>
 __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene, const RenderParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     const SmLdsPlan p = planSmLds(scene, blockDim.x, (uint32_t)prm.sm_lds_depth);
 
     // ---- staging
@@ -790,7 +790,7 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 template <class Rays, bool kCount, int kForm = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
-    extern __shared__ __align__(64) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 64);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
     if constexpr (!kWide)
         for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
@@ -1090,7 +1090,7 @@ enum : int { kQInner = 0, kQLeaf = 1, kQFree = 2 };
 
 template <class Rays, bool kCount>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernelSched(const WfTraceArgs a, const Rays rays, double* ray_scratch) {
-    extern __shared__ __align__(64) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 64);
     MCRT_LDS_AS SchedLds* L = reinterpret_cast<MCRT_LDS_AS SchedLds*>((MCRT_LDS_AS unsigned char*)lds);
     const uint32_t lane = laneId();
     // every slot starts free
@@ -1434,7 +1434,7 @@ struct DevWfEnv {
 // measured C3 1122 -> 1158 Mray/s against the natural 221 VGPRs / 2 waves, 1017 at 4 waves (spills take over).
 template <bool kPhoton>
 __global__ void __launch_bounds__(kWfBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) wfShadeKernel(const DeviceScene scene, const WfShadeArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     MCRT_LDS_AS uint32_t* ltab = ldsAt<uint32_t>(lds, 0);
     // Staging in ONE round trip: every load of the Sobol tables, the sin/cos table and the lane's own flags word is issued before
     // the first LDS write (loop after loop, each waiting for its loads, was five to six trips before a workgroup could start).
@@ -1677,7 +1677,7 @@ struct PmExtra {
 // register budget causes in the per-lane path code do not matter next to that.
 template <bool kCount, bool kAll, int kLanes = (int)kBlock, int R = kWaveRows>
 __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene, const RenderParams prm, const PmExtra pmx) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;
@@ -1966,7 +1966,7 @@ __device__ inline unsigned long long waveAppend(bool store, unsigned long long* 
 
 template <bool kAll>
 __global__ void __launch_bounds__(kBlock) emitKernel(const DeviceScene scene, const EmitParams prm) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;
@@ -2045,7 +2045,7 @@ template <bool kAll>
 __global__ void __launch_bounds__(kBlock) intersectKernel(const DeviceScene scene, uint64_t n, const double* start,
                                                        const double* direction, double* out_t, uint32_t* out_surface,
                                                        double* out_uv, StackEntry* spill, uint32_t total_lanes) {
-    extern __shared__ __align__(16) unsigned char lds[];
+    MCRT_DYNAMIC_LDS(lds, 16);
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
     SobolTab tab;

@@ -30,6 +30,11 @@ __device__ __forceinline__ unsigned long long waveBallot(bool p) { return __buil
 #define MCRT_LDS_AS
 #endif
 
+// A kernel's dynamic LDS. (A macro so that the host emulation of workgroups, tests/emu/wave_emu.hpp, can give the kernels one array.)
+#if !defined(MCRT_DYNAMIC_LDS)
+#define MCRT_DYNAMIC_LDS(name, alignment) extern __shared__ __align__(alignment) unsigned char name[]
+#endif
+
 namespace mcrt {
 
 template <class T, bool kLds>

@@ -143,6 +143,8 @@ def wave_kernel_emu():
     L.wemu_trace_kernel.restype = C.c_int
     L.wemu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
     L.wemu_render.restype = C.c_int
+    L.wemu_render_pipeline.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]
+    L.wemu_render_pipeline.restype = C.c_int
     return L
 
 

@@ -81,11 +81,14 @@ struct Wave {  // a workgroup of `waves` wavefronts (1 for wemu::run); lane l of
     bool waiting[kMaxWaves * kLanes];
     uint64_t pub[kMaxWaves * kLanes], snap[kMaxWaves * kLanes];
     uint32_t op[kMaxWaves * kLanes];
+    const char* site_file[kMaxWaves * kLanes];  // where in the SOURCE the lane waits: file and line of the cross-lane operation
+    int site_line[kMaxWaves * kLanes];          // (code addresses will not do: the compiler duplicates calls into both sides of a branch)
+    bool member[kMaxWaves * kLanes];       // the lane takes part in the operation its wave was last released from
     bool at_sync[kMaxWaves];  // the wave has arrived at __syncthreads and waits for the others
     int waves = 1;
     int cur = -1;             // fiber index
     std::function<void(int)> body;
-    unsigned long long collectives = 0;
+    unsigned long long collectives = 0, divergent = 0;  // operations served; of them with the wave split over several call sites
 };
 
 inline Wave*& current() {
@@ -119,50 +122,86 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
     current() = &w;
     w.body = body;
     w.waves = waves;
-    w.collectives = 0;
+    w.collectives = w.divergent = 0;
     for (int l = 0; l < threads; l++) {
         w.done[l] = w.waiting[l] = false;
+        w.member[l] = true;
         w.pub[l] = w.snap[l] = 0;
         w.op[l] = 0;
+        w.site_file[l] = nullptr;
+        w.site_line[l] = 0;
         makeFiber(w.ctx[l], stacks[l].data(), stack_bytes, trampoline);
     }
     for (int v = 0; v < waves; v++) w.at_sync[v] = false;
+    unsigned long long passes = 0;
     for (;;) {
+        if (++passes > 2000000ull) {  // (a kernel of the tests is a few hundred thousand passes: this is a livelock)
+            fprintf(stderr, "wave_emu: no end after %llu passes; lane states of wave 0:\n", passes);
+            for (int l = 0; l < kLanes; l++)
+                fprintf(stderr, "  lane %d done %d waiting %d member %d op %u at %s:%d\n", l, (int)w.done[l], (int)w.waiting[l], (int)w.member[l], w.op[l],
+                        w.site_file[l] ? w.site_file[l] : "-", w.site_line[l]);
+            abort();
+        }
         bool any = false;
         for (int v = 0; v < waves; v++) {
             if (w.at_sync[v]) {
                 any = true;
                 continue;  // parked at __syncthreads
             }
+            // resume the lanes of the wave that were released last time (all of them the first time); lanes parked at another
+            // operation stay parked
             bool alive_wave = false;
             for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
                 if (w.done[l]) continue;
                 alive_wave = any = true;
+                if (w.waiting[l]) continue;  // parked: not released yet
                 w.cur = l;
-                w.waiting[l] = false;
                 switchTo(w.sched, w.ctx[l]);
             }
             if (!alive_wave) continue;
-            // every lane of the wave still alive must have stopped at the SAME kind of operation: anything else is divergence
-            // around a cross-lane operation, which the device code must not have ("all lanes must call")
-            uint32_t kind = 0;
-            bool still = false;
+            // Every live lane now waits at a cross-lane operation. Usually the same one: the wave is converged. Device code may also
+            // run such operations under divergent control flow (wave-aggregated atomics that elect a leader among the ACTIVE lanes:
+            // the shade launch's queue appends) - then the lanes wait at different call sites, and like the hardware, which runs the
+            // sides of a branch one after the other with the other side's lanes masked off, ONE group goes: the lanes at the earliest
+            // source line (inner / earlier code first, so that it catches up with the lanes ahead of it). __syncthreads is never
+            // released for a part of a wave.
+            const char* pick_file = nullptr;
+            int pick_line = 0;
+            uint32_t pick_op = 0;
+            bool have = false, mixed = false;
             for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
                 if (w.done[l]) continue;
-                still = true;
                 if (!w.waiting[l]) {
                     fprintf(stderr, "wave_emu: thread %d neither finished nor at a cross-lane operation\n", l);
                     abort();
                 }
-                if (kind == 0) kind = w.op[l];
-                if (w.op[l] != kind) {
-                    fprintf(stderr, "wave_emu: divergence - thread %d is at operation %u, an earlier lane of its wave at %u\n", l, w.op[l], kind);
-                    abort();
+                const bool same = have && w.site_file[l] == pick_file && w.site_line[l] == pick_line && w.op[l] == pick_op;
+                if (have && !same) mixed = true;
+                const bool earlier = w.site_file[l] != pick_file ? w.site_file[l] < pick_file : w.site_line[l] < pick_line;
+                const bool better = !have || (pick_op == kSync && w.op[l] != kSync) || (w.op[l] != kSync && pick_op != kSync && earlier);
+                if (better) {
+                    have = true;
+                    pick_file = w.site_file[l];
+                    pick_line = w.site_line[l];
+                    pick_op = w.op[l];
                 }
             }
-            if (!still) continue;
-            if (kind == kSync) w.at_sync[v] = true;
-            else memcpy(w.snap + v * kLanes, w.pub + v * kLanes, sizeof(uint64_t) * kLanes);
+            if (pick_op == kSync) {
+                if (mixed) {
+                    fprintf(stderr, "wave_emu: a part of a wave at __syncthreads\n");
+                    abort();
+                }
+                w.at_sync[v] = true;  // (its lanes stay `waiting` until every wave has arrived)
+                w.collectives++;
+                continue;
+            }
+            for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
+                const bool in = !w.done[l] && w.site_file[l] == pick_file && w.site_line[l] == pick_line && w.op[l] == pick_op;
+                w.member[l] = in;
+                w.snap[l] = in ? w.pub[l] : 0;
+                if (in) w.waiting[l] = false;
+            }
+            if (mixed) w.divergent++;
             w.collectives++;
         }
         if (!any) break;
@@ -176,7 +215,13 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
             all = all && w.at_sync[v];
         }
         if (some && all)
-            for (int v = 0; v < waves; v++) w.at_sync[v] = false;
+            for (int v = 0; v < waves; v++) {
+                w.at_sync[v] = false;
+                for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
+                    w.member[l] = !w.done[l];
+                    if (!w.done[l]) w.waiting[l] = false;
+                }
+            }
     }
     current() = saved;
 }
@@ -186,18 +231,25 @@ inline void run(const std::function<void(int)>& body, size_t stack_bytes = 1u <<
 inline int lane() { return current()->cur & 63; }
 inline int thread() { return current()->cur; }
 
-// publish v, wait for the wave, return the snapshot of everybody's operands (valid until this lane's next cross-lane operation)
-inline const uint64_t* exchange(Op op, uint64_t v) {
+// publish v, wait for the wave, return the snapshot of the operands of the lanes that take part (0 for the others; valid until this
+// lane's next cross-lane operation). file / line: where the operation stands in the code under test.
+inline const uint64_t* exchange(Op op, uint64_t v, const char* file = nullptr, int line = 0) {
     Wave* w = current();
     const int l = w->cur;
     w->pub[l] = v;
     w->op[l] = op;
+    w->site_file[l] = file;
+    w->site_line[l] = line;
     w->waiting[l] = true;
     switchTo(w->ctx[l], w->sched);
     w->cur = l;  // (the scheduler set it before resuming; restated for clarity)
     return w->snap + (l & ~63);  // this wave's operands
 }
-inline bool alive(int l) { return !current()->done[(current()->cur & ~63) + l]; }  // lane l of the caller's wave
+inline bool alive(int l) {  // lane l of the caller's wave takes part in the operation the caller was just released from
+    const Wave* w = current();
+    const int t = (w->cur & ~63) + l;
+    return !w->done[t] && w->member[t];
+}
 
 // v_mov_b32_dpp: the source lane of lane i under dpp_ctrl, or -1 when the control has no valid source for it
 inline int dppSource(int i, int ctrl) {
@@ -234,43 +286,42 @@ struct double2 {
 };
 
 inline unsigned __lane_id() { return (unsigned)wemu::lane(); }
-inline unsigned long long waveBallot(bool p) {
-    const uint64_t* s = wemu::exchange(wemu::kBallot, p ? 1u : 0u);
+inline unsigned long long waveBallot_at(bool p, const char* f_, int l_) {
+    const uint64_t* s = wemu::exchange(wemu::kBallot, p ? 1u : 0u, f_, l_);
     unsigned long long m = 0;
     for (int l = 0; l < wemu::kLanes; l++)
         if (s[l] & 1u) m |= 1ull << l;
     return m;
 }
-inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return waveBallot(p); }
-inline int __builtin_amdgcn_readlane(int v, int src) {
-    const uint64_t* s = wemu::exchange(wemu::kReadlane, (uint32_t)v);
+inline int wemu_readlane_at(int v, int src, const char* f_, int l_) {
+    const uint64_t* s = wemu::exchange(wemu::kReadlane, (uint32_t)v, f_, l_);
     return (int)(uint32_t)s[src & 63];
 }
-inline int __builtin_amdgcn_readfirstlane(int v) {
-    const uint64_t* s = wemu::exchange(wemu::kReadfirst, (uint32_t)v);
+inline int wemu_readfirstlane_at(int v, const char* f_, int l_) {
+    const uint64_t* s = wemu::exchange(wemu::kReadfirst, (uint32_t)v, f_, l_);
     for (int l = 0; l < wemu::kLanes; l++)
         if (wemu::alive(l)) return (int)(uint32_t)s[l];
     return v;
 }
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-    const uint64_t* s = wemu::exchange(wemu::kDpp, (uint32_t)src);
+inline int wemu_update_dpp_at(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, const char* f_, int l_) {
+    const uint64_t* s = wemu::exchange(wemu::kDpp, (uint32_t)src, f_, l_);
     const int i = wemu::lane();
     if (!((row_mask >> (i >> 4)) & 1) || !((bank_mask >> ((i & 15) >> 2)) & 1)) return old;  // this lane's row / bank is not written
     const int j = wemu::dppSource(i, ctrl);
     if (j < 0 || !wemu::alive(j)) return bound_ctrl ? 0 : old;
     return (int)(uint32_t)s[j];
 }
-inline void __builtin_amdgcn_wave_barrier() { (void)wemu::exchange(wemu::kBarrier, 0); }
-inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) {
-    const uint64_t* s = wemu::exchange(wemu::kBpermute, (uint32_t)v);
+inline void wemu_wave_barrier_at(const char* f_, int l_) { (void)wemu::exchange(wemu::kBarrier, 0, f_, l_); }
+inline int wemu_ds_bpermute_at(int byte_addr, int v, const char* f_, int l_) {
+    const uint64_t* s = wemu::exchange(wemu::kBpermute, (uint32_t)v, f_, l_);
     return (int)(uint32_t)s[(byte_addr >> 2) & 63];
 }
 template <class T>
-inline T __shfl_xor(T v, int mask, int width = 64) {
+inline T wemu_shfl_xor_at(T v, int mask, int width, const char* f_, int l_) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");
     uint32_t u;
     memcpy(&u, &v, 4);
-    const uint64_t* s = wemu::exchange(wemu::kShfl, u);
+    const uint64_t* s = wemu::exchange(wemu::kShfl, u, f_, l_);
     const uint32_t r = (uint32_t)s[(wemu::lane() ^ mask) & (width - 1) & 63];
     T out;
     memcpy(&out, &r, 4);
@@ -333,8 +384,9 @@ static const struct { wemu::ThreadIdxX x; } threadIdx = {};
 static const struct { wemu::BlockIdxX x; } blockIdx = {};
 static const struct { wemu::BlockDimX x; } blockDim = {};
 static const struct { wemu::GridDimX x; } gridDim = {};
-inline void __syncthreads() { (void)wemu::exchange(wemu::kSync, 0); }
-#define __shared__
+inline void wemu_syncthreads_at(const char* f_, int l_) { (void)wemu::exchange(wemu::kSync, 0, f_, l_); }
+#define __shared__ static            // a kernel's static LDS arrays: one copy for the (one) workgroup that runs at a time
+#define MCRT_DYNAMIC_LDS(name, alignment)  // ... and its dynamic LDS: the array `lds` the harness defines at namespace scope
 #define __align__(n) __attribute__((aligned(n)))
 #define __launch_bounds__(...)
 template <class T, class U>
@@ -344,11 +396,11 @@ inline T atomicAdd(T* p, U v) {  // (one OS thread: fibers switch only at cross-
     return old;
 }
 template <class T>
-inline T __shfl_down(T v, int delta, int width = 64) {
+inline T wemu_shfl_down_at(T v, int delta, int width, const char* f_, int l_) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");
     uint32_t u;
     memcpy(&u, &v, 4);
-    const uint64_t* s = wemu::exchange(wemu::kShfl, u);
+    const uint64_t* s = wemu::exchange(wemu::kShfl, u, f_, l_);
     const int l = wemu::lane(), src = l + delta;
     const uint32_t r = (src < 64 && (src / width) == (l / width)) ? (uint32_t)s[src] : u;
     T out;
@@ -368,3 +420,15 @@ struct float4 {
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+
+// The operations carry their SOURCE position (what the scheduler groups waiting lanes by): function-like macros over the shims above.
+#define waveBallot(p) waveBallot_at((p), __FILE__, __LINE__)
+#define __builtin_amdgcn_ballot_w64(p) waveBallot_at((p), __FILE__, __LINE__)
+#define __builtin_amdgcn_readlane(v, src) wemu_readlane_at((v), (src), __FILE__, __LINE__)
+#define __builtin_amdgcn_readfirstlane(v) wemu_readfirstlane_at((v), __FILE__, __LINE__)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu_update_dpp_at((old), (src), (ctrl), (rm), (bm), (bc), __FILE__, __LINE__)
+#define __builtin_amdgcn_wave_barrier() wemu_wave_barrier_at(__FILE__, __LINE__)
+#define __builtin_amdgcn_ds_bpermute(addr, v) wemu_ds_bpermute_at((addr), (v), __FILE__, __LINE__)
+#define __syncthreads() wemu_syncthreads_at(__FILE__, __LINE__)
+#define __shfl_xor(v, mask, ...) wemu_shfl_xor_at((v), (mask), 64, __FILE__, __LINE__)
+#define __shfl_down(v, delta, ...) wemu_shfl_down_at((v), (delta), 64, __FILE__, __LINE__)

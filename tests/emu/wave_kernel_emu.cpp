@@ -320,4 +320,173 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
     return stats[5] ? -100 : stats[7] ? -101 : 0;
 }
 
+// The wavefront pipeline - wfShadeKernel, wfTraceKernel<PoolRays>, for photon-mapped frames wfKnnKernel<eval>, then sampleResolveKernel -
+// launched the way launchWavefront (mcrt_hip.hip) launches them: slot pool and ray queue in (host) memory, control words, a shade
+// launch and a trace launch per iteration until a shade launch queues nothing. One pass, box filter, one stream. `slots`: pool slots
+// (a multiple of 256 is made of it); trace_grid x trace_waves: the trace launches' shape; trace_form as wemu_trace_kernel.
+// launches_out: kernel launches of the frame. The pool starts as garbage except for the planes the device clears too.
+int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, const mcrt_photon_map_desc* cmap, uint32_t k_nearest,
+                         int direct_visualization, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, uint32_t slots_wanted,
+                         uint32_t trace_grid, uint32_t trace_waves, int trace_form, double* out_rgb, unsigned long long* stats_out,
+                         uint32_t* launches_out) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return rc;
+    DeviceScene d;
+    fillDeviceScene(scene, E, d, 64u);
+    if (d.q_nodes == 0 || trace_grid == 0 || trace_waves == 0 || trace_waves > 16) return -200;
+    const bool photon = integrator == MCRT_INTEGRATOR_PHOTON_MAPPER;
+    if (photon && k_nearest > waveMaxK(kWaveRows)) return -203;
+    WfFrame fr;
+    memset(&fr, 0, sizeof(fr));
+    fr.cam = *cam;
+    fr.global_seed = global_seed;
+    fr.spp = cam->sqrtspp * cam->sqrtspp;
+    fr.tiles_x = (cam->width + 7) / 8;
+    fr.film.type = MCRT_FILM_BOX;
+    const uint32_t owned_rows = cam->height;
+    const uint64_t pixels = (uint64_t)cam->width * owned_rows;
+    const uint64_t slots = std::max<uint64_t>((slots_wanted + kWfBlock - 1) / kWfBlock * kWfBlock, kWfBlock);
+    {
+        const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels));
+        fr.chunk_shift = cp.shift;
+        fr.chunk = cp.chunk;
+    }
+    std::vector<double> samples((size_t)fr.spp * pixels * 3, 0.0);
+    fr.samples = samples.data();
+    fr.row_base = 0;
+    fr.row_end = owned_rows;
+    fr.pass_pixels = pixels;
+    fr.work_items = ((unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull) << fr.chunk_shift;
+    std::vector<unsigned long long> pool((size_t)slots * kWfWords, 0xDEADBEEFCAFEF00Dull);  // garbage, like fresh device memory
+    for (uint64_t i = 0; i < slots; i++) pool[(size_t)kWfFlags * slots + i] = pool[(size_t)kWfSeq * slots + i] = 0ull;
+    const size_t cap = ((size_t)slots + 2 * kWfBlock) * 2;
+    std::vector<uint32_t> qwords(2 * cap + 2 * (2 * 8 * cap), 0xA5A5A5A5u);  // item, light, then two sets of eight planes of doubles
+    unsigned long long ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, work = 0;
+    std::vector<unsigned long long> stats(kStatsWords + 32, 0ull);
+
+    // trace launch (planTrace)
+    const uint32_t tblock = trace_waves * 64u;
+    std::vector<SmStackEntry> spill((size_t)trace_grid * tblock * d.stack_depth);
+    const uint32_t lds_stack = kLdsStackDepth;
+    const uint32_t stack_bytes = lds_stack * tblock * (uint32_t)sizeof(SmStackEntry);
+    WfTraceArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.stats = stats.data();
+    ta.nodes = d.nodes64;
+    ta.qblocks = d.qblocks;
+    ta.wnodes = d.wnodes;
+    ta.num_nodes = d.q_nodes;
+    ta.lds_blocks = trace_form == 1 ? 0u : (uint32_t)std::min<uint64_t>(d.num_qblocks, ((uint64_t)sizeof(lds) - stack_bytes - 128u - trace_waves * kShareMapBytes) / 64u);
+    ta.q_root_a = d.q_root_a;
+    ta.q_root_m = d.q_root_m;
+    ta.prim = d.prim;
+    ta.spill = spill.data();
+    ta.total_lanes = trace_grid * tblock;
+    ta.refill_lanes = 16;
+    ta.leaf_lanes = trace_form == 3 ? 16 : 24;
+    ta.leaf_items = 1 << 20;
+    ta.min_inner = 8;
+    ta.lds_stack = (int)lds_stack;
+    ta.max_stack = d.stack_depth;
+    ta.deal_shift = 6;
+    ta.pop = ctrl + 2;
+    if (trace_form == 1 && !d.wnodes) return -201;
+    PoolRays pr;
+    pr.pool.w = pool.data();
+    pr.pool.n = (uint32_t)slots;
+    pr.q.item = qwords.data();
+    pr.q.light = qwords.data() + cap;
+    pr.q.ray = reinterpret_cast<double*>(qwords.data() + 2 * cap);
+    pr.q.prev_ray = pr.q.ray + 8 * cap;
+    pr.q.cap = cap;
+    uint32_t shade_tables = wfShadeTableBytes(d.num_materials, d.num_lights);
+    if (shade_tables > kWfShadeTableMax) shade_tables = 0;
+    WfShadeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.pool = pr.pool;
+    sa.slot_base = 0;
+    sa.slot_count = (uint32_t)slots;
+    sa.fr = fr;
+    sa.queue = pr.q;
+    sa.pop_reset = ctrl + 2;
+    sa.work = &work;
+    sa.stats = stats.data();
+    sa.lds_tables = shade_tables;
+    const uint32_t shade_grid = (sa.slot_count + kWfBlock - 1) / kWfBlock;
+    // photon mapper: requests and the kNN launch that serves them
+    WaveMap wg, wc;
+    WfKnnArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    std::vector<uint32_t> requests, knn_spill;
+    std::vector<double> stage, est;
+    const uint32_t knn_grid = 2;
+    if (photon) {
+        if (wg.init(gmap, k_nearest) || wc.init(cmap, k_nearest)) return -301;
+        requests.resize(slots);
+        stage.resize((size_t)slots * kStageDoubles);
+        est.resize((size_t)slots * 6);
+        knn_spill.resize((size_t)knn_grid * 4 * kWaveSpill * 3);
+        ka.pool = pr.pool;
+        ka.requests = requests.data();
+        ka.pop = ctrl + 6;
+        ka.stats = stats.data();
+        ka.maps[0] = wg.view;
+        ka.maps[1] = wc.view;
+        ka.k = k_nearest;
+        ka.stage = stage.data();
+        ka.est = est.data();
+        ka.spill = knn_spill.data();
+        sa.requests = requests.data();
+        sa.rpop_reset = ctrl + 6;
+        sa.pm.photons[0] = wg.view.base.photons;
+        sa.pm.photons[1] = wc.view.base.photons;
+        sa.pm.k = k_nearest;
+        sa.pm.direct_visualization = direct_visualization != 0;
+        sa.pm.est = est.data();
+        sa.stage = stage.data();
+    }
+    uint32_t launches = 0;
+    for (uint64_t it = 0;; it++) {
+        if (it > 100000) return -400;
+        sa.count_out = ctrl + (it & 1);
+        sa.count_reset = ctrl + ((it + 1) & 1);
+        double* set0 = reinterpret_cast<double*>(qwords.data() + 2 * cap);
+        pr.q.ray = set0 + (it & 1) * 8 * cap;
+        pr.q.prev_ray = set0 + ((it + 1) & 1) * 8 * cap;
+        sa.queue = pr.q;
+        if (photon) {
+            sa.rcount_out = ctrl + 4 + (it & 1);
+            sa.rcount_reset = ctrl + 4 + ((it + 1) & 1);
+            launchGrid(shade_grid, kWfBlock, [&] { wfShadeKernel<true>(d, sa); });
+        } else {
+            launchGrid(shade_grid, kWfBlock, [&] { wfShadeKernel<false>(d, sa); });
+        }
+        launches++;
+        if (ctrl[it & 1] == 0ull && (!photon || ctrl[4 + (it & 1)] == 0ull)) break;  // nothing queued: every slot is done
+        ta.count = ctrl + (it & 1);
+        for (uint32_t g = 0; g < trace_grid; g++) {
+            wemu::launch().block_idx = g;
+            wemu::launch().block_dim = tblock;
+            wemu::launch().grid_dim = trace_grid;
+            wemu::runGroup((int)trace_waves, [&](int) {
+                if (trace_form == 0) wfTraceKernel<PoolRays, true, 0>(ta, pr);
+                else if (trace_form == 1) wfTraceKernel<PoolRays, true, 1>(ta, pr);
+                else if (trace_form == 2) wfTraceKernel<PoolRays, true, 2>(ta, pr);
+                else wfTraceKernel<PoolRays, true, 3>(ta, pr);
+            });
+        }
+        launches++;
+        if (photon) {
+            ka.count = ctrl + 4 + (it & 1);
+            launchGrid(knn_grid, 256, [&] { wfKnnKernel<true>(ka); });
+            launches++;
+        }
+    }
+    launchGrid((uint32_t)((pixels + 255) / 256), 256, [&] { sampleResolveKernel(fr.samples, pixels, fr.spp, out_rgb); });
+    launches++;
+    if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
+    if (launches_out) *launches_out = launches;
+    return stats[5] ? -100 : stats[7] ? -101 : 0;
+}
+
 }  // extern "C"

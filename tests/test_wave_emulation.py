@@ -270,3 +270,61 @@ def test_photon_mapping_kernel_on_the_host(pkg, wave_kernel_emu, oracle, manifes
     rel = np.abs(out - want) / np.maximum(np.abs(want), 1e-3)
     print("hexagon_room_pm through renderKernelPM on the host: max rel %.3e, %d searches" % (rel.max(), int(stats[4])))
     assert rel.max() <= 1e-12
+
+
+def _emulated_pipeline_frame(wave_kernel_emu, img, cam, seed, integrator, slots, grid, waves, form):
+    out = np.zeros((cam.height, cam.width, 3))
+    stats = np.zeros(64, dtype=np.uint64)
+    launches = C.c_uint32(0)
+    g, c = img.photons(0), img.photons(1)
+    rc = wave_kernel_emu.wemu_render_pipeline(C.byref(img.scene), C.byref(g) if g is not None else None, C.byref(c) if c is not None else None,
+                                              img.param("k_nearest_photons") or 50, int(img.param("direct_visualization") or 0), C.byref(cam), seed,
+                                              integrator, slots, grid, waves, form, out.ctypes.data, stats.ctypes.data, C.byref(launches))
+    return rc, out, stats, launches.value
+
+
+# (pool slots, trace workgroups, waves per trace workgroup, trace kernel form)
+PIPELINE_LAUNCHES = [(512, 2, 2, 3), (256, 1, 4, 2), (1024, 3, 1, 0), (768, 2, 2, 1)]
+
+
+@pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "hexagon_room", "hexagon_room_dof", "quadric", "metals", "veach_mis", "ggx_test",
+                                  "dragon_room", "shell_room"])
+def test_wavefront_pipeline_on_the_host_gives_the_oracle_frame(pkg, wave_kernel_emu, oracle, manifest, name):
+    """The wavefront pipeline as launchWavefront runs it - wfShadeKernel (one lane per pool slot: NEE finish, shading, regeneration, rays
+    appended to the queue with wave-aggregated atomics under divergent control flow), wfTraceKernel<PoolRays> in every form, launch after
+    launch until a shade launch queues nothing, then sampleResolveKernel - on emulated workgroups, the slot pool starting as garbage
+    like device memory: the oracle's frame, bit for bit, for several pool sizes and launch shapes. (Its ray count may fall short of the
+    oracle's by the shadow rays whose BSDF term is zero: the pipeline does not trace them.)"""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    from conftest import camera_for
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 24, 14, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+    for slots, grid, waves, form in PIPELINE_LAUNCHES:
+        rc, out, stats, launches = _emulated_pipeline_frame(wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, slots, grid, waves, form)
+        if rc == -201:
+            continue  # (no eight-wide nodes for this tree)
+        what = "%s: %d slots, trace %d x %d waves, form %d" % (name, slots, grid, waves, form)
+        assert rc == 0, what
+        assert int(stats[0]) == cam.width * cam.height * 4 and 0 <= info["rays"] - int(stats[1]) <= 0.03 * info["rays"], what
+        assert launches > 6
+        np.testing.assert_array_equal(out, want, err_msg=what)
+
+
+def test_photon_mapped_pipeline_on_the_host(pkg, wave_kernel_emu, oracle, manifest):
+    """... and the photon-mapped pipeline: estimate requests staged by the shade launch, served by wfKnnKernel<eval> (one request per
+    wave), read back by the next shade launch."""
+    from conftest import camera_for
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 20, 12, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    rc, out, stats, launches = _emulated_pipeline_frame(wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER, 512, 2, 2, 3)
+    assert rc == 0 and int(stats[4]) > 0
+    rel = np.abs(out - want) / np.maximum(np.abs(want), 1e-3)
+    print("hexagon_room_pm through the pipeline on the host: max rel %.3e, %d searches, %d launches" % (rel.max(), int(stats[4]), launches))
+    assert rel.max() <= 1e-12
