@@ -93,7 +93,7 @@ def wave_emu():
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         tmp = "%s.%d.tmp" % (out, os.getpid())
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fno-inline", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
         os.replace(tmp, out)
     L = C.CDLL(out)
     L.wemu_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -113,7 +113,7 @@ def wave_walk_emu():
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         tmp = "%s.%d.tmp" % (out, os.getpid())
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fno-inline", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
         os.replace(tmp, out)
     L = C.CDLL(out)
     L.wemu_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -135,7 +135,7 @@ def wave_kernel_emu():
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         tmp = "%s.%d.tmp" % (out, os.getpid())
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fno-inline", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
         os.replace(tmp, out)
     L = C.CDLL(out)
     vp = C.c_void_p
@@ -145,6 +145,8 @@ def wave_kernel_emu():
     L.wemu_render.restype = C.c_int
     L.wemu_render_pipeline.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]
     L.wemu_render_pipeline.restype = C.c_int
+    L.wemu_emit.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp]
+    L.wemu_emit.restype = C.c_int
     return L
 
 

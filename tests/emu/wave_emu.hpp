@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -84,6 +85,10 @@ struct Wave {  // a workgroup of `waves` wavefronts (1 for wemu::run); lane l of
     const char* site_file[kMaxWaves * kLanes];  // where in the SOURCE the lane waits: file and line of the cross-lane operation
     int site_line[kMaxWaves * kLanes];          // (code addresses will not do: the compiler duplicates calls into both sides of a branch)
     bool member[kMaxWaves * kLanes];       // the lane takes part in the operation its wave was last released from
+    unsigned long long stamp[kMaxWaves * kLanes];  // when the lane arrived where it waits
+    unsigned long long clock = 0;
+    size_t depth[kMaxWaves * kLanes];      // how deep in calls it waits: bytes of its fiber's stack in use
+    uintptr_t stack_top[kMaxWaves * kLanes];
     bool at_sync[kMaxWaves];  // the wave has arrived at __syncthreads and waits for the others
     int waves = 1;
     int cur = -1;             // fiber index
@@ -131,6 +136,8 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
         w.site_file[l] = nullptr;
         w.site_line[l] = 0;
         makeFiber(w.ctx[l], stacks[l].data(), stack_bytes, trampoline);
+        w.stack_top[l] = (uintptr_t)stacks[l].data() + stack_bytes;
+        w.depth[l] = 0;
     }
     for (int v = 0; v < waves; v++) w.at_sync[v] = false;
     unsigned long long passes = 0;
@@ -160,14 +167,18 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
             }
             if (!alive_wave) continue;
             // Every live lane now waits at a cross-lane operation. Usually the same one: the wave is converged. Device code may also
-            // run such operations under divergent control flow (wave-aggregated atomics that elect a leader among the ACTIVE lanes:
-            // the shade launch's queue appends) - then the lanes wait at different call sites, and like the hardware, which runs the
-            // sides of a branch one after the other with the other side's lanes masked off, ONE group goes: the lanes at the earliest
-            // source line (inner / earlier code first, so that it catches up with the lanes ahead of it). __syncthreads is never
-            // released for a part of a wave.
+            // run such operations under divergent control flow (a tree walk only the lanes with a ray take part in; wave-aggregated
+            // atomics that elect a leader among the ACTIVE lanes) - then the lanes wait at different places in the source. The
+            // hardware runs the sides of a branch one after the other and the lanes that skipped it wait where the sides meet. Here
+            // ONE group goes, chosen so that lanes inside a branch catch up with the ones waiting behind it: the group deepest in
+            // calls (the harnesses are built without inlining: an operation inside a function called from the branch is deeper than
+            // one after the branch), among equals the earliest line of the same file, else the one that arrived last.
+            // __syncthreads is never released for a part of a wave.
             const char* pick_file = nullptr;
             int pick_line = 0;
             uint32_t pick_op = 0;
+            unsigned long long pick_stamp = 0;
+            size_t pick_depth = 0;
             bool have = false, mixed = false;
             for (int l = v * kLanes; l < (v + 1) * kLanes; l++) {
                 if (w.done[l]) continue;
@@ -177,13 +188,26 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
                 }
                 const bool same = have && w.site_file[l] == pick_file && w.site_line[l] == pick_line && w.op[l] == pick_op;
                 if (have && !same) mixed = true;
-                const bool earlier = w.site_file[l] != pick_file ? w.site_file[l] < pick_file : w.site_line[l] < pick_line;
-                const bool better = !have || (pick_op == kSync && w.op[l] != kSync) || (w.op[l] != kSync && pick_op != kSync && earlier);
+                if (same) {
+                    pick_stamp = std::max(pick_stamp, w.stamp[l]);
+                    pick_depth = std::max(pick_depth, w.depth[l]);
+                    continue;
+                }
+                bool better = !have || (pick_op == kSync && w.op[l] != kSync);
+                if (!better && w.op[l] != kSync && pick_op != kSync) {
+                    // (frames of one function differ by a few bytes from lane to lane only through alignment: compare in steps of 64)
+                    const size_t da = w.depth[l] / 64, db = pick_depth / 64;
+                    if (da != db) better = da > db;
+                    else if (w.site_file[l] == pick_file) better = w.site_line[l] < pick_line;
+                    else better = w.stamp[l] > pick_stamp;
+                }
                 if (better) {
                     have = true;
                     pick_file = w.site_file[l];
                     pick_line = w.site_line[l];
                     pick_op = w.op[l];
+                    pick_stamp = w.stamp[l];
+                    pick_depth = w.depth[l];
                 }
             }
             if (pick_op == kSync) {
@@ -201,7 +225,18 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
                 w.snap[l] = in ? w.pub[l] : 0;
                 if (in) w.waiting[l] = false;
             }
-            if (mixed) w.divergent++;
+            if (mixed) {
+                w.divergent++;
+                static const bool dbg = getenv("WEMU_DEBUG") != nullptr;
+                static int shown = 0;
+                if (dbg && shown < 40) {
+                    shown++;
+                    fprintf(stderr, "wave_emu: split wave %d - released %s:%d op %u;", v, pick_file ? strrchr(pick_file, '/') : "-", pick_line, pick_op);
+                    for (int l = v * kLanes; l < (v + 1) * kLanes; l++)
+                        if (!w.done[l] && w.waiting[l]) fprintf(stderr, " [%d @%s:%d op %u]", l & 63, w.site_file[l] ? strrchr(w.site_file[l], '/') : "-", w.site_line[l], w.op[l]);
+                    fprintf(stderr, "\n");
+                }
+            }
             w.collectives++;
         }
         if (!any) break;
@@ -240,6 +275,8 @@ inline const uint64_t* exchange(Op op, uint64_t v, const char* file = nullptr, i
     w->op[l] = op;
     w->site_file[l] = file;
     w->site_line[l] = line;
+    w->stamp[l] = ++w->clock;
+    w->depth[l] = (size_t)(w->stack_top[l] - (uintptr_t)__builtin_frame_address(0));
     w->waiting[l] = true;
     switchTo(w->ctx[l], w->sched);
     w->cur = l;  // (the scheduler set it before resuming; restated for clarity)

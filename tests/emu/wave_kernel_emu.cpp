@@ -489,4 +489,67 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
     return stats[5] ? -100 : stats[7] ? -101 : 0;
 }
 
+// emitKernel (the photon pass: PhotonMapper's emission loop, photon-mapper.cpp:96-110 / 225-277) on emulated workgroups, its arguments
+// filled as emitOnDevice (mcrt_hip.hip) fills them: the work split over the lights, one launch with lists of `capacity` photons, with
+// the sizing pilot's stride (1 = every path). Lists out as the device leaves them (unordered); counts[0..1] = photons counted (may
+// exceed the capacity: then the lists hold the first `capacity`), counts[2] = paths, counts[3] = rays. Returns 0 / -100 / -101.
+int wemu_emit(const mcrt_scene_desc* scene, double emissions, double caustic_factor, uint32_t global_seed, uint32_t stride, uint32_t grid,
+              uint64_t capacity, float* out_global, unsigned long long* keys_global, float* out_caustic, unsigned long long* keys_caustic,
+              unsigned long long* counts) {
+    Emu E;
+    if (int rc = setup(E, scene, 0)) return rc;
+    DeviceScene d;
+    fillDeviceScene(scene, E, d, 64u);
+    d.flat = 0;  // the emission kernel walks the BVH
+    const uint32_t nl = scene->num_lights;
+    if (nl == 0 || grid == 0 || stride == 0) return -200;
+    const size_t photon_emissions = (size_t)((double)(size_t)emissions * caustic_factor);
+    double total_add_flux = 0.0;
+    std::vector<double> flux((size_t)nl * 3);
+    for (uint32_t i = 0; i < nl; i++) {
+        const uint32_t ls = scene->light_surface[i];
+        for (int c = 0; c < 3; c++) flux[(size_t)i * 3 + c] = scene->materials[scene->surf_material[ls]].emittance[c] * scene->surf_area[ls];
+        total_add_flux += 0.0 + flux[(size_t)i * 3] + flux[(size_t)i * 3 + 1] + flux[(size_t)i * 3 + 2];
+    }
+    std::vector<unsigned long long> first(nl + 1, 0ull);
+    std::vector<double> pflux((size_t)nl * 3);
+    for (uint32_t i = 0; i < nl; i++) {
+        const double* f = &flux[(size_t)i * 3];
+        const double share = (0.0 + f[0] + f[1] + f[2]) / total_add_flux;
+        const size_t n = (size_t)((double)photon_emissions * share);
+        first[i + 1] = first[i] + n;
+        for (int c = 0; c < 3; c++) pflux[(size_t)i * 3 + c] = f[c] / (double)n;
+    }
+    const uint32_t block = kBlock;
+    const uint32_t lds_bytes = planLds(d, block).total;
+    if (lds_bytes > kEmuMaxLds || lds_bytes > sizeof(lds)) return -202;
+    unsigned long long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<StackEntry> spill((size_t)grid * block * (d.stack_depth - kLdsStackDepth) + 16);
+    EmitParams prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.num_lights = nl;
+    prm.light_first = first.data();
+    prm.light_photon_flux = pflux.data();
+    prm.total_emissions = first[nl];
+    prm.first_emission = 0;
+    prm.stride = stride;
+    prm.global_seed = global_seed;
+    prm.non_caustic_reject = 1.0 / caustic_factor;
+    prm.photons[0] = out_global;
+    prm.photons[1] = out_caustic;
+    prm.keys[0] = keys_global;
+    prm.keys[1] = keys_caustic;
+    prm.capacity[0] = prm.capacity[1] = capacity;
+    prm.counters = counters;
+    prm.spill = spill.data();
+    prm.total_lanes = grid * block;
+    if (d.stage_all) launchGrid(grid, block, [&] { emitKernel<true>(d, prm); });
+    else launchGrid(grid, block, [&] { emitKernel<false>(d, prm); });
+    counts[0] = counters[1];
+    counts[1] = counters[2];
+    counts[2] = counters[3];
+    counts[3] = counters[4];
+    return counters[5] ? -100 : counters[6] ? -101 : 0;
+}
+
 }  // extern "C"

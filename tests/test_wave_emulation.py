@@ -328,3 +328,33 @@ def test_photon_mapped_pipeline_on_the_host(pkg, wave_kernel_emu, oracle, manife
     rel = np.abs(out - want) / np.maximum(np.abs(want), 1e-3)
     print("hexagon_room_pm through the pipeline on the host: max rel %.3e, %d searches, %d launches" % (rel.max(), int(stats[4]), launches))
     assert rel.max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["hexagon_room_pm", "coffee_maker_qsah"])
+def test_emission_kernel_on_the_host_gives_the_oracle_photons(pkg, wave_kernel_emu, oracle, manifest, name):
+    """emitKernel on emulated workgroups (photon paths regenerated from a counter, photons appended with wave-aggregated atomics): the
+    oracle's photon lists, record for record by (light, emission, bounce) key - and the sizing pilot (every 64th path, capacity 0)
+    counts what it should: within a few per cent of a 64th of the lists."""
+    from conftest import sort_by_key
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    emissions, factor = 300, 10.0
+    want = oracle.emit_photons(img, emissions, factor, manifest["seed"])
+    cap = 1 << 16
+    g, gk = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+    c, ck = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+    counts = np.zeros(4, dtype=np.uint64)
+    rc = wave_kernel_emu.wemu_emit(C.byref(img.scene), float(emissions), factor, manifest["seed"], 1, 2, cap, g.ctypes.data, gk.ctypes.data, c.ctypes.data,
+                                   ck.ctypes.data, counts.ctypes.data)
+    assert rc == 0
+    assert int(counts[2]) == want["paths"] and int(counts[3]) == want["rays"]
+    for (ph, keys, n), (wph, wkeys) in (((g, gk, int(counts[0])), want["global_"]), ((c, ck, int(counts[1])), want["caustic"])):
+        assert n == len(wkeys)
+        a, ak = sort_by_key(ph[:n], keys[:n])
+        np.testing.assert_array_equal(ak, wkeys)
+        np.testing.assert_array_equal(a.view(np.uint32), wph.view(np.uint32))
+    pilot = np.zeros(4, dtype=np.uint64)
+    rc = wave_kernel_emu.wemu_emit(C.byref(img.scene), float(emissions), factor, manifest["seed"], 8, 1, 0, None, None, None, None, pilot.ctypes.data)
+    assert rc == 0 and int(pilot[2]) == -(-want["paths"] // 8)
+    total, sample = int(counts[0]) + int(counts[1]), (int(pilot[0]) + int(pilot[1])) * 8
+    assert abs(sample - total) <= 0.25 * total
