@@ -52,3 +52,31 @@ for name in ("coffee_maker_qsah", "quadric"):
         t, surf, uv = np.full(n, np.nan), np.zeros(n, dtype=np.uint32), np.zeros((n, 2))
         rc = L.wemu_intersect(C.byref(sc), n, start.ctypes.data, d.ctypes.data, which, holes, t.ctypes.data, surf.ctypes.data, uv.ctypes.data)
         print(name, which, holes, rc, np.array_equal(surf, s0))
+
+# ---- whole kernels: frame kernels, the wavefront pipeline, the emission kernel
+K = C.CDLL("/tmp/mcrt_wave_asan/libwave_kernel_emu.so")
+vp = C.c_void_p
+K.wemu_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
+K.wemu_render_pipeline.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp]
+K.wemu_emit.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp]
+for name, integ in (("hexagon_room", 0), ("coffee_maker_qsah", 0), ("quadric", 0), ("hexagon_room_pm", 1)):
+    case = man["cases"][name]
+    img = pkg.SceneImage(conftest.golden_path(case["image"]))
+    cam = conftest.camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 16, 10, 2
+    want, _ = oracle_lib.render(img, cam, man["seed"], integ)
+    g, c = img.photons(0), img.photons(1)
+    gp, cp = (C.byref(g) if g is not None else None), (C.byref(c) if c is not None else None)
+    k = img.param("k_nearest_photons") or 50
+    out = np.zeros((cam.height, cam.width, 3)); stats = np.zeros(64, dtype=np.uint64); kid = C.c_int(0); launches = C.c_uint32(0)
+    rc = K.wemu_render(C.byref(img.scene), gp, cp, k, 0, C.byref(cam), man["seed"], integ, 0, 1, out.ctypes.data, stats.ctypes.data, C.byref(kid))
+    print(name, "frame kernel", kid.value, rc, np.allclose(out, want, rtol=1e-12, atol=0))
+    rc = K.wemu_render_pipeline(C.byref(img.scene), gp, cp, k, 0, C.byref(cam), man["seed"], integ, 256, 2, 2, 3, out.ctypes.data, stats.ctypes.data, C.byref(launches))
+    print(name, "pipeline", rc, launches.value, np.allclose(out, want, rtol=1e-12, atol=0))
+img = pkg.SceneImage(conftest.golden_path(man["cases"]["coffee_maker_qsah"]["image"]))
+cap = 1 << 14
+g, gk = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+c, ck = np.zeros((cap, 8), dtype=np.float32), np.zeros(cap, dtype=np.uint64)
+counts = np.zeros(4, dtype=np.uint64)
+rc = K.wemu_emit(C.byref(img.scene), 100.0, 10.0, man["seed"], 1, 2, cap, g.ctypes.data, gk.ctypes.data, c.ctypes.data, ck.ctypes.data, counts.ctypes.data)
+print("emission", rc, counts)
