@@ -776,8 +776,12 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // 1024 lanes 485.2 (split next-event estimate: 454 / 493 / 563) — fewer instructions per ray, and the spills of the
     // narrow instances (107 / 169 VGPRs) now cost more than the extra waves hide.
     const int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", 512);
+    // MCRT_FLAT_SHARE=1 (off by default: its speed is not measured yet): the FP64 survivor tests of a bounce dealt over the wave
+    // (mcrt_flatshare.hpp; 512 lanes, scenes of at most 32 triangles and 32 spheres)
+    const bool flat_share = flat_only && ctxOptOn(ctx, "MCRT_FLAT_SHARE") && flatShareFits(ctx->scene.flat_tris, ctx->scene.num_surfaces);
     if (flat_only)
-        kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
+        kernel = flat_share ? renderKernel<PT, false, true, false, 5>
+                 : flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
     // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
     // wave-synchronous one for A/B runs)
@@ -906,6 +910,16 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         if (!launch_scene.stage_all && fixed < ctx->max_lds)
             launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, (ctx->max_lds - fixed) / 64u);
         g.lds_bytes = planSmLds(launch_scene, g.block, (uint32_t)sm_depth).total;
+        if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)g.block, g.lds_bytes));
+        if (per_cu < 1) per_cu = 1;
+        g.grid = (uint32_t)(per_cu * ctx->num_cus);
+        g.total_lanes = g.grid * g.block;
+    } else if (flat_share) {  // plan 2 (512 lanes, no stack) + the waves' share areas behind it
+        g.block = kBlock;
+        g.lds_bytes = alignUp(planLds(launch_scene, g.block, false).total, 16) + (g.block / 64) * kFlatShareBytes;
         if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
         int per_cu = 0;

@@ -339,8 +339,11 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // the integrator kernel
 // ------------------------------------------------------------------------------------------------
+#include "mcrt_flatshare.hpp"  // optional form of the flat megakernel: the FP64 survivor tests dealt over the wave (kFlat == 5)
+
 // kFlat != 0: instance for flat-mode scenes only (path tracer): no BVH walk in the code, no traversal stack in LDS;
-// kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs).
+// kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs);
+// kFlat == 5: 512 lanes, both intersections of a bounce served by the whole wave (mcrt_flatshare.hpp; option MCRT_FLAT_SHARE).
 template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
 __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
     MCRT_DYNAMIC_LDS(lds, 16);
@@ -401,7 +404,22 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
             if (!waveBallot(!exhausted)) break;
             continue;
         }
-        if (have_pixel) {
+        if constexpr (kFlat == 5) {
+            // (every lane goes through the bounce: the intersections are the wave's business; lanes without a pixel carry no ray)
+            if (have_pixel && !path_active) {
+                st.smp.setIndex(sample);  // camera.cpp:77
+                pathBegin(st, rh, cameraRay<!kAll>(prm.cam, sh.scene_ior, px, py, st.smp, tab));
+                path_active = true;
+                paths++;
+            }
+            const FlatShare F = flatShareAt(lds, alignUp(planLds(scene, blockDim.x, false).total, 16), threadIdx.x >> 6);
+            const bool done = pathTracerBounceFlatShared<kCount>(have_pixel, st, rh, sv, sh, F, cnt, tab);
+            if (have_pixel && done) {
+                storeSample(prm, sample, px, ly, st.radiance);
+                path_active = false;
+                if (++sample == sample_end) have_pixel = false;
+            }
+        } else if (have_pixel) {
             if (!path_active) {
                 if (kProf) prof.mark(kPhRegen);
                 st.smp.setIndex(sample);  // camera.cpp:77

@@ -257,6 +257,10 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
         lds_bytes = planSmLds(launch_scene, block, (uint32_t)kLdsStackDepth).total;
     } else {
         lds_bytes = planLds(launch_scene, block, !flat_only).total;
+        if (flat_only && force == 5) {  // the flat megakernel's shared form (MCRT_FLAT_SHARE=1, mcrt_flatshare.hpp)
+            if (!flatShareFits(launch_scene.flat_tris, launch_scene.num_surfaces)) return -204;
+            lds_bytes = alignUp(planLds(launch_scene, block, false).total, 16) + (block / 64) * kFlatShareBytes;
+        }
     }
     if (lds_bytes > kEmuMaxLds || lds_bytes > sizeof(lds)) return -202;
     const uint32_t total_lanes = grid * block;
@@ -307,8 +311,9 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
         if (all) launchGrid(grid, block, [&] { renderKernelSM<false, true>(launch_scene, prm); });
         else launchGrid(grid, block, [&] { renderKernelSM<false, false>(launch_scene, prm); });
     } else if (flat_only) {
-        kernel_id = 1;
-        launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
+        kernel_id = force == 5 ? 15 : 1;
+        if (force == 5) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 5>(launch_scene, prm); });
+        else launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
     } else {
         kernel_id = 2;
         if (all) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true>(launch_scene, prm); });

@@ -358,3 +358,25 @@ def test_emission_kernel_on_the_host_gives_the_oracle_photons(pkg, wave_kernel_e
     assert rc == 0 and int(pilot[2]) == -(-want["paths"] // 8)
     total, sample = int(counts[0]) + int(counts[1]), (int(pilot[0]) + int(pilot[1])) * 8
     assert abs(sample - total) <= 0.25 * total
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_diffuse", "hexagon_room_ggx", "hexagon_room_dof", "veach_mis", "metals", "ggx_test",
+                                  "oren_nayar_test", "ior_test", "dragon_room"])
+def test_flat_megakernel_shared_form_on_the_host(pkg, wave_kernel_emu, oracle, manifest, name):
+    """The optional form of the flat megakernel (MCRT_FLAT_SHARE=1, csrc/mcrt_flatshare.hpp: a wave's (ray, cull survivor) pairs dealt
+    over all 64 lanes for the FP64 tests, both intersections of a bounce served by the whole wave) on emulated workgroups: the oracle's
+    frame bit for bit, the oracle's ray count - the same hits as the per-lane survivor loops whatever the order of the tests."""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    from conftest import camera_for
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 28, 16, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+    rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, 5, 2)
+    if rc == -204:
+        pytest.skip("more than 32 triangles or spheres: the per-lane loop")
+    assert rc == 0 and kid == 15  # (15: the harness ran the shared instance)
+    assert int(stats[0]) == cam.width * cam.height * 4 and int(stats[1]) == info["rays"]
+    np.testing.assert_array_equal(out, want)
