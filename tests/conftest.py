@@ -147,6 +147,8 @@ def wave_kernel_emu():
     L.wemu_render_pipeline.restype = C.c_int
     L.wemu_emit.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp]
     L.wemu_emit.restype = C.c_int
+    L.wemu_set_shuffle.argtypes = [C.c_uint64]
+    L.wemu_set_shuffle.restype = None
     return L
 
 

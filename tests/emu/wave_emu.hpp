@@ -96,6 +96,11 @@ struct Wave {  // a workgroup of `waves` wavefronts (1 for wemu::run); lane l of
     unsigned long long collectives = 0, divergent = 0;  // operations served; of them with the wave split over several call sites
 };
 
+inline unsigned long long& shuffleSeed() {
+    static unsigned long long seed = getenv("WEMU_SHUFFLE") ? strtoull(getenv("WEMU_SHUFFLE"), nullptr, 0) : 0ull;
+    return seed;
+}
+
 inline Wave*& current() {
     static thread_local Wave* w = nullptr;
     return w;
@@ -150,7 +155,28 @@ inline void runGroup(int waves, const std::function<void(int)>& body, size_t sta
             abort();
         }
         bool any = false;
-        for (int v = 0; v < waves; v++) {
+        // shuffleSeed() != 0 (WEMU_SHUFFLE=<seed>, or set by the harness): the waves of the workgroup are visited in a random order that changes from pass to pass (and a wave may
+        // be skipped for a pass), instead of round robin - what the hardware's arbitration may do. Results must not depend on it.
+        const unsigned long long shuffle_seed = shuffleSeed();
+        int order[kMaxWaves];
+        for (int v = 0; v < waves; v++) order[v] = v;
+        if (shuffle_seed) {
+            static thread_local unsigned long long rng = 0, rng_seed = 0;
+            if (rng_seed != shuffle_seed) {
+                rng_seed = shuffle_seed;
+                rng = shuffle_seed * 0x9E3779B97F4A7C15ull + 1ull;
+            }
+            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+            for (int v = waves - 1; v > 0; v--) std::swap(order[v], order[(int)(next() % (unsigned long long)(v + 1))]);
+            // skip one wave this pass now and then (as long as another one can run)
+            if (waves > 1 && (next() & 3ull) == 0ull) order[waves - 1] = -1;
+        }
+        for (int vi = 0; vi < waves; vi++) {
+            const int v = order[vi];
+            if (v < 0) {
+                any = true;
+                continue;
+            }
             if (w.at_sync[v]) {
                 any = true;
                 continue;  // parked at __syncthreads

@@ -557,4 +557,7 @@ int wemu_emit(const mcrt_scene_desc* scene, double emissions, double caustic_fac
     return counters[5] ? -100 : counters[6] ? -101 : 0;
 }
 
+// 0: the waves of a workgroup take turns; otherwise the seed of a random visiting order (wave_emu.hpp)
+void wemu_set_shuffle(unsigned long long seed) { wemu::shuffleSeed() = seed; }
+
 }  // extern "C"

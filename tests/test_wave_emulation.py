@@ -380,3 +380,33 @@ def test_flat_megakernel_shared_form_on_the_host(pkg, wave_kernel_emu, oracle, m
     assert rc == 0 and kid == 15  # (15: the harness ran the shared instance)
     assert int(stats[0]) == cam.width * cam.height * 4 and int(stats[1]) == info["rays"]
     np.testing.assert_array_equal(out, want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_frames_do_not_depend_on_the_order_the_waves_run_in(pkg, wave_kernel_emu, oracle, manifest, seed):
+    """The waves of an emulated workgroup normally take turns; here they are visited in a random order that changes from pass to pass,
+    a wave sitting a pass out now and then - arbitration as arbitrary as the hardware's. Work units, queue entries and photon slots
+    are then handed out in other orders; frames (flat megakernel, lane state machine, pipeline, photon mapper) and photon sets are not
+    allowed to notice."""
+    from conftest import camera_for, sort_by_key
+    try:
+        wave_kernel_emu.wemu_set_shuffle(seed)
+        for name, integ in (("hexagon_room", pkg.INTEGRATOR_PATH_TRACER), ("coffee_maker_qsah", pkg.INTEGRATOR_PATH_TRACER),
+                            ("hexagon_room_pm", pkg.INTEGRATOR_PHOTON_MAPPER)):
+            case = manifest["cases"][name]
+            img = pkg.SceneImage(golden_path(case["image"]))
+            cam = camera_for(img, case["renders"][0])
+            cam.width, cam.height, cam.sqrtspp = 20, 12, 2
+            want, info = oracle.render(img, cam, manifest["seed"], integ)
+            rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu, img, cam, manifest["seed"], integ, 0, 2)
+            assert rc == 0
+            rc2, pipe, stats2, _ = _emulated_pipeline_frame(wave_kernel_emu, img, cam, manifest["seed"], integ, 512, 2, 3, 3)
+            assert rc2 == 0
+            if integ == pkg.INTEGRATOR_PATH_TRACER:
+                np.testing.assert_array_equal(out, want, err_msg=name)
+                np.testing.assert_array_equal(pipe, want, err_msg=name + " (pipeline)")
+            else:
+                assert (np.abs(out - want) / np.maximum(np.abs(want), 1e-3)).max() <= 1e-12
+                assert (np.abs(pipe - want) / np.maximum(np.abs(want), 1e-3)).max() <= 1e-12
+    finally:
+        wave_kernel_emu.wemu_set_shuffle(0)
