@@ -410,3 +410,35 @@ def test_frames_do_not_depend_on_the_order_the_waves_run_in(pkg, wave_kernel_emu
                 assert (np.abs(pipe - want) / np.maximum(np.abs(want), 1e-3)).max() <= 1e-12
     finally:
         wave_kernel_emu.wemu_set_shuffle(0)
+
+
+@pytest.mark.parametrize("name", ["c3", "c5"])
+def test_large_scene_kernels_on_the_host(pkg, wave_kernel_emu, oracle, name):
+    """The kernels of the scaled BASELINE configurations on their own trees, without a GPU: C3 (metal_bunnies stand-in, 491 592 triangles:
+    lane state machine and the wavefront pipeline) and C5 (water_caustics stand-in, 6 898 815 triangles, photon-mapped: renderKernelPM's
+    instance for trees in memory - per-lane stacks partly in LDS, shared-leaf walks, the spill list's state in LDS - and the photon-
+    mapped pipeline) render a small frame of the config's camera on emulated workgroups: the oracle's frame (bit for bit path-traced;
+    1e-12 photon-mapped: sum order). The images are made by integration/large_scenes/make_large.py (skipped where they are not)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
+    import make_large
+    p = make_large.ensure_image(name)
+    if p is None:
+        pytest.skip("oracle/_ref (reference binary + scene copies) not on this machine")
+    img = pkg.SceneImage(p)
+    cam = img.camera
+    cam.width, cam.height, cam.sqrtspp = 20, 12, 1
+    photon = bool(make_large.CONFIGS[name]["photon"])
+    integ = pkg.INTEGRATOR_PHOTON_MAPPER if photon else pkg.INTEGRATOR_PATH_TRACER
+    want, info = oracle.render(img, cam, 0x12345678, integ)
+    rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu, img, cam, 0x12345678, integ, 0, 1)
+    assert rc == 0 and kid == (5 if photon else 3) and int(stats[1]) == info["rays"]
+    rc2, pipe, stats2, launches = _emulated_pipeline_frame(wave_kernel_emu, img, cam, 0x12345678, integ, 256, 2, 2, 3)
+    assert rc2 == 0 and 0 <= info["rays"] - int(stats2[1]) <= 0.03 * info["rays"] + 1
+    if photon:
+        for got in (out, pipe):
+            assert (np.abs(got - want) / np.maximum(np.abs(want), 1e-3)).max() <= 1e-12
+    else:
+        np.testing.assert_array_equal(out, want)
+        np.testing.assert_array_equal(pipe, want)
