@@ -204,6 +204,7 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
                 base = dict(value=sample_rays / r["seconds"] / 1e6, unit="Mray/s", cores=best_t, kind="reference",
                             sample="reference Camera::samplePixel at its best thread count (%d of %d hardware threads): rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s); "
                                    "thread scan on row %d" % (best_t, threads, q0, q0 + n_rows, cam.width, cam.height, spp, r["paths"], r["seconds"], mid),
+                            quoted="value = the reference at its best thread count; BASELINE.md 3's all-hardware-threads figure = all_threads_value",
                             best_value=sample_rays / r["seconds"] / 1e6, best_cores=best_t,
                             all_threads_value=cal[threads] / 1e6, all_threads_cores=threads,
                             by_threads={str(k): v / 1e6 for k, v in sorted(cal.items())},
@@ -645,6 +646,117 @@ def leg_roofline(m, counts, kernel_id, kernel_ms, rays_per_launch, knn_per_launc
     return add_physical_fractions(r, counts, kernel_ms, rays_per_launch, knn_per_launch, pmc)
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# the line the driver parses: short (the driver's record keeps ~8 KB of stdout), the LAST line of stdout
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 8000           # characters; tests/test_bench_line.py holds compact_line() to it
+FULL_RECORD = os.path.join(PROFILE_DIR, "bench_full.json")
+
+
+def _rnd(v, sig=6):
+    """Floats to `sig` significant digits (the full-precision record is bench_full.json)."""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _rnd(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_rnd(x, sig) for x in v]
+    return v
+
+
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_ray", "rays_per_launch",
+                 "algorithmic_GBs", "algorithmic_frac", "hbm_frac_measured", "traffic_GBs", "valu_issue_frac", "fp64_frac", "fp64_TFLOPs",
+                 "frac_necessary", "traffic_over_algorithmic")
+COUNTER_KEYS = ("valu_busy", "lane_utilisation", "waves_waiting", "measured_clock_GHz", "l2_hit_rate", "frame_scale", "lane_ops_per_ray")
+LEG_ROOFLINE_KEYS = ("bound", "frac", "hbm_frac_measured", "valu_issue_frac", "fp64_frac", "algorithmic_frac", "frac_necessary", "kernel_ms")
+
+
+def compact_roofline(r, keys=ROOFLINE_KEYS, counters=COUNTER_KEYS):
+    if not r:
+        return None
+    out = {k: r[k] for k in keys if r.get(k) is not None or k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if "unit" in out and out["unit"] and out["unit"].startswith("G lane-op/s"):
+        out["unit"] = "G lane-op/s"     # FP64-rate lane slots: 1024 SIMDs x 16 lanes x 2.4 GHz (DESIGN.md 4.8)
+    c = r.get("counters") or {}
+    for k in counters:
+        if c.get(k) is not None:
+            out[k] = c[k]
+    if c.get("errors"):
+        out["counter_errors"] = str(c["errors"])[:200]
+    return out
+
+
+def compact_cpu(b, sample_chars=150):
+    if not b:
+        return None
+    out = {k: b[k] for k in ("value", "unit", "cores", "kind") if k in b}
+    out["sample"] = (b.get("sample") or "")[:sample_chars]
+    for k in ("all_threads_value", "all_threads_cores", "port_value", "port_cores", "knn_searches_per_s", "quoted"):
+        if b.get(k) is not None:
+            out[k] = b[k]
+    return out
+
+
+def compact_line(result):
+    """The headline line: the contract's keys, `config`, `parity`, `cpu_baseline`, `roofline` of the headline leg, and per secondary leg a
+    dozen numbers. Everything else (per-leg counters, prices, notes, thread scans, photon-pass breakdowns) is in bench_full.json /
+    profiles/. Stays under LINE_LIMIT characters whatever the legs hold: optional keys are shed in a fixed order if it does not."""
+    core = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: result.get(k) for k in core}
+    cfg = result.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "width", "height", "spp", "integrator", "seed", "sharding", "rays_per_step", "paths_per_step",
+                                             "kernel", "kernel_launches_per_step", "frame_finite", "frame_mean_radiance") if k in cfg}
+    for k in ("per_rank", "gather_ms", "photon_allgather_ms", "frame_with_photon_pass_ms"):
+        if result.get(k) is not None:
+            out[k] = result[k]
+    if result.get("parity"):
+        out["parity"] = {k: result["parity"].get(k) for k in ("rows", "pixels", "max_rel", "outliers_gt_1e-4", "bit_identical", "tolerance")}
+    out["cpu_baseline"] = compact_cpu(result.get("cpu_baseline"))
+    out["roofline"] = compact_roofline(result.get("roofline"))
+    legs = {}
+    for name, leg in (result.get("secondary") or {}).items():
+        if "error" in leg:
+            legs[name] = {"error": str(leg["error"])[:160]}
+            continue
+        c, r, b = leg.get("config") or {}, leg.get("roofline") or {}, leg.get("cpu_baseline") or {}
+        e = {"workload": (c.get("workload") or "")[:60], "value": leg.get("value"), "unit": leg.get("unit"), "steps": leg.get("steps"), "ms_per_step": leg.get("ms_per_step"),
+             "kernel": c.get("kernel"), "launches_per_step": c.get("kernel_launches_per_step")}
+        for k in ("frame_with_photon_pass_ms", "value_with_photon_pass"):
+            if leg.get(k) is not None:
+                e[k] = leg[k]
+        if c.get("knn_searches_per_s"):
+            e["knn_searches_per_s"] = c["knn_searches_per_s"]
+        if leg.get("parity"):
+            e["bit_identical"] = leg["parity"].get("bit_identical")
+        e.update({k: r[k] for k in LEG_ROOFLINE_KEYS if r.get(k) is not None})
+        for k in ("lane_utilisation", "measured_clock_GHz"):
+            if (r.get("counters") or {}).get(k) is not None:
+                e[k] = r["counters"][k]
+        if b:
+            e["cpu"] = {"value": b.get("value"), "cores": b.get("cores"), "kind": b.get("kind")}
+        legs[name] = e
+    if legs:
+        out["secondary"] = legs
+    out["detail"] = "gpurun_out/bench_profiles/bench_full.json (+ pmc_<leg>.md); committed as profiles/rNN_bench_full.json"
+    out = _rnd(out)
+    # shed optional keys, least important first, until the line fits (never the contract's keys)
+    shed = [("secondary", k) for k in ("workload", "measured_clock_GHz", "lane_utilisation", "frac_necessary", "launches_per_step", "cpu", "kernel_ms")] + \
+           [("roofline", k) for k in ("traffic_over_algorithmic", "lane_ops_per_ray", "l2_hit_rate", "waves_waiting", "frac_necessary")]
+    line = json.dumps(out)
+    while len(line) > LINE_LIMIT and shed:
+        where, key = shed.pop(0)
+        if where == "secondary":
+            for e in out.get("secondary", {}).values():
+                e.pop(key, None)
+        elif out.get(where):
+            out[where].pop(key, None)
+        line = json.dumps(out)
+    if len(line) > LINE_LIMIT:
+        out.pop("secondary", None)
+        line = json.dumps(out)
+    return line
+
 PARITY_ROWS = {"c2": "hexagon_room.c2_1920x1080_s16_rows536_540.f64", "c2_ggx": "hexagon_room_ggx.c2ggx_1920x1080_s16_rows536_540.f64"}
 
 
@@ -829,7 +941,16 @@ def main():
                 leg = {"error": repr(ex)}
             result["secondary"][name] = leg
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        # the full record: a file (and stderr), never stdout - the driver parses the LAST stdout line and keeps ~8 KB of it
+        try:
+            os.makedirs(PROFILE_DIR, exist_ok=True)
+            with open(FULL_RECORD, "w") as f:
+                json.dump(result, f)
+        except OSError:
+            pass
+        sys.stderr.write("bench.py full record: %s\n" % json.dumps(result))
+        sys.stderr.flush()
+        print(compact_line(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
