@@ -98,6 +98,14 @@ EMISSIONS = {"pm": 1e6, "c5": 1e7}
 # timed part is its eye pass only, and paths / rays / searches per row do not depend on the map)
 REF_EMISSIONS = {"pm": 1e6, "c5": 1e6}
 SEED = 0x12345678
+# --rehearse-dist: the collectives of the N > 1 path (RCCL init, the photon all-gathers, the per-frame gather, barriers, reductions,
+# destroy) run with a process group of ONE rank on one GPU, so that branch has executed before the driver's only 8-GPU run
+REHEARSE_DIST = False
+
+
+def _collectives(world):
+    return world > 1 or REHEARSE_DIST
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector-ALU peak in FP64-rate lane slots: 256 CUs x 4 SIMDs, a wave64 FP64 instruction occupies its SIMD for 4 cycles
 # (16 lanes per cycle), 2.4 GHz max clock (MI355X_MICROARCH.md chip parameters) = 39.3e12 lane-ops/s (x2 = 78.6 TFLOP/s FMA)
@@ -235,16 +243,20 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
 # ------------------------------------------------------------------------------------------------------------------
 # in-run hardware counters: one frame of the workload in a child process under rocprofv3 --pmc (one pass per counter set)
 # ------------------------------------------------------------------------------------------------------------------
-SQ_SET = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
-          "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+SQ_SET = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+          "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "GRBM_GUI_ACTIVE"]
+# the typed VALU instruction counters (wave instructions by operand type; 8 SQ slots per pass: six ride with the write pass, whose SQ
+# slots were free, two with the read pass): what the FP64 roofline fraction is made of (round 5)
+SQ_TYPED = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64",
+            "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32"]
 # Two passes (TCC has 4 counter slots, SQ 8, GRBM 2 - MI355X_MICROARCH.md "rocprofv3 PMC slots"): reads by request size class
 # together with the SQ set, then writes + L2 hit/miss. Calibrated on known byte counts in the kernels' own access patterns
 # (tools/calibrate_traffic.py -> profiles/r03_traffic_calibration.json): every fabric read is a 128-byte L2 line, so
 # read bytes = 32 n32 + 64 n64 + 128 n128 = 2 x FETCH_SIZE for streams, 8 KB photon runs, 64-byte blocks and 80-byte records alike
 # (a scattered 64-byte block MOVES 128 bytes); WRITE_SIZE is exact for streamed stores and counts 32-byte sectors for scattered ones.
 PMC_PASSES = (("read+sq", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"] + SQ_SET),
-              ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]))
-PMC_FALLBACK = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET))  # round 2's passes, if a combined pass is refused
+              ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"] + SQ_TYPED))
+PMC_FALLBACK = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_SET), ("typed", SQ_TYPED))  # separate passes, if a combined pass is refused
 # every kernel between the HIP events that time a frame: the integrator kernels and the in-order resolve of the per-sample store
 INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKernel", "sampleResolveKernel")
 PROFILE_DIR = os.path.join(ROOT, "gpurun_out", "bench_profiles")  # per-leg counter summaries of THIS run (copied to profiles/ when committed)
@@ -361,6 +373,18 @@ def counters_summary(pmc, scale=1.0):
         s["valu_insts"] = c.get("SQ_INSTS_VALU", 0.0) * scale
         if c.get("SQ_WAVE_CYCLES"):
             s["waves_waiting"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        # instruction mix by operand type (wave instructions; counts, so they scale with the frame). FP64 = add/sub + mul + fma + transcendental
+        # (rcp, rsq, sqrt: the divisions and square roots of the path); everything the typed counters do not name - moves, selects,
+        # compares, conversions, min / max, bit operations - is "other".
+        if all(k in c for k in SQ_TYPED) and c.get("SQ_INSTS_VALU"):
+            f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+            f32 = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c.get("SQ_INSTS_VALU_FMA_F32", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            integer = c["SQ_INSTS_VALU_INT32"] + c["SQ_INSTS_VALU_INT64"]
+            total = c["SQ_INSTS_VALU"]
+            s["fp64_insts"] = f64 * scale                                                 # wave instructions
+            s["fp64_flop_insts"] = (f64 + c["SQ_INSTS_VALU_FMA_F64"]) * scale             # an fma is two flops
+            s["inst_mix"] = {"f64": f64 / total, "f64_fma_share": c["SQ_INSTS_VALU_FMA_F64"] / max(f64, 1.0), "f32": f32 / total, "int": integer / total,
+                             "other": max(0.0, 1.0 - (f64 + f32 + integer) / total)}
         if c.get("GRBM_GUI_ACTIVE"):
             clk = c["GRBM_GUI_ACTIVE"] / frame_s
             if clk > 3.0e9:  # summed over the 8 XCDs
@@ -396,7 +420,9 @@ def write_leg_profile(name, desc, pmc_raw, summary, roofline):
                     "(all kernels between the frame's HIP events: integrator kernels + sampleResolveKernel); hbm_frac_measured = traffic / kernel_ms of the timed "
                     "frame / 8 TB/s; valu_issue_frac = SQ_THREAD_CYCLES_VALU x frame_scale / kernel_ms / (1024 SIMDs x 16 lanes x 2.4 GHz); valu_busy = "
                     "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x counted kernel time x 2.4 GHz); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
-                    "frac = max(hbm_frac_measured, valu_issue_frac).\n")
+                    "fp64_frac = (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + FMA_F64 + TRANS_F64) x frame_scale x 64 x lane_utilisation / kernel_ms / 39.3 T lane-op/s (the FP64 peak "
+                    "without fma contraction; the library is built -ffp-contract=off); inst_mix = the typed counters / SQ_INSTS_VALU; "
+                    "frac = max(hbm_frac_measured, valu_issue_frac). valu_busy, waves_waiting and measured_clock_GHz are time ratios of the COUNTED frame.\n")
     except OSError:
         pass
 
@@ -424,7 +450,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
         import make_large
         if local_rank == 0 and make_large.ensure_image(name) is None:
             raise RuntimeError("%s needs oracle/_ref (python __graft_entry__.py build in the build container)" % name)
-        if world > 1:
+        if _collectives(world):
             dist.barrier()
     path = os.path.join(ROOT, "tests", "golden", image_file)
     if not os.path.exists(path):
@@ -440,7 +466,8 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     wl.pm_maps, wl.emit_info = None, None
     wl.photon = name in ("pm", "c5")
     wl.emissions = args.emissions or EMISSIONS.get(name, 1e6)
-    if wl.photon and world == 1 and not args.host_octree:
+    wl.photon_allgather_ms = None
+    if wl.photon and not _collectives(world) and not args.host_octree:
         # one GPU: the whole photon pass on the device (mcrt_photon_pass_device: emission, sort, octants, boxes, record lists;
         # no photon list crosses PCIe)
         wl.integrator = m.INTEGRATOR_PHOTON_MAPPER
@@ -473,6 +500,8 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
                 self.__cuda_array_interface__ = {"shape": (n, 8), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
         lists = []
+        torch.cuda.synchronize(dev)
+        t_gather = time.perf_counter()
         for key in ("global_", "caustic"):
             ptr, n = em[key]
             ph = torch.as_tensor(_DevList(ptr, n), device=dev) if n else torch.zeros((0, 8), dtype=torch.float32, device=dev)
@@ -489,6 +518,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
         # the lists were produced on torch's streams (all_gather on RCCL's, cat / contiguous on the current one); the library builds the
         # maps on the context's own stream and include/mcrt.h requires device inputs to be COMPLETE when the call is made
         torch.cuda.synchronize(dev)
+        wl.photon_allgather_ms = (time.perf_counter() - t_gather) * 1e3   # counts + padded lists of both maps, incl. the concatenation
         t_build = time.perf_counter()
         ps = wl.ctx.upload_photons_device(lists[0].data_ptr(), lists[0].shape[0], lists[1].data_ptr(), lists[1].shape[0], sc.bb_min[:], sc.bb_max[:],
                                           200, 50, False)
@@ -506,7 +536,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
         lists = []
         for key in ("global_", "caustic"):
             ph = torch.from_numpy(em[key][0]).to(torch.device("cuda", local_rank))
-            if world > 1:
+            if _collectives(world):
                 sizes = [torch.zeros(1, dtype=torch.int64, device=ph.device) for _ in range(world)]
                 dist.all_gather(sizes, torch.tensor([ph.shape[0]], dtype=torch.int64, device=ph.device))
                 cap = int(max(int(x.item()) for x in sizes))
@@ -526,7 +556,7 @@ def setup_workload(name, args, m, tiling, rank, world, local_rank, dist, sqrtspp
     wl.my_rows = m.shard_rows(wl.cam)
     wl.dev = torch.device("cuda", local_rank)
     wl.tile = torch.zeros((tiling.max_rows(wl.full, world, SHARD_ROWS), W, 3), dtype=torch.float64, device=wl.dev)  # packed owned rows (+ padding)
-    wl.gathered = [torch.empty_like(wl.tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    wl.gathered = [torch.empty_like(wl.tile) for _ in range(world)] if (_collectives(world) and rank == 0) else None
     wl.stream = torch.cuda.current_stream(wl.dev).cuda_stream
     return wl
 
@@ -539,12 +569,12 @@ def run_steps(wl, steps, warmup, world, dist, warm_sqrtspp=None):
     def step(cam=None):
         wl.ctx.render_device(cam or wl.cam, SEED, wl.integrator, wl.tile.data_ptr(), wl.stream)
         st = wl.ctx.render_finish()
-        if world > 1:
+        if _collectives(world):
             dist.gather(wl.tile, wl.gathered, dst=0)  # the single collective of the data path
         return st
 
     def sync():
-        if world > 1:
+        if _collectives(world):
             dist.barrier()
         torch.cuda.synchronize(wl.dev)
 
@@ -558,7 +588,15 @@ def run_steps(wl, steps, warmup, world, dist, warm_sqrtspp=None):
     t0 = time.perf_counter()
     stats = [step() for _ in range(steps)]
     sync()
-    return time.perf_counter() - t0, stats
+    elapsed = time.perf_counter() - t0
+    wl.gather_ms = None
+    if _collectives(world):  # after the timed region: what the frame's one collective costs by itself (the same tiles again)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dist.gather(wl.tile, wl.gathered, dst=0)
+        sync()
+        wl.gather_ms = (time.perf_counter() - t1) * 1e3 / 3.0
+    return elapsed, stats
 
 
 # Necessary work of the REFERENCE's algorithm on the same rays, in FP64 lane-ops (one +, -, x, /, sqrt, min, max or compare = 1): the
@@ -601,10 +639,27 @@ def add_physical_fractions(r, counts, kernel_ms, rays_per_launch, knn_per_launch
     if pmc and pmc.get("valu_lane_ops"):
         r["valu_G_lane_ops_per_s"] = pmc["valu_lane_ops"] / sec / 1e9
         r["valu_issue_frac"] = r["valu_G_lane_ops_per_s"] / VALU_PEAK_GLANEOPS
+    r["fp64_frac"] = None
+    if pmc and pmc.get("fp64_insts") and pmc.get("lane_utilisation"):
+        # the FP64 roofline of a kernel compiled -ffp-contract=off: one FP64 lane-op per lane slot, 39.3 T/s (an fma, two flops, also takes
+        # one slot: the 78.6 TFLOP/s peak is out of reach without contraction). Lanes: the wave instructions counted by type x 64 x the
+        # measured share of lanes that were on (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU, the kernels' average over ALL their VALU
+        # instructions - the typed counters have no per-lane form)
+        r["fp64_G_lane_ops_per_s"] = pmc["fp64_insts"] * 64.0 * pmc["lane_utilisation"] / sec / 1e9
+        r["fp64_frac"] = r["fp64_G_lane_ops_per_s"] / VALU_PEAK_GLANEOPS
+        r["fp64_TFLOPs"] = pmc["fp64_flop_insts"] * 64.0 * pmc["lane_utilisation"] / sec / 1e12
+        r["fp64_peak_TFLOPs"] = VALU_PEAK_GLANEOPS / 1e3
+        r["inst_mix"] = pmc.get("inst_mix")
     if pmc:
+        # counts (bytes, instructions) scale with the frame and are priced over the TIMED frame; time ratios (valu_busy, waves_waiting)
+        # and the clock belong to the COUNTED frame - a child process under rocprofv3, possibly at fewer samples per pixel - and are
+        # reported as that frame's, never carried over (counted_frame: its spp and kernel time)
         keep = ("valu_busy", "lane_utilisation", "waves_waiting", "valu_insts", "measured_clock_GHz", "fetch_bytes", "write_bytes", "l2_hit_rate", "frame_scale",
                 "pass_wall_s", "errors")
         r["counters"] = {k: pmc[k] for k in keep if k in pmc}
+        if pmc.get("frame"):
+            r["counters"]["counted_frame"] = {"spp": pmc["frame"].get("spp"), "kernel_ms": pmc["frame"].get("kernel_ms"),
+                                              "time_ratios_are_of_this_frame": ["valu_busy", "waves_waiting", "measured_clock_GHz"]}
         if pmc.get("valu_lane_ops"):
             r["counters"]["lane_ops_per_ray"] = pmc["valu_lane_ops"] / rays_per_launch
             r["counters"]["valu_insts_per_ray"] = pmc["valu_insts"] * 64.0 / rays_per_launch  # wave instructions x 64 lanes
@@ -668,7 +723,7 @@ def _rnd(v, sig=6):
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_ray", "rays_per_launch",
                  "algorithmic_GBs", "algorithmic_frac", "hbm_frac_measured", "traffic_GBs", "valu_issue_frac", "fp64_frac", "fp64_TFLOPs",
                  "frac_necessary", "traffic_over_algorithmic")
-COUNTER_KEYS = ("valu_busy", "lane_utilisation", "waves_waiting", "measured_clock_GHz", "l2_hit_rate", "frame_scale", "lane_ops_per_ray")
+COUNTER_KEYS = ("valu_busy", "lane_utilisation", "waves_waiting", "measured_clock_GHz", "l2_hit_rate", "frame_scale", "lane_ops_per_ray")  # (of the counted frame)
 LEG_ROOFLINE_KEYS = ("bound", "frac", "hbm_frac_measured", "valu_issue_frac", "fp64_frac", "algorithmic_frac", "frac_necessary", "kernel_ms")
 
 
@@ -682,6 +737,10 @@ def compact_roofline(r, keys=ROOFLINE_KEYS, counters=COUNTER_KEYS):
     for k in counters:
         if c.get(k) is not None:
             out[k] = c[k]
+    if r.get("inst_mix"):
+        out["inst_mix"] = {k: round(v, 4) for k, v in r["inst_mix"].items()}
+    if (c.get("counted_frame") or {}).get("spp") is not None:
+        out["counted_spp"] = c["counted_frame"]["spp"]
     if c.get("errors"):
         out["counter_errors"] = str(c["errors"])[:200]
     return out
@@ -786,7 +845,14 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     acc = torch.tensor([float(sum(s["rays"] for s in stats)), float(sum(s["paths"] for s in stats)),
                         float(sum(s["kernel_ms"] for s in stats)), float(sum(s["knn_searches"] for s in stats))], dtype=torch.float64, device=dev)
-    if world > 1:
+    per_rank = None
+    if _collectives(world):
+        mine = torch.tensor([elapsed / steps * 1e3, float(sum(s["kernel_ms"] for s in stats)) / steps, wl.gather_ms or 0.0, wl.photon_allgather_ms or 0.0],
+                            dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = {"ms_per_step": [float(e[0]) for e in every], "kernel_ms": [float(e[1]) for e in every],
+                    "gather_ms": max(float(e[2]) for e in every), "photon_allgather_ms": max(float(e[3]) for e in every) or None}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kmax = acc[2:3].clone()
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
@@ -796,7 +862,7 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
     total_rays, total_paths, kernel_ms_sum, total_knn = (float(x) for x in acc)
     result = None
     if rank == 0:
-        if world > 1:  # sanity: the gathered frame is complete and finite
+        if _collectives(world):  # sanity: the gathered frame is complete and finite
             frame = torch.zeros((wl.H, wl.W, 3), dtype=torch.float64, device=dev)
             for r in range(world):
                 rows = torch.from_numpy(tiling.rows_of(wl.full, r, world, SHARD_ROWS)).to(dev)
@@ -823,6 +889,13 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
             pp_ms = wl.emit_info["photon_pass_s"] * 1e3
             result["frame_with_photon_pass_ms"] = result["ms_per_step"] + pp_ms
             result["value_with_photon_pass"] = (total_rays / steps + wl.emit_info["rays"]) / (result["frame_with_photon_pass_ms"] * 1e-3) / 1e6
+        if per_rank:
+            result["per_rank"] = {k: per_rank[k] for k in ("ms_per_step", "kernel_ms")}
+            result["gather_ms"] = per_rank["gather_ms"]
+            if per_rank["photon_allgather_ms"]:
+                result["photon_allgather_ms"] = per_rank["photon_allgather_ms"]
+            if REHEARSE_DIST:
+                result["rehearsal"] = "collectives of the N > 1 path run with a process group of one rank (--rehearse-dist): not a scaling measurement"
         par = c2_parity(wl, frame) if world == 1 else None
         if par:
             result["parity"] = par
@@ -892,6 +965,8 @@ def main():
     ap.add_argument("--host-octree", action="store_true", help="build the photon octrees with the host builder instead of the GPU-assisted one")
     ap.add_argument("--emissions", type=float, default=None,
                     help="photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths); default: pm 1e6, c5 1e7 (BASELINE configs[4]: 1e8 emission paths)")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="one GPU: run the collectives of the N > 1 path (RCCL init, gathers, reductions, destroy) with a process group of one rank")
     ap.add_argument("--child-frame", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -914,7 +989,13 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    global REHEARSE_DIST
+    REHEARSE_DIST = bool(args.rehearse_dist) and world == 1
+    if REHEARSE_DIST:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if _collectives(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group(backend="gloo")
@@ -923,7 +1004,7 @@ def main():
 
     m = importlib.import_module("monte-carlo-ray-tracer_amd")
     tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
-    single = world == 1
+    single = world == 1 and not REHEARSE_DIST   # (the rehearsal is the N > 1 line's shape: no CPU leg, no counter passes, no secondary legs)
     result, ref_threads = measure(args.workload, args, m, tiling, rank, world, local_rank, dist, args.steps, args.warmup,
                                   want_cpu=single and not args.no_cpu, want_counters=single and not args.no_counters, headline=True)
     if single and args.workload == "c2" and not args.no_secondary:
@@ -951,7 +1032,7 @@ def main():
         sys.stderr.write("bench.py full record: %s\n" % json.dumps(result))
         sys.stderr.flush()
         print(compact_line(result), flush=True)
-    if world > 1:
+    if _collectives(world):
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,13 +27,21 @@
 
 #if defined(__HIPCC__) || defined(MCRT_WAVE_EMU)  // (MCRT_WAVE_EMU: tests/emu/wave_emu.hpp runs this file on the host, 64 fibers per wave)
 
-// Where the code below leans on the lanes of a wave running in lockstep - one lane reads what another wrote a few instructions
-// earlier with no cross-lane operation in between - it says so: nothing on the device, a rendezvous of the 64 fibers when the file
-// runs on the host (tests/emu/wave_emu.hpp, where a lane runs its whole stretch between two cross-lane operations at once).
+// Where one lane reads what ANOTHER lane of its wave wrote to LDS a few instructions earlier, with no cross-lane operation in between,
+// the code says so. On the device that is a wavefront-scope fence plus the compiler's wave barrier: LDS operations of one wave execute in
+// order, so no instruction is needed (tools/compare_device_code.py: the kernels' instructions are unchanged), but the hand-off is now
+// inside the memory model - the compiler may not move the write below or the read above this point. On the host
+// (tests/emu/wave_emu.hpp) it is a rendezvous of the 64 fibers, where a lane runs its whole stretch between two cross-lane
+// operations at once.
 #if defined(MCRT_WAVE_EMU)
 #define MCRT_LOCKSTEP() __builtin_amdgcn_wave_barrier()
 #else
-#define MCRT_LOCKSTEP() ((void)0)
+#define MCRT_LOCKSTEP()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 #endif
 
 namespace mcrt {

@@ -111,7 +111,15 @@ def _bench(gpus, extra, env=None):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
-    return json.loads(lines[0])
+    # the driver's line: short, the LAST line of stdout; the full record (what these tests compare) goes to stderr and bench_full.json
+    assert p.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8000
+    short = json.loads(lines[0])
+    full = [l for l in p.stderr.splitlines() if l.startswith("bench.py full record: ")]
+    assert len(full) == 1
+    full = json.loads(full[0][len("bench.py full record: "):])
+    assert abs(short["value"] - full["value"]) <= 1e-5 * full["value"] and short["n_gpus"] == full["n_gpus"] and short["steps"] == full["steps"]
+    full["_line"] = short
+    return full
 
 
 @pytest.mark.parametrize("workload,extra", [("c1", []), ("pm", ["--emissions", "20000"])])
@@ -133,3 +141,24 @@ def test_bench_n2_line_equals_n1_work(workload, extra):
         assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]
         assert two["config"]["frame_mean_radiance"] == one["config"]["frame_mean_radiance"]
     assert "roofline" in two and two["roofline"]["kernel_id"] == one["roofline"]["kernel_id"]
+
+
+@pytest.mark.parametrize("workload,extra", [("c1", []), ("pm", ["--emissions", "20000"])])
+def test_bench_rccl_branch_rehearsal_on_one_gpu(workload, extra):
+    """bench.py --rehearse-dist: the N > 1 branch with backend "nccl" (RCCL) and a process group of ONE rank on this box's GPU - init
+    with device_id, the barrier, the photon all-gathers on device pointers, the per-frame gather into rank 0's list, the reductions of
+    the timing, destroy. Same work as the plain N = 1 line; the line names itself a rehearsal and carries the per-rank figures."""
+    common = ["--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-counters", "--no-secondary"] + extra
+    one = _bench(1, common, env={"MCRT_BENCH_SHARE_GPU": "0"})
+    reh = _bench(1, common + ["--rehearse-dist"], env={"MCRT_BENCH_SHARE_GPU": "0"})
+    assert "rehearsal" in reh and reh["n_gpus"] == 1
+    assert reh["config"]["paths_per_step"] == one["config"]["paths_per_step"]
+    assert len(reh["per_rank"]["ms_per_step"]) == 1 and reh["per_rank"]["ms_per_step"][0] > 0 and reh["gather_ms"] > 0
+    assert reh["_line"]["per_rank"]["ms_per_step"] and reh["_line"]["gather_ms"] > 0
+    if workload == "pm":
+        assert reh["photon_allgather_ms"] > 0
+        assert reh["config"]["photon_pass"]["global_photons"] == one["config"]["photon_pass"]["global_photons"]
+        assert abs(reh["config"]["frame_mean_radiance"] - one["config"]["frame_mean_radiance"]) <= 1e-9 * abs(one["config"]["frame_mean_radiance"])
+    else:
+        assert reh["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+        assert reh["config"]["frame_mean_radiance"] == one["config"]["frame_mean_radiance"]
