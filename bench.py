@@ -1021,6 +1021,10 @@ def main():
             except Exception as ex:  # a leg that cannot run here (scene image absent) must not cost the headline
                 leg = {"error": repr(ex)}
             result["secondary"][name] = leg
+    # the process group goes first: whatever RCCL / torch print while it is torn down must not follow the line the driver parses
+    if _collectives(world):
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         # the full record: a file (and stderr), never stdout - the driver parses the LAST stdout line and keeps ~8 KB of it
         try:
@@ -1031,10 +1035,8 @@ def main():
             pass
         sys.stderr.write("bench.py full record: %s\n" % json.dumps(result))
         sys.stderr.flush()
+        sys.stdout.flush()
         print(compact_line(result), flush=True)
-    if _collectives(world):
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

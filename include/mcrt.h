@@ -195,6 +195,10 @@ typedef struct mcrt_ctx mcrt_ctx; /* opaque; owns all device memory and one HIP 
 /* Lifecycle. device_id = HIP ordinal of the gfx950 device this context drives (one context per
  * device / per process rank). */
 int  mcrt_create(mcrt_ctx** out, int device_id);
+/* Number of HIP devices this process sees (0: none, or the runtime cannot start) - what a one-process host sizes its set of contexts
+ * by before mcrt_render_multi; the reference's counterpart is std::thread::hardware_concurrency() (integrator/integrator.cpp:20-24).
+ * mcrt_create still refuses a device that is not gfx950. */
+int  mcrt_device_count(void);
 void mcrt_destroy(mcrt_ctx* ctx);
 const char* mcrt_last_error(const mcrt_ctx* ctx); /* ctx may be NULL: last create error */
 
@@ -355,9 +359,10 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
 /* The libm calls of the path as the DEVICE computes them (csrc/mcrt_libm.hpp: glibc 2.35's algorithms restated so that the GPU returns
  * the bits the reference's std::sin / std::cos pairs (= sincos: sampling/sampling.hpp:29-44, material/ggx.cpp:77-79, surface/sphere.cpp:43),
  * std::sin alone (camera/filter.hpp:64), std::asin (scene/scene.cpp:221) and std::atan2 (integrator/photon-mapper/photon.hpp:10-11)
- * return on an x86-64 host with FMA). fn selects the function; a[n] (and b[n] for atan2: a = y, b = x) are the arguments, out0[n]
- * (and out1[n] for sincos: out0 = sine, out1 = cosine) the results. Known-answer tests only; no scene needed. */
-enum { MCRT_LIBM_SINCOS = 0, MCRT_LIBM_SIN = 1, MCRT_LIBM_COS = 2, MCRT_LIBM_ASIN = 3, MCRT_LIBM_ATAN2 = 4 };
+ * return on an x86-64 host with FMA; SINCOSF: sincosf, the sine / cosine pairs of Photon::dir's two float angles, photon.hpp:19-27 - a[n]
+ * holds float values, out0 / out1 the float results widened). fn selects the function; a[n] (and b[n] for atan2: a = y, b = x) are the
+ * arguments, out0[n] (and out1[n] for sincos / sincosf: out0 = sine, out1 = cosine) the results. Known-answer tests only; no scene needed. */
+enum { MCRT_LIBM_SINCOS = 0, MCRT_LIBM_SIN = 1, MCRT_LIBM_COS = 2, MCRT_LIBM_ASIN = 3, MCRT_LIBM_ATAN2 = 4, MCRT_LIBM_SINCOSF = 5 };
 int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1);
 
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map

@@ -1,50 +1,161 @@
-// integration/camera_sample_image_gpu.cpp — the drop-in, built for real: the replacement body of
+// integration/camera_sample_image_gpu.cpp — the drop-in, built for real: the replacement bodies of
 //
-//     void Camera::sampleImage();          // reference: source/camera/camera.cpp:101-145
+//     void Camera::sampleImage();                          // reference: source/camera/camera.cpp:101-145
+//     PhotonMapper::PhotonMapper(const nlohmann::json&);   // reference: source/integrator/photon-mapper/photon-mapper.cpp:24-223
 //
 // that INTEGRATION.md §2 describes, linked with the reference's OWN objects (every translation unit of
 // /root/reference/source incl. main.cpp, compiled unmodified by oracle/Makefile) and libmcrt_hip.so into
 // oracle/_ref/mcrt_ref_gpu. The reference's definition of Camera::sampleImage() in camera.o is made a weak symbol
-// (objcopy --weaken-symbol, oracle/Makefile) so that this strong definition is the one Camera::capture() (camera.cpp:170-181)
-// calls; everything else — main(), the stdin menu, JSON/OBJ loading, BVH::BVH, Scene::generateEmissives, the photon pass of
-// PhotonMapper::PhotonMapper, Camera::saveImage / Image::save — is the reference's code, untouched.
+// (objcopy --weaken-symbol) and its PhotonMapper constructor is RENAMED in a copy of photon-mapper.o (objcopy --redefine-sym,
+// oracle/Makefile), so that the strong definitions below are the ones Camera::capture() (camera.cpp:170-181) and
+// Camera::Camera's std::make_shared<PhotonMapper> call; everything else — main(), the stdin menu, JSON/OBJ loading,
+// BVH::BVH, Scene::generateEmissives, Camera::saveImage / Image::save — is the reference's code, untouched.
+//
+// What the two seams bind (round 5: the whole node, not one GPU):
+//   * one context per HIP device the process sees (mcrt_device_count; MCRT_DROPIN_CONTEXTS=n forces n contexts, dealt round robin
+//     over the devices — two contexts on one GPU is how the one-GPU test box exercises the fan-out) and mcrt_render_multi in place
+//     of the worker-thread fan-out of camera.cpp:120-136: rows dealt in groups of 8, every context driven by its own host thread;
+//   * the photon pass on the GPUs: PhotonMapper's constructor only reads the "photon_map" object (photon-mapper.cpp:28-38) and
+//     leaves both maps empty; sampleImage then runs mcrt_photon_pass_device (emission + both octrees on the device) on every
+//     context — the same maps on every GPU, nothing crosses the host. MCRT_DROPIN_CPU_PHOTONS=1 keeps the reference's own CPU
+//     photon pass instead (its constructor, under its new name, builds a second PhotonMapper whose maps are moved over) and
+//     uploads those maps: the path the .tga parity test of the photon-mapped frame was first made with.
 //
 // Contract kept (camera.cpp:138-144): on return image(x, y) holds the filtered mean radiance of every pixel.
 // Test infrastructure (reference code + our library), not the product: tests/test_gpu_dropin.py runs the binary on the GPU box
 // and compares the .tga files the reference's Image::save writes with the committed reference-written ones.
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <new>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "ref_flatten.hpp"
+#include "common/util.hpp"  // getOptional
+
+namespace {
+
+// "photon_map" values the reference's constructor consumes without keeping them (photon-mapper.cpp:30-38), per PhotonMapper
+struct PhotonPassParams {
+    double emissions = 0.0, caustic_factor = 1.0;
+    bool cpu = false;  // the maps in the object come from the reference's own CPU pass
+};
+std::map<const PhotonMapper*, PhotonPassParams>& passParams() {
+    static std::map<const PhotonMapper*, PhotonPassParams> m;
+    return m;
+}
+
+long envLong(const char* k, long d) {
+    const char* v = std::getenv(k);
+    return v && *v ? std::strtol(v, nullptr, 10) : d;
+}
+
+// The contexts of the process, created once: one per device, or MCRT_DROPIN_CONTEXTS of them over the devices.
+std::vector<mcrt_ctx*>& contexts() {
+    static std::vector<mcrt_ctx*> ctxs;
+    if (!ctxs.empty()) return ctxs;
+    const int devices = mcrt_device_count();
+    if (devices <= 0) throw std::runtime_error("mcrt drop-in: no HIP device");  // the reference's convention: exceptions reach main (main.cpp:48-56)
+    const long want = envLong("MCRT_DROPIN_CONTEXTS", devices);
+    for (long i = 0; i < (want > 0 ? want : devices); i++) {
+        mcrt_ctx* c = nullptr;
+        if (mcrt_create(&c, (int)(i % devices)) != MCRT_OK) throw std::runtime_error(mcrt_last_error(nullptr));
+        ctxs.push_back(c);
+    }
+    return ctxs;
+}
+
+// every context does `fn(ctx)` on its own host thread (uploads and the photon pass: the GPUs work side by side); first error wins
+template <class F>
+void onEveryContext(const std::vector<mcrt_ctx*>& ctxs, F fn) {
+    std::vector<std::string> err(ctxs.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < ctxs.size(); i++)
+        th.emplace_back([&, i] {
+            if (fn(ctxs[i]) != MCRT_OK) err[i] = mcrt_last_error(ctxs[i]);
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : err)
+        if (!e.empty()) throw std::runtime_error(e);
+}
+
+}  // namespace
+
+// The reference's own constructor (complete-object form), under the name oracle/Makefile gives it in the drop-in's copy of photon-mapper.o
+void refPhotonMapperConstructor(PhotonMapper* self, const nlohmann::json& j) asm("mcrt_ref_PhotonMapper_ctor");
+
+PhotonMapper::PhotonMapper(const nlohmann::json& j) : Integrator(j)
+{
+    const nlohmann::json& pm = j.at("photon_map");                       // photon-mapper.cpp:28-38
+    PhotonPassParams p;
+    p.caustic_factor = pm.at("caustic_factor");
+    p.emissions = (double)pm.at("emissions").get<size_t>();
+    k_nearest_photons = getOptional(pm, "k_nearest_photons", 50);
+    non_caustic_reject = 1.0 / p.caustic_factor;
+    max_node_data = getOptional(pm, "max_photons_per_octree_leaf", 200);
+    direct_visualization = getOptional(pm, "direct_visualization", false);
+    if (envLong("MCRT_DROPIN_CPU_PHOTONS", 0) != 0) {
+        // the reference's CPU photon pass: its constructor builds a whole second PhotonMapper (scene included); its maps move here
+        alignas(PhotonMapper) static unsigned char raw[sizeof(PhotonMapper)];
+        PhotonMapper* tmp = reinterpret_cast<PhotonMapper*>(raw);
+        refPhotonMapperConstructor(tmp, j);
+        caustic_map = std::move(tmp->caustic_map);
+        global_map = std::move(tmp->global_map);
+        tmp->~PhotonMapper();
+        p.cpu = true;
+    }
+    passParams()[this] = p;
+}
 
 void Camera::sampleImage()
 {
-    static mcrt_ctx* ctx = nullptr;  // one context (device 0) for the life of the process
-    if (!ctx && mcrt_create(&ctx, 0) != MCRT_OK)
-        throw std::runtime_error(mcrt_last_error(nullptr));  // the reference's convention: exceptions reach main (main.cpp:48-56)
+    const std::vector<mcrt_ctx*>& ctxs = contexts();
 
     Flat flat;
-    flattenScene(integrator->scene, flat);  // arrays stay owned by the host, copied during the call
-    if (mcrt_upload_scene(ctx, &flat.desc) != MCRT_OK) throw std::runtime_error(mcrt_last_error(ctx));
+    flattenScene(integrator->scene, flat);  // arrays stay owned by the host, copied during the calls
+    onEveryContext(ctxs, [&](mcrt_ctx* c) { return mcrt_upload_scene(c, &flat.desc); });
 
     int mode = MCRT_INTEGRATOR_PATH_TRACER;
     if (auto pm = dynamic_cast<PhotonMapper*>(integrator.get())) {
-        FlatMap g, c;
-        flattenMap(pm->global_map, g);
-        flattenMap(pm->caustic_map, c);
-        if (mcrt_upload_photons(ctx, g.desc.num_octants ? &g.desc : nullptr, c.desc.num_octants ? &c.desc : nullptr,
-                                (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0) != MCRT_OK)
-            throw std::runtime_error(mcrt_last_error(ctx));
+        const PhotonPassParams p = passParams()[pm];
+        if (p.cpu) {
+            FlatMap g, c;
+            flattenMap(pm->global_map, g);
+            flattenMap(pm->caustic_map, c);
+            onEveryContext(ctxs, [&](mcrt_ctx* x) {
+                return mcrt_upload_photons(x, g.desc.num_octants ? &g.desc : nullptr, c.desc.num_octants ? &c.desc : nullptr,
+                                           (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0);
+            });
+        } else {
+            // PhotonMapper::PhotonMapper's pass (photon-mapper.cpp:40-207) on the GPUs: every context emits all the paths and builds
+            // both maps in its own memory (identical maps: the emission is a function of the seed; 0.4 s at C5's 1e8 paths)
+            std::vector<mcrt_photon_pass_stats> ps(ctxs.size());
+            std::vector<std::string> err(ctxs.size());
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < ctxs.size(); i++)
+                th.emplace_back([&, i] {
+                    if (mcrt_photon_pass_device(ctxs[i], p.emissions, p.caustic_factor, Sampler::global_seed, flat.desc.bb_min, flat.desc.bb_max,
+                                                (uint32_t)pm->max_node_data, (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0,
+                                                &ps[i]) != MCRT_OK)
+                        err[i] = mcrt_last_error(ctxs[i]);
+                });
+            for (auto& t : th) t.join();
+            for (auto& e : err)
+                if (!e.empty()) throw std::runtime_error(e);
+            std::printf("\n[mcrt_hip] PhotonMapper pass on the GPU(s): %llu emission paths, %llu global + %llu caustic photons, %.1f ms per context\n",
+                        (unsigned long long)ps[0].emission_paths, (unsigned long long)ps[0].global_count, (unsigned long long)ps[0].caustic_count,
+                        ps[0].total_ms);
+        }
         mode = MCRT_INTEGRATOR_PHOTON_MAPPER;
     }
 
-    const mcrt_camera_desc cam = flattenCamera(*this);  // shard_count = 1: the whole frame on this GPU
+    const mcrt_camera_desc cam = flattenCamera(*this);  // mcrt_render_multi deals the rows over the contexts
     std::vector<double> rgb(image.width * image.height * 3);
     mcrt_stats stats;
-    if (mcrt_render(ctx, &cam, Sampler::global_seed, mode, rgb.data(), &stats) != MCRT_OK)
-        throw std::runtime_error(mcrt_last_error(ctx));
+    if (mcrt_render_multi(ctxs.data(), (uint32_t)ctxs.size(), &cam, Sampler::global_seed, mode, rgb.data(), &stats) != MCRT_OK)
+        throw std::runtime_error(mcrt_last_error(ctxs[0]));
     num_sampled_pixels = image.width * image.height;
 
     for (size_t y = 0; y < image.height; y++)  // camera.cpp:138-144
@@ -53,9 +164,9 @@ void Camera::sampleImage()
             image(x, y) = glm::dvec3(p[0], p[1], p[2]);
         }
 
-    std::printf("\n[mcrt_hip] Camera::sampleImage on the GPU: %llu paths, %llu rays, kernel %u (%u launches), %.3f ms, %.1f Mray/s\n",
+    std::printf("\n[mcrt_hip] Camera::sampleImage on the GPU: %llu paths, %llu rays, kernel %u (%u launches), %.3f ms, %.1f Mray/s, %zu context(s) on %d device(s)\n",
                 (unsigned long long)stats.paths, (unsigned long long)stats.rays, stats.kernel_id, stats.kernel_launches, stats.kernel_ms,
-                stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms / 1e3 : 0.0);
+                stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms / 1e3 : 0.0, ctxs.size(), mcrt_device_count());
     if (const char* dump = std::getenv("MCRT_DROPIN_DUMP")) {  // FP64 frame for the parity test (the .tga is 8 bit)
         if (FILE* f = std::fopen(dump, "wb")) {
             std::fwrite(rgb.data(), sizeof(double), rgb.size(), f);

@@ -22,7 +22,7 @@ ABI_VERSION = 2
 FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
-LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2 = range(5)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
+LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2, LIBM_SINCOSF = range(6)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
 # mcrt_stats.kernel_id (include/mcrt.h MCRT_KERNEL_*)
 KERNEL_NONE, KERNEL_FLAT, KERNEL_WAVESYNC, KERNEL_LANE_SM, KERNEL_WAVEFRONT, KERNEL_PM_WAVE, KERNEL_PM_LANE, KERNEL_WAVEFRONT_PM = range(8)
 KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernel<path_tracer, flat>", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
@@ -196,6 +196,8 @@ def lib():
     vp = C.c_void_p
     L.mcrt_abi_version.restype = C.c_uint32
     L.mcrt_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.mcrt_device_count.argtypes = []
+    L.mcrt_device_count.restype = C.c_int
     L.mcrt_destroy.argtypes = [vp]
     L.mcrt_destroy.restype = None
     L.mcrt_last_error.argtypes = [vp]
@@ -635,13 +637,14 @@ class Context:
         return out
 
     def libm(self, fn, a, b=None):
-        """mcrt_libm: the device's sincos (fn 0 -> (sin, cos)), sin (1), cos (2), asin (3), atan2 (4: a = y, b = x) on arrays."""
+        """mcrt_libm: the device's sincos (fn 0 -> (sin, cos)), sin (1), cos (2), asin (3), atan2 (4: a = y, b = x), sincosf (5: float
+        values in, (sin, cos) widened out) on arrays."""
         a = np.ascontiguousarray(a, dtype=np.float64)
         out0, out1 = np.zeros_like(a), np.zeros_like(a)
         bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
         self._check(self._lib.mcrt_libm(self._h, int(fn), a.size, _ptr(a, C.c_double), _ptr(bb, C.c_double) if bb is not None else None,
                                         _ptr(out0, C.c_double), _ptr(out1, C.c_double)), "mcrt_libm")
-        return (out0, out1) if fn == 0 else out0
+        return (out0, out1) if fn in (LIBM_SINCOS, LIBM_SINCOSF) else out0
 
     def knn(self, which, points, k):
         self._sync_env()

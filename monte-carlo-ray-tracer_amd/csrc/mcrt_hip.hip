@@ -87,6 +87,7 @@ struct mcrt_ctx {
     size_t max_lds_trace = 0;  // ... a kernel that only walks the tree (no static LDS)
 
     bool has_scene = false;
+    bool q_single = false;  // HostLayout::q_single of the uploaded scene
     DeviceScene scene{};
     DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_rec, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
@@ -504,10 +505,15 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool sched = ctxOptOn(ctx, "MCRT_WF_SCHED") && halvesWanted(ctx) < 2;
     const bool defer = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0;  // deferred leaves: the default since round 3 (C3 / C4 -1.3 %)
     const bool share = defer && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // ... tested by the whole wave (travSharedLeafStep): round 4
-    void (*trace)(WfTraceArgs, PoolRays) = wide    ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
-                                           : share ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)
-                                           : defer ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
-                                                   : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
+    // MCRT_WF_LEAN (round 5; default 1): the shared form's inner visit is travInnerStepQLean - with one block per visit when the tree
+    // has no node with more than four children (every quaternary tree); 0: round 4's visit
+    const int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
+    void (*trace)(WfTraceArgs, PoolRays) = wide        ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
+                                           : lean == 3 ? wfTraceKernel<PoolRays, false, 3, 3>
+                                           : lean == 1 ? wfTraceKernel<PoolRays, false, 3, 1>
+                                           : share     ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)
+                                           : defer     ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
+                                                       : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
     void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
     // + the materials and the light tables when they are small (MCRT_WF_LDS_TABLES=0: read them from memory)
     uint32_t shade_tables = wfShadeTableBytes(ctx->scene.num_materials, ctx->scene.num_lights);
@@ -776,12 +782,10 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // 1024 lanes 485.2 (split next-event estimate: 454 / 493 / 563) — fewer instructions per ray, and the spills of the
     // narrow instances (107 / 169 VGPRs) now cost more than the extra waves hide.
     const int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", 512);
-    // MCRT_FLAT_SHARE=1 (off by default: its speed is not measured yet): the FP64 survivor tests of a bounce dealt over the wave
-    // (mcrt_flatshare.hpp; 512 lanes, scenes of at most 32 triangles and 32 spheres)
-    const bool flat_share = flat_only && ctxOptOn(ctx, "MCRT_FLAT_SHARE") && flatShareFits(ctx->scene.flat_tris, ctx->scene.num_surfaces);
+    // (Round 4 built a form that dealt a wave's (ray, cull survivor) pairs over all 64 lanes for the FP64 tests; measured in round 5 it
+    // LOST 8 % on C2 and on C2-GGX - 482 ms against 446, 663 against 614, profiles/r05_ab_c2_flat_share.log - and was removed.)
     if (flat_only)
-        kernel = flat_share ? renderKernel<PT, false, true, false, 5>
-                 : flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
+        kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
     // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
     // wave-synchronous one for A/B runs)
@@ -910,16 +914,6 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         if (!launch_scene.stage_all && fixed < ctx->max_lds)
             launch_scene.stage_nodes = std::min<uint32_t>(launch_scene.stage_nodes, (ctx->max_lds - fixed) / 64u);
         g.lds_bytes = planSmLds(launch_scene, g.block, (uint32_t)sm_depth).total;
-        if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-        int per_cu = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)g.block, g.lds_bytes));
-        if (per_cu < 1) per_cu = 1;
-        g.grid = (uint32_t)(per_cu * ctx->num_cus);
-        g.total_lanes = g.grid * g.block;
-    } else if (flat_share) {  // plan 2 (512 lanes, no stack) + the waves' share areas behind it
-        g.block = kBlock;
-        g.lds_bytes = alignUp(planLds(launch_scene, g.block, false).total, 16) + (g.block / 64) * kFlatShareBytes;
         if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
         int per_cu = 0;
@@ -1115,6 +1109,15 @@ int uploadMap(mcrt_ctx* ctx, int which, const mcrt_photon_map_desc* m) {
 // ================================================================================================
 extern "C" {
 
+int mcrt_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count > 0 ? count : 0;
+}
+
 int mcrt_create(mcrt_ctx** out, int device_id) {
     if (!out) return MCRT_ERR_INVALID;
     *out = nullptr;
@@ -1308,6 +1311,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     }
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
+    ctx->q_single = L.q_single;
     d.wnodes = L.wnodes.empty() ? nullptr : ctx->wnodes.as<WNode>();
     d.num_wnodes = (uint32_t)L.wnodes.size();
     d.leaf_pre = leaf_cull ? ctx->leaf_pre.as<float>() : nullptr;
@@ -1797,7 +1801,12 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
         const bool wide = useWideNodes(ctx);
         const bool share = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0 && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // the pipeline's default form
-        auto trace = wide ? wfTraceKernel<ArrayRays, false, 1> : share ? wfTraceKernel<ArrayRays, false, 3> : wfTraceKernel<ArrayRays, false>;
+        const int lean = share && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;  // as launchWavefront
+        auto trace = wide        ? wfTraceKernel<ArrayRays, false, 1>
+                     : lean == 3 ? wfTraceKernel<ArrayRays, false, 3, 3>
+                     : lean == 1 ? wfTraceKernel<ArrayRays, false, 3, 1>
+                     : share     ? wfTraceKernel<ArrayRays, false, 3>
+                                 : wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
         if (int rc = planTrace(ctx, trace, n, tp, wide, false, share)) return rc;
         DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
@@ -1906,9 +1915,10 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
 
 int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
     if (!ctx) return MCRT_ERR_INVALID;
-    if (fn < MCRT_LIBM_SINCOS || fn > MCRT_LIBM_ATAN2) return fail(ctx, MCRT_ERR_INVALID, "mcrt_libm: unknown function selector");
+    if (fn < MCRT_LIBM_SINCOS || fn > MCRT_LIBM_SINCOSF) return fail(ctx, MCRT_ERR_INVALID, "mcrt_libm: unknown function selector");
     if (n == 0) return MCRT_OK;
-    if (!a || !out0 || (fn == MCRT_LIBM_ATAN2 && !b) || (fn == MCRT_LIBM_SINCOS && !out1)) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    const bool two = fn == MCRT_LIBM_SINCOS || fn == MCRT_LIBM_SINCOSF;
+    if (!a || !out0 || (fn == MCRT_LIBM_ATAN2 && !b) || (two && !out1)) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     REJECT_IF_PENDING(ctx, "mcrt_libm");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf &da = ctx->op_buf[0], &db = ctx->op_buf[1], &d0 = ctx->op_buf[2], &d1 = ctx->op_buf[3];
@@ -1922,7 +1932,7 @@ int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* 
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out0, d0.p, n * 8, hipMemcpyDeviceToHost));
-    if (fn == MCRT_LIBM_SINCOS) HIP_TRY(ctx, hipMemcpy(out1, d1.p, n * 8, hipMemcpyDeviceToHost));
+    if (two) HIP_TRY(ctx, hipMemcpy(out1, d1.p, n * 8, hipMemcpyDeviceToHost));
     return MCRT_OK;
 }
 

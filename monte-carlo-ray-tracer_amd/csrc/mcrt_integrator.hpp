@@ -361,10 +361,13 @@ MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnSc
     return count;
 }
 
-MCRT_HD d3 photonDirection(const float* ph) {  // Photon::dir, photon.hpp:19-27 (float sin/cos overloads)
+MCRT_HD d3 photonDirection(const float* ph) {  // Photon::dir, photon.hpp:19-27 (float sin/cos overloads: glibc's sincosf, refSinCosF)
     float phi = ph[6], theta = ph[7];
-    double sin_theta = (double)sinf(theta);
-    return d3{sin_theta * (double)cosf(phi), sin_theta * (double)sinf(phi), (double)cosf(theta)};
+    float st, ct, sp, cp;
+    refSinCosF(theta, st, ct);
+    refSinCosF(phi, sp, cp);
+    double sin_theta = (double)st;
+    return d3{sin_theta * (double)cp, sin_theta * (double)sp, (double)ct};
 }
 
 struct PhotonViews {

@@ -339,11 +339,8 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // the integrator kernel
 // ------------------------------------------------------------------------------------------------
-#include "mcrt_flatshare.hpp"  // optional form of the flat megakernel: the FP64 survivor tests dealt over the wave (kFlat == 5)
-
 // kFlat != 0: instance for flat-mode scenes only (path tracer): no BVH walk in the code, no traversal stack in LDS;
-// kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs);
-// kFlat == 5: 512 lanes, both intersections of a bounce served by the whole wave (mcrt_flatshare.hpp; option MCRT_FLAT_SHARE).
+// kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs).
 template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
 __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
     MCRT_DYNAMIC_LDS(lds, 16);
@@ -404,22 +401,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
             if (!waveBallot(!exhausted)) break;
             continue;
         }
-        if constexpr (kFlat == 5) {
-            // (every lane goes through the bounce: the intersections are the wave's business; lanes without a pixel carry no ray)
-            if (have_pixel && !path_active) {
-                st.smp.setIndex(sample);  // camera.cpp:77
-                pathBegin(st, rh, cameraRay<!kAll>(prm.cam, sh.scene_ior, px, py, st.smp, tab));
-                path_active = true;
-                paths++;
-            }
-            const FlatShare F = flatShareAt(lds, alignUp(planLds(scene, blockDim.x, false).total, 16), threadIdx.x >> 6);
-            const bool done = pathTracerBounceFlatShared<kCount>(have_pixel, st, rh, sv, sh, F, cnt, tab);
-            if (have_pixel && done) {
-                storeSample(prm, sample, px, ly, st.radiance);
-                path_active = false;
-                if (++sample == sample_end) have_pixel = false;
-            }
-        } else if (have_pixel) {
+        if (have_pixel) {
             if (!path_active) {
                 if (kProf) prof.mark(kPhRegen);
                 st.smp.setIndex(sample);  // camera.cpp:77
@@ -805,9 +787,12 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // kForm: 0 = the first walk (4-wide quantised blocks, a lane waits at its leaf), 1 = eight-wide nodes (mcrt_wbvh.hpp), 2 = deferred
 // leaves (mcrt_lanesm.hpp), 3 = deferred leaves tested by the whole wave (travSharedLeafStep above; the default since round 4). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
 // default form a register spill and ~1 % of a frame.
-template <class Rays, bool kCount, int kForm = 0>
+// kLean (forms 2 / 3; round 5): bit 0 = the inner visit is travInnerStepQLean (mcrt_qbvh.hpp: FP32 ray kept in the Trav, the three
+// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per visit).
+template <class Rays, bool kCount, int kForm = 0, int kLean = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
+    static_assert(kLean == 0 || kShare, "the lean visit pops at the loop's one pop site and leaves best_up to the shared leaf step");
     MCRT_DYNAMIC_LDS(lds, 64);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
     if constexpr (!kWide)
@@ -984,7 +969,11 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 ph_in_lanes += __popcll(mi);
                 ti = clock64();
             }
-            if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
+            if constexpr ((kLean & 1) != 0) {
+                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, stk, cnt);
+            } else {
+                if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
+            }
             if (inner && !T.fast) travInnerStep<false, kCount, true>(sv, T, stk, cnt);  // zero direction component: exact records
             if (kCount) ph_in_cyc += clock64() - ti;
             const bool pend = have && P.n != 0u;
@@ -2116,6 +2105,11 @@ __global__ void __launch_bounds__(256) libmKernel(int fn, uint64_t n, const doub
             out0[i] = refCos(x);
         } else if (fn == 3) {
             out0[i] = refAsin(x);
+        } else if (fn == 5) {
+            float sn, cs;
+            refSinCosF((float)x, sn, cs);
+            out0[i] = (double)sn;
+            out1[i] = (double)cs;
         } else {
             out0[i] = refAtan2(x, b[i]);
         }

@@ -102,6 +102,8 @@ struct Trav {
     // is in the stack's memory too), a pop takes it without waiting for an LDS read and asks for the entry below at once - that read
     // lands while the wave runs its next step. top_key == kTopNone: not cached, read the stack.
     uint32_t top_key = 0xFFFFFFFFu, top_a = 0u;
+    // (travInnerStepQLean, mcrt_qbvh.hpp) the ray rounded to FP32 and the smallest float >= best.t, kept instead of recomputed per visit
+    float of[3] = {0.0f, 0.0f, 0.0f}, invf[3] = {0.0f, 0.0f, 0.0f}, best_up = 0.0f;
     bool fast;         // v_min/v_max box test allowed (no NaN slab products possible)
     bool shadow;
     uint32_t light;    // shadow query: surface aimed at

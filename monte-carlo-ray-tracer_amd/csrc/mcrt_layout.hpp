@@ -38,6 +38,7 @@ struct HostLayout {
     std::vector<Node64> nodes64;       // [n] box + meta records, same order as node_bounds
     std::vector<QBlock> qblocks;       // quantised child blocks (mcrt_qbvh.hpp), breadth-first over the inner nodes
     uint32_t q_root_a = 0, q_root_m = 0;
+    bool q_single = false;             // every inner node is ONE block (no node with more than four children): travInnerStepQLean<.., kSingle>
     // FP32 cull records of the primitives in BVH order, one 128-byte record per ALIGNED pair (2p, 2p + 1) (mcrt_lanesm.hpp "leaf cull")
     std::vector<float> leaf_pre;
     double leaf_centre[3] = {0.0, 0.0, 0.0}, leaf_bound = 0.0;
@@ -119,6 +120,7 @@ inline int buildQBlocks(HostLayout& L, std::string& err) {
     const uint32_t n = (uint32_t)L.nodes64.size();
     L.qblocks.clear();
     L.q_root_a = L.q_root_m = 0;
+    L.q_single = false;
     if (n == 0) return MCRT_OK;
     std::vector<uint32_t> first_block(n, 0);
     uint32_t total = 0;
@@ -128,6 +130,11 @@ inline int buildQBlocks(HostLayout& L, std::string& err) {
             total += ((L.nodes64[i].m & 0xFFu) + 3u) / 4u;
         }
     L.qblocks.assign(total, QBlock{});
+    {
+        uint32_t inner = 0;
+        for (uint32_t i = 0; i < n; i++) inner += (L.nodes64[i].m & kSmInner) ? 1u : 0u;
+        L.q_single = inner != 0 && total == inner;
+    }
     auto link = [&](uint32_t node, uint32_t& a, uint32_t& m) {
         m = L.nodes64[node].m;
         a = (m & kSmInner) ? first_block[node] : L.nodes64[node].a;

@@ -500,4 +500,54 @@ MCRT_HD double refAtan2(double y, double x) {
     return copySign(z, y);
 }
 
+// ---- sincosf: Photon::dir (photon.hpp:19-27) -----------------------------------------------------------------------------------------
+// Photon::dir takes std::sin / std::cos of the photon's two FLOAT angles; g++ pairs them into sincosf calls (the reference binary
+// imports sincosf), which on every x86-64 CPU with FMA + AVX2 resolves to __sincosf_fma: glibc 2.35's sysdeps/ieee754/flt-32/s_sincosf.c
+// (Szabolcs Nagy's single-precision routines: the argument widened to double, one Cody-Waite step x - n pi/2 with n from x * 2^24 * 2/pi,
+// two short polynomials in double, one rounding to float at the end) built with the x86 polynomial kernel sysdeps/x86/fpu/sincosf_poly.h
+// and FMA contraction. The operation sequence below is that build's, read off its instructions (Ubuntu GLIBC 2.35-0ubuntu3.11,
+// __sincosf_fma; every `a + b c` of the source is one fused multiply-add, the products x2 x, x2 x2, x3 x2, x4 x2 are plain): the
+// coefficients are __sincosf_table's (libm's .rodata, checked by tests/test_libm.py against the running libm). Range: |y| < 120 - the
+// photon angles are atan2 results, |y| <= pi; beyond, the platform's sincosf. tests/test_libm.py: EVERY float of [-4, 4] and a
+// sample of the rest against the host's sincosf, sinf and cosf, bit for bit; on the GPU through mcrt_libm (MCRT_LIBM_SINCOSF).
+MCRT_HD void refSinCosF(float y, float& sn_out, float& cs_out) {
+    using glibc235::fmaD;
+    constexpr double kFHpiInv = 0x1.45F306DC9C883p+23, kFHpi = 0x1.921FB54442D18p0;
+    constexpr double kFC0 = 1.0, kFC1 = -0x1.ffffffd0c621cp-2, kFC2 = 0x1.55553e1068f19p-5, kFC3 = -0x1.6c087e89a359dp-10, kFC4 = 0x1.99343027bf8c3p-16;
+    constexpr double kFS1 = -0x1.555545995a603p-3, kFS2 = 0x1.1107605230bc4p-7, kFS3 = -0x1.994eb3774cf24p-13;
+    const uint32_t top = (floatBits(y) >> 20) & 0x7FFu;  // abstop12
+    double x = (double)y, sign = 1.0, flip = 1.0;        // flip: the table for quadrants 2 and 3 is the first one's cosine coefficients negated
+    int n = 0;
+    if (top <= 0x3F3u) {                                 // |y| < pi/4
+        if (top <= 0x397u) {                             // |y| < 2^-12
+            sn_out = y;
+            cs_out = 1.0f;
+            return;
+        }
+    } else if (top <= 0x42Eu) {                          // |y| < 120: reduce_fast
+        const double r = x * kFHpiInv;
+        n = ((int)r + 0x800000) >> 24;                   // (cvttsd2si, arithmetic shift)
+        x = fmaD<true>(-(double)n, kFHpi, x);             // vfnmadd: x - n * hpi, one rounding
+        sign = (n & 3) == 1 || (n & 3) == 2 ? -1.0 : 1.0;  // sign[n & 3] = {1, -1, -1, 1}
+        flip = (n & 2) ? -1.0 : 1.0;
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        sn_out = sinf(y);
+        cs_out = cosf(y);
+#else
+        sincosf(y, &sn_out, &cs_out);
+#endif
+        return;
+    }
+    const double xs = x * sign, x2 = x * x;
+    const double x3 = x2 * xs, x4 = x2 * x2;
+    const double s1 = fmaD<true>(x2, kFS3, kFS2), c2 = fmaD<true>(x2, flip * kFC4, flip * kFC3);
+    const double x5 = x2 * x3, x6 = x2 * x4;
+    const double c1 = fmaD<true>(x2, flip * kFC1, flip * kFC0);
+    const double s = fmaD<true>(x3, kFS1, xs), c = fmaD<true>(x4, flip * kFC2, c1);
+    const float sn = (float)fmaD<true>(s1, x5, s), cs = (float)fmaD<true>(c2, x6, c);
+    sn_out = (n & 1) ? cs : sn;                          // odd quadrants swap the two
+    cs_out = (n & 1) ? sn : cs;
+}
+
 }  // namespace mcrt

@@ -71,6 +71,10 @@ MCRT_HD void travBeginQ(const SmSceneView<kAll>& sv, const QView<kLds>& qv, Trav
     if (T.fast) {  // from here on node_a / node_m are block links
         T.node_a = qv.root_a;
         T.node_m = qv.root_m;
+        // the ray as travInnerStepQ rounds it at every visit, once (read by travInnerStepQLean only)
+        T.of[0] = (float)start.x; T.of[1] = (float)start.y; T.of[2] = (float)start.z;
+        T.invf[0] = (float)inv_direction.x; T.invf[1] = (float)inv_direction.y; T.invf[2] = (float)inv_direction.z;
+        T.best_up = floatAbove(T.best.t);
     }
 }
 
@@ -264,6 +268,128 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
         T.need_pop = true;
     } else {
         travPop(T, stk);
+    }
+}
+
+// ---- The lean visit (round 5) -------------------------------------------------------------------------------------------------
+// What a visit of travInnerStepQ costs beyond its slab tests (ISA of wfTraceKernel<PoolRays, false, 3>, ~230 issue slots): ~25 slots
+// of prologue that depend on the RAY only and were redone at every node (seven v_cvt_f32_f64 and three v_cmp_*_f64 at the FP64 rate:
+// the ray in FP32, floatAbove(best.t), the direction signs); ~20 for the "node with more than four children" loop around the block
+// (the next-block fetch, the merge of a block's nearest with the earlier blocks', a fourth push) that a quaternary tree never needs;
+// and ~55 in the pushes: up to four of them, each `if (key != miss) if (sp < max) if (sp < lds_depth) LDS else memory`, three nested
+// exec-mask regions that a wave of 50 rays always enters. Here
+//   * the FP32 ray and floatAbove(best.t) live in the Trav (set by travBeginQ, best_up again wherever the hit improves; a stale
+//     LARGER best_up only keeps a child the pop would cull anyway);
+//   * kSingle (the tree has no node with more than four children: HostLayout knows) visits exactly one block;
+//   * the three pushes are ONE block: the sorted keys' misses are a suffix, so with cnt children to push the entry of rank j goes
+//     to stack position sp + cnt - j and a miss to a position ABOVE the new top (junk there is never read) - three unconditional
+//     ds_write_b64 when sp + 3 fits the lane's LDS rows; only lanes whose stack is about to leave LDS take the general pushes.
+//     No overflow test: the stack is sized to the tree's own bound (HostLayout::stack_bound), no walk can exceed it.
+// Same blocks, same tests, same keys, same order of the kept children: the walk visits exactly what travInnerStepQ visits.
+template <bool kLds, bool kCount, bool kSingle>
+MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
+    const float best_up = T.best_up;
+    const float of[3] = {T.of[0], T.of[1], T.of[2]}, invf[3] = {T.invf[0], T.invf[1], T.invf[2]};
+    const bool pos[3] = {invf[0] >= 0.0f, invf[1] >= 0.0f, invf[2] >= 0.0f};  // (|inv| >= 1: the float keeps the sign, never zero)
+    uint32_t near_key = kQMissKey, near_a = 0;
+    auto push = [&](uint32_t key, uint32_t a) {
+        SmStackEntry e;
+        e.key = key;
+        e.a = a;
+        stk.put(T.sp++, e);
+        T.top_key = key;
+        T.top_a = a;
+    };
+    uint32_t bi = T.node_a;
+    bool more = true;
+    while (more) {
+        const QBlock b = qFetch(qv, bi++);
+        const uint32_t n = (b.w[3] >> 24) & 0x7Fu;
+        more = !kSingle && (b.w[3] >> 31) != 0u;
+        float A[3], Cn[3], Cf[3];
+        uint32_t wn[3], wf[3];
+        for (int ax = 0; ax < 3; ax++) {  // (the error bounds: travInnerStepQ)
+            const float cell = bitsFloat((((b.w[3] >> (8 * ax)) & 0xFFu) - 1u) << 23);
+            A[ax] = cell * invf[ax];
+            const float C = (bitsFloat(b.w[ax]) - of[ax]) * invf[ax];
+            const float m = fmaf(fmaf(255.0f, fabsf(A[ax]), fabsf(C)), 4.76837158203125e-07f, fmaf(fabsf(of[ax] * invf[ax]), 2.384185791015625e-07f, 1e-30f));
+            Cn[ax] = C - m;
+            Cf[ax] = C + m;
+            wn[ax] = pos[ax] ? b.w[4 + 2 * ax] : b.w[5 + 2 * ax];
+            wf[ax] = pos[ax] ? b.w[5 + 2 * ax] : b.w[4 + 2 * ax];
+        }
+        uint32_t key[4], a[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int c = 0; c < 4; c++) {
+            const float tnx = fmaf((float)((wn[0] >> (8 * c)) & 0xFFu), A[0], Cn[0]);
+            const float tny = fmaf((float)((wn[1] >> (8 * c)) & 0xFFu), A[1], Cn[1]);
+            const float tnz = fmaf((float)((wn[2] >> (8 * c)) & 0xFFu), A[2], Cn[2]);
+            const float tfx = fmaf((float)((wf[0] >> (8 * c)) & 0xFFu), A[0], Cf[0]);
+            const float tfy = fmaf((float)((wf[1] >> (8 * c)) & 0xFFu), A[1], Cf[1]);
+            const float tfz = fmaf((float)((wf[2] >> (8 * c)) & 0xFFu), A[2], Cf[2]);
+            const float lo = fmaxf(fmaxf(tnx, tny), tnz), hi = fminf(fminf(tfx, tfy), tfz);
+            const float t = fmaxf(lo, 0.0f);
+            const bool keep = (uint32_t)c < n && hi >= t && t <= best_up;
+            if (kCount) cnt.node_tests += (uint32_t)c < n ? 1u : 0u;
+            const uint32_t m = (b.w[14 + c / 2] >> (16 * (c % 2))) & 0x1FFu;
+            key[c] = keep ? ((floatBits(t) & ~0x1FFu) | m) : kQMissKey;
+            a[c] = b.w[10 + c];
+        }
+        auto exchange = [&](int i, int j) {  // afterwards key[i] <= key[j]
+            const bool sw = key[j] < key[i];
+            const uint32_t ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];
+            const uint32_t ai = sw ? a[j] : a[i], aj = sw ? a[i] : a[j];
+            key[i] = ki; key[j] = kj; a[i] = ai; a[j] = aj;
+        };
+        exchange(0, 1);
+        exchange(2, 3);
+        exchange(0, 2);
+        exchange(1, 3);
+        exchange(1, 2);
+        // key[1..3] ascending, misses last: cnt of them are pushed, farthest first (rank 3 at the bottom, rank 1 on top)
+        const uint32_t cnt3 = key[3] != kQMissKey ? 3u : key[2] != kQMissKey ? 2u : key[1] != kQMissKey ? 1u : 0u;
+        if (T.sp + 3 <= stk.lds_depth) {
+            const uint32_t p1 = cnt3 > 1u ? cnt3 - 1u : 0u;               // rank 1: the new top (cnt3 == 0: junk at sp)
+            const uint32_t p2 = cnt3 >= 2u ? cnt3 - 2u : 1u;              // rank 2 (a miss: junk at sp + 1, above the top)
+            const uint32_t p3 = cnt3 == 3u ? 0u : 2u;                     // rank 3 (a miss: junk at sp + 2)
+            SmStackEntry e;
+            e.key = key[3]; e.a = a[3];
+            stk.lds[stackSlot(T.sp + (int)p3, stk.lds_stride)] = e;
+            e.key = key[2]; e.a = a[2];
+            stk.lds[stackSlot(T.sp + (int)p2, stk.lds_stride)] = e;
+            e.key = key[1]; e.a = a[1];
+            stk.lds[stackSlot(T.sp + (int)p1, stk.lds_stride)] = e;
+            T.sp += (int)cnt3;
+            if (cnt3 != 0u) {
+                T.top_key = key[1];
+                T.top_a = a[1];
+            }
+        } else {  // (this lane's stack is about to leave its LDS rows: the general pushes)
+            if (key[3] != kQMissKey) push(key[3], a[3]);
+            if (key[2] != kQMissKey) push(key[2], a[2]);
+            if (key[1] != kQMissKey) push(key[1], a[1]);
+        }
+        if (kSingle) {
+            near_key = key[0];
+            near_a = a[0];
+        } else {
+            const bool better = key[0] < near_key;
+            const uint32_t lose_key = better ? near_key : key[0], lose_a = better ? near_a : a[0];
+            if (better) {
+                near_key = key[0];
+                near_a = a[0];
+            }
+            if (lose_key != kQMissKey) push(lose_key, lose_a);
+        }
+    }
+    if (near_key != kQMissKey) {
+        T.node_a = near_a;
+        T.node_m = near_key & 0x1FFu;
+    } else {  // (popped at the loop's one pop site: mcrt_kernels.hpp)
+        T.active = false;
+        T.need_pop = true;
     }
 }
 

@@ -888,6 +888,32 @@ void emu_atan2_check(uint64_t n, uint64_t seed, int scale, uint64_t* out) {
     }
 }
 
+// refSinCosF (mcrt_libm.hpp) against this host's sincosf, sinf and cosf - each through its own volatile pointer - on EVERY float whose
+// bit pattern lies in [first, last] (both signs: the pattern with and without the sign bit). out: {arguments where the sine / the cosine
+// of sincosf differs, where sinf / cosf differ from the restatement, first differing argument's bits}.
+void emu_sincosf_check(uint32_t first, uint32_t last, uint64_t* out) {
+    float (*volatile f_sin)(float) = ::sinf;
+    float (*volatile f_cos)(float) = ::cosf;
+    void (*volatile f_sincos)(float, float*, float*) = ::sincosf;
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0;
+    for (uint64_t b = first; b <= last; b++)
+        for (uint32_t sgn = 0; sgn < 2; sgn++) {
+            const uint32_t bits = (uint32_t)b | (sgn << 31);
+            const float y = bitsFloat(bits);
+            float s0, c0, s1, c1;
+            refSinCosF(y, s0, c0);
+            f_sincos(y, &s1, &c1);
+            const float s2 = f_sin(y), c2 = f_cos(y);
+            const bool bad_s = floatBits(s0) != floatBits(s1), bad_c = floatBits(c0) != floatBits(c1);
+            const bool bad_s2 = floatBits(s0) != floatBits(s2), bad_c2 = floatBits(c0) != floatBits(c2);
+            if ((bad_s || bad_c || bad_s2 || bad_c2) && !(out[0] | out[1] | out[2] | out[3])) out[4] = bits;
+            out[0] += bad_s;
+            out[1] += bad_c;
+            out[2] += bad_s2;
+            out[3] += bad_c2;
+        }
+}
+
 // This host's libm on arrays (the expected values of the GPU known-answer test of mcrt_libm): fn as MCRT_LIBM_*. Every function is
 // called through its own volatile pointer, one call per argument (a sin and a cos of one argument would be merged into sincos).
 void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
@@ -896,8 +922,14 @@ void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double*
     double (*volatile f_asin)(double) = ::asin;
     double (*volatile f_atan2)(double, double) = ::atan2;
     void (*volatile f_sincos)(double, double*, double*) = ::sincos;
+    void (*volatile f_sincosf)(float, float*, float*) = ::sincosf;
     for (uint64_t i = 0; i < n; i++) {
-        if (fn == 0) f_sincos(a[i], &out0[i], &out1[i]);
+        if (fn == 5) {
+            float sn, cs;
+            f_sincosf((float)a[i], &sn, &cs);
+            out0[i] = (double)sn;
+            out1[i] = (double)cs;
+        } else if (fn == 0) f_sincos(a[i], &out0[i], &out1[i]);
         else if (fn == 1) out0[i] = f_sin(a[i]);
         else if (fn == 2) out0[i] = f_cos(a[i]);
         else if (fn == 3) out0[i] = f_asin(a[i]);

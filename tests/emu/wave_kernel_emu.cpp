@@ -52,13 +52,13 @@ struct WaveMap {
     }
 };
 
-template <int kForm>
+template <int kForm, int kLean = 0>
 void launchTrace(const WfTraceArgs& a, const ArrayRays& rays, uint32_t grid, uint32_t waves) {
     for (uint32_t g = 0; g < grid; g++) {
         wemu::launch().block_idx = g;
         wemu::launch().block_dim = waves * 64u;
         wemu::launch().grid_dim = grid;
-        wemu::runGroup((int)waves, [&](int) { wfTraceKernel<ArrayRays, true, kForm>(a, rays); });
+        wemu::runGroup((int)waves, [&](int) { wfTraceKernel<ArrayRays, true, kForm, kLean>(a, rays); });
     }
 }
 }  // namespace
@@ -114,7 +114,11 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     if (form == 0) launchTrace<0>(a, rays, grid, waves);
     else if (form == 1) launchTrace<1>(a, rays, grid, waves);
     else if (form == 2) launchTrace<2>(a, rays, grid, waves);
-    else launchTrace<3>(a, rays, grid, waves);
+    else if (form == 11) launchTrace<3, 1>(a, rays, grid, waves);  // the lean visit (MCRT_WF_LEAN), any tree
+    else if (form == 27) {                                          // ... one block per visit: trees without a node of more than four children
+        if (!E.L.q_single) return -203;
+        launchTrace<3, 3>(a, rays, grid, waves);
+    } else launchTrace<3>(a, rays, grid, waves);
     if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
     return stats[5] ? -100 : 0;
 }
@@ -257,10 +261,6 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
         lds_bytes = planSmLds(launch_scene, block, (uint32_t)kLdsStackDepth).total;
     } else {
         lds_bytes = planLds(launch_scene, block, !flat_only).total;
-        if (flat_only && force == 5) {  // the flat megakernel's shared form (MCRT_FLAT_SHARE=1, mcrt_flatshare.hpp)
-            if (!flatShareFits(launch_scene.flat_tris, launch_scene.num_surfaces)) return -204;
-            lds_bytes = alignUp(planLds(launch_scene, block, false).total, 16) + (block / 64) * kFlatShareBytes;
-        }
     }
     if (lds_bytes > kEmuMaxLds || lds_bytes > sizeof(lds)) return -202;
     const uint32_t total_lanes = grid * block;
@@ -311,9 +311,8 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
         if (all) launchGrid(grid, block, [&] { renderKernelSM<false, true>(launch_scene, prm); });
         else launchGrid(grid, block, [&] { renderKernelSM<false, false>(launch_scene, prm); });
     } else if (flat_only) {
-        kernel_id = force == 5 ? 15 : 1;
-        if (force == 5) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 5>(launch_scene, prm); });
-        else launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
+        kernel_id = 1;
+        launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
     } else {
         kernel_id = 2;
         if (all) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true>(launch_scene, prm); });
@@ -388,7 +387,7 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
     ta.spill = spill.data();
     ta.total_lanes = trace_grid * tblock;
     ta.refill_lanes = 16;
-    ta.leaf_lanes = trace_form == 3 ? 16 : 24;
+    ta.leaf_lanes = (trace_form & 7) == 3 ? 16 : 24;
     ta.leaf_items = 1 << 20;
     ta.min_inner = 8;
     ta.lds_stack = (int)lds_stack;
@@ -396,6 +395,7 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
     ta.deal_shift = 6;
     ta.pop = ctrl + 2;
     if (trace_form == 1 && !d.wnodes) return -201;
+    if (trace_form == 27 && !E.L.q_single) return -204;
     PoolRays pr;
     pr.pool.w = pool.data();
     pr.pool.n = (uint32_t)slots;
@@ -474,7 +474,9 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
             wemu::launch().block_dim = tblock;
             wemu::launch().grid_dim = trace_grid;
             wemu::runGroup((int)trace_waves, [&](int) {
-                if (trace_form == 0) wfTraceKernel<PoolRays, true, 0>(ta, pr);
+                if (trace_form == 11) wfTraceKernel<PoolRays, true, 3, 1>(ta, pr);
+                else if (trace_form == 27) wfTraceKernel<PoolRays, true, 3, 3>(ta, pr);
+                else if (trace_form == 0) wfTraceKernel<PoolRays, true, 0>(ta, pr);
                 else if (trace_form == 1) wfTraceKernel<PoolRays, true, 1>(ta, pr);
                 else if (trace_form == 2) wfTraceKernel<PoolRays, true, 2>(ta, pr);
                 else wfTraceKernel<PoolRays, true, 3>(ta, pr);

@@ -38,10 +38,18 @@ def _scene_dir(tmp_path, scene, render, emissions=None):
     return d, cam["savename"]
 
 
-@pytest.mark.parametrize("name,scene,answers,emissions", [("hexagon_room", "hexagon_room.json", "0\nn\n", None),
-                                                          ("metals", "metals.json", "0\n", None),
-                                                          ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000)])
-def test_reference_main_renders_through_the_gpu(manifest, tmp_path, name, scene, answers, emissions):
+# extra: the drop-in's switches (integration/camera_sample_image_gpu.cpp). Default = one context per device the process sees and the
+# photon pass on the GPU (the reference's PhotonMapper constructor replaced); MCRT_DROPIN_CONTEXTS=2/3: the fan-out over several
+# contexts (mcrt_render_multi) exercised on the one GPU of the test box; MCRT_DROPIN_CPU_PHOTONS=1: the reference's own CPU photon pass.
+@pytest.mark.parametrize("name,scene,answers,emissions,extra", [
+    ("hexagon_room", "hexagon_room.json", "0\nn\n", None, {}),
+    ("hexagon_room", "hexagon_room.json", "0\nn\n", None, {"MCRT_DROPIN_CONTEXTS": "2"}),
+    ("metals", "metals.json", "0\n", None, {"MCRT_DROPIN_CONTEXTS": "3"}),
+    ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {}),
+    ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CONTEXTS": "2"}),
+    ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CPU_PHOTONS": "1"})],
+    ids=["hexagon_room", "hexagon_room-2ctx", "metals-3ctx", "hexagon_room_pm-gpu_photons", "hexagon_room_pm-gpu_photons-2ctx", "hexagon_room_pm-cpu_photons"])
+def test_reference_main_renders_through_the_gpu(manifest, tmp_path, name, scene, answers, emissions, extra):
     if not os.path.exists(BIN) or not os.path.exists(os.path.join(SCENES, scene)):
         pytest.skip("oracle/_ref/mcrt_ref_gpu not built (python __graft_entry__.py build in the build container)")
     case = manifest["cases"][name]
@@ -50,11 +58,16 @@ def test_reference_main_renders_through_the_gpu(manifest, tmp_path, name, scene,
     d, savename = _scene_dir(tmp_path, scene, r, emissions)
     dump = str(tmp_path / "frame.f64")
     env = dict(os.environ, MCRT_REF_SEED=str(manifest["seed"]), MCRT_DROPIN_DUMP=dump)
+    env.update(extra)
     p = subprocess.run([BIN, "scenes"], input=answers, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "[mcrt_hip] Camera::sampleImage on the GPU" in p.stdout and "Render Completed" in p.stdout
     paths = r["width"] * r["height"] * r["sqrtspp"] ** 2
     assert "%d paths" % paths in p.stdout
+    assert "%s context(s) on" % extra.get("MCRT_DROPIN_CONTEXTS", "1") in p.stdout
+    if emissions:  # where the photon maps came from: the GPU pass unless the switch keeps the reference's constructor
+        assert ("PhotonMapper pass on the GPU(s): %d emission paths" % (emissions * 10) in p.stdout) == ("MCRT_DROPIN_CPU_PHOTONS" not in extra)
+        assert ("PHOTON MAPPING PASS" in p.stdout) == ("MCRT_DROPIN_CPU_PHOTONS" in extra)
 
     # the frame the GPU handed to camera.image vs the reference's own radiance
     frame = np.fromfile(dump).reshape(r["height"], r["width"], 3)

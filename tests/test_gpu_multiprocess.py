@@ -112,7 +112,7 @@ def _bench(gpus, extra, env=None):
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
     # the driver's line: short, the LAST line of stdout; the full record (what these tests compare) goes to stderr and bench_full.json
-    assert p.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8000
+    assert p.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8000, p.stdout[-600:]
     short = json.loads(lines[0])
     full = [l for l in p.stderr.splitlines() if l.startswith("bench.py full record: ")]
     assert len(full) == 1

@@ -419,27 +419,6 @@ def test_c2_full_size_frame(pkg, ctx, manifest):
     assert np.array_equal(part[536:544], out[536:544])
 
 
-@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_ggx"])
-def test_c2_shared_flat_form_is_the_reference_too(pkg, manifest, name):
-    """MCRT_FLAT_SHARE=1 (csrc/mcrt_flatshare.hpp: a wave's (ray, cull survivor) pairs dealt over all 64 lanes for the FP64 tests) on the
-    full-size C2 / C2-GGX frame: rows 536-540 are the reference's bits, like the default form's."""
-    case = manifest["cases"][name]
-    r = [x for x in case["renders"] if x["width"] == 1920][0]
-    img = pkg.SceneImage(golden_path(case["image"]))
-    c = pkg.Context(0)
-    try:
-        c.set_option("MCRT_FLAT_SHARE", 1)
-        c.upload_image(img)
-        cam = camera_for(img, r)
-        cam.shard_index, cam.shard_count, cam.shard_rows = 67, 135, 8  # rows 536..543 only: the per-pixel seeds do not depend on the split
-        out, st = c.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
-        r0, r1 = r["rows"]
-        _check(out[r0:r1], load_radiance(r), "%s full-size rows %d-%d, shared flat form" % (name, r0, r1), exact=True)
-        assert st["kernel_id"] == pkg.KERNEL_FLAT
-    finally:
-        c.close()
-
-
 def test_options_are_per_context_and_not_the_environment(pkg, manifest, monkeypatch):
     """mcrt_set_option / mcrt_get_option: the environment seeds a context's options in mcrt_create and is never read again by
     the library; two contexts in one process can run different kernel forms; NULL restores the default."""

@@ -73,6 +73,28 @@ def test_restated_atan2_equals_glibc(emu, n, scale):
     assert out[0] == 0, "atan2 differs on %d pairs, first at y = %r, x = %r" % (out[0], f[0], f[1])
 
 
+def test_restated_sincosf_equals_glibc_on_every_float_of_the_range(emu):
+    """refSinCosF (Photon::dir's sine / cosine pairs of two float angles, photon.hpp:19-27) = glibc 2.35's __sincosf_fma - and its sinf
+    and cosf - bit for bit on EVERY float with |y| <= 4 (the photon angles are atan2 results, |y| <= pi: 2.1e9 arguments, all of them),
+    and on every 4096th float from there to 120 (the end of the restated range)."""
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the restatement is of x86-64 glibc")
+    if not (_has("fma") and _has("avx2")):
+        pytest.skip("this CPU has no FMA/AVX2: libm's sincosf is another IFUNC variant than the one restated")
+    emu.emu_sincosf_check.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    out = np.zeros(5, dtype=np.uint64)
+    four = int(np.float32(4.0).view(np.uint32))
+    emu.emu_sincosf_check(0, four, out.ctypes.data)
+    assert not out[:4].any(), "sincosf / sinf / cosf differ on %s arguments of [-4, 4], first at bits %#x" % (out[:4], int(out[4]))
+    top = int(np.float32(120.0).view(np.uint32)) - 1
+    bad = np.zeros(4, dtype=np.uint64)
+    for b in range(four, top, 4096):
+        emu.emu_sincosf_check(b, b, out.ctypes.data)
+        bad += out[:4]
+    emu.emu_sincosf_check(top, top, out.ctypes.data)
+    assert not (bad + out[:4]).any(), "sincosf differs on %s sampled arguments of (4, 120)" % (bad + out[:4])
+
+
 @pytest.mark.gpu
 def test_device_libm_equals_glibc_bits(pkg, emu):
     """The DEVICE's sincos / sin / cos / asin / atan2 (mcrt_libm through the C ABI: the functions the kernels inline, compiled for
@@ -120,6 +142,12 @@ def test_device_libm_equals_glibc_bits(pkg, emu):
     g, h = ctx.libm(pkg.LIBM_ATAN2, y, x), host(4, y, x)[0]
     bad = g.view(np.uint64) != h.view(np.uint64)
     assert not bad.any(), "atan2: %d pairs differ, first y = %r, x = %r" % (bad.sum(), y[bad][0], x[bad][0])
+    # sincosf (Photon::dir): float angles as the photon records hold them - atan2 results in [-pi, pi] - and wider / tiny arguments
+    a = np.concatenate([(rng.random(3000000) * 2.0 - 1.0) * math.pi, (rng.random(500000) - 0.5) * 230.0, (rng.random(500000) - 0.5) * 1e-3,
+                        (rng.random(200000) - 0.5) * 2.0 ** -11]).astype(np.float32).astype(np.float64)
+    gs, gc = ctx.libm(pkg.LIBM_SINCOSF, a)
+    hs, hc = host(5, a)
+    assert same(gs, hs) and same(gc, hc), "sincosf: %d / %d arguments differ" % ((gs != hs).sum(), (gc != hc).sum())
     ctx.close()
 
 
