@@ -977,6 +977,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.child_frame:
         return child_frame(args)
+    # From here on file descriptor 1 is the process's stderr: whatever a library prints to "stdout" - RCCL's version banner sits in C
+    # stdio's buffer until the process exits, AFTER anything this script printed (that cost round 5's first rehearsal its last line) -
+    # cannot follow, precede or interleave with the one line the driver parses. That line goes to the real stdout, kept here.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1036,7 +1042,7 @@ def main():
         sys.stderr.write("bench.py full record: %s\n" % json.dumps(result))
         sys.stderr.flush()
         sys.stdout.flush()
-        print(compact_line(result), flush=True)
+        os.write(real_stdout, (compact_line(result) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -226,9 +226,13 @@ int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed
 /* Same, but the image stays in DEVICE memory owned by the caller (e.g. the buffer RCCL gathers
  * from) and the launch is asynchronous on `stream` (a hipStream_t; NULL = the context's stream).
  * d_out_rgb holds owned rows only, packed in ascending row order: mcrt_shard_rows() rows of
- * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. (Scenes whose tree is walked by the
- * wavefront pipeline — BVHs of 65 536 nodes or more — run as a host-driven sequence of launches on `stream`; for them
- * the call returns when the frame is complete and mcrt_render_finish() only collects the statistics.)
+ * width*3 doubles. Call mcrt_render_finish() to wait and collect stats. (Path-traced frames whose tree is walked by the
+ * wavefront pipeline run as a host-driven sequence of launches on `stream`; for them the call BLOCKS until the frame is complete and
+ * mcrt_render_finish() only collects the statistics. The pipeline is chosen for BVHs of 65 536 nodes or more (MCRT_WF_MIN_NODES) and,
+ * for ANY tree that is not staged whole in LDS, for calls of 32 M path samples or more (MCRT_WF_MIN_PATHS) — counted over the rows THIS
+ * call owns, the work the pipeline's launches are amortised over: the measured crossover. Shards of one frame that
+ * straddle the threshold may therefore run different kernel forms on different ranks; every form returns the same bits, so the frame
+ * does not depend on it, only mcrt_stats.kernel_id and whether this call blocks. MCRT_KERNEL=wf / sm pins the form.)
  * ORDERING: queue consumers of d_out_rgb (copies, reductions, the gather) AFTER mcrt_render_finish() has returned MCRT_OK, not right
  * after this call: a megakernel frame in which a path nests deeper than the eight dielectric media a lane keeps in LDS is rendered
  * AGAIN by mcrt_render_finish through the wavefront pipeline (32 media; mcrt_stats.kernel_id then says MCRT_KERNEL_WAVEFRONT[_PM] and

@@ -14,6 +14,10 @@ RENDER_BIN = os.path.join(HOST, "mcrt_render")
 # -ffp-contract=off: the CPU reference is compiled by g++ for baseline x86-64 (no FMA contraction);
 # per-pixel FP64 parity needs the same rounding sequence on the GPU.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# MCRT_PLATFORM_LIBM=1: a build without the restated glibc routines and their tables (csrc/mcrt_libm.hpp "BUILD SWITCH", NOTICE): the
+# platform's libm instead - frames within 1e-12 of the reference's rather than its bits
+if os.environ.get("MCRT_PLATFORM_LIBM") == "1":
+    HIPCC_FLAGS.append("-DMCRT_PLATFORM_LIBM")
 
 
 def _hipcc():

@@ -209,7 +209,12 @@ int launchGeometry(mcrt_ctx* ctx, K kernel, const DeviceScene& s, LaunchGeom& g,
 
 int ensureSpill(mcrt_ctx* ctx, size_t bytes) {  // traversal-stack spill area, shared by every kernel (one render at a time)
     if (ctx->spill_bytes < bytes) {
-        HIP_TRY(ctx, ctx->spill.alloc(bytes));
+        if (ctx->spill.alloc(bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->spill_bytes = 0;
+            return fail(ctx, MCRT_ERR_UNSUPPORTED, "the traversal stacks of this tree (" + std::to_string(ctx->scene.stack_depth) + " entries per ray: a depth-first walk may hold that many "
+                                                   "pending nodes) need " + std::to_string(bytes >> 20) + " MiB of device memory, which could not be allocated");
+        }
         ctx->spill_bytes = bytes;
     }
     return MCRT_OK;
@@ -507,8 +512,11 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool share = defer && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // ... tested by the whole wave (travSharedLeafStep): round 4
     // MCRT_WF_LEAN (round 5; default 1): the shared form's inner visit is travInnerStepQLean - with one block per visit when the tree
     // has no node with more than four children (every quaternary tree); 0: round 4's visit
-    const int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
+    // (MCRT_WF_LEAN=2: the block loop kept on a quaternary tree; MCRT_WF_PK=1: packed multiply-adds - A/B runs)
+    int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
+    if (lean == 3 && ctxOptL(ctx, "MCRT_WF_PK", 0) != 0) lean = 7;
     void (*trace)(WfTraceArgs, PoolRays) = wide        ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
+                                           : lean == 7 ? wfTraceKernel<PoolRays, false, 3, 7>
                                            : lean == 3 ? wfTraceKernel<PoolRays, false, 3, 3>
                                            : lean == 1 ? wfTraceKernel<PoolRays, false, 3, 1>
                                            : share     ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)
@@ -1296,15 +1304,16 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     // kMaxStackDepth entries; the spill slabs behind the LDS part are sized from it at launch (ensureSpill)
     d.stack_depth = std::max<uint32_t>((uint32_t)kMaxStackDepth, L.stack_bound + 1u);
     {
-        // the deepest spill slab a frame allocates: two trace launches x 256 CUs x 1024 lanes x 8 bytes per entry. A tree degenerate
-        // enough to need more than a quarter of the device's memory for it (tens of thousands of stack entries: a BVH that is a list)
-        // is refused here, with its number, instead of failing in some later hipMalloc.
+        // the deepest spill slab a frame allocates: two trace launches x 256 CUs x the 2048 lanes a CU can hold (planTrace's grid is
+        // occupancy x CUs) x 8 bytes per entry. A tree degenerate enough to need more than a quarter of the device's memory for it
+        // (tens of thousands of stack entries: a BVH that is a list) is refused here, with its number; ensureSpill says the same
+        // should an allocation below that bound fail all the same.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
             (void)hipGetLastError();
             total_b = (size_t)64 << 30;
         }
-        const size_t slab = (size_t)d.stack_depth * sizeof(StackEntry) * 2u * (size_t)ctx->num_cus * kTraceMaxBlock;
+        const size_t slab = (size_t)d.stack_depth * sizeof(StackEntry) * 2u * (size_t)ctx->num_cus * 2048u;
         if (slab > total_b / 4)
             return fail(ctx, MCRT_ERR_UNSUPPORTED, "BVH so unbalanced that a depth-first walk may hold " + std::to_string(L.stack_bound) +
                                                        " pending nodes per ray: the traversal stacks would not fit in device memory");
@@ -1470,11 +1479,11 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_launches = ctx->launches;
         stats->kernel_id = ctx->kernel_id;
     }
+    if (h[5] >= kKnnOverflowUnit)
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more than 128 + 1024 octants pending at once (the wave's registers + its list in memory); a "
+                                               "photon octree whose leaves hold far fewer photons than k_nearest_photons can do that");
     if (h[5])
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER
-                                                   ? "kNN frontier overflow: a search had more than 128 + 1024 octants pending at once (registers + the wave's list in memory); a photon "
-                                                     "octree whose leaves hold far fewer photons than k_nearest_photons can do that (or, internal error, a traversal stack overflowed)"
-                                                   : "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
         // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
         // (32). A frame that nested deeper than 8 media is rendered AGAIN through the pipeline: slower for the scenes the megakernels
@@ -1980,7 +1989,8 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         }
         unsigned long long f = 0;
         HIP_TRY(ctx, hipMemcpy(&f, flags.p, 8, hipMemcpyDeviceToHost));
-        if (f) return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow (octree deeper than the 128-entry wave frontier)");
+        if (f) return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more octants pending at once than the wave's frontier holds (128 in registers + a "
+                                                      "1024-entry list in memory for the wave-per-query kernel; 128 for the four-queries-per-wave kernel of small k)");
         HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));

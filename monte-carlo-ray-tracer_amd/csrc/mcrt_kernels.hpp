@@ -118,6 +118,9 @@ __device__ inline void storeSample(const RenderParams& prm, uint32_t sample, uin
 // LDS carving
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
+// stats[5] counts two things the host tells apart: lanes whose traversal stack overflowed (low word; cannot happen - the stacks are sized
+// to the tree's own bound) and waves whose kNN frontier did (high word: octrees with leaves far smaller than k)
+constexpr unsigned long long kKnnOverflowUnit = 1ull << 32;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
 constexpr uint32_t kPmLdsIors = 2;  // refraction-history entries per lane the 1024-lane photon-mapping kernel keeps in LDS
@@ -788,7 +791,8 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // leaves (mcrt_lanesm.hpp), 3 = deferred leaves tested by the whole wave (travSharedLeafStep above; the default since round 4). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
 // default form a register spill and ~1 % of a frame.
 // kLean (forms 2 / 3; round 5): bit 0 = the inner visit is travInnerStepQLean (mcrt_qbvh.hpp: FP32 ray kept in the Trav, the three
-// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per visit).
+// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per
+// visit), bit 2 = packed multiply-adds for the plane distances.
 template <class Rays, bool kCount, int kForm = 0, int kLean = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
@@ -970,7 +974,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 ti = clock64();
             }
             if constexpr ((kLean & 1) != 0) {
-                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, stk, cnt);
+                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0, (kLean & 4) != 0>(qv, T, stk, cnt);
             } else {
                 if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
             }
@@ -982,6 +986,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             ShareOffer so;
             bool go = m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner);
             if constexpr (kShare) {  // the shared step is gated by what it would TEST: enough offered primitives to fill the wave
+                // (counting the offers only for a step that is going to run - the item gate is off by default - was tried in round 5: the
+                // extra branch cost the kernel a spilled register and 20 instructions)
                 so = shareOffer(pend, P);
                 go = go || (int)so.total >= a.leaf_items;
             }
@@ -1627,7 +1633,7 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     if (lane == 0) {
         if (searches) atomicAdd(a.stats + 4, (unsigned long long)searches);
         if (visits) atomicAdd(a.stats + 6, (unsigned long long)visits);
-        if (overflow) atomicAdd(a.stats + 5, 1ull);
+        if (overflow) atomicAdd(a.stats + 5, kKnnOverflowUnit);
     }
 }
 
@@ -1838,7 +1844,8 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         waveAccumulate(prm.stats + 3, cnt.prim_tests);
     }
     waveAccumulate(prm.stats + 4, searches);
-    waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
+    waveAccumulate(prm.stats + 5, cnt.overflow);
+    if (waveBallot(knn_overflow != 0u) && __lane_id() == 0) atomicAdd(prm.stats + 5, kKnnOverflowUnit);
     waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     waveAccumulate(prm.stats + 6, octant_visits);
     if (kCount && __lane_id() == 0) {

@@ -14,7 +14,7 @@
 // primitive order, so ties go to the lowest index: the tie rule of `closer`), pulls that item's u / v and updates its hit exactly as
 // travPendStep does. Same tests (primTestRec: the reference's FP64 arithmetic), same minimum, same tie rule: the hit is the one
 // every other form returns. A leaf of up to four primitives is one step instead of two, a step costs one primitive test instead of
-// two, and it is worth issuing with far fewer pending lanes (the gate MCRT_WF_LEAF drops from 24 to 12), so lanes wait less at
+// two, and it is worth issuing with far fewer pending lanes (the gate MCRT_WF_LEAF drops from 24 to 16), so lanes wait less at
 // their leaves. Shadow queries: the winner is the closest accepted item, so "an occluder closer than t_near" is seen on the winner
 // (an occluder that is not the winner has a closer one in front of it).
 constexpr uint32_t kShareMapBytes = 64;  // per wave

@@ -265,3 +265,27 @@ def sort_by_key(photons, keys):
 def photon_set_bytes(photons):
     """The photon list as a sorted array of opaque 32-byte records (order-free exact comparison)."""
     return np.sort(np.ascontiguousarray(photons, dtype=np.float32).view("V32").ravel())
+
+
+def host_libm_is_the_restated_one():
+    """True where the ORACLE's libm calls return what csrc/mcrt_libm.hpp restates: x86-64 glibc 2.35 on a CPU with FMA + AVX2 (the IFUNC
+    variants that were transcribed). Anywhere else the oracle itself differs from the reference in last bits, and tests that compare the
+    GPU with the ORACLE (not with reference-made fixtures, which do not depend on the host) fall back to a tolerance."""
+    import platform
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return False
+    libc, ver = platform.libc_ver()
+    return platform.machine() == "x86_64" and libc == "glibc" and ver.startswith("2.35") and "fma" in flags and "avx2" in flags
+
+
+def assert_oracle_bits(got, want, what="", rel=2e-6):
+    """Float arrays of the GPU (or of device code run on the host) against the oracle's: the same bits where the host's libm is the
+    restated one, within `rel` elsewhere (photon records are FP32: angles and positions rounded from FP64 values that differ by an ulp)."""
+    got, want = np.asarray(got), np.asarray(want)
+    if host_libm_is_the_restated_one():
+        np.testing.assert_array_equal(got.view(np.uint32 if got.dtype == np.float32 else np.uint64), want.view(np.uint32 if want.dtype == np.float32 else np.uint64),
+                                      err_msg=what)
+    else:
+        np.testing.assert_allclose(got, want, rtol=rel, atol=rel, err_msg=what + " (host libm is not x86-64 glibc 2.35 with FMA: tolerance instead of bits)")
