@@ -512,11 +512,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     const bool share = defer && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // ... tested by the whole wave (travSharedLeafStep): round 4
     // MCRT_WF_LEAN (round 5; default 1): the shared form's inner visit is travInnerStepQLean - with one block per visit when the tree
     // has no node with more than four children (every quaternary tree); 0: round 4's visit
-    // (MCRT_WF_LEAN=2: the block loop kept on a quaternary tree; MCRT_WF_PK=1: packed multiply-adds - A/B runs)
-    int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
-    if (lean == 3 && ctxOptL(ctx, "MCRT_WF_PK", 0) != 0) lean = 7;
+    // (MCRT_WF_LEAN=2: the block loop kept on a quaternary tree - A/B runs)
+    const int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
     void (*trace)(WfTraceArgs, PoolRays) = wide        ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
-                                           : lean == 7 ? wfTraceKernel<PoolRays, false, 3, 7>
                                            : lean == 3 ? wfTraceKernel<PoolRays, false, 3, 3>
                                            : lean == 1 ? wfTraceKernel<PoolRays, false, 3, 1>
                                            : share     ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)

@@ -791,8 +791,7 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // leaves (mcrt_lanesm.hpp), 3 = deferred leaves tested by the whole wave (travSharedLeafStep above; the default since round 4). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
 // default form a register spill and ~1 % of a frame.
 // kLean (forms 2 / 3; round 5): bit 0 = the inner visit is travInnerStepQLean (mcrt_qbvh.hpp: FP32 ray kept in the Trav, the three
-// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per
-// visit), bit 2 = packed multiply-adds for the plane distances.
+// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per visit).
 template <class Rays, bool kCount, int kForm = 0, int kLean = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
@@ -974,7 +973,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 ti = clock64();
             }
             if constexpr ((kLean & 1) != 0) {
-                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0, (kLean & 4) != 0>(qv, T, stk, cnt);
+                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, stk, cnt);
             } else {
                 if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
             }

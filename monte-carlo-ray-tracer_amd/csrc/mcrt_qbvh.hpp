@@ -286,17 +286,9 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
 //     ds_write_b64 when sp + 3 fits the lane's LDS rows; only lanes whose stack is about to leave LDS take the general pushes.
 //     No overflow test: the stack is sized to the tree's own bound (HostLayout::stack_bound), no walk can exceed it.
 // Same blocks, same tests, same keys, same order of the kept children: the walk visits exactly what travInnerStepQ visits.
-//   * kPk: the two plane distances of an axis - entry and exit - are ONE packed multiply-add (v_pk_fma_f32: {qn, qf} {A, A} + {Cn, Cf});
-//     the same two fused operations, three instructions per child instead of six.
-typedef float qf2 __attribute__((vector_size(8)));
-MCRT_HD qf2 qPkFma(qf2 a, qf2 b, qf2 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    return qf2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
-#endif
-}
-template <bool kLds, bool kCount, bool kSingle, bool kPk = false>
+// (Tried on top, round 5: the entry and exit distance of an axis as ONE v_pk_fma_f32 - 12 instructions fewer per visit and 0.6 % SLOWER
+// on C3 and C4, profiles/r05_ab_trace_pk_stack.log: a packed FP32 operation takes the SIMD as long as the two it replaces. Removed.)
+template <bool kLds, bool kCount, bool kSingle>
 MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
     const float best_up = T.best_up;
     const float of[3] = {T.of[0], T.of[1], T.of[2]}, invf[3] = {T.invf[0], T.invf[1], T.invf[2]};
@@ -333,20 +325,12 @@ MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const SmStack& s
 #pragma unroll
 #endif
         for (int c = 0; c < 4; c++) {
-            float tnx, tny, tnz, tfx, tfy, tfz;
-            if constexpr (kPk) {
-                const qf2 tx = qPkFma(qf2{(float)((wn[0] >> (8 * c)) & 0xFFu), (float)((wf[0] >> (8 * c)) & 0xFFu)}, qf2{A[0], A[0]}, qf2{Cn[0], Cf[0]});
-                const qf2 ty = qPkFma(qf2{(float)((wn[1] >> (8 * c)) & 0xFFu), (float)((wf[1] >> (8 * c)) & 0xFFu)}, qf2{A[1], A[1]}, qf2{Cn[1], Cf[1]});
-                const qf2 tz = qPkFma(qf2{(float)((wn[2] >> (8 * c)) & 0xFFu), (float)((wf[2] >> (8 * c)) & 0xFFu)}, qf2{A[2], A[2]}, qf2{Cn[2], Cf[2]});
-                tnx = tx[0]; tfx = tx[1]; tny = ty[0]; tfy = ty[1]; tnz = tz[0]; tfz = tz[1];
-            } else {
-                tnx = fmaf((float)((wn[0] >> (8 * c)) & 0xFFu), A[0], Cn[0]);
-                tny = fmaf((float)((wn[1] >> (8 * c)) & 0xFFu), A[1], Cn[1]);
-                tnz = fmaf((float)((wn[2] >> (8 * c)) & 0xFFu), A[2], Cn[2]);
-                tfx = fmaf((float)((wf[0] >> (8 * c)) & 0xFFu), A[0], Cf[0]);
-                tfy = fmaf((float)((wf[1] >> (8 * c)) & 0xFFu), A[1], Cf[1]);
-                tfz = fmaf((float)((wf[2] >> (8 * c)) & 0xFFu), A[2], Cf[2]);
-            }
+            const float tnx = fmaf((float)((wn[0] >> (8 * c)) & 0xFFu), A[0], Cn[0]);
+            const float tny = fmaf((float)((wn[1] >> (8 * c)) & 0xFFu), A[1], Cn[1]);
+            const float tnz = fmaf((float)((wn[2] >> (8 * c)) & 0xFFu), A[2], Cn[2]);
+            const float tfx = fmaf((float)((wf[0] >> (8 * c)) & 0xFFu), A[0], Cf[0]);
+            const float tfy = fmaf((float)((wf[1] >> (8 * c)) & 0xFFu), A[1], Cf[1]);
+            const float tfz = fmaf((float)((wf[2] >> (8 * c)) & 0xFFu), A[2], Cf[2]);
             const float lo = fmaxf(fmaxf(tnx, tny), tnz), hi = fminf(fminf(tfx, tfy), tfz);
             const float t = fmaxf(lo, 0.0f);
             const bool keep = (uint32_t)c < n && hi >= t && t <= best_up;

@@ -115,10 +115,9 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     else if (form == 1) launchTrace<1>(a, rays, grid, waves);
     else if (form == 2) launchTrace<2>(a, rays, grid, waves);
     else if (form == 11) launchTrace<3, 1>(a, rays, grid, waves);  // the lean visit (MCRT_WF_LEAN), any tree
-    else if (form == 27 || form == 59) {                            // ... one block per visit: trees without a node of more than four children
+    else if (form == 27) {                                          // ... one block per visit: trees without a node of more than four children
         if (!E.L.q_single) return -203;
-        if (form == 59) launchTrace<3, 7>(a, rays, grid, waves);    // ... and packed multiply-adds
-        else launchTrace<3, 3>(a, rays, grid, waves);
+        launchTrace<3, 3>(a, rays, grid, waves);
     } else launchTrace<3>(a, rays, grid, waves);
     if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
     return stats[5] ? -100 : 0;
