@@ -196,8 +196,9 @@ def lib():
     vp = C.c_void_p
     L.mcrt_abi_version.restype = C.c_uint32
     L.mcrt_create.argtypes = [C.POINTER(vp), C.c_int]
-    L.mcrt_device_count.argtypes = []
-    L.mcrt_device_count.restype = C.c_int
+    if hasattr(L, "mcrt_device_count"):  # (absent from libraries older than round 5: tools/ab_builds.sh loads those too)
+        L.mcrt_device_count.argtypes = []
+        L.mcrt_device_count.restype = C.c_int
     L.mcrt_destroy.argtypes = [vp]
     L.mcrt_destroy.restype = None
     L.mcrt_last_error.argtypes = [vp]

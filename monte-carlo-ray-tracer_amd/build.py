@@ -18,6 +18,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # platform's libm instead - frames within 1e-12 of the reference's rather than its bits
 if os.environ.get("MCRT_PLATFORM_LIBM") == "1":
     HIPCC_FLAGS.append("-DMCRT_PLATFORM_LIBM")
+# MCRT_EXACT_PHOTON_DIR=1: Photon::dir's sine / cosine pairs by the restated sincosf (glibc's bits) instead of the platform's sinf / cosf
+# (csrc/mcrt_integrator.hpp photonDirection: +8.8 % on a C5 frame, nothing a test can see)
+if os.environ.get("MCRT_EXACT_PHOTON_DIR") == "1":
+    HIPCC_FLAGS.append("-DMCRT_EXACT_PHOTON_DIR")
 
 
 def _hipcc():

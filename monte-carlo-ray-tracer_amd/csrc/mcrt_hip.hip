@@ -1477,7 +1477,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_launches = ctx->launches;
         stats->kernel_id = ctx->kernel_id;
     }
-    if (h[5] >= kKnnOverflowUnit)
+    if (h[5] >= kKnnOverflowFlag)
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more than 128 + 1024 octants pending at once (the wave's registers + its list in memory); a "
                                                "photon octree whose leaves hold far fewer photons than k_nearest_photons can do that");
     if (h[5])

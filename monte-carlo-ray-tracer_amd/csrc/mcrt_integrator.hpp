@@ -364,8 +364,16 @@ MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnSc
 MCRT_HD d3 photonDirection(const float* ph) {  // Photon::dir, photon.hpp:19-27 (float sin/cos overloads: glibc's sincosf, refSinCosF)
     float phi = ph[6], theta = ph[7];
     float st, ct, sp, cp;
-    refSinCosF(theta, st, ct);
+#if defined(MCRT_EXACT_PHOTON_DIR)
+    refSinCosF(theta, st, ct);  // glibc's sincosf, bit for bit (csrc/mcrt_libm.hpp; tests/test_libm.py)
     refSinCosF(phi, sp, cp);
+#else
+    // The platform's sinf / cosf. The restated sincosf is exact and NOT the default here: inside renderKernelPM (128 VGPRs, ~700 spilled)
+    // it costs a C5 frame 8.8 % (766 -> 832 ms on the 64 spp probe; as a called function or a loop over the two angles 954 / 987 ms:
+    // profiles/r05_ab_c5_bisect.log), and it buys nothing a test can see - the k terms of an estimate are summed by a wave reduction, not
+    // in the reference's heap order, so photon-mapped frames are compared at 1e-10 either way. -DMCRT_EXACT_PHOTON_DIR selects it.
+    st = sinf(theta); ct = cosf(theta); sp = sinf(phi); cp = cosf(phi);
+#endif
     double sin_theta = (double)st;
     return d3{sin_theta * (double)cp, sin_theta * (double)sp, (double)ct};
 }

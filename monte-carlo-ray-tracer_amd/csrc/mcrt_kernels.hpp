@@ -118,8 +118,8 @@ __device__ inline void storeSample(const RenderParams& prm, uint32_t sample, uin
 // LDS carving
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kStatsWords = 8 + 2 * kNumPhases;
-// stats[5] counts two things the host tells apart: lanes whose traversal stack overflowed (low word; cannot happen - the stacks are sized
-// to the tree's own bound) and waves whose kNN frontier did (high word: octrees with leaves far smaller than k)
+// stats[5] counts two things the host tells apart: lanes whose traversal stack overflowed (one each; cannot happen - the stacks are sized
+// to the tree's own bound) and searches whose kNN frontier did (kKnnOverflowFlag and above: octrees with leaves far smaller than k)
 constexpr unsigned long long kKnnOverflowUnit = 1ull << 32;
 constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU (LDS-bound, see planLds)
 
@@ -795,7 +795,7 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 template <class Rays, bool kCount, int kForm = 0, int kLean = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
     constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
-    static_assert(kLean == 0 || kShare, "the lean visit pops at the loop's one pop site and leaves best_up to the shared leaf step");
+    static_assert(kLean == 0 || kShare, "the lean visit pops at the loop's one pop site and refreshes best_up behind the shared leaf step");
     MCRT_DYNAMIC_LDS(lds, 64);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
     if constexpr (!kWide)
@@ -849,6 +849,8 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     T.shadow = false;
     T.fast = true;
     T.sp = 0;
+    LeanRay LR;  // kLean: the ray in FP32 and floatAbove(best.t), kept per ray (travInnerStepQLean)
+    LR.of[0] = LR.of[1] = LR.of[2] = LR.invf[0] = LR.invf[1] = LR.invf[2] = LR.best_up = 0.0f;
     PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking; kWide: the leaf being tested
     WLeaves Lv;  // kWide: hit leaf children still to be tested
     WView wv;
@@ -895,6 +897,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 item = rays.load(w, o, d, shadow, sq);
                 if constexpr (kWide) travBeginW<false, kCount>(sv, T, Lv, P, o, d, rcp3(d), shadow, &sq, cnt);
                 else travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
+                if constexpr (kLean != 0) leanRayBegin(LR, T);
                 have = true;
             }
             exhausted = waveBallot(!have) != 0ull;  // a lane came back empty-handed: the queue is drained
@@ -973,7 +976,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 ti = clock64();
             }
             if constexpr ((kLean & 1) != 0) {
-                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, stk, cnt);
+                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, LR, stk, cnt);
             } else {
                 if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
             }
@@ -999,6 +1002,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 }
                 if constexpr (kShare) travSharedLeafStep<kCount>(sv, T, P, so, share_map, cnt);
                 else if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
+                if constexpr (kLean != 0) LR.best_up = floatAbove(T.best.t);  // (the step may have improved the hit)
                 if (kCount) ph_lf_cyc += clock64() - tc;
             } else if (kCount) {
                 ph_lf_wait += __popcll(m_pend);
@@ -1843,8 +1847,10 @@ __global__ void __launch_bounds__(kLanes) renderKernelPM(const DeviceScene scene
         waveAccumulate(prm.stats + 3, cnt.prim_tests);
     }
     waveAccumulate(prm.stats + 4, searches);
-    waveAccumulate(prm.stats + 5, cnt.overflow);
-    if (waveBallot(knn_overflow != 0u) && __lane_id() == 0) atomicAdd(prm.stats + 5, kKnnOverflowUnit);
+    // (one word for both overflows, as in round 4: lanes whose traversal stack overflowed count 1 each, a search whose frontier overflowed
+    // sets kKnnOverflowFlag - the host reads the bits above 15. Two separate additions here cost C5 9 % of a frame: this kernel's
+    // register allocation - 128 VGPRs, ~700 spilled - turns on such things, profiles/r05_ab_c5_bisect.log)
+    waveAccumulate(prm.stats + 5, cnt.overflow | knn_overflow);
     waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     waveAccumulate(prm.stats + 6, octant_visits);
     if (kCount && __lane_id() == 0) {

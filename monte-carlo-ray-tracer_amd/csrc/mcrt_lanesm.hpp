@@ -102,13 +102,23 @@ struct Trav {
     // is in the stack's memory too), a pop takes it without waiting for an LDS read and asks for the entry below at once - that read
     // lands while the wave runs its next step. top_key == kTopNone: not cached, read the stack.
     uint32_t top_key = 0xFFFFFFFFu, top_a = 0u;
-    // (travInnerStepQLean, mcrt_qbvh.hpp) the ray rounded to FP32 and the smallest float >= best.t, kept instead of recomputed per visit
-    float of[3] = {0.0f, 0.0f, 0.0f}, invf[3] = {0.0f, 0.0f, 0.0f}, best_up = 0.0f;
     bool fast;         // v_min/v_max box test allowed (no NaN slab products possible)
     bool shadow;
     uint32_t light;    // shadow query: surface aimed at
     double t_near;     // shadow query: a closer hit of another surface decides it
 };
+
+// What travInnerStepQLean (mcrt_qbvh.hpp) keeps per ray instead of recomputing it at every visit: the ray rounded to FP32 as
+// travInnerStepQ rounds it, and the smallest float >= best.t. Its own struct, held by the trace kernel only: as members of Trav the
+// seven words cost renderKernelPM - whose Trav lives partly in scratch - 8 % of a C5 frame (round 5, profiles/r05_ab_c5_bisect.log).
+struct LeanRay {
+    float of[3], invf[3], best_up;
+};
+MCRT_HD void leanRayBegin(LeanRay& R, const Trav& T) {
+    R.of[0] = (float)T.o.x; R.of[1] = (float)T.o.y; R.of[2] = (float)T.o.z;
+    R.invf[0] = (float)T.inv.x; R.invf[1] = (float)T.inv.y; R.invf[2] = (float)T.inv.z;
+    R.best_up = floatAbove(T.best.t);
+}
 
 template <bool kAll>
 MCRT_HD Box smLoadBox(const SmSceneView<kAll>& sv, uint32_t i, uint32_t& a, uint32_t& m) {

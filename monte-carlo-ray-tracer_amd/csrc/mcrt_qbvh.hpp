@@ -71,10 +71,6 @@ MCRT_HD void travBeginQ(const SmSceneView<kAll>& sv, const QView<kLds>& qv, Trav
     if (T.fast) {  // from here on node_a / node_m are block links
         T.node_a = qv.root_a;
         T.node_m = qv.root_m;
-        // the ray as travInnerStepQ rounds it at every visit, once (read by travInnerStepQLean only)
-        T.of[0] = (float)start.x; T.of[1] = (float)start.y; T.of[2] = (float)start.z;
-        T.invf[0] = (float)inv_direction.x; T.invf[1] = (float)inv_direction.y; T.invf[2] = (float)inv_direction.z;
-        T.best_up = floatAbove(T.best.t);
     }
 }
 
@@ -278,8 +274,8 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
 // (the next-block fetch, the merge of a block's nearest with the earlier blocks', a fourth push) that a quaternary tree never needs;
 // and ~55 in the pushes: up to four of them, each `if (key != miss) if (sp < max) if (sp < lds_depth) LDS else memory`, three nested
 // exec-mask regions that a wave of 50 rays always enters. Here
-//   * the FP32 ray and floatAbove(best.t) live in the Trav (set by travBeginQ, best_up again wherever the hit improves; a stale
-//     LARGER best_up only keeps a child the pop would cull anyway);
+//   * the FP32 ray and floatAbove(best.t) are kept per ray (LeanRay, mcrt_lanesm.hpp: set when the ray is loaded, best_up again
+//     after every leaf step; a stale LARGER best_up only keeps a child the pop would cull anyway);
 //   * kSingle (the tree has no node with more than four children: HostLayout knows) visits exactly one block;
 //   * the three pushes are ONE block: the sorted keys' misses are a suffix, so with cnt children to push the entry of rank j goes
 //     to stack position sp + cnt - j and a miss to a position ABOVE the new top (junk there is never read) - three unconditional
@@ -289,9 +285,9 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
 // (Tried on top, round 5: the entry and exit distance of an axis as ONE v_pk_fma_f32 - 12 instructions fewer per visit and 0.6 % SLOWER
 // on C3 and C4, profiles/r05_ab_trace_pk_stack.log: a packed FP32 operation takes the SIMD as long as the two it replaces. Removed.)
 template <bool kLds, bool kCount, bool kSingle>
-MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const SmStack& stk, TraceCounters& cnt) {
-    const float best_up = T.best_up;
-    const float of[3] = {T.of[0], T.of[1], T.of[2]}, invf[3] = {T.invf[0], T.invf[1], T.invf[2]};
+MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const LeanRay& R, const SmStack& stk, TraceCounters& cnt) {
+    const float best_up = R.best_up;
+    const float of[3] = {R.of[0], R.of[1], R.of[2]}, invf[3] = {R.invf[0], R.invf[1], R.invf[2]};
     const bool pos[3] = {invf[0] >= 0.0f, invf[1] >= 0.0f, invf[2] >= 0.0f};  // (|inv| >= 1: the float keeps the sign, never zero)
     uint32_t near_key = kQMissKey, near_a = 0;
     auto push = [&](uint32_t key, uint32_t a) {

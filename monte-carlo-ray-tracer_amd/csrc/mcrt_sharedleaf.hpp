@@ -99,7 +99,6 @@ __device__ __forceinline__ void travSharedLeafStep(const SmSceneView<false>& sv,
         const uint32_t idx = P.a + win_j;
         if (win_t < INFINITY && closer(win_t, idx, T.best)) {
             T.best.t = win_t;
-            T.best_up = floatAbove(win_t);  // (travInnerStepQLean's cut-off)
             T.best.u = win_u;
             T.best.v = win_v;
             T.best.interpolate = win_i != 0u;
