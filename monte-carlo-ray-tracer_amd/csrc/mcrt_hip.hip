@@ -721,10 +721,15 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
 
 // Frames of DIFFERENT contexts on ONE device never overlap on the GPU: a launch waits (on the GPU, hipStreamWaitEvent) for the
 // frame the device's previous launcher queued, and the host side of a launch — the whole frame for the wavefront pipeline — runs
-// under the device's mutex. Why: an experimental build (hit records as one record per slot) gave wrong frames when two contexts of
-// one process rendered on the same GPU at the same time (two host threads, one stream each: ray counts identical, radiance a few
-// per cent low, different from run to run) and was never understood. The committed kernels have not shown it,
-// but nothing relies on concurrent frames of one device. One context per device, the production shape, never waits here.
+// under the device's mutex. Two reasons. (i) The mutex makes "size this kernel's dynamic LDS, then launch it" one step:
+// hipFuncSetAttribute is state of the kernel FUNCTION, shared by every context of the process - two contexts that render different
+// scenes through the same kernel instance would otherwise race for it (a launch that asks for more LDS than the other context just
+// set fails; loudly, but it fails). (ii) History: an experimental build of round 3 (hit records as one record per slot, never
+// committed) gave wrong frames when two contexts of one process rendered on the same GPU at the same time, and was never understood.
+// The committed kernels do not show it: tools/shared_gpu_stress.py with the ordering switched off - 3 processes x 2 contexts and 2 x 4,
+// every kernel form, dirty memory, 1 680 concurrent frames compared bit for bit with the reference's / the oracle's - found none wrong
+// (round 5, profiles/r05_shared_gpu_stress.log). So the GPU-side wait is a belt; the mutex is needed. One context per device, the
+// production shape, never waits here.
 struct DeviceOrder {
     std::mutex m;
     hipEvent_t last = nullptr;
@@ -737,6 +742,21 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
 int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out, hipStream_t stream,
                  double* film_out = nullptr) {
     if (!ctx) return MCRT_ERR_INVALID;
+    // MCRT_DEVICE_ORDER=0 in the ENVIRONMENT (read once per process) switches the ordering off: for tools/shared_gpu_stress.py, which
+    // looks for the fault the ordering was added against (round 5: 3 processes x 2 contexts, 600 concurrent frames, none wrong)
+    static const bool ordered = !(getenv("MCRT_DEVICE_ORDER") && atoi(getenv("MCRT_DEVICE_ORDER")) == 0);
+    if (!ordered) {
+        const int rc = launchRenderImpl(ctx, cam, global_seed, integrator, d_out, stream, film_out);
+        if (rc == MCRT_OK && ctx->pending) {
+            if (cam != &ctx->last_cam) ctx->last_cam = *cam;
+            ctx->last_seed = global_seed;
+            ctx->last_integrator = integrator;
+            ctx->last_out = d_out;
+            ctx->last_film = film_out;
+            ctx->last_stream = stream;
+        }
+        return rc;
+    }
     DeviceOrder& o = g_device_order[(unsigned)ctx->device & 63u];
     std::lock_guard<std::mutex> guard(o.m);
     if (o.owner && o.owner != ctx) {
@@ -892,14 +912,17 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
                     break;
                 }
         }
+        // (round 5: a 768-lane instance - 3 waves per SIMD, 168 VGPRs, 639 instead of 769 spill instructions - measured 895 ms against
+        // 762 on the C5 probe and 112 against 101 on pm, profiles/r05_ab_pm768.log: this kernel wants its four waves)
         if (want == 1024) {
-            if (launch_scene.flat && ldsBytes(1024, kLdsStackDepth) <= ctx->max_lds) {
-                g.block = 1024;
+            const uint32_t wb = 1024u;
+            if (launch_scene.flat && ldsBytes(wb, kLdsStackDepth) <= ctx->max_lds) {
+                g.block = wb;
             } else if (!launch_scene.stage_all) {
                 const uint32_t depth_max = ctxOpt(ctx, "MCRT_PM_STACK") ? (uint32_t)std::max(2, (int)ctxOptL(ctx, "MCRT_PM_STACK", 16)) & ~1u : 16u;
                 for (uint32_t depth = depth_max; depth >= 2 && g.block == kBlock; depth -= 2)
-                    if (ldsBytes(1024, depth) <= ctx->max_lds) {
-                        g.block = 1024;
+                    if (ldsBytes(wb, depth) <= ctx->max_lds) {
+                        g.block = wb;
                         pm_stack_depth = depth;
                     }
             }
