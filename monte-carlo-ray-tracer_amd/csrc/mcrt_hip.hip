@@ -88,6 +88,7 @@ struct mcrt_ctx {
 
     bool has_scene = false;
     bool q_single = false;  // HostLayout::q_single of the uploaded scene
+    std::vector<float> flat_pre_host;  // the flat loop's cull records, host copy: renderKernelFlatK takes them as a kernel argument
     DeviceScene scene{};
     DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_rec, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
@@ -810,6 +811,11 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     const int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", 512);
     // (Round 4 built a form that dealt a wave's (ray, cull survivor) pairs over all 64 lanes for the FP64 tests; measured in round 5 it
     // LOST 8 % on C2 and on C2-GGX - 482 ms against 446, 663 against 614, profiles/r05_ab_c2_flat_share.log - and was removed.)
+    // MCRT_FLAT_KARG (round 5, default 1): the cull records travel in the kernel's argument block and are read with scalar loads
+    // (renderKernelFlatK) - when they fit it, and for the default 512-lane shape
+    const bool flat_karg = flat_only && flat_block == 512 && ctxOptL(ctx, "MCRT_FLAT_KARG", 1) != 0 && !ctx->flat_pre_host.empty() &&
+                           ctx->flat_pre_host.size() <= kFlatPreArgFloats &&
+                           ctx->flat_pre_host.size() == (size_t)ctx->scene.pre_tri_pairs * kTriPairFloats + (size_t)ctx->scene.pre_sph_pairs * kSphPairFloats;
     if (flat_only)
         kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
@@ -950,6 +956,8 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         if (per_cu < 1) per_cu = 1;
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * g.block;
+    } else if (flat_karg && launch_scene.flat_pre) {
+        if (int rc = launchGeometry(ctx, renderKernelFlatK, launch_scene, g, 2)) return rc;
     } else if (int rc = launchGeometry(ctx, kernel, launch_scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
         return rc;
     }
@@ -1051,8 +1059,16 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
             // never launch more lanes than there is work
             const uint32_t grid = (uint32_t)std::min<uint64_t>(g.grid, (prm.work_items + g.block - 1) / g.block);
             HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter.p, 0, sizeof(unsigned long long), stream));
-            if (use_pm_wave) hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pmx);
-            else hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
+            if (use_pm_wave) {
+                hipLaunchKernelGGL(pm_kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pmx);
+            } else if (flat_karg && launch_scene.flat_pre) {
+                FlatPreArg pre;
+                memset(&pre, 0, sizeof(pre));
+                memcpy(pre.v, ctx->flat_pre_host.data(), ctx->flat_pre_host.size() * sizeof(float));
+                hipLaunchKernelGGL(renderKernelFlatK, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
+            } else {
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
+            }
             hipLaunchKernelGGL(sampleResolveKernel, dim3((uint32_t)((prm.pass_pixels + 255) / 256)), dim3(256), 0, stream, prm.samples,
                                prm.pass_pixels, prm.spp, d_out + (size_t)prm.row_base * cam->width * 3);
             ctx->launches += 2;
@@ -1292,6 +1308,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->prim, prim.data(), prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_prim, L.flat_prim.data(), L.flat_prim.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->flat_index, L.flat_index.data(), L.flat_index.size())) return rc;
+    ctx->flat_pre_host = L.flat_pre;
     if (L.flat_pre.empty()) ctx->flat_pre.release();
     else if (int rc = uploadArray(ctx, ctx->flat_pre, L.flat_pre.data(), L.flat_pre.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_v, L.num_quadric_surfaces ? L.surf_v_patched.data() : s->surf_v, ns * 9)) return rc;

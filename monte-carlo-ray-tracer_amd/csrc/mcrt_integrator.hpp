@@ -74,12 +74,12 @@ MCRT_HD void pathBegin(PathState& st, RefractionHistory& rh, const Ray& camera_r
 
 // One iteration of the while(true) in PathTracer::sampleRay. Returns true when the path has ended;
 // st.radiance then holds sampleRay's return value.
-template <bool kCount, bool kAll, bool kProf = false, bool kFlat = false>
+template <bool kCount, bool kAll, bool kProf = false, bool kFlat = false, bool kPreK = false>
 MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneViewT<kAll>& sv, const ShadeViewT<kAll>& sh, const LaneStack& stk,
                               TraceCounters& cnt, SobolTab tab, PhaseProf<kProf>* prof = nullptr) {
     if (kProf) prof->mark(kPhTraverse);
     st.smp.shuffle();                                                     // :23
-    Hit isect = sceneIntersect<kAll, kCount, false, kFlat>(sv, st.ray, stk, cnt);  // :25
+    Hit isect = sceneIntersect<kAll, kCount, false, kFlat, kPreK>(sv, st.ray, stk, cnt);  // :25
     if (kProf) prof->mark(kPhShade);
     if (isect.surface == kNoSurface) {                                    // :27-30
         st.radiance = st.radiance + skyColor(st.ray) * st.throughput;
@@ -92,7 +92,7 @@ MCRT_HD bool pathTracerBounce(PathState& st, RefractionHistory& rh, const SceneV
     DirectQuery dq;                                                       // :35 Integrator::sampleDirect
     if (sampleDirectSetup(sh, ia, st.ls, dq, st.smp, tab)) {
         if (kProf) prof->mark(kPhShadow);
-        Hit shadow = sceneIntersect<kAll, kCount, true, kFlat>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
+        Hit shadow = sceneIntersect<kAll, kCount, true, kFlat, kPreK>(sv, dq.shadow_ray, stk, cnt, &dq.sq);
         if (kProf) prof->mark(kPhSample);
         st.radiance = st.radiance + sampleDirectFinish(sh, ia, st.ls, dq, shadow) * st.throughput;
     }

@@ -344,8 +344,9 @@ __device__ inline void waveAccumulate(unsigned long long* dst, uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // kFlat != 0: instance for flat-mode scenes only (path tracer): no BVH walk in the code, no traversal stack in LDS;
 // kFlat == 2: 768-lane workgroups (3 waves per SIMD, 168 VGPRs); kFlat == 3: 1024 lanes (4 waves per SIMD, 128 VGPRs).
-template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
-__global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
+// pre_k (kPreK): the flat loop's cull records as part of the kernel's argument block (renderKernelFlatK below), or null.
+template <int kIntegrator, bool kCount, bool kAll, bool kProf, int kFlat, bool kPreK>
+__device__ __forceinline__ void renderKernelBody(const DeviceScene& scene, const RenderParams& prm, const float* pre_k) {
     MCRT_DYNAMIC_LDS(lds, 16);
     SceneViewT<kAll> sv;
     ShadeViewT<kAll> sh;
@@ -353,6 +354,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
     LaneStack stk;
     RefractionHistory rh;
     setupViews<kAll, kFlat != 0>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    sv.flat_pre_k = pre_k;
 
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
     KnnScratch ks;
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
             if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER)
                 done = photonMapperBounce<kCount, kAll>(st, rh, sv, sh, pv, stk, ks, cnt, searches, octant_visits, tab);
             else
-                done = pathTracerBounce<kCount, kAll, kProf, kFlat != 0>(st, rh, sv, sh, stk, cnt, tab, &prof);
+                done = pathTracerBounce<kCount, kAll, kProf, kFlat != 0, kPreK>(st, rh, sv, sh, stk, cnt, tab, &prof);
             if (kProf) prof.mark(kPhLoop);
             if (done) {
                 storeSample(prm, sample, px, ly, st.radiance);
@@ -443,6 +445,20 @@ __global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock)
             atomicAdd(prm.stats + 8 + kNumPhases + i, prof.lane_cycles[i]);
         }
     }
+}
+template <int kIntegrator, bool kCount, bool kAll, bool kProf = false, int kFlat = 0>
+__global__ void __launch_bounds__(kFlat == 3 ? 1024 : kFlat == 2 ? 768 : kBlock) renderKernel(const DeviceScene scene, const RenderParams prm) {
+    renderKernelBody<kIntegrator, kCount, kAll, kProf, kFlat, false>(scene, prm, nullptr);
+}
+// The flat megakernel with its cull records in the ARGUMENT BLOCK (round 5; scenes whose records fit kFlatPreArgFloats: C1, C2,
+// C2-GGX): sceneIntersect's kPreK. 512 lanes like kFlat == 1. An argument block holds 4 KB; DeviceScene + RenderParams take under 1 KB.
+constexpr uint32_t kFlatPreArgFloats = 704;  // 2 816 bytes: e.g. 14 triangle pairs + 16 sphere pairs, or 22 triangle pairs
+struct FlatPreArg {
+    float v[kFlatPreArgFloats];
+};
+static_assert(sizeof(DeviceScene) + sizeof(RenderParams) + sizeof(FlatPreArg) + 64 <= 4096, "the argument block of renderKernelFlatK");
+__global__ void __launch_bounds__(kBlock) renderKernelFlatK(const DeviceScene scene, const RenderParams prm, const FlatPreArg pre) {
+    renderKernelBody<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1, true>(scene, prm, pre.v);
 }
 
 // ------------------------------------------------------------------------------------------------

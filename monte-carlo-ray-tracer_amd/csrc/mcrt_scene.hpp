@@ -108,6 +108,8 @@ struct SceneViewT {
     cptr<float, kAll> flat_pre;
     uint32_t pre_tri_pairs, pre_sph_pairs;
     double pre_cx, pre_cy, pre_cz, pre_bound;
+    // the same records as a KERNEL ARGUMENT (renderKernelFlatK, kPreK below): read with scalar loads into SGPRs, not from LDS
+    const float* flat_pre_k = nullptr;
 };
 
 struct LaneStack {
@@ -495,7 +497,12 @@ struct ShadowQuery {
 };
 
 // kFlat: the caller knows the scene is in flat mode (a kernel instance for such scenes only): the BVH walk is not compiled in.
-template <bool kAll, bool kCount, bool kShadow, bool kFlat = false>
+// kPreK (with kFlat; round 5): the cull records are read through sv.flat_pre_k - the kernel's own argument block, i.e. constant
+// memory at an address every lane shares - so the compiler loads a pair's record with s_load_dwordx16 / x8 / x2 into SGPRs and the
+// packed instructions take them as scalar operands, instead of seven wave-wide ds_read (1 KB returned each for 16 bytes of
+// information) into 26 VGPRs. C2 -2.0 %, C2-GGX -1.1 % (profiles/r05_ab_c2_flat_karg.log). Asking for the NEXT pair's record ahead
+// of this pair's arithmetic (double-buffered SGPRs) was 10 % SLOWER: 26 s_mov per pair on a wave's single issue stream.
+template <bool kAll, bool kCount, bool kShadow, bool kFlat = false, bool kPreK = false>
 MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const LaneStack& stk, TraceCounters& cnt,
                            const ShadowQuery* sq = nullptr) {
     Hit best;
@@ -524,8 +531,13 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                 // 32 primitives (16 pairs) per mask word
                 for (uint32_t base = 0; base < nt; base += 32u) {
                     const uint32_t left = nt - base, pairs_left = sv.pre_tri_pairs - base / 2u;
-                    uint32_t mt = cullTriangles(sv.flat_pre + (size_t)(base / 2u) * kTriPairFloats, sv.pre_tri_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
-                                                left < 32u ? left : 32u, cr);
+                    uint32_t mt;
+                    if constexpr (kPreK)
+                        mt = cullTriangles(sv.flat_pre_k + (size_t)(base / 2u) * kTriPairFloats, sv.pre_tri_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                           left < 32u ? left : 32u, cr);
+                    else
+                        mt = cullTriangles(sv.flat_pre + (size_t)(base / 2u) * kTriPairFloats, sv.pre_tri_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                           left < 32u ? left : 32u, cr);
                     if (kCount) cnt.prim_tests += (uint32_t)__builtin_popcount(mt);
                     while (mt) {
                         const uint32_t i = base + lowestBit(mt);
@@ -545,10 +557,16 @@ MCRT_HD Hit sceneIntersect(const SceneViewT<kAll>& sv, const Ray& ray, const Lan
                     }
                 }
                 cptr<float, kAll> spre = sv.flat_pre + (size_t)sv.pre_tri_pairs * kTriPairFloats;
+                const float* spre_k = kPreK ? sv.flat_pre_k + (size_t)sv.pre_tri_pairs * kTriPairFloats : nullptr;
                 for (uint32_t base = 0; base < ns - nt; base += 32u) {
                     const uint32_t left = ns - nt - base, pairs_left = sv.pre_sph_pairs - base / 2u;
-                    uint32_t ms = cullSpheres(spre + (size_t)(base / 2u) * kSphPairFloats, sv.pre_sph_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
-                                              left < 32u ? left : 32u, cr);
+                    uint32_t ms;
+                    if constexpr (kPreK)
+                        ms = cullSpheres(spre_k + (size_t)(base / 2u) * kSphPairFloats, sv.pre_sph_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                         left < 32u ? left : 32u, cr);
+                    else
+                        ms = cullSpheres(spre + (size_t)(base / 2u) * kSphPairFloats, sv.pre_sph_pairs ? (pairs_left < 16u ? pairs_left : 16u) : 0u,
+                                         left < 32u ? left : 32u, cr);
                     if (kCount) cnt.prim_tests += (uint32_t)__builtin_popcount(ms);
                     while (ms) {
                         const uint32_t i = nt + base + lowestBit(ms);

@@ -312,7 +312,17 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
         else launchGrid(grid, block, [&] { renderKernelSM<false, false>(launch_scene, prm); });
     } else if (flat_only) {
         kernel_id = 1;
-        launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
+        if (force == 6) {  // the cull records as a kernel argument (renderKernelFlatK, MCRT_FLAT_KARG)
+            const size_t floats = (size_t)launch_scene.pre_tri_pairs * kTriPairFloats + (size_t)launch_scene.pre_sph_pairs * kSphPairFloats;
+            if (!launch_scene.flat_pre || floats > kFlatPreArgFloats || floats != E.L.flat_pre.size()) return -206;
+            FlatPreArg pre;
+            memset(&pre, 0, sizeof(pre));
+            memcpy(pre.v, E.L.flat_pre.data(), floats * sizeof(float));
+            kernel_id = 16;
+            launchGrid(grid, block, [&] { renderKernelFlatK(launch_scene, prm, pre); });
+        } else {
+            launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
+        }
     } else {
         kernel_id = 2;
         if (all) launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true>(launch_scene, prm); });

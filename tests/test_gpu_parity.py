@@ -419,6 +419,27 @@ def test_c2_full_size_frame(pkg, ctx, manifest):
     assert np.array_equal(part[536:544], out[536:544])
 
 
+@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_ggx", "hexagon_room_dof", "dragon_room", "veach_mis"])
+def test_flat_cull_records_from_the_argument_block_or_from_lds(pkg, manifest, name):
+    """The flat megakernel reads its FP32 cull records from the kernel's argument block (renderKernelFlatK, MCRT_FLAT_KARG default 1,
+    scalar loads) when they fit it, from LDS otherwise or with the option at 0: the reference's bits either way."""
+    case = manifest["cases"][name]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    r = case["renders"][0]
+    cam = camera_for(img, r)
+    c = pkg.Context(0)
+    try:
+        c.upload_image(img)
+        a, sa = c.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+        c.set_option("MCRT_FLAT_KARG", 0)
+        b, sb = c.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+        assert sa["kernel_id"] == sb["kernel_id"] == pkg.KERNEL_FLAT and sa["rays"] == sb["rays"]
+        _check(a, load_radiance(r), "%s, cull records as a kernel argument (where they fit)" % name, exact=True)
+        np.testing.assert_array_equal(a, b)
+    finally:
+        c.close()
+
+
 def test_options_are_per_context_and_not_the_environment(pkg, manifest, monkeypatch):
     """mcrt_set_option / mcrt_get_option: the environment seeds a context's options in mcrt_create and is never read again by
     the library; two contexts in one process can run different kernel forms; NULL restores the default."""
