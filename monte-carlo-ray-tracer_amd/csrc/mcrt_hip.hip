@@ -808,14 +808,16 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // With the FP32 cull in front of the FP64 tests (mcrt_scene.hpp) the order is reversed: 512 lanes 448.7 ms, 768 lanes 455.8,
     // 1024 lanes 485.2 (split next-event estimate: 454 / 493 / 563) — fewer instructions per ray, and the spills of the
     // narrow instances (107 / 169 VGPRs) now cost more than the extra waves hide.
-    const int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", 512);
+    // MCRT_FLAT_KARG (round 5, default 1): the cull records travel in the kernel's argument block and are read with scalar loads
+    // (renderKernelFlatK) - when they fit it. With the records in SGPRs the 768-lane shape (3 waves per SIMD, 168 VGPRs) is the
+    // fastest: C2 439.6 ms against 442.8 at 512 lanes and 478 at 1024, C2-GGX 596.9 against 614.6 and 649
+    // (profiles/r05_ab_c2_flat_karg.log) - so that is the default where the argument-block form applies, 512 lanes elsewhere.
+    const bool flat_karg = flat_only && ctxOptL(ctx, "MCRT_FLAT_KARG", 1) != 0 && !ctx->flat_pre_host.empty() && ctx->flat_pre_host.size() <= kFlatPreArgFloats &&
+                           ctx->flat_pre_host.size() == (size_t)ctx->scene.pre_tri_pairs * kTriPairFloats + (size_t)ctx->scene.pre_sph_pairs * kSphPairFloats;
+    int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", flat_karg ? 768 : 512);
+    if (flat_block != 512 && flat_block != 768 && flat_block != 1024) flat_block = 512;
     // (Round 4 built a form that dealt a wave's (ray, cull survivor) pairs over all 64 lanes for the FP64 tests; measured in round 5 it
     // LOST 8 % on C2 and on C2-GGX - 482 ms against 446, 663 against 614, profiles/r05_ab_c2_flat_share.log - and was removed.)
-    // MCRT_FLAT_KARG (round 5, default 1): the cull records travel in the kernel's argument block and are read with scalar loads
-    // (renderKernelFlatK) - when they fit it, and for the default 512-lane shape
-    const bool flat_karg = flat_only && flat_block == 512 && ctxOptL(ctx, "MCRT_FLAT_KARG", 1) != 0 && !ctx->flat_pre_host.empty() &&
-                           ctx->flat_pre_host.size() <= kFlatPreArgFloats &&
-                           ctx->flat_pre_host.size() == (size_t)ctx->scene.pre_tri_pairs * kTriPairFloats + (size_t)ctx->scene.pre_sph_pairs * kSphPairFloats;
     if (flat_only)
         kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
                                     : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
@@ -957,7 +959,10 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * g.block;
     } else if (flat_karg && launch_scene.flat_pre) {
-        if (int rc = launchGeometry(ctx, renderKernelFlatK, launch_scene, g, 2)) return rc;
+        if (int rc = flat_block == 1024  ? launchGeometry(ctx, renderKernelFlatK<1024>, launch_scene, g, 4)
+                     : flat_block == 768 ? launchGeometry(ctx, renderKernelFlatK<768>, launch_scene, g, 3)
+                                         : launchGeometry(ctx, renderKernelFlatK<>, launch_scene, g, 2))
+            return rc;
     } else if (int rc = launchGeometry(ctx, kernel, launch_scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
         return rc;
     }
@@ -1065,7 +1070,9 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
                 FlatPreArg pre;
                 memset(&pre, 0, sizeof(pre));
                 memcpy(pre.v, ctx->flat_pre_host.data(), ctx->flat_pre_host.size() * sizeof(float));
-                hipLaunchKernelGGL(renderKernelFlatK, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
+                if (g.block == 1024u) hipLaunchKernelGGL(renderKernelFlatK<1024>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
+                else if (g.block == 768u) hipLaunchKernelGGL(renderKernelFlatK<768>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
+                else hipLaunchKernelGGL(renderKernelFlatK<>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
             } else {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
             }

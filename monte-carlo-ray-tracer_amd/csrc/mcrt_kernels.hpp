@@ -457,8 +457,9 @@ struct FlatPreArg {
     float v[kFlatPreArgFloats];
 };
 static_assert(sizeof(DeviceScene) + sizeof(RenderParams) + sizeof(FlatPreArg) + 64 <= 4096, "the argument block of renderKernelFlatK");
-__global__ void __launch_bounds__(kBlock) renderKernelFlatK(const DeviceScene scene, const RenderParams prm, const FlatPreArg pre) {
-    renderKernelBody<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1, true>(scene, prm, pre.v);
+template <int kLanes = (int)kBlock>  // 512, 768 (3 waves per SIMD, 168 VGPRs) or 1024 (4 waves, 128 VGPRs): MCRT_FLAT_BLOCK
+__global__ void __launch_bounds__(kLanes) renderKernelFlatK(const DeviceScene scene, const RenderParams prm, const FlatPreArg pre) {
+    renderKernelBody<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, kLanes == 1024 ? 3 : kLanes == 768 ? 2 : 1, true>(scene, prm, pre.v);
 }
 
 // ------------------------------------------------------------------------------------------------

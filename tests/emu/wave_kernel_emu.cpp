@@ -319,7 +319,7 @@ int wemu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, 
             memset(&pre, 0, sizeof(pre));
             memcpy(pre.v, E.L.flat_pre.data(), floats * sizeof(float));
             kernel_id = 16;
-            launchGrid(grid, block, [&] { renderKernelFlatK(launch_scene, prm, pre); });
+            launchGrid(grid, block, [&] { renderKernelFlatK<>(launch_scene, prm, pre); });
         } else {
             launchGrid(grid, block, [&] { renderKernel<MCRT_INTEGRATOR_PATH_TRACER, false, true, false, 1>(launch_scene, prm); });
         }
