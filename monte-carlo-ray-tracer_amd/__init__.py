@@ -25,7 +25,7 @@ INTEGRATOR_PHOTON_MAPPER = 1
 LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2, LIBM_SINCOSF = range(6)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
 # mcrt_stats.kernel_id (include/mcrt.h MCRT_KERNEL_*)
 KERNEL_NONE, KERNEL_FLAT, KERNEL_WAVESYNC, KERNEL_LANE_SM, KERNEL_WAVEFRONT, KERNEL_PM_WAVE, KERNEL_PM_LANE, KERNEL_WAVEFRONT_PM = range(8)
-KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernel<path_tracer, flat>", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
+KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernelFlatK (flat loop; renderKernel<path_tracer, flat> when the cull records do not fit the argument block)", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
                 KERNEL_LANE_SM: "renderKernelSM", KERNEL_WAVEFRONT: "wfTraceKernel + wfShadeKernel", KERNEL_PM_WAVE: "renderKernelPM",
                 KERNEL_PM_LANE: "renderKernel<photon_mapper>", KERNEL_WAVEFRONT_PM: "wfTraceKernel + wfKnnKernel + wfShadeKernel"}
 SURF_TRIANGLE, SURF_SPHERE = 0, 1
