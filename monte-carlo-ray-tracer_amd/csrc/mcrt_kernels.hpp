@@ -845,7 +845,9 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     // contiguous share per workgroup has no atomics either, but neighbouring entries are rays from the same part of the
     // image and the parts differ in cost: the same rays traced 12 % faster shuffled than in pixel order and 20 % slower
     // sorted by origin; dealt in blocks of 64 every order gains and pixel order is the fastest, tools/ray_sort_probe.py.
-    // Interleaved blocks keep a refill's reads consecutive and give every workgroup a sample of the whole queue.)
+    // Interleaved blocks keep a refill's reads consecutive and give every workgroup a sample of the whole queue. Numbering a round's
+    // blocks XCD by XCD - the workgroups that share an L2 taking 2048+ NEIGHBOURING rays - changes nothing: +-0.1 % on C3 / C4 /
+    // spaceship, round 5, profiles/r05_ab_trace_deal_xcd.log.)
     const unsigned long long n = *a.count;
     MCRT_LDS_AS uint32_t* cursor = ldsAt<uint32_t>(lds, a.lds_blocks * 64u + (uint32_t)a.lds_stack * blockDim.x * (uint32_t)sizeof(SmStackEntry));
     // (behind the cursor's 64 bytes: the rank -> lane map of every wave's shared leaf steps)

@@ -283,7 +283,10 @@ MCRT_HD void travInnerStepQ(const QView<kLds>& qv, Trav& T, const SmStack& stk, 
 //     No overflow test: the stack is sized to the tree's own bound (HostLayout::stack_bound), no walk can exceed it.
 // Same blocks, same tests, same keys, same order of the kept children: the walk visits exactly what travInnerStepQ visits.
 // (Tried on top, round 5: the entry and exit distance of an axis as ONE v_pk_fma_f32 - 12 instructions fewer per visit and 0.6 % SLOWER
-// on C3 and C4, profiles/r05_ab_trace_pk_stack.log: a packed FP32 operation takes the SIMD as long as the two it replaces. Removed.)
+// on C3 and C4, profiles/r05_ab_trace_pk_stack.log: a packed FP32 operation takes the SIMD as long as the two it replaces. Removed.
+// Also tried: asking for the first word of the block the ray continues with at the END of the visit that chose it, so that the block
+// is on its way to the L2 while the wave runs its leaf step - one more load and register per visit, 1.0 % / 0.7 % SLOWER on C3 / C4,
+// profiles/r05_ab_builds_touch_flags.log. Removed.)
 template <bool kLds, bool kCount, bool kSingle>
 MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const LeanRay& R, const SmStack& stk, TraceCounters& cnt) {
     const float best_up = R.best_up;
