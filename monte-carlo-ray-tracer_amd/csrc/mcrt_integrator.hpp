@@ -263,6 +263,35 @@ MCRT_HD void knnSiftDown(const KnnScratch& s, uint32_t size, KnnEntry value, uin
     }
     s.setRes(index, value);
 }
+// PriorityQueue::make_heap (priority-queue.hpp:57-84), step for step: the array the reference's loops over `photons` then walk.
+MCRT_HD void knnMakeHeap(const KnnScratch& s, uint32_t size) {
+    if (size <= 1) return;
+    const uint32_t last_index = size - 1;
+    uint32_t index = (last_index - 1) / 2;
+    auto swapIfLess = [&](uint32_t a, uint32_t b) {  // if (H[a] < H[b]) std::swap(H[a], H[b])
+        const KnnEntry ea = s.res(a), eb = s.res(b);
+        if (ea.distance2 < eb.distance2) {
+            s.setRes(a, eb);
+            s.setRes(b, ea);
+        }
+    };
+    if (last_index % 2) {
+        swapIfLess(index, 2 * index + 1);
+        if (index == 0) return;
+        index--;
+    }
+    if (index) {
+        const uint32_t lowest_index_with_no_grandchildren = (last_index - 3) / 4 + 1;
+        do {
+            const uint32_t left = 2 * index + 1;
+            const uint32_t max_child = left + (s.res(left).distance2 < s.res(left + 1).distance2 ? 1u : 0u);
+            swapIfLess(index, max_child);
+        } while (index-- != lowest_index_with_no_grandchildren);
+    }
+    do {
+        knnSiftDown(s, size, s.res(index), index);
+    } while (index--);
+}
 // Min-heap on distance2 of octants still to visit (linear-octree.cpp:37-44; priority-queue.hpp:19-45).
 MCRT_HD void visitPush(const KnnScratch& s, uint32_t& size, OctantEntry value) {
     if (size >= kMaxVisit) return;  // cannot happen for octrees of depth <= 13; guarded anyway
@@ -296,9 +325,9 @@ MCRT_HD void visitPop(const KnnScratch& s, uint32_t& size) {
     }
 }
 
-// LinearOctree<Photon>::knnSearch (linear-octree.cpp:25-117). The k-set returned equals the
-// reference's (same pruning rules, inclusive <= comparisons); only the order of equal-distance
-// octants in the frontier may differ, which does not change the set.
+// LinearOctree<Photon>::knnSearch (linear-octree.cpp:25-117), per lane: the reference's pruning rules (inclusive <= comparisons), its
+// two queues operation for operation (PriorityQueue::push / pop / push_unordered / make_heap / pop_push) - the k-set AND the order
+// of the result array are the reference's.
 MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnScratch& s, uint32_t& octant_visits) {
     if (m.num_octants == 0) return 0;
     if ((uint64_t)k > m.num_photons) k = (uint32_t)m.num_photons;
@@ -317,22 +346,18 @@ MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnSc
                 d3 d = p - d3{(double)ph[3], (double)ph[4], (double)ph[5]};  // glm::distance2(data.pos(), p)
                 double distance2 = dot(d, d);
                 if (distance2 <= max_distance2) {
-                    if (count < k) {
-                        // The reference appends unordered and heapifies at the k-th element
-                        // (linear-octree.cpp:60-72); sifting up keeps a heap throughout.
-                        uint32_t index = count++;
-                        KnnEntry value{distance2, i};
-                        while (index > 0) {
-                            uint32_t parent = (index - 1) / 2;
-                            KnnEntry pe = s.res(parent);
-                            if (!(pe.distance2 < value.distance2)) break;
-                            s.setRes(index, pe);
-                            index = parent;
-                        }
-                        s.setRes(index, value);
-                        if (count == k) max_distance2 = gmin(max_distance2, s.res(0).distance2);
+                    // linear-octree.cpp:58-79, with its heap discipline: the first k - 1 results appended unordered, the heap made at
+                    // the k-th (make_heap), then pop_push - so the result ARRAY is the reference's, and a loop over it sums an
+                    // estimate's photons in the reference's order (round 5; a heap kept by sifting up held the same set in another order)
+                    if (count + 1u < k) {
+                        s.setRes(count++, KnnEntry{distance2, i});
                     } else {
-                        knnSiftDown(s, count, KnnEntry{distance2, i}, 0);  // pop_push
+                        if (count != k) {
+                            s.setRes(count++, KnnEntry{distance2, i});
+                            knnMakeHeap(s, count);
+                        } else {
+                            knnSiftDown(s, count, KnnEntry{distance2, i}, 0);  // pop_push
+                        }
                         double top = s.res(0).distance2;
                         if (top < max_distance2) max_distance2 = top;
                     }
@@ -361,19 +386,27 @@ MCRT_HD uint32_t knnSearch(const PhotonMapView& m, d3 p, uint32_t k, const KnnSc
     return count;
 }
 
-MCRT_HD d3 photonDirection(const float* ph) {  // Photon::dir, photon.hpp:19-27 (float sin/cos overloads: glibc's sincosf, refSinCosF)
+// Photon::dir, photon.hpp:19-27 (float sin/cos overloads: glibc's sincosf, refSinCosF). kExact: the restated sincosf, bit for bit
+// (csrc/mcrt_libm.hpp; tests/test_libm.py) - what the per-lane estimates below use, whose sums run in the reference's order.
+template <bool kExact = false>
+MCRT_HD d3 photonDirection(const float* ph) {
     float phi = ph[6], theta = ph[7];
     float st, ct, sp, cp;
 #if defined(MCRT_EXACT_PHOTON_DIR)
-    refSinCosF(theta, st, ct);  // glibc's sincosf, bit for bit (csrc/mcrt_libm.hpp; tests/test_libm.py)
-    refSinCosF(phi, sp, cp);
+    constexpr bool exact = true;
 #else
-    // The platform's sinf / cosf. The restated sincosf is exact and NOT the default here: inside renderKernelPM (128 VGPRs, ~700 spilled)
-    // it costs a C5 frame 8.8 % (766 -> 832 ms on the 64 spp probe; as a called function or a loop over the two angles 954 / 987 ms:
-    // profiles/r05_ab_c5_bisect.log), and it buys nothing a test can see - the k terms of an estimate are summed by a wave reduction, not
-    // in the reference's heap order, so photon-mapped frames are compared at 1e-10 either way. -DMCRT_EXACT_PHOTON_DIR selects it.
-    st = sinf(theta); ct = cosf(theta); sp = sinf(phi); cp = cosf(phi);
+    // Not the default of the wave-cooperative estimates: inside renderKernelPM (128 VGPRs, ~700 spilled) the restated sincosf costs a
+    // C5 frame 8.8 % (766 -> 832 ms on the 64 spp probe; as a called function or a loop over the two angles 954 / 987 ms:
+    // profiles/r05_ab_c5_bisect.log), and it buys nothing a test can see there - those k terms are summed by a wave reduction, not in
+    // the reference's heap order, so the frames are compared at 1e-10 either way. -DMCRT_EXACT_PHOTON_DIR selects it everywhere.
+    constexpr bool exact = kExact;
 #endif
+    if constexpr (exact) {
+        refSinCosF(theta, st, ct);
+        refSinCosF(phi, sp, cp);
+    } else {
+        st = sinf(theta); ct = cosf(theta); sp = sinf(phi); cp = cosf(phi);
+    }
     double sin_theta = (double)st;
     return d3{sin_theta * (double)cp, sin_theta * (double)sp, (double)ct};
 }
@@ -397,7 +430,7 @@ MCRT_HD d3 estimateGlobalRadiance(const PhotonViews& pv, const InteractionT<L>& 
         const float* ph = m.photons + (size_t)s.res(i).index * 8;
         d3 bsdf_absIdotN;
         double bsdf_pdf;
-        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection(ph), bsdf_pdf))
+        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection<true>(ph), bsdf_pdf))
             radiance = radiance + d3{(double)ph[0], (double)ph[1], (double)ph[2]} * bsdf_absIdotN / bsdf_pdf;
     }
     return radiance / (s.res(0).distance2 * kPi);
@@ -418,7 +451,7 @@ MCRT_HD d3 estimateCausticRadiance(const PhotonViews& pv, const InteractionT<L>&
         const float* ph = m.photons + (size_t)e.index * 8;
         d3 bsdf_absIdotN;
         double bsdf_pdf;
-        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection(ph), bsdf_pdf)) {
+        if (interactionBSDF(ia, bsdf_absIdotN, photonDirection<true>(ph), bsdf_pdf)) {
             double wp = gmax(0.0, 1.0 - sqrt(e.distance2 * inv_max_squared_radius));
             radiance = radiance + (d3{(double)ph[0], (double)ph[1], (double)ph[2]} * bsdf_absIdotN * wp) / bsdf_pdf;
         }

@@ -151,8 +151,9 @@ def test_photon_mapper_device_code(pkg, emu, manifest):
     r = case["renders"][0]
     out, _ = _emu_render(emu, pkg, img, camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER, r["rows"], 1)
     ref = load_radiance(r)
-    # the k photons are summed in heap-array order, which differs from the reference's -> few ulp
-    assert rel_error(out, ref).max() < 1e-12
+    # the per-lane search keeps the reference's heap discipline (push_unordered / make_heap / pop_push), so the k photons of an
+    # estimate are summed in the reference's order: the photon-mapped frame is the reference's bits
+    np.testing.assert_array_equal(out, ref)
 
 
 def test_sampler_byte_tables_equal_reference(emu, manifest):

@@ -92,7 +92,7 @@ def _config(pkg, name):
     return pkg.SceneImage(p), make_large.CONFIGS[name], make_large.golden_path(name)
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm", "c5_s16", "baroque", "lego", "pipes"])
+@pytest.mark.parametrize("name", ["c3", "c4", "c5", "c3:sm", "c5_s16:legacy", "c5_s16", "baroque", "lego", "pipes"])
 def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     """A few full-width rows of the real frame — C3: 491 592 triangles @ 1024 spp; C4: 457 200 triangles, 3840 wide
     @ 1024 spp; C5: 6 898 815 triangles, photon-mapped; baroque_table / lego_bulldozer / pipes: the reference's own scene
@@ -126,7 +126,16 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     differing = int((got != ref).any(axis=2).sum())
     print("%s rows %d-%d: max rel %.3e, pixels that are not the reference's bits %d / %d, %.1f Mray/s, %.2f rays/path" %
           (name, r0, r1, rel.max(), differing, rel.size, st["rays"] / st["kernel_ms"] / 1e3, st["rays"] / st["paths"]))
-    if c["photon"]:
+    if c["photon"] and kernel == "legacy":
+        # The per-lane kernel keeps the reference's heap discipline and its sincosf: on the SAME map its photon-mapped rows are the
+        # reference's bits (tests/test_gpu_parity.py: hexagon_room_pm, map and frame from one run of the reference). This image's
+        # map was traced by another run of the reference than its golden rows - same photons, leaves filled in another, thread-
+        # dependent order (tests/test_oracle_large.py) - so the judge here is the oracle, the reference's algorithm on THIS map:
+        import oracle_lib
+        want, _ = oracle_lib.render(img, cam, 0x12345678, integ, rows=(r0, r1))
+        np.testing.assert_array_equal(got, want, err_msg="%s: the per-lane kernel's rows are not the oracle's bits" % name)
+        assert rel.max() <= 1e-10
+    elif c["photon"]:
         # photon-mapped rows: the k photons of an estimate are summed by a wave reduction, not in the reference's heap order
         assert rel.max() <= 1e-10
     elif differing:
@@ -146,7 +155,7 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
         # (round 4, first run with every libm call restated and the exact shadow query: no frame needs this branch - C3, C4, baroque_table,
         # lego_bulldozer, pipes and the spaceship cockpit are all the reference's bits; the branch stays as the only admissible way out)
     # (the pipeline is the default for trees of 65 536 nodes or more: baroque_table and lego_bulldozer stay with the lane state machine)
-    want = pkg.KERNEL_PM_WAVE if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" or c["nodes"] < 65536 else pkg.KERNEL_WAVEFRONT
+    want = (pkg.KERNEL_PM_LANE if kernel == "legacy" else pkg.KERNEL_PM_WAVE) if c["photon"] else pkg.KERNEL_LANE_SM if kernel == "sm" or c["nodes"] < 65536 else pkg.KERNEL_WAVEFRONT
     assert st["kernel_id"] == want, pkg.KERNEL_NAMES.get(st["kernel_id"])
     ctx.close()
 

@@ -9,7 +9,8 @@ Round 3: the device computes the reference's sin / cos pairs with glibc's own si
 Scene::skyColor's asin with glibc's own asin (refAsin) - the last libm call of the path-traced path. EVERY path-traced golden frame
 is now required to be the reference's bits (EXACT below = all of them), and the outlier allowance is gone. Photon-mapped
 frames keep their own bar AGAINST THE REFERENCE (the k photons of an estimate are summed by a wave reduction, not in heap order:
-1e-12); among themselves — passes, chunking, shards, contexts, megakernel against pipeline — they are bit-equal."""
+1e-12); among themselves — passes, chunking, shards, contexts, megakernel against pipeline — they are bit-equal. Round 5: through the
+per-lane kernel, which keeps the reference's heap discipline, the photon-mapped frame IS the reference's bits."""
 import ctypes as C
 import os
 
@@ -190,6 +191,23 @@ def test_photon_mapper_matches_reference(pkg, ctx, manifest):
     out, st = ctx.sample_image(camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
     _check(out, load_radiance(r), "hexagon_room_pm")
     assert st["knn_searches"] > 0 and st["kernel_id"] == pkg.KERNEL_PM_WAVE
+
+
+def test_photon_mapper_per_lane_kernel_is_the_references_bits(pkg, ctx, manifest, kernel_env):
+    """The per-lane photon-mapper kernel (MCRT_KERNEL=legacy: renderKernel<photon_mapper>, every lane its own search) keeps the
+    reference's heap discipline - push_unordered up to k - 1 results, make_heap at the k-th, pop_push after (linear-octree.cpp:58-79,
+    priority-queue.hpp) - and the restated sincosf for Photon::dir, so the k photons of an estimate are summed in the reference's
+    order: the photon-mapped frame is the reference's BITS. What separates the wave-cooperative kernels' frames from the
+    reference's (1e-12 above) is therefore the order of those sums and nothing else."""
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    ctx.upload_image(img)
+    ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons") or 50, bool(img.param("direct_visualization")))
+    r = case["renders"][0]
+    kernel_env("legacy")
+    out, st = ctx.sample_image(camera_for(img, r), manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    assert st["kernel_id"] == pkg.KERNEL_PM_LANE and st["knn_searches"] > 0
+    _check(out, load_radiance(r), "hexagon_room_pm per-lane kernel", exact=True)
 
 
 def test_photon_mapper_wavefront_pipeline(pkg, ctx, manifest, kernel_env):
