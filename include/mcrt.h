@@ -364,9 +364,10 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
  * the bits the reference's std::sin / std::cos pairs (= sincos: sampling/sampling.hpp:29-44, material/ggx.cpp:77-79, surface/sphere.cpp:43),
  * std::sin alone (camera/filter.hpp:64), std::asin (scene/scene.cpp:221) and std::atan2 (integrator/photon-mapper/photon.hpp:10-11)
  * return on an x86-64 host with FMA; SINCOSF: sincosf, the sine / cosine pairs of Photon::dir's two float angles, photon.hpp:19-27 - a[n]
- * holds float values, out0 / out1 the float results widened). fn selects the function; a[n] (and b[n] for atan2: a = y, b = x) are the
+ * holds float values, out0 / out1 the float results widened). fn selects the function; a[n] (and b[n] for atan2: a = y, b = x, and for pow: a^b) are the
  * arguments, out0[n] (and out1[n] for sincos / sincosf: out0 = sine, out1 = cosine) the results. Known-answer tests only; no scene needed. */
-enum { MCRT_LIBM_SINCOS = 0, MCRT_LIBM_SIN = 1, MCRT_LIBM_COS = 2, MCRT_LIBM_ASIN = 3, MCRT_LIBM_ATAN2 = 4, MCRT_LIBM_SINCOSF = 5 };
+enum { MCRT_LIBM_SINCOS = 0, MCRT_LIBM_SIN = 1, MCRT_LIBM_COS = 2, MCRT_LIBM_ASIN = 3, MCRT_LIBM_ATAN2 = 4, MCRT_LIBM_SINCOSF = 5,
+       MCRT_LIBM_POW = 6 /* std::pow(a, b): sRGB::gammaCompress, color/srgb.hpp:54-62 - the one libm call of Image::save (csrc/mcrt_libm_pow.hpp) */ };
 int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1);
 
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map

@@ -22,7 +22,7 @@ ABI_VERSION = 2
 FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
 INTEGRATOR_PATH_TRACER = 0
 INTEGRATOR_PHOTON_MAPPER = 1
-LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2, LIBM_SINCOSF = range(6)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
+LIBM_SINCOS, LIBM_SIN, LIBM_COS, LIBM_ASIN, LIBM_ATAN2, LIBM_SINCOSF, LIBM_POW = range(7)  # mcrt_libm function selectors (include/mcrt.h MCRT_LIBM_*)
 # mcrt_stats.kernel_id (include/mcrt.h MCRT_KERNEL_*)
 KERNEL_NONE, KERNEL_FLAT, KERNEL_WAVESYNC, KERNEL_LANE_SM, KERNEL_WAVEFRONT, KERNEL_PM_WAVE, KERNEL_PM_LANE, KERNEL_WAVEFRONT_PM = range(8)
 KERNEL_NAMES = {KERNEL_NONE: "none", KERNEL_FLAT: "renderKernelFlatK (flat loop; renderKernel<path_tracer, flat> when the cull records do not fit the argument block)", KERNEL_WAVESYNC: "renderKernel<path_tracer>",
@@ -639,7 +639,7 @@ class Context:
 
     def libm(self, fn, a, b=None):
         """mcrt_libm: the device's sincos (fn 0 -> (sin, cos)), sin (1), cos (2), asin (3), atan2 (4: a = y, b = x), sincosf (5: float
-        values in, (sin, cos) widened out) on arrays."""
+        values in, (sin, cos) widened out), pow (6: a ** b) on arrays."""
         a = np.ascontiguousarray(a, dtype=np.float64)
         out0, out1 = np.zeros_like(a), np.zeros_like(a)
         bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None

@@ -1969,21 +1969,25 @@ int mcrt_bsdf(mcrt_ctx* ctx, uint64_t n, const double* in, const double* consts,
 
 int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
     if (!ctx) return MCRT_ERR_INVALID;
-    if (fn < MCRT_LIBM_SINCOS || fn > MCRT_LIBM_SINCOSF) return fail(ctx, MCRT_ERR_INVALID, "mcrt_libm: unknown function selector");
+    if (fn < MCRT_LIBM_SINCOS || fn > MCRT_LIBM_POW) return fail(ctx, MCRT_ERR_INVALID, "mcrt_libm: unknown function selector");
     if (n == 0) return MCRT_OK;
-    const bool two = fn == MCRT_LIBM_SINCOS || fn == MCRT_LIBM_SINCOSF;
-    if (!a || !out0 || (fn == MCRT_LIBM_ATAN2 && !b) || (two && !out1)) return fail(ctx, MCRT_ERR_INVALID, "null argument");
+    const bool two = fn == MCRT_LIBM_SINCOS || fn == MCRT_LIBM_SINCOSF, pair = fn == MCRT_LIBM_ATAN2 || fn == MCRT_LIBM_POW;
+    if (!a || !out0 || (pair && !b) || (two && !out1)) return fail(ctx, MCRT_ERR_INVALID, "null argument");
     REJECT_IF_PENDING(ctx, "mcrt_libm");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf &da = ctx->op_buf[0], &db = ctx->op_buf[1], &d0 = ctx->op_buf[2], &d1 = ctx->op_buf[3];
     if (int rc = uploadInto(ctx, da, a, n)) return rc;
-    if (fn == MCRT_LIBM_ATAN2)
+    if (pair)
         if (int rc = uploadInto(ctx, db, b, n)) return rc;
     HIP_TRY(ctx, d0.reserve(n * 8));
     HIP_TRY(ctx, d1.reserve(n * 8));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(4096, (n + 255) / 256);
-    hipLaunchKernelGGL(libmKernel, dim3(grid), dim3(256), 0, ctx->stream, fn, n, da.as<double>(), db.as<double>(), d0.as<double>(), d1.as<double>());
-    HIP_TRY(ctx, hipGetLastError());
+    if (fn == MCRT_LIBM_POW) {  // (the output stage's function: its kernel lives with that stage, mcrt_output.hip)
+        HIP_TRY(ctx, (hipError_t)launchPowKat(ctx->stream, n, da.as<double>(), db.as<double>(), d0.as<double>()));
+    } else {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(4096, (n + 255) / 256);
+        hipLaunchKernelGGL(libmKernel, dim3(grid), dim3(256), 0, ctx->stream, fn, n, da.as<double>(), db.as<double>(), d0.as<double>(), d1.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out0, d0.p, n * 8, hipMemcpyDeviceToHost));
     if (two) HIP_TRY(ctx, hipMemcpy(out1, d1.p, n * 8, hipMemcpyDeviceToHost));

@@ -19,4 +19,7 @@ bool ctxOptOn(const mcrt_ctx* ctx, const char* key);            // set and not 0
 int bvhOctreeGpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, struct ::mcrt_bvh* out);
 // mcrt_sah_gpu.hip: the binned-SAH hierarchies level by level with the per-surface passes on the GPU of ctx (mcrt_sah_shared.hpp)
 int bvhSahGpu(mcrt_ctx* ctx, const mcrt_scene_desc* scene, int arity, int bins, struct ::mcrt_bvh* out);
+// mcrt_output.hip: refPow (mcrt_libm_pow.hpp, the output stage's one libm call) on device arrays, launched on `stream`: out[i] =
+// pow(a[i], b[i]). The known-answer kernel behind mcrt_libm's MCRT_LIBM_POW; returns the hipError_t of the launch as an int.
+int launchPowKat(void* stream, uint64_t n, const double* a, const double* b, double* out);
 }  // namespace mcrt

@@ -10,6 +10,7 @@
 // 1920x1080 frame, some tens of microseconds per pass; the histogram atomics go to L2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -198,6 +199,18 @@ extern "C" int mcrt_tonemap(mcrt_ctx* ctx, const double* rgb, const mcrt_image_d
     OUT_TRY(hipStreamSynchronize(stream));
     (void)hipFree(scratch);
     return MCRT_OK;
+}
+
+// mcrt_libm(MCRT_LIBM_POW): the pow the develop kernel inlines, on arrays (known-answer test against the host's glibc, tests/test_libm.py)
+namespace {
+__global__ void __launch_bounds__(256) powKatKernel(uint64_t n, const double* a, const double* b, double* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = mcrt::refPow(a[i], b[i]);
+}
+}  // namespace
+int mcrt::launchPowKat(void* stream, uint64_t n, const double* a, const double* b, double* out) {
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(powKatKernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+    return (int)hipGetLastError();
 }
 
 // HeaderTGA (camera/image.hpp:39-50): 12 bytes {0, 0, 2, 0...}, width, height (little-endian 16 bit), {24, 32}; then the

@@ -6,6 +6,7 @@
 #pragma once
 
 #include "../../include/mcrt.h"
+#include "mcrt_libm_pow.hpp"
 #include "mcrt_math.hpp"
 
 namespace mcrt {
@@ -59,8 +60,8 @@ MCRT_HD uint32_t histogramBin(double v, double bin_size) {
     return !(q < (double)(kHistogramBins - 1)) ? kHistogramBins - 1 : (uint32_t)q;
 }
 
-MCRT_HD double gammaCompress(double x) {  // srgb.hpp:55-63
-    return x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
+MCRT_HD double gammaCompress(double x) {  // srgb.hpp:55-63; std::pow = glibc's, restated (mcrt_libm_pow.hpp)
+    return x <= 0.0031308 ? 12.92 * x : 1.055 * refPow(x, 1.0 / 2.4) - 0.055;
 }
 
 // truncate(sRGB::gammaCompress(tonemap(p * exposure) * gain)) -> bytes b, g, r (image.cpp:47, pixel-operators.cpp:51-55);

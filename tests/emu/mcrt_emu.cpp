@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_libm.hpp"
+#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_libm_pow.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_layout.hpp"
@@ -914,6 +915,49 @@ void emu_sincosf_check(uint32_t first, uint32_t last, uint64_t* out) {
         }
 }
 
+// refPow (mcrt_libm_pow.hpp) against this host's pow. family 0: n arguments x uniform in [lo, hi] with y = 1 / 2.4 (sRGB::gammaCompress);
+// family 1: x = 2^e m with e uniform in [-300, 300], m in [1, 2), y uniform in [-2.4, 2.4]; family 2: x within a few thousand ulps of 1 and
+// of the table's interval boundaries (bits OFF + (i << 45)), y = 1 / 2.4 and y uniform in [-2.4, 2.4] alternately (|y log x| < 512 throughout:
+// the restated main path; beyond it refPow IS the platform's pow). out: {differing results,
+// bits of the first differing x, bits of its y}.
+void emu_pow_check(int family, uint64_t n, double lo, double hi, uint64_t seed, uint64_t* out) {
+    double (*volatile f_pow)(double, double) = ::pow;
+    out[0] = out[1] = out[2] = 0;
+    uint64_t state = seed;
+    auto next = [&]() {
+        uint64_t zz = (state += 0x9E3779B97F4A7C15ull);
+        zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+        zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+        return zz ^ (zz >> 31);
+    };
+    auto unit = [&]() { return (double)(next() >> 11) * 0x1.0p-53; };
+    const double g = 1.0 / 2.4;
+    for (uint64_t i = 0; i < n; i++) {
+        double x, y;
+        if (family == 0) {
+            x = lo + (hi - lo) * unit();
+            y = g;
+        } else if (family == 1) {
+            const int e = (int)(next() % 601u) - 300;
+            x = ldexp(1.0 + unit(), e);
+            y = -2.4 + 4.8 * unit();
+        } else {
+            const uint64_t r = next();
+            const uint64_t centre = (r & 1u) ? 0x3ff0000000000000ull : 0x3fe6955500000000ull + (((r >> 1) & 127u) << 45);
+            x = bitsD(centre + ((r >> 8) & 0x1FFFu) - 0x1000u);
+            y = (r & 0x200000u) ? g : -2.4 + 4.8 * unit();
+        }
+        const double a = refPow(x, y), b = f_pow(x, y);
+        if (dBits(a) != dBits(b)) {
+            if (!out[0]) {
+                out[1] = dBits(x);
+                out[2] = dBits(y);
+            }
+            out[0]++;
+        }
+    }
+}
+
 // This host's libm on arrays (the expected values of the GPU known-answer test of mcrt_libm): fn as MCRT_LIBM_*. Every function is
 // called through its own volatile pointer, one call per argument (a sin and a cos of one argument would be merged into sincos).
 void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double* out0, double* out1) {
@@ -923,8 +967,11 @@ void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double*
     double (*volatile f_atan2)(double, double) = ::atan2;
     void (*volatile f_sincos)(double, double*, double*) = ::sincos;
     void (*volatile f_sincosf)(float, float*, float*) = ::sincosf;
+    double (*volatile f_pow)(double, double) = ::pow;
     for (uint64_t i = 0; i < n; i++) {
-        if (fn == 5) {
+        if (fn == 6) {
+            out0[i] = f_pow(a[i], b[i]);
+        } else if (fn == 5) {
             float sn, cs;
             f_sincosf((float)a[i], &sn, &cs);
             out0[i] = (double)sn;

@@ -97,8 +97,13 @@ def test_tga_save_writes_the_reference_file(pkg, manifest, tmp_path):
 # GPU: the kernels of mcrt_output.hip through the C ABI
 # ---------------------------------------------------------------------------------------------------------------------
 def _assert_bytes_close(bgr, want, what):
-    """Every step but pow() is exact; ocml's pow may differ from glibc's in the last bit, which moves a byte only when
-    the value sits within an ulp of an integer."""
+    """Round 5: gammaCompress's pow is glibc's, restated (csrc/mcrt_libm_pow.hpp; tests/test_libm.py), so EVERY byte is the reference's
+    - on a host whose libm is the restated one (the oracle / the goldens' maker called it). Elsewhere the round-4 bar: ocml-class
+    last-bit differences of pow move a byte only where the value sits within an ulp of an integer."""
+    from conftest import host_libm_is_the_restated_one
+    if host_libm_is_the_restated_one():
+        np.testing.assert_array_equal(bgr, want, err_msg="%s: not the reference's bytes" % what)
+        return
     diff = bgr.astype(np.int16) - want.astype(np.int16)
     assert np.abs(diff).max() <= 1, what
     assert np.count_nonzero(diff) <= max(1, diff.size // 10000), "%s: %d bytes differ" % (what, np.count_nonzero(diff))

@@ -95,6 +95,22 @@ def test_restated_sincosf_equals_glibc_on_every_float_of_the_range(emu):
     assert not (bad + out[:4]).any(), "sincosf differs on %s sampled arguments of (4, 120)" % (bad + out[:4])
 
 
+def test_restated_pow_equals_glibc(emu):
+    """refPow (sRGB::gammaCompress's std::pow(x, 1 / 2.4), color/srgb.hpp:54-62 - the one libm call of Image::save) = the FMA variant of
+    glibc 2.35's pow, bit for bit: the gamma curve's own range densely, 600 binades of x with random exponents y, and the neighbourhoods of
+    1 and of every boundary of the log table."""
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        pytest.skip("the restatement is of x86-64 glibc")
+    if not (_has("fma") and _has("avx2")):
+        pytest.skip("this CPU has no FMA/AVX2: libm's pow is another IFUNC variant than the one restated")
+    emu.emu_pow_check.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_void_p]
+    out = np.zeros(3, dtype=np.uint64)
+    for family, n, lo, hi in ((0, 4000000, 0.0031308, 1.0), (0, 2000000, 1.0, 64.0), (0, 500000, 0.0, 0.0032), (1, 3000000, 0, 0), (2, 2000000, 0, 0)):
+        emu.emu_pow_check(family, n, lo, hi, 20260927 + family, out.ctypes.data)
+        f = out[1:].view(np.float64)
+        assert out[0] == 0, "pow differs on %d of %d arguments of family %d, first at x = %r (%s), y = %r" % (out[0], n, family, f[0], float(f[0]).hex(), f[1])
+
+
 @pytest.mark.gpu
 def test_device_libm_equals_glibc_bits(pkg, emu):
     """The DEVICE's sincos / sin / cos / asin / atan2 (mcrt_libm through the C ABI: the functions the kernels inline, compiled for
@@ -148,6 +164,17 @@ def test_device_libm_equals_glibc_bits(pkg, emu):
     gs, gc = ctx.libm(pkg.LIBM_SINCOSF, a)
     hs, hc = host(5, a)
     assert same(gs, hs) and same(gc, hc), "sincosf: %d / %d arguments differ" % ((gs != hs).sum(), (gc != hc).sum())
+    # pow (sRGB::gammaCompress: x^(1 / 2.4) over the tone-mapped range), other exponents over 600 binades (|y log x| < 512: the restated
+    # main path - beyond it refPow hands over to the platform's pow), around 1 and the log table's boundaries
+    g24 = 1.0 / 2.4
+    near = (0x3fe6955500000000 + (rng.integers(0, 128, 500000).astype(np.uint64) << np.uint64(45)) + rng.integers(-4096, 4097, 500000).astype(np.uint64)).view(np.float64)
+    x = np.concatenate([0.0031308 + rng.random(3000000) * 1.2, rng.random(500000) * 64.0, np.ldexp(1.0 + rng.random(1000000), rng.integers(-300, 301, 1000000)),
+                        near, 1.0 + rng.integers(-4096, 4097, 200000) * 2.0 ** -52])
+    y = np.concatenate([np.full(3500000, g24), rng.random(1000000) * 4.8 - 2.4, np.where(rng.random(500000) < 0.5, g24, rng.random(500000) * 4.8 - 2.4),
+                        np.full(200000, g24)])
+    g, h = ctx.libm(pkg.LIBM_POW, x, y), host(6, x, y)[0]
+    bad = g.view(np.uint64) != h.view(np.uint64)
+    assert not bad.any(), "pow: %d pairs differ, first x = %r (%s), y = %r" % (bad.sum(), x[bad][0], float(x[bad][0]).hex(), y[bad][0])
     ctx.close()
 
 
