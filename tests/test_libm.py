@@ -178,6 +178,20 @@ def test_device_libm_equals_glibc_bits(pkg, emu):
     ctx.close()
 
 
+def test_pow_tables_are_glibcs():
+    """The committed tables of refPow against an independent evaluation (Fractions, no libm): every log entry's logc + logctail is
+    -log(invc) to 2^-68 with invc = j / 256 near its interval, ln 2 splits as the algorithm needs, every exp entry is 2^(i/128) to
+    half an ulp with a tail below an ulp (tools/make_glibc_pow_tables.py, which found them in libm.so.6 by content)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_glibc_pow_tables", os.path.join(root, "tools", "make_glibc_pow_tables.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    logd, expd, etab = tool.committed()
+    assert len(tool.verify(logd, expd, etab)) == 128
+
+
 def test_sincos_table_is_glibcs():
     """The committed table against an independent evaluation of sin / cos at k/128 (high words must be the correctly rounded
     values; glibc's low words are within 2^-40 of the exact remainders, 17 of them not the nearest double)."""

@@ -47,24 +47,19 @@ def find_unique(blob, lead, length, what):
     return at
 
 
-def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else "/lib/x86_64-linux-gnu/libm.so.6"
-    blob = open(path, "rb").read()
-    # ---- __pow_log_data
-    ln2hi, ln2lo = float.fromhex("0x1.62e42fefa3800p-1"), float.fromhex("0x1.ef35793c76730p-45")
-    n_log = 9 + 128 * 4
-    at = find_unique(blob, struct.pack("<3d", ln2hi, ln2lo, -0.5), n_log * 8, "__pow_log_data")
-    logd = struct.unpack_from("<%dd" % n_log, blob, at)
+def verify(logd, expd, etab):
+    """The structure checks, independent of libm: logd = ln2hi, ln2lo, poly[7], then 128 x {invc, pad, logc, logctail}; expd = invln2N,
+    shift, negln2hiN, negln2loN, C2 .. C5; etab = 128 x {tail bits, scale bits}. Returns the 128 (invc, logc, logctail)."""
+    assert logd[0] == float.fromhex("0x1.62e42fefa3800p-1") and logd[1] == float.fromhex("0x1.ef35793c76730p-45")
     poly = logd[2:9]
     # (e_pow_log_data.c: a degree-7 fit of log1p(r) - r, its coefficients scaled by -2 - A[0] * r * r is the -r^2 / 2 term)
     assert poly[0] == -0.5 and abs(poly[1] + 2.0 / 3.0) < 1e-12 and abs(poly[2] - 0.5) < 1e-12
-    OFF = struct.unpack("<d", struct.pack("<Q", 0x3fe6955500000000))[0]
     tab = []
     for i in range(128):
         invc, pad, logc, logctail = logd[9 + 4 * i: 13 + 4 * i]
         assert pad == 0.0
         c = 1.0 / invc
-        # entry i serves z in [OFF * 2^(i/128 ...)): tmp >> 45 & 127 = i, i.e. z's bits in [OFF + i << 45, OFF + (i + 1) << 45) mod the exponent wrap
+        # entry i serves the z whose bits lie in [OFF + (i << 45), OFF + ((i + 1) << 45)): c must be near them
         z_lo = struct.unpack("<d", struct.pack("<Q", 0x3fe6955500000000 + (i << 45)))[0]
         assert abs(c / z_lo - 1.0) < 1.0 / 64, (i, c, z_lo)
         f = Fraction(invc) * 256
@@ -72,19 +67,13 @@ def main():
         val = -log_frac(Fraction(invc))
         assert abs(Fraction(logc) + Fraction(logctail) - val) < Fraction(1, 2 ** 68), (i, float(Fraction(logc) + Fraction(logctail) - val))
         tab.append((invc, logc, logctail))
-    # ---- __exp_data
-    invln2n, shift = float.fromhex("0x1.71547652b82fep0") * 128, float.fromhex("0x1.8p52")
-    ea = find_unique(blob, struct.pack("<2d", invln2n, shift), 8 * 8, "__exp_data")
-    expd = struct.unpack_from("<8d", blob, ea)
+    assert expd[0] == float.fromhex("0x1.71547652b82fep0") * 128 and expd[1] == float.fromhex("0x1.8p52")
     negln2hin, negln2lon = expd[2], expd[3]
     assert negln2hin == -float.fromhex("0x1.62e42fefa0000p-8") and abs(negln2lon + float.fromhex("0x1.cf79abc9e3b3ap-47")) < 1e-25
+    # -(negln2hiN + negln2loN) * 128 = ln 2 to 2^-90
+    assert abs(-(Fraction(negln2hin) + Fraction(negln2lon)) * 128 - log_frac(Fraction(2))) < Fraction(1, 2 ** 90)
     c2, c3, c4, c5 = expd[4:8]
     assert abs(c2 - 0.5) < 1e-12 and abs(c3 - 1 / 6.0) < 1e-12 and abs(c4 - 1 / 24.0) < 1e-7 and abs(c5 - 1 / 120.0) < 1e-7
-    # the table follows exp2shift and exp2_poly[5] (e_exp_data.c): located by ITS first entry {0, bits of 1.0}
-    ta = blob.find(struct.pack("<2Q", 0, 0x3ff0000000000000), ea, ea + 0x100)
-    if ta < 0:
-        raise SystemExit("__exp_data.tab not found behind its constants")
-    etab = struct.unpack_from("<256Q", blob, ta)
     for i in range(128):
         tail, sbits = etab[2 * i], etab[2 * i + 1]
         scale = struct.unpack("<d", struct.pack("<Q", (sbits + (i << 45)) & 0xFFFFFFFFFFFFFFFF))[0]
@@ -93,6 +82,42 @@ def main():
         assert abs(r - 1) < Fraction(128, 2 ** 52), (i, float(r - 1))
         t = struct.unpack("<d", struct.pack("<Q", tail))[0]
         assert abs(t) < 2.0 ** -52, (i, t)
+    return tab
+
+
+def committed():
+    """(logd with the pad words put back, expd, etab) of the committed .inc."""
+    import re
+    text = open(OUT).read()
+    arrays = {m.group(1): [int(w, 16) for w in re.findall(r"0x([0-9a-f]{16})ull", m.group(2))]
+              for m in re.finditer(r"MCRT_POWTAB_DECL\((\w+), \d+\) = \{(.*?)\};", text, re.S)}
+    d = lambda w: struct.unpack("<d", struct.pack("<Q", w))[0]
+    head, tab = arrays["kPowLogHead"], arrays["kPowLogTab"]
+    assert len(head) == 9 and len(tab) == 384 and len(arrays["kPowExpHead"]) == 8 and len(arrays["kPowExpTab"]) == 256
+    logd = [d(w) for w in head]
+    for i in range(128):
+        logd += [d(tab[3 * i]), 0.0, d(tab[3 * i + 1]), d(tab[3 * i + 2])]
+    return logd, [d(w) for w in arrays["kPowExpHead"]], arrays["kPowExpTab"]
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else "/lib/x86_64-linux-gnu/libm.so.6"
+    blob = open(path, "rb").read()
+    # ---- __pow_log_data
+    ln2hi, ln2lo = float.fromhex("0x1.62e42fefa3800p-1"), float.fromhex("0x1.ef35793c76730p-45")
+    n_log = 9 + 128 * 4
+    at = find_unique(blob, struct.pack("<3d", ln2hi, ln2lo, -0.5), n_log * 8, "__pow_log_data")
+    logd = struct.unpack_from("<%dd" % n_log, blob, at)
+    # ---- __exp_data
+    invln2n, shift = float.fromhex("0x1.71547652b82fep0") * 128, float.fromhex("0x1.8p52")
+    ea = find_unique(blob, struct.pack("<2d", invln2n, shift), 8 * 8, "__exp_data")
+    expd = struct.unpack_from("<8d", blob, ea)
+    # the table follows exp2shift and exp2_poly[5] (e_exp_data.c): located by ITS first entry {0, bits of 1.0}
+    ta = blob.find(struct.pack("<2Q", 0, 0x3ff0000000000000), ea, ea + 0x100)
+    if ta < 0:
+        raise SystemExit("__exp_data.tab not found behind its constants")
+    etab = struct.unpack_from("<256Q", blob, ta)
+    tab = verify(logd, expd, etab)
     bits = lambda v: "0x%016xull" % struct.unpack("<Q", struct.pack("<d", v))[0]
     with open(OUT, "w") as f:
         f.write("// glibc 2.35 e_pow.c data as IEEE-754 bit patterns (e_pow_log_data.c, e_exp_data.c; (C) Free Software Foundation / ARM Ltd,\n"
