@@ -87,6 +87,9 @@ REF_SCENES = {
 # c2_ggx: the "GGX + Fresnel" reading of BASELINE configs[1] (hexagon_room.json with specular_roughness 0.1 on
 # `green` and 0.05 on `crystal`, "report both"): same frame size as the headline, its own parity block against reference-made rows
 SECONDARY = ("c2_ggx", "spaceship", "pm", "c3", "c4", "c5")
+# legs whose scene is the reference's own file as shipped (the others replace meshes the reference tree lacks, .MISSING_LARGE_BLOBS,
+# by deterministic stand-ins of the same triangle counts): what the line's "data" says
+REFERENCE_SCENE_LEGS = ("c1", "c2", "c2_ggx", "pm")
 # per leg: timed steps (None = --secondary-steps), spp of the untimed warm-up frame (None = the leg's own), spp of the frame the PMC
 # child passes count (None = the leg's own; per-sample work is the same at any spp, the scale is stated in frame_scale)
 LEG_PLAN = {"c3": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=8),
@@ -202,21 +205,37 @@ def cpu_baseline(m, img, cam, budget_s=12.0, integrator=0, pm_maps=None, scan_th
                     cal[ref_threads] = rays_per_row / r["seconds"]
             if cal:
                 best_t = max(cal, key=cal.get) if (scan_threads or not ref_threads) else ref_threads
-                n_rows = int(max(1, min(rows, 0.5 * budget_s * cal[best_t] / rays_per_row)))
-                q0 = max(r0, mid - n_rows // 2)
-                r = _run_reference(img.path, cam, q0, q0 + n_rows, best_t)
-                sample_rays = rays_per_row * n_rows
-                # `value` / `cores`: the reference at the thread count where it runs BEST on this host - the baseline to quote. With every
-                # hardware thread it is slower (all_threads_value): BVH::intersect copies a shared_ptr per visited node (bvh.cpp:80-129)
-                # and the reference counts contend across sockets - an artefact of the reference's host code, not of the hardware.
-                base = dict(value=sample_rays / r["seconds"] / 1e6, unit="Mray/s", cores=best_t, kind="reference",
-                            sample="reference Camera::samplePixel at its best thread count (%d of %d hardware threads): rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s); "
-                                   "thread scan on row %d" % (best_t, threads, q0, q0 + n_rows, cam.width, cam.height, spp, r["paths"], r["seconds"], mid),
-                            quoted="value = the reference at its best thread count; BASELINE.md 3's all-hardware-threads figure = all_threads_value",
-                            best_value=sample_rays / r["seconds"] / 1e6, best_cores=best_t,
-                            all_threads_value=cal[threads] / 1e6, all_threads_cores=threads,
-                            by_threads={str(k): v / 1e6 for k, v in sorted(cal.items())},
-                            port_value=port["value"], port_cores=threads)
+
+                def sample_at(t, seconds):  # rows around the middle of the frame worth `seconds` of the reference at t threads
+                    n = int(max(1, min(cam.height, seconds * cal[t] / rays_per_row)))
+                    q = min(max(0, mid - n // 2), cam.height - n)
+                    return _run_reference(img.path, cam, q, q + n, t), q, n
+
+                if scan_threads:
+                    # the headline's baseline, as BASELINE.md section 3 plans it: the reference with EVERY hardware thread of this host
+                    # (num_render_threads = -1, integrator.cpp:20-24) on >= 25 s of its own work. Beside it the thread count where the
+                    # reference runs best on this host (best_value / best_cores): BVH::intersect copies a shared_ptr per visited node
+                    # (bvh.cpp:80-129) whose reference counts contend across sockets, so fewer threads are faster - an artefact of the
+                    # reference's host code, quoted, not chosen.
+                    r, q0, n_rows = sample_at(threads, max(25.0, budget_s))
+                    rb, _, nb = sample_at(best_t, 0.5 * budget_s) if best_t != threads else (r, q0, n_rows)
+                    base = dict(value=rays_per_row * n_rows / r["seconds"] / 1e6, unit="Mray/s", cores=threads, kind="reference",
+                                sample="reference Camera::samplePixel at all %d hardware threads: rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s of CPU work); "
+                                       "thread scan on row %d" % (threads, q0, q0 + n_rows, cam.width, cam.height, spp, r["paths"], r["seconds"], mid),
+                                quoted="value = the reference at all hardware threads (BASELINE.md 3); best_value = at the thread count where it runs best on this host",
+                                best_value=rays_per_row * nb / rb["seconds"] / 1e6, best_cores=best_t, best_sample_s=rb["seconds"],
+                                all_threads_value=rays_per_row * n_rows / r["seconds"] / 1e6, all_threads_cores=threads,
+                                by_threads={str(k): v / 1e6 for k, v in sorted(cal.items())},
+                                port_value=port["value"], port_cores=threads)
+                else:
+                    # secondary legs: one sample at the thread count the headline found best (a few seconds each, so that the run stays short)
+                    r, q0, n_rows = sample_at(best_t, 0.5 * budget_s)
+                    base = dict(value=rays_per_row * n_rows / r["seconds"] / 1e6, unit="Mray/s", cores=best_t, kind="reference",
+                                sample="reference Camera::samplePixel at %d of %d hardware threads (the headline's best count): rows %d-%d of %dx%d @ %d spp (%d paths, %.1f s)"
+                                       % (best_t, threads, q0, q0 + n_rows, cam.width, cam.height, spp, r["paths"], r["seconds"]),
+                                best_value=rays_per_row * n_rows / r["seconds"] / 1e6, best_cores=best_t,
+                                all_threads_value=cal.get(threads, 0.0) / 1e6 or None, all_threads_cores=threads,
+                                port_value=port["value"], port_cores=threads)
         except Exception as ex:  # keep the port numbers
             base = dict(port, note="reference run failed: %r" % (ex,))
     elif ref_emissions:
@@ -262,6 +281,24 @@ INTEGRATOR_KERNELS = ("renderKernel", "wfTraceKernel", "wfShadeKernel", "wfKnnKe
 PROFILE_DIR = os.path.join(ROOT, "gpurun_out", "bench_profiles")  # per-leg counter summaries of THIS run (copied to profiles/ when committed)
 
 
+def kernel_instance_name(kname):
+    """`void (anonymous namespace)::renderKernelFlatK<768>((anonymous namespace)::DeviceScene, ...)` -> `renderKernelFlatK<768>`:
+    the function's name with its template arguments, without return type, namespaces and parameter list."""
+    k = kname.replace("(anonymous namespace)::", "").replace("mcrt::", "")
+    if k.startswith("void "):
+        k = k[5:]
+    depth = 0
+    for i, ch in enumerate(k):  # cut at the parameter list: the first '(' outside the template argument list
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            k = k[:i]
+            break
+    return k.strip()
+
+
 def _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out):
     """One rocprofv3 --pmc pass over one frame (child process). Returns True when counters came back."""
     tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
@@ -291,14 +328,11 @@ def _pmc_pass(rocprof, tag, names, workload, sqrtspp, emissions, timeout, out):
             con.close()
 
             def bucket(kname):
-                key = next((k for k in INTEGRATOR_KERNELS if k in kname), None)
-                if key is None:
+                """The kernel's own name WITH its template arguments (renderKernelFlatK<768>, wfTraceKernel<PoolRays, false, 3, 3>, ...):
+                the per-leg profile names the instance that ran, not a family."""
+                if not any(k in kname for k in INTEGRATOR_KERNELS):
                     return None  # memsets, torch kernels, the photon pass
-                if "renderKernelSM" in kname:
-                    return "renderKernelSM"
-                if "renderKernelPM" in kname:
-                    return "renderKernelPM"
-                return key
+                return kernel_instance_name(kname)
             for kname, cname, val, n in rows:
                 kk = bucket(kname)
                 if kk is None:
@@ -751,7 +785,7 @@ def compact_cpu(b, sample_chars=150):
         return None
     out = {k: b[k] for k in ("value", "unit", "cores", "kind") if k in b}
     out["sample"] = (b.get("sample") or "")[:sample_chars]
-    for k in ("all_threads_value", "all_threads_cores", "port_value", "port_cores", "knn_searches_per_s", "quoted"):
+    for k in ("best_value", "best_cores", "port_value", "port_cores", "knn_searches_per_s", "quoted"):
         if b.get(k) is not None:
             out[k] = b[k]
     return out
@@ -797,6 +831,19 @@ def compact_line(result):
         legs[name] = e
     if legs:
         out["secondary"] = legs
+    tol = result.get("tolerance_build")
+    if tol:
+        out["tolerance_build"] = {}
+        for name, e in tol.items() if isinstance(tol, dict) and "error" not in tol else []:
+            if "error" in e:
+                out["tolerance_build"][name] = {"error": str(e["error"])[:120]}
+                continue
+            t = {"value": e.get("value"), "ms_per_step": e.get("ms_per_step"), "vs_exact_build": e.get("vs_exact_build")}
+            if e.get("parity"):
+                t.update({k: e["parity"].get(k) for k in ("max_rel", "p999_rel", "outliers_gt_1e-4")})
+            out["tolerance_build"][name] = t
+        if isinstance(tol, dict) and "error" in tol:
+            out["tolerance_build"] = {"error": str(tol["error"])[:120]}
     out["detail"] = "gpurun_out/bench_profiles/bench_full.json (+ pmc_<leg>.md); committed as profiles/rNN_bench_full.json"
     out = _rnd(out)
     # shed optional keys, least important first, until the line fits (never the contract's keys)
@@ -874,7 +921,7 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
             "metric": "Mray/s (whole node), 1920x1080 @ 256 spp path trace" if name.startswith("c2") else "Mray/s (whole node)",
             "value": total_rays / elapsed / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "reference scene" if name in REFERENCE_SCENE_LEGS else "reference scene, synthetic stand-in meshes",
             "config": {"workload": wl.desc, "width": wl.W, "height": wl.H, "spp": wl.sqrtspp ** 2, "integrator": "photon_mapper" if wl.photon else "path_tracer",
                        "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
                        "rays_per_step": total_rays / steps, "paths_per_step": total_paths / steps,
@@ -896,7 +943,7 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
                 result["photon_allgather_ms"] = per_rank["photon_allgather_ms"]
             if REHEARSE_DIST:
                 result["rehearsal"] = "collectives of the N > 1 path run with a process group of one rank (--rehearse-dist): not a scaling measurement"
-        par = c2_parity(wl, frame) if world == 1 else None
+        par = c2_parity(wl, frame)  # any world: rank 0 holds the assembled frame of the last timed step
         if par:
             result["parity"] = par
         counts = None
@@ -935,6 +982,99 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
     return result, ref_threads
 
 
+def rows_parity(m, name):
+    """Full-size golden rows of a large leg (C3: rows 540-542 of 1080p @ 1024 spp; C5: row 500 at 256 spp on the image's own photon map)
+    against the REFERENCE's radiance (tests/golden, made by integration/large_scenes/make_large.py with the reference itself)."""
+    sys.path.insert(0, os.path.join(ROOT, "integration", "large_scenes"))
+    import make_large
+    cfg_name = {"c3": "c3", "c4": "c4", "c5": "c5_s16"}.get(name)
+    if cfg_name is None or cfg_name not in make_large.CONFIGS:
+        return None
+    c = make_large.CONFIGS[cfg_name]
+    p, g = make_large.ensure_image(cfg_name), make_large.golden_path(cfg_name)
+    if p is None or not os.path.exists(g):
+        return None
+    img = m.SceneImage(p)
+    ctx = m.Context(0)
+    ctx.upload_image(img)
+    cam = img.camera
+    cam.sqrtspp = c["sqrtspp"]
+    r0, r1 = c["rows"]
+    cam.shard_rows, cam.shard_count = r1 - r0, (cam.height + r1 - r0 - 1) // (r1 - r0)
+    cam.shard_index = r0 // (r1 - r0)
+    integ = m.INTEGRATOR_PATH_TRACER
+    if c["photon"]:
+        integ = m.INTEGRATOR_PHOTON_MAPPER
+        ctx.upload_photons(img.photons(0), img.photons(1), int(img.param("k_nearest_photons")), bool(img.param("direct_visualization")))
+    out, _ = ctx.sample_image(cam, SEED, integ)
+    ctx.close()
+    ref = np.fromfile(g).reshape(r1 - r0, c["width"], 3)
+    got = out[r0:r1]
+    rel = (np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)).max(axis=2)
+    return {"rows": [r0, r1], "pixels": int(rel.size), "max_rel": float(rel.max()), "p999_rel": float(np.quantile(rel, 0.999)),
+            "outliers_gt_1e-4": int((rel > 1e-4).sum()), "bit_identical": bool(np.array_equal(got, ref)), "tolerance": 1e-4,
+            "reference": "tests/golden/%s (rendered by the reference)" % os.path.basename(g)}
+
+
+def child_leg(args):
+    """One leg timed in a process of its own and printed as one JSON line: how the parent measures the TOLERANCE build (the parent has
+    the exact library loaded; MCRT_TOLERANCE_BUILD=1 in this process's environment selected libmcrt_hip_tol.so at import)."""
+    import torch
+
+    m = importlib.import_module("monte-carlo-ray-tracer_amd")
+    tiling = importlib.import_module("monte-carlo-ray-tracer_amd.tiling")
+    torch.cuda.set_device(0)
+    if args.workload in TOLERANCE_PLAN:  # short legs: the run as a whole has to stay within minutes
+        LEG_PLAN[args.workload] = dict(LEG_PLAN.get(args.workload, {}), **TOLERANCE_PLAN[args.workload])
+    leg, _ = measure(args.workload, args, m, tiling, 0, 1, 0, None, args.steps, args.warmup, want_cpu=False, want_counters=False,
+                     headline=args.workload == "c2")
+    if "parity" not in leg:
+        par = rows_parity(m, args.workload)
+        if par:
+            leg["parity"] = par
+    leg["library"] = os.path.basename(m.LIB_PATH)
+    print(json.dumps({"child_leg": args.workload, "leg": leg}), flush=True)
+
+
+TOLERANCE_LEGS = ("c2", "c3", "c5")   # the opt-in build's figures beside the exact build's: headline, pipeline, photon mapper
+TOLERANCE_PLAN = {"c3": dict(steps=1, warm_sqrtspp=8), "c5": dict(steps=2, warm_sqrtspp=4)}   # (c2: 5 timed frames after one warm-up frame)
+
+
+def tolerance_legs(args, exact):
+    """The same legs through libmcrt_hip_tol.so (-ffp-contract=fast + the platform's libm: monte-carlo-ray-tracer_amd/build.py), each
+    in a child process, with the parity block against the reference's own rows at BASELINE.json's 1e-4 bar. `exact` = the exact
+    build's legs of this run, for the ratio. Reported, never the headline."""
+    out = {}
+    lib_tol = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc", "libmcrt_hip_tol.so")
+    if not os.path.exists(lib_tol):
+        return {"error": "libmcrt_hip_tol.so not built"}
+    for name in TOLERANCE_LEGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--child-leg", "--workload", name, "--steps", str(min(args.steps, 5) if name == "c2" else args.secondary_steps),
+               "--warmup", "1"]
+        if args.emissions:
+            cmd += ["--emissions", str(args.emissions)]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MCRT_TOLERANCE_BUILD="1"))
+            lines = [l for l in p.stdout.splitlines() if l.startswith('{"child_leg"')]
+            if p.returncode != 0 or not lines:
+                out[name] = {"error": "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+                continue
+            leg = json.loads(lines[-1])["leg"]
+            e = {"value": leg["value"], "unit": leg["unit"], "steps": leg["steps"], "ms_per_step": leg["ms_per_step"], "library": leg.get("library"),
+                 "build": "-ffp-contract=fast -DMCRT_PLATFORM_LIBM (MCRT_TOLERANCE_BUILD=1)"}
+            if leg.get("frame_with_photon_pass_ms") is not None:
+                e["frame_with_photon_pass_ms"] = leg["frame_with_photon_pass_ms"]
+            if leg.get("parity"):
+                e["parity"] = {k: leg["parity"].get(k) for k in ("rows", "pixels", "max_rel", "p999_rel", "outliers_gt_1e-4", "bit_identical", "tolerance")}
+            ex = exact.get(name)
+            if ex and ex.get("value"):
+                e["vs_exact_build"] = leg["value"] / ex["value"]
+            out[name] = e
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
+    return out
+
+
 def child_frame(args):
     """One frame of a workload and nothing else: the process rocprofv3 wraps for the counter passes."""
     import torch
@@ -968,6 +1108,8 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one GPU: run the collectives of the N > 1 path (RCCL init, gathers, reductions, destroy) with a process group of one rank")
     ap.add_argument("--child-frame", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-tolerance", action="store_true", help="skip the legs of the opt-in tolerance build (libmcrt_hip_tol.so)")
     args = ap.parse_args()
 
     import torch
@@ -977,6 +1119,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.child_frame:
         return child_frame(args)
+    if args.child_leg:
+        return child_leg(args)
     # From here on file descriptor 1 is the process's stderr: whatever a library prints to "stdout" - RCCL's version banner sits in C
     # stdio's buffer until the process exits, AFTER anything this script printed (that cost round 5's first rehearsal its last line) -
     # cannot follow, precede or interleave with the one line the driver parses. That line goes to the real stdout, kept here.
@@ -1027,6 +1171,9 @@ def main():
             except Exception as ex:  # a leg that cannot run here (scene image absent) must not cost the headline
                 leg = {"error": repr(ex)}
             result["secondary"][name] = leg
+    if single and args.workload == "c2" and not args.no_secondary and not args.no_tolerance:
+        exact = dict(result.get("secondary") or {}, c2=result)
+        result["tolerance_build"] = tolerance_legs(args, exact)
     # the process group goes first: whatever RCCL / torch print while it is torn down must not follow the line the driver parses
     if _collectives(world):
         dist.barrier()

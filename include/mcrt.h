@@ -314,6 +314,15 @@ typedef struct mcrt_photon_pass_stats {
 int mcrt_photon_pass_device(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_t global_seed, const double bb_min[3],
                             const double bb_max[3], uint32_t max_photons_per_leaf, uint32_t k_nearest_photons,
                             int direct_visualization, mcrt_photon_pass_stats* stats);
+/* The same pass for the contexts of ONE host process (the reference's shape: one executable, PhotonMapper::PhotonMapper
+ * fanning its emission work out to worker threads, integrator/photon-mapper/photon-mapper.cpp:40-115), sharded: context i traces
+ * shard i of `count` of the emission paths, the lists cross between the GPUs on device pointers (hipMemcpyPeer: xGMI between
+ * two devices), every context builds both maps from the same concatenation in shard order - the same maps everywhere, the
+ * emission's time divided by `count`. ctxs[i] holds the scene already; count == 1 is mcrt_photon_pass_device.
+ * stats: one record PER CONTEXT ([count]; may be NULL): emission_paths / rays / emission_ms of its own shard, the maps' counts. */
+int mcrt_photon_pass_multi(mcrt_ctx* const* ctxs, uint32_t count, double emissions, double caustic_factor, uint32_t global_seed,
+                           const double bb_min[3], const double bb_max[3], uint32_t max_photons_per_leaf, uint32_t k_nearest_photons,
+                           int direct_visualization, mcrt_photon_pass_stats* stats);
 /* The emission pass alone with the lists left in device memory (owned by the context, valid until the next emission): for
  * hosts that exchange the lists between GPUs (RCCL all-gather on the device pointers) before building the maps. */
 typedef struct mcrt_photon_emission_device {

@@ -16,8 +16,10 @@
 //     over the devices — two contexts on one GPU is how the one-GPU test box exercises the fan-out) and mcrt_render_multi in place
 //     of the worker-thread fan-out of camera.cpp:120-136: rows dealt in groups of 8, every context driven by its own host thread;
 //   * the photon pass on the GPUs: PhotonMapper's constructor only reads the "photon_map" object (photon-mapper.cpp:28-38) and
-//     leaves both maps empty; sampleImage then runs mcrt_photon_pass_device (emission + both octrees on the device) on every
-//     context — the same maps on every GPU, nothing crosses the host. MCRT_DROPIN_CPU_PHOTONS=1 keeps the reference's own CPU
+//     leaves both maps empty; sampleImage then runs mcrt_photon_pass_multi (round 6): every context traces ITS shard of the emission
+//     paths, the lists cross between the GPUs on device pointers (hipMemcpyPeer), every context builds both octrees from their
+//     concatenation — the same maps on every GPU, nothing crosses the host, the emission's time divided by the number of GPUs
+//     (MCRT_DROPIN_REPLICATED_PHOTONS=1: round 5's form, every context tracing all paths). MCRT_DROPIN_CPU_PHOTONS=1 keeps the reference's own CPU
 //     photon pass instead (its constructor, under its new name, builds a second PhotonMapper whose maps are moved over) and
 //     uploads those maps: the path the .tga parity test of the photon-mapped frame was first made with.
 //
@@ -27,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <thread>
@@ -42,6 +45,13 @@ struct PhotonPassParams {
     double emissions = 0.0, caustic_factor = 1.0;
     bool cpu = false;  // the maps in the object come from the reference's own CPU pass
 };
+// Keyed by the integrator's address, written by its constructor and read by sampleImage under one lock. An entry outlives its
+// integrator (the reference's class has no hook to erase it), which is harmless: a new PhotonMapper at a reused address overwrites the
+// entry in its constructor before any sampleImage can read it.
+std::mutex& passParamsLock() {
+    static std::mutex m;
+    return m;
+}
 std::map<const PhotonMapper*, PhotonPassParams>& passParams() {
     static std::map<const PhotonMapper*, PhotonPassParams> m;
     return m;
@@ -81,6 +91,16 @@ void onEveryContext(const std::vector<mcrt_ctx*>& ctxs, F fn) {
         if (!e.empty()) throw std::runtime_error(e);
 }
 
+// the first message any context recorded (a failure inside mcrt_render_multi / mcrt_photon_pass_multi is recorded on the context it
+// happened on and, prefixed with that context's number, on the first one)
+std::string firstError(const std::vector<mcrt_ctx*>& ctxs) {
+    for (mcrt_ctx* c : ctxs) {
+        const char* e = mcrt_last_error(c);
+        if (e && *e) return e;
+    }
+    return "mcrt: unknown error";
+}
+
 }  // namespace
 
 // The reference's own constructor (complete-object form), under the name oracle/Makefile gives it in the drop-in's copy of photon-mapper.o
@@ -106,7 +126,10 @@ PhotonMapper::PhotonMapper(const nlohmann::json& j) : Integrator(j)
         tmp->~PhotonMapper();
         p.cpu = true;
     }
-    passParams()[this] = p;
+    {
+        std::lock_guard<std::mutex> g(passParamsLock());
+        passParams()[this] = p;
+    }
 }
 
 void Camera::sampleImage()
@@ -119,7 +142,11 @@ void Camera::sampleImage()
 
     int mode = MCRT_INTEGRATOR_PATH_TRACER;
     if (auto pm = dynamic_cast<PhotonMapper*>(integrator.get())) {
-        const PhotonPassParams p = passParams()[pm];
+        PhotonPassParams p;
+        {
+            std::lock_guard<std::mutex> g(passParamsLock());
+            p = passParams()[pm];
+        }
         if (p.cpu) {
             FlatMap g, c;
             flattenMap(pm->global_map, g);
@@ -129,24 +156,34 @@ void Camera::sampleImage()
                                            (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0);
             });
         } else {
-            // PhotonMapper::PhotonMapper's pass (photon-mapper.cpp:40-207) on the GPUs: every context emits all the paths and builds
-            // both maps in its own memory (identical maps: the emission is a function of the seed; 0.4 s at C5's 1e8 paths)
+            // PhotonMapper::PhotonMapper's pass (photon-mapper.cpp:40-207) on the GPUs, SHARDED (round 6, mcrt_photon_pass_multi): context i
+            // traces shard i of the emission paths, the lists cross between the GPUs on device pointers, every context builds the same
+            // two maps from their concatenation. MCRT_DROPIN_REPLICATED_PHOTONS=1: round 5's form - every context traces ALL paths.
             std::vector<mcrt_photon_pass_stats> ps(ctxs.size());
-            std::vector<std::string> err(ctxs.size());
-            std::vector<std::thread> th;
-            for (size_t i = 0; i < ctxs.size(); i++)
-                th.emplace_back([&, i] {
-                    if (mcrt_photon_pass_device(ctxs[i], p.emissions, p.caustic_factor, Sampler::global_seed, flat.desc.bb_min, flat.desc.bb_max,
-                                                (uint32_t)pm->max_node_data, (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0,
-                                                &ps[i]) != MCRT_OK)
-                        err[i] = mcrt_last_error(ctxs[i]);
-                });
-            for (auto& t : th) t.join();
-            for (auto& e : err)
-                if (!e.empty()) throw std::runtime_error(e);
-            std::printf("\n[mcrt_hip] PhotonMapper pass on the GPU(s): %llu emission paths, %llu global + %llu caustic photons, %.1f ms per context\n",
-                        (unsigned long long)ps[0].emission_paths, (unsigned long long)ps[0].global_count, (unsigned long long)ps[0].caustic_count,
-                        ps[0].total_ms);
+            if (envLong("MCRT_DROPIN_REPLICATED_PHOTONS", 0) != 0) {
+                std::vector<std::string> err(ctxs.size());
+                std::vector<std::thread> th;
+                for (size_t i = 0; i < ctxs.size(); i++)
+                    th.emplace_back([&, i] {
+                        if (mcrt_photon_pass_device(ctxs[i], p.emissions, p.caustic_factor, Sampler::global_seed, flat.desc.bb_min, flat.desc.bb_max,
+                                                    (uint32_t)pm->max_node_data, (uint32_t)pm->k_nearest_photons, pm->direct_visualization ? 1 : 0,
+                                                    &ps[i]) != MCRT_OK)
+                            err[i] = mcrt_last_error(ctxs[i]);
+                    });
+                for (auto& t : th) t.join();
+                for (auto& e : err)
+                    if (!e.empty()) throw std::runtime_error(e);
+            } else if (mcrt_photon_pass_multi(ctxs.data(), (uint32_t)ctxs.size(), p.emissions, p.caustic_factor, Sampler::global_seed, flat.desc.bb_min,
+                                              flat.desc.bb_max, (uint32_t)pm->max_node_data, (uint32_t)pm->k_nearest_photons,
+                                              pm->direct_visualization ? 1 : 0, ps.data()) != MCRT_OK) {
+                throw std::runtime_error(firstError(ctxs));
+            }
+            unsigned long long paths = 0;
+            for (auto& s : ps) paths += s.emission_paths;
+            std::printf("\n[mcrt_hip] PhotonMapper pass on the GPU(s): %llu emission paths over %zu context(s) (%llu by the first), %llu global + %llu caustic photons, "
+                        "%.1f ms (emission %.1f ms in the first context)\n",
+                        paths, ctxs.size(), (unsigned long long)ps[0].emission_paths, (unsigned long long)ps[0].global_count,
+                        (unsigned long long)ps[0].caustic_count, ps[0].total_ms, ps[0].emission_ms);
         }
         mode = MCRT_INTEGRATOR_PHOTON_MAPPER;
     }
@@ -155,7 +192,7 @@ void Camera::sampleImage()
     std::vector<double> rgb(image.width * image.height * 3);
     mcrt_stats stats;
     if (mcrt_render_multi(ctxs.data(), (uint32_t)ctxs.size(), &cam, Sampler::global_seed, mode, rgb.data(), &stats) != MCRT_OK)
-        throw std::runtime_error(mcrt_last_error(ctxs[0]));
+        throw std::runtime_error(firstError(ctxs));
     num_sampled_pixels = image.width * image.height;
 
     for (size_t y = 0; y < image.height; y++)  // camera.cpp:138-144

@@ -16,7 +16,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmcrt_hip.so")
+# MCRT_TOLERANCE_BUILD=1 in the environment at import: the opt-in tolerance library (build.py LIB_TOL: FP64 contraction + the platform's
+# libm; frames within BASELINE.json's 1e-4 relative bar instead of the reference's bits). Default: the exact library.
+TOLERANCE_BUILD = os.environ.get("MCRT_TOLERANCE_BUILD") == "1"
+LIB_PATH = os.path.join(_HERE, "csrc", "libmcrt_hip_tol.so" if TOLERANCE_BUILD else "libmcrt_hip.so")
 ABI_VERSION = 2
 
 FILM_FILTERS = {"box": 0, "mitchell-netravali": 1, "catmull-rom": 2, "b-spline": 3, "hermite": 4, "gaussian": 5, "lanczos": 6}
@@ -168,6 +171,21 @@ def render_multi(contexts, cam, global_seed, integrator=INTEGRATOR_PATH_TRACER):
     return out, st.as_dict()
 
 
+def photon_pass_multi(contexts, emissions, caustic_factor, global_seed, bb_min, bb_max, max_photons_per_leaf=200, k_nearest=50,
+                      direct_visualization=False):
+    """mcrt_photon_pass_multi: the photon pass sharded over several contexts of this process (emission shards exchanged on device
+    pointers, the same maps built in every context). Returns one stats dict per context."""
+    for c in contexts:
+        c._sync_env()
+    st = (PhotonPassStats * len(contexts))()
+    lo, hi = (C.c_double * 3)(*bb_min), (C.c_double * 3)(*bb_max)
+    handles = (C.c_void_p * len(contexts))(*[c._h.value for c in contexts])
+    rc = lib().mcrt_photon_pass_multi(handles, len(contexts), float(emissions), float(caustic_factor), int(global_seed), lo, hi,
+                                      int(max_photons_per_leaf), int(k_nearest), 1 if direct_visualization else 0, st)
+    contexts[0]._check(rc, "mcrt_photon_pass_multi")
+    return [s.as_dict() for s in st]
+
+
 def tga_save(path, bgr):
     """mcrt_tga_save: the reference's .tga (HeaderTGA + B,G,R bytes) for a [H,W,3] uint8 array."""
     bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
@@ -242,6 +260,9 @@ def lib():
     L.mcrt_photon_map_free.argtypes = [vp]
     L.mcrt_photon_map_free.restype = None
     L.mcrt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(CameraDesc), C.c_uint32, C.c_int, _dp, C.POINTER(Stats)]
+    if hasattr(L, "mcrt_photon_pass_multi"):  # (round 6; absent from older libraries that tools/ab_builds.sh swaps in)
+        L.mcrt_photon_pass_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                             C.c_uint32, C.c_uint32, C.c_int, C.POINTER(PhotonPassStats)]
     L.mcrt_render_film_device.argtypes = [vp, C.POINTER(CameraDesc), C.c_uint32, C.c_int, vp, vp]
     L.mcrt_film_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mcrt_tonemap_device.argtypes = [vp, vp, C.POINTER(ImageDesc), vp, _dp, vp]

@@ -9,6 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libmcrt_hip.so")
+# The opt-in TOLERANCE build (MCRT_TOLERANCE_BUILD=1 selects it at import, monte-carlo-ray-tracer_amd/__init__.py): the kernels' translation unit
+# compiled with -ffp-contract=fast (mul + add pairs fuse into FP64 fma: half the instructions of a dot product) and -DMCRT_PLATFORM_LIBM
+# (the platform's sin / cos / asin / atan2 / pow instead of the restated glibc routines). Frames then agree with the reference within
+# BASELINE.json's 1e-4 relative bar (measured: tests/test_gpu_tolerance_build.py, bench.py's *_tol legs) instead of bit for bit. The exact
+# build stays the default, the headline and what every parity test runs.
+LIB_TOL = os.path.join(CSRC, "libmcrt_hip_tol.so")
+TOL_FLAGS = ["-ffp-contract=fast", "-DMCRT_PLATFORM_LIBM", "-DMCRT_TOLERANCE_BUILD"]
 RENDER_BIN = os.path.join(HOST, "mcrt_render")
 
 # -ffp-contract=off: the CPU reference is compiled by g++ for baseline x86-64 (no FMA contraction);
@@ -66,20 +73,36 @@ def _stale(obj, depfile):
     return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force=False, verbose=True):
-    """One object per translation unit (compiled side by side, only the stale ones — hipcc's own -MD dependency files
-    decide), then one link. The objects stay under csrc/_obj/ (git-ignored)."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    os.makedirs(OBJ, exist_ok=True)
+def _compile_jobs(force, variants):
+    """hipcc command lines for the stale objects of the given variants (False = exact, True = tolerance). The tolerance library only
+    has its own object for the kernels' translation unit; every other object is the exact build's."""
     hipcc = _hipcc()
     flags = [f for f in HIPCC_FLAGS if f != "-shared"]
     jobs = []
     for tu in TUS:
-        obj = os.path.join(OBJ, tu + ".o")
-        dep = os.path.join(OBJ, tu + ".d")
-        if force or _stale(obj, dep):
-            jobs.append([hipcc] + flags + ["-MD", "-MF", dep, "-c", os.path.join(CSRC, tu), "-o", obj])
+        for tol in sorted(set(bool(v) and tu == "mcrt_hip.hip" for v in variants)):
+            stem = os.path.join(OBJ, tu + (".tol" if tol else ""))
+            obj, dep = stem + ".o", stem + ".d"
+            if force or _stale(obj, dep):
+                f = [x for x in flags if x != "-ffp-contract=off"] + TOL_FLAGS if tol else flags
+                jobs.append([hipcc] + f + ["-MD", "-MF", dep, "-c", os.path.join(CSRC, tu), "-o", obj])
+    return jobs
+
+
+def _objects(tolerance):
+    return [os.path.join(OBJ, tu + (".tol" if tolerance and tu == "mcrt_hip.hip" else "") + ".o") for tu in TUS]
+
+
+def build_lib(force=False, verbose=True, tolerance=False, both=False):
+    """One object per translation unit (compiled side by side, only the stale ones — hipcc's own -MD dependency files
+    decide), then one link. The objects stay under csrc/_obj/ (git-ignored). tolerance=True: libmcrt_hip_tol.so - the kernels'
+    translation unit (mcrt_hip.hip) recompiled with TOL_FLAGS, linked with the exact build's other objects (builders, output stage).
+    both=True: the two libraries, their two compiles of mcrt_hip.hip (minutes each) side by side."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ, exist_ok=True)
+    variants = (False, True) if both else (bool(tolerance),)
+    jobs = _compile_jobs(force, variants)
 
     def run(cmd):
         if verbose:
@@ -89,10 +112,11 @@ def build_lib(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, tu + ".o") for tu in TUS]
-    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    for tol in variants:
+        lib, objs = (LIB_TOL if tol else LIB), _objects(tol)
+        if jobs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+            run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return LIB_TOL if tolerance and not both else LIB
 
 
 def build_host(force=False, verbose=True):
@@ -111,7 +135,7 @@ def build_host(force=False, verbose=True):
 
 
 def build_all(force=False):
-    build_lib(force)
+    build_lib(force, both=os.environ.get("MCRT_SKIP_TOLERANCE_BUILD") != "1")
     build_host(force)
 
 

@@ -1599,8 +1599,11 @@ struct WfKnnArgs {
 // kEval: the launch evaluates the estimate itself — the k photons' BSDF terms by k lanes at once, a wave reduction
 // (waveEvalPhotons, as in renderKernelPM) — from the Interaction the shade launch staged, instead of handing the k photons
 // back for a per-lane loop in the next shade launch (2 x k x 12 B per slot written and read, k divergent BSDF evaluations).
+#ifndef MCRT_KNN_OCC
+#define MCRT_KNN_OCC  // (build-time A/B: __attribute__((amdgpu_waves_per_eu(4, 4))) = 128 VGPRs, 21 spilled)
+#endif
 template <bool kEval, int R = kWaveRows>
-__global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
+__global__ void __launch_bounds__(256) MCRT_KNN_OCC wfKnnKernel(const WfKnnArgs a) {
     __shared__ double s_d2[4 * waveCand(R)];
     __shared__ uint32_t s_idx[4 * waveCand(R)];
     __shared__ uint32_t s_hist[4 * kWaveHist];
@@ -1613,15 +1616,30 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
     const unsigned long long n = *a.count;
     const uint32_t slots = a.pool.n;
     uint32_t overflow = 0, visits = 0, searches = 0;
+    // Requests are taken kKnnBatch at a time (round 6). One returning atomic per REQUEST on one word was this launch's ceiling: a
+    // device-scope counter serves ~88 M dequeues per second (MI355X_MICROARCH.md, price list "dequeue") and C5 files 126 M requests per
+    // 64-spp frame - the launch ran at 110 M searches/s whatever the searches cost (profiles/r06_kernel_trace_c5_pipeline_before.md).
+    // Now lane j of the wave reads request base + j and that slot's position (three coalesced round trips for the whole batch instead of
+    // three dependent ones per request), and the wave works the batch off with readlane broadcasts.
+    constexpr uint32_t kKnnBatch = 16;
     for (;;) {
-        unsigned long long w = 0ull;
-        if (lane == 0) w = atomicAdd(a.pop, 1ull);
-        w = waveBroadcast64(w, 0);
-        if (w >= n) break;
-        const uint32_t req = a.requests[w];
+        unsigned long long w0 = 0ull;
+        if (lane == 0) w0 = atomicAdd(a.pop, (unsigned long long)kKnnBatch);
+        w0 = waveBroadcast64(w0, 0);
+        if (w0 >= n) break;
+        const uint32_t in_batch = n - w0 < (unsigned long long)kKnnBatch ? (uint32_t)(n - w0) : kKnnBatch;
+        uint32_t req_l = 0u;
+        d3 p_l = splat(0.0);
+        if (lane < in_batch) {
+            req_l = a.requests[w0 + lane];
+            const uint32_t s = req_l & 0x7FFFFFFFu;
+            // Interaction::position = ray(t) (interaction.cpp:15)
+            p_l = a.pool.get3(kWfRayO, s) + a.pool.get3(kWfRayD, s) * a.pool.getd(kWfHit0T, s);
+        }
+        for (uint32_t j = 0; j < in_batch; j++) {
+        const uint32_t req = (uint32_t)__builtin_amdgcn_readlane((int)req_l, (int)j);
         const uint32_t slot = req & 0x7FFFFFFFu;
-        // Interaction::position = ray(t) (interaction.cpp:15)
-        const d3 p = a.pool.get3(kWfRayO, slot) + a.pool.get3(kWfRayD, slot) * a.pool.getd(kWfHit0T, slot);
+        const d3 p = d3{bitsD(waveBroadcast64(dBits(p_l.x), (int)j)), bitsD(waveBroadcast64(dBits(p_l.y), (int)j)), bitsD(waveBroadcast64(dBits(p_l.z), (int)j))};
         for (int map = 1; map >= ((req >> 31) ? 0 : 1); map--) {  // caustic map always, global map on request
             double r2;
             const uint32_t c = waveKnnSearch<R>(a.maps[map], p, a.k, W, r2, overflow, visits);
@@ -1645,11 +1663,12 @@ __global__ void __launch_bounds__(256) wfKnnKernel(const WfKnnArgs a) {
                 a.res_n[(size_t)map * slots + slot] = c;
                 a.res_r2[(size_t)map * slots + slot] = r2;
             }
-            for (uint32_t j = lane; j < c; j += 64) {
-                const size_t at = ((size_t)map * a.k + j) * slots + slot;
-                a.res_idx[at] = W.idx[j];
-                a.res_d2[at] = W.d2[j];
+            for (uint32_t j2 = lane; j2 < c; j2 += 64) {
+                const size_t at = ((size_t)map * a.k + j2) * slots + slot;
+                a.res_idx[at] = W.idx[j2];
+                a.res_d2[at] = W.d2[j2];
             }
+        }
         }
     }
     if (lane == 0) {

@@ -1,0 +1,36 @@
+"""CPU tier: the default-path kernels of the BUILT library spill no more than tests/golden/kernel_spill_budget.json allows
+(tools/kernel_spill_table.py reads the code objects' metadata: vgpr_spill_count, private_segment_fixed_size). A kernel that starts to
+spill more gets slower without any parity test noticing - round 5's renderKernelPM moved +-10 % on unrelated one-line edits."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("kernel_spill_table", os.path.join(ROOT, "tools", "kernel_spill_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="llvm-readelf not in this image")
+def test_default_path_kernels_stay_within_their_spill_budgets():
+    t = _tool()
+    if not os.path.exists(t.LIB):
+        pytest.skip("libmcrt_hip.so not built")
+    want = json.load(open(t.BUDGET))["kernels"]
+    have = {k["name"]: k for k in t.kernels_of()}
+    assert want, "empty budget"
+    for name, w in want.items():
+        assert name in have, "default-path kernel %s is not in the library" % name
+        k = have[name]
+        assert k["vgpr_spill"] <= w["vgpr_spill"], "%s spills %d VGPRs (budget %d)" % (name, k["vgpr_spill"], w["vgpr_spill"])
+        assert k["scratch"] <= w["scratch"], "%s uses %d B of scratch per lane (budget %d)" % (name, k["scratch"], w["scratch"])
+    # the trace kernel of the pipeline must not spill at all: it runs at 4 waves per SIMD on 128 VGPRs
+    for name, k in have.items():
+        if name.startswith("wfTraceKernel<PoolRays, false, 3"):
+            assert k["vgpr_spill"] == 0 and k["scratch"] == 0, name

@@ -226,3 +226,47 @@ def test_device_resident_photon_pass(pkg, oracle, manifest):
         dev.close()
         host.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_sharded_photon_pass_over_the_contexts_of_one_process(pkg, manifest, n_ctx):
+    """mcrt_photon_pass_multi (round 6): context i traces shard i of the emission paths, the lists cross between the contexts on
+    device pointers (hipMemcpyPeer; the contexts share the one GPU of the test box), every context builds both maps from the same
+    concatenation. The maps of EVERY context are the trees of the one-context pass (octants, boxes, photons per leaf), the shards'
+    path and ray counts add up to the one-context pass's, and a photon-mapped frame rendered over the contexts (mcrt_render_multi)
+    is the one-context frame to 1e-12 (the photons of a leaf arrive in another order - emission appends with atomics - and an
+    estimate's wave reduction adds them in that order; searches and photon sets are identical)."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    s = img.scene
+    one = pkg.Context(0)
+    one.upload_image(img)
+    ctxs = [pkg.Context(0) for _ in range(n_ctx)]
+    for c in ctxs:
+        c.upload_image(img)
+    cam = img.camera.copy()
+    cam.width, cam.height, cam.sqrtspp = 96, 72, 2
+    for emissions in (4000, 1e5):
+        st1 = one.photon_pass_device(emissions, 10.0, manifest["seed"], s.bb_min[:], s.bb_max[:], 200, 50, False)
+        sts = pkg.photon_pass_multi(ctxs, emissions, 10.0, manifest["seed"], s.bb_min[:], s.bb_max[:], 200, 50, False)
+        assert len(sts) == n_ctx
+        assert sum(x["emission_paths"] for x in sts) == st1["emission_paths"] and sum(x["rays"] for x in sts) == st1["rays"]
+        assert all(x["emission_paths"] < st1["emission_paths"] for x in sts)  # every context traced a shard, not the whole
+        for x in sts:
+            assert (x["global_count"], x["caustic_count"], x["global_octants"], x["caustic_octants"]) == \
+                   (st1["global_count"], st1["caustic_count"], st1["global_octants"], st1["caustic_octants"])
+        for which in (0, 1):
+            want = one.download_map(which)
+            for c in ctxs:
+                got = c.download_map(which)
+                assert_same_octree(want.arrays(), got.arrays())
+                got.close()
+            want.close()
+        frame_one, _ = one.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        frame_multi, st = pkg.render_multi(ctxs, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+        assert st["knn_searches"] > 0
+        assert np.abs(frame_multi - frame_one).max() <= 1e-12 * max(1.0, np.abs(frame_one).max())
+        print("%d contexts, %g emissions: per-context emission %.2f ms of the one-context pass's %.2f ms; maps identical, frames within 1e-12"
+              % (n_ctx, emissions, max(x["emission_ms"] for x in sts), st1["emission_ms"]))
+    for c in ctxs + [one]:
+        c.close()

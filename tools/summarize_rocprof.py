@@ -13,9 +13,20 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(renderKernelSM|renderKernelPM|renderKernel|wfTraceKernel|wfShadeKernel|emitKernel|intersectKernel|knnWaveKernel|"
-                  r"knnKernel|samplerKernel|cellCodeKernel|gatherKernel|leafBoundsKernel)(<[^(]*>)?", name)
-    return m.group(0).replace("(anonymous namespace)::", "") if m else name[:60]
+    """The kernel's name with its template arguments, without return type, namespaces and parameter list."""
+    k = name.replace("(anonymous namespace)::", "").replace("mcrt::", "")
+    if k.startswith("void "):
+        k = k[5:]
+    depth = 0
+    for i, ch in enumerate(k):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            k = k[:i]
+            break
+    return k.strip()[:90]
 
 
 def main(root):
@@ -36,9 +47,13 @@ def main(root):
                 print("| `%s` | %d | %.3f | %.3f | %.2f |" % (short(n), c, tot / 1e3, avg / 1e3, pct))
             try:
                 k = list(con.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
-                                     "from kernels where name like '%renderKernel%' or name like '%wfTraceKernel%' limit 2"))
+                                     "from kernels where name like '%renderKernel%' or name like '%wfTraceKernel%' or name like '%wfShadeKernel%'"))
+                seen = set()
                 for n, g, w, lds, scr, v, a, s in k:
-                    print("\nlaunch: grid %d threads, block %d, LDS %d B/block, scratch %d B/lane, VGPR %d, AGPR %d, SGPR %d\n" % (g, w, lds, scr, v, a, s))
+                    if short(n) in seen:
+                        continue
+                    seen.add(short(n))
+                    print("\nlaunch of `%s`: grid %d threads, block %d, LDS %d B/block, scratch %d B/lane, VGPR %d, AGPR %d, SGPR %d\n" % (short(n), g, w, lds, scr, v, a, s))
             except sqlite3.Error:
                 pass
         try:
