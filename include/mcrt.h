@@ -206,7 +206,7 @@ const char* mcrt_last_error(const mcrt_ctx* ctx); /* ctx may be NULL: last creat
  * options" lists them; defaults are the measured best). Keys are MCRT_* names, values decimal numbers or words. The process
  * environment SEEDS the options once, in mcrt_create (so `MCRT_KERNEL=wf ./host` still works); after that the library never
  * reads the environment: a host changes behaviour with mcrt_set_option, between frames (value NULL = back to the default).
- * Options that shape the uploaded scene (MCRT_LEAF_CULL, MCRT_FLAT_MAX) take effect at the next mcrt_upload_scene.
+ * Options that shape the uploaded scene (MCRT_FLAT_MAX) take effect at the next mcrt_upload_scene.
  * The reference has no counterpart (its knobs are compile-time constants); mcrt_get_option returns the value or NULL. */
 int mcrt_set_option(mcrt_ctx* ctx, const char* key, const char* value);
 const char* mcrt_get_option(const mcrt_ctx* ctx, const char* key);
@@ -219,7 +219,13 @@ int mcrt_upload_photons(mcrt_ctx* ctx, const mcrt_photon_map_desc* global_map,
 /* Replaces the thread fan-out of Camera::sampleImage (camera.cpp:120-144): renders every owned
  * pixel with spp = sqrtspp^2 samples and writes image(x,y) as FP64 RGB, row-major, width*height*3
  * doubles, into caller-allocated HOST memory (rows not owned by this shard are left untouched).
- * global_seed replaces Sampler::global_seed (sampling/sampler.hpp:58). */
+ * global_seed replaces Sampler::global_seed (sampling/sampler.hpp:58).
+ * PARITY: a path-traced frame (MCRT_INTEGRATOR_PATH_TRACER) of the default (exact) library is the reference's bits. A photon-mapped
+ * frame of the default kernels is held to 1e-10 relative of the reference, not to its bits: the k photons of a radiance estimate are
+ * added by a wave reduction instead of in the reference's heap order, and Photon::dir takes the platform's sinf / cosf (measured
+ * <= 1e-12). Option MCRT_KERNEL=legacy selects the per-lane photon kernel, which keeps the reference's heap discipline and its
+ * sincosf - its frames ARE the reference's bits, at a tenth of the speed. The opt-in tolerance library (libmcrt_hip_tol.so) is held
+ * to BASELINE.json's 1e-4 for every frame. */
 int mcrt_render(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator,
                 double* out_rgb, mcrt_stats* stats /* may be NULL */);
 

@@ -4,6 +4,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -105,9 +106,21 @@ def build_lib(force=False, verbose=True, tolerance=False, both=False):
     jobs = _compile_jobs(force, variants)
 
     def run(cmd):
-        if verbose:
-            print("[build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        # hipcc reads a translation unit's headers twice (device pass, then host pass), minutes apart for mcrt_hip.hip: a header saved in
+        # between gives ONE object whose kernels and launch code disagree about a struct's layout (round 6: a memory fault on the GPU that
+        # no CPU test could see). A compile whose dependencies changed while it ran is therefore done again.
+        for attempt in range(3):
+            t_start = time.time()
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            dep = cmd[cmd.index("-MF") + 1] if "-MF" in cmd else None
+            deps = _deps_of(dep) if dep else None
+            if not deps or all(os.path.exists(d) and os.path.getmtime(d) < t_start for d in deps):
+                return
+            if verbose:
+                print("[build] a dependency changed during the compile: again", flush=True)
+        raise RuntimeError("sources kept changing while %s was being compiled" % cmd[-3])
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:

@@ -16,7 +16,6 @@
 #include "mcrt_integrator.hpp"
 #include "mcrt_lanesm.hpp"
 #include "mcrt_qbvh.hpp"
-#include "mcrt_wbvh.hpp"
 #include "mcrt_wavefront.hpp"
 #include "mcrt_waveknn.hpp"
 #include "mcrt_groupknn.hpp"
@@ -90,7 +89,7 @@ struct mcrt_ctx {
     bool q_single = false;  // HostLayout::q_single of the uploaded scene
     std::vector<float> flat_pre_host;  // the flat loop's cull records, host copy: renderKernelFlatK takes them as a kernel argument
     DeviceScene scene{};
-    DevBuf node_bounds, node_meta, nodes64, qblocks, wnodes, leaf_pre, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_rec, surf_vn, surf_area, surf_material, surf_kind, materials,
+    DevBuf node_bounds, node_meta, nodes64, qblocks, quadrics, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_rec, surf_vn, surf_area, surf_material, surf_kind, materials,
         light_surface, light_cdf, sobol_tab;
 
     bool has_photons = false;
@@ -120,7 +119,8 @@ struct mcrt_ctx {
     double* last_film = nullptr;
     hipStream_t last_stream = nullptr;
     bool force_wf = false;
-    DevBuf wf_ray_scratch;  // slot-scheduled trace kernel: the FP64 rays of the slots, [workgroup][slot][8]
+    uint32_t iors_depth = kMaxIorsDeep;  // RefractionHistory entries per pipeline slot (8 in LDS + deep rows); grows when a frame nests deeper
+    DevBuf wf_iors_deep;
     DevPool pass_pool;  // work buffers of the device photon pass (mcrt_photon_device.hpp)
     DevBuf pm_stage; // estimate requests of the photon-mapping kernel, one record per resident lane (mcrt_waveknn.hpp)
 
@@ -135,8 +135,6 @@ struct mcrt_ctx {
     uint32_t wf_res_slots = 0, wf_res_k = 0;
     uint32_t wf_slots = 0;
     unsigned long long* wf_host = nullptr;   // pinned: one read-back word per half
-    hipStream_t wf_stream[2] = {nullptr, nullptr};
-    hipEvent_t wf_ev[3] = {nullptr, nullptr, nullptr};
 
     // in-flight render
     bool pending = false;
@@ -302,50 +300,8 @@ using mcrt::ctxOpt;
 using mcrt::ctxOptL;
 using mcrt::ctxOptOn;
 
-// MCRT_WF_WIDE=1: the trace kernel walks the eight-wide nodes (mcrt_wbvh.hpp) instead of the 4-wide blocks. Bit-identical frames;
-// measured on C3: 12.1 instead of 15.7 inner steps per ray but 7.0 instead of 6.1 leaf steps and a costlier step - 469 vs 466 ms
-// per 64-spp frame, so the 4-wide blocks stay the default.
-bool useWideNodes(const mcrt_ctx* ctx) {
-    return ctx->scene.wnodes != nullptr && ctxOptOn(ctx, "MCRT_WF_WIDE");
-}
-
-long halvesWanted(const mcrt_ctx* ctx) { return ctxOptL(ctx, "MCRT_WF_HALVES", 1); }
-
 template <class K>
-int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool wide = false, bool sched = false, bool share_leaves = false) {
-    if (sched) {  // slot-scheduled kernel: one 1024-lane workgroup per CU, all of its LDS for the ray slots
-        tp.block = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_SCHED_WAVES", 16), 1), kTraceMaxBlock / 64) * 64u;
-        tp.lds_bytes = (uint32_t)sizeof(SchedLds);
-        if (tp.lds_bytes > ctx->max_lds_trace) return fail(ctx, MCRT_ERR_UNSUPPORTED, "slot-scheduled trace kernel: needs 156 KB of LDS per workgroup");
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
-        tp.grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus, (max_items + kSchedSlots - 1) / kSchedSlots);
-        if (tp.grid < 1) tp.grid = 1;
-        const uint32_t total_slots = tp.grid * kSchedSlots;
-        if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-        if (int rc = ensureSpill(ctx, (size_t)total_slots * ctx->scene.stack_depth * sizeof(StackEntry))) return rc;
-        HIP_TRY(ctx, ctx->wf_ray_scratch.reserve((size_t)total_slots * 128));
-        WfTraceArgs& ta = tp.args;
-        memset(&ta, 0, sizeof(ta));
-        ta.stats = ctx->stats.as<unsigned long long>();
-        ta.nodes = ctx->scene.nodes64;
-        ta.qblocks = ctx->scene.qblocks;
-        ta.wnodes = ctx->scene.wnodes;
-        ta.num_nodes = ctx->scene.q_nodes;
-        ta.q_root_a = ctx->scene.q_root_a;
-        ta.q_root_m = ctx->scene.q_root_m;
-        ta.prim = ctx->scene.prim;
-        ta.leaf_pre = ctx->scene.leaf_pre;
-        ta.leaf_cx = ctx->scene.leaf_cx;
-        ta.leaf_cy = ctx->scene.leaf_cy;
-        ta.leaf_cz = ctx->scene.leaf_cz;
-        ta.leaf_bound = ctx->scene.leaf_bound;
-        ta.spill = ctx->spill.as<SmStackEntry>();
-        ta.total_lanes = total_slots;
-        ta.lds_stack = (int)kSchedStack;
-        ta.max_stack = ctx->scene.stack_depth;
-        ta.deal_shift = (uint32_t)std::min<long>(std::max<long>(ctxOptL(ctx, "MCRT_WF_DEAL", 6), 6), 20);
-        return MCRT_OK;
-    }
+int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     auto envi = [ctx](const char* k, long d) { return ctxOptL(ctx, k, d); };
     const uint32_t waves = (uint32_t)std::min<long>(std::max<long>(envi("MCRT_TRACE_WAVES", 16), 1), kTraceMaxBlock / 64);
     tp.block = waves * 64u;
@@ -353,7 +309,7 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     const uint32_t stack_bytes = lds_stack * tp.block * (uint32_t)sizeof(SmStackEntry);
     const long lds_cap = std::min<long>((long)ctx->max_lds_trace, envi("MCRT_TRACE_LDS", (long)ctx->max_lds_trace));
     if ((long)stack_bytes + 128 + (long)(waves * kShareMapBytes) > lds_cap) return fail(ctx, MCRT_ERR_INVALID, "trace kernel: traversal stacks exceed the LDS");
-    const uint32_t lds_blocks = wide ? 0u : (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 128u - waves * kShareMapBytes) / 64u);
+    const uint32_t lds_blocks = (uint32_t)std::min<uint64_t>(ctx->scene.num_qblocks, ((uint64_t)lds_cap - stack_bytes - 128u - waves * kShareMapBytes) / 64u);
     tp.lds_bytes = lds_blocks * 64u + stack_bytes + 64u + waves * kShareMapBytes + 64u;  // + the workgroup's queue cursor + the waves' shared-leaf maps + the root's record
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
     int per_cu = 0;
@@ -363,29 +319,22 @@ int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp, bool w
     if (tp.grid < 1) tp.grid = 1;
     const uint32_t total_lanes = tp.grid * tp.block;
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
-    // two trace launches (the two halves of the wavefront pool) can be resident at once; a region holds kMaxStackDepth entries
-    // per lane whatever part of them lives in LDS
-    if (int rc = ensureSpill(ctx, (size_t)2 * total_lanes * ctx->scene.stack_depth * sizeof(StackEntry))) return rc;
+    // a region holds stack_depth entries per lane whatever part of them lives in LDS
+    if (int rc = ensureSpill(ctx, (size_t)total_lanes * ctx->scene.stack_depth * sizeof(StackEntry))) return rc;
     WfTraceArgs& ta = tp.args;
     memset(&ta, 0, sizeof(ta));
     ta.stats = ctx->stats.as<unsigned long long>();
     ta.nodes = ctx->scene.nodes64;
     ta.qblocks = ctx->scene.qblocks;
-    ta.wnodes = ctx->scene.wnodes;
     ta.num_nodes = ctx->scene.q_nodes;
     ta.lds_blocks = lds_blocks;
     ta.q_root_a = ctx->scene.q_root_a;
     ta.q_root_m = ctx->scene.q_root_m;
     ta.prim = ctx->scene.prim;
-    ta.leaf_pre = ctx->scene.leaf_pre;
-    ta.leaf_cx = ctx->scene.leaf_cx;
-    ta.leaf_cy = ctx->scene.leaf_cy;
-    ta.leaf_cz = ctx->scene.leaf_cz;
-    ta.leaf_bound = ctx->scene.leaf_bound;
     ta.spill = ctx->spill.as<SmStackEntry>();
     ta.total_lanes = total_lanes;
     ta.refill_lanes = (int)envi("MCRT_WF_REFILL", 16);  // (32 while the queue cursor was one global atomic)
-    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", share_leaves ? 16 : 24);  // (shared step, C3 64 spp: 8 / 12 / 16 / 20 pending lanes 412.7 / 402.1 / 398.1 / 402.3 ms; gating on 48-56 offered primitives instead: 398.4-399.0)
+    ta.leaf_lanes = (int)envi("MCRT_WF_LEAF", 16);  // (shared step, C3 64 spp: 8 / 12 / 16 / 20 pending lanes 412.7 / 402.1 / 398.1 / 402.3 ms; gating on 48-56 offered primitives instead: 398.4-399.0)
     ta.leaf_items = (int)envi("MCRT_WF_LEAF_ITEMS", 1 << 20);
     ta.min_inner = (int)envi("MCRT_WF_MININNER", 8);
     ta.lds_stack = (int)lds_stack;
@@ -496,6 +445,12 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         HIP_TRY(ctx, ctx->wf_queue.alloc(((size_t)slots + 2 * kWfBlock) * 2 * (2 * sizeof(uint32_t) + 2 * 8 * sizeof(double))));
         ctx->wf_slots = (uint32_t)slots;
     }
+    {   // deep refraction-history rows: [iors_depth - kMaxIors][slots] doubles (never initialised: an entry is written before it is read)
+        const size_t need = (size_t)(ctx->iors_depth - kMaxIors) * slots * sizeof(double);
+        if (ctx->wf_iors_deep.bytes < need) HIP_TRY(ctx, ctx->wf_iors_deep.alloc(need));
+        fr.iors_deep = ctx->wf_iors_deep.as<double>();
+        fr.iors_deep_rows = ctx->iors_depth - (uint32_t)kMaxIors;
+    }
     if (!ctx->wf_ctrl.p) HIP_TRY(ctx, ctx->wf_ctrl.alloc(kWfCtrlWords * sizeof(unsigned long long)));
     if (!ctx->wf_host) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host), 2 * sizeof(unsigned long long)));
     auto runPass = [&]() -> int {  // the rows [fr.row_base, fr.row_end): shade / trace launches until nothing is queued
@@ -506,81 +461,45 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfFlags * slots, 0, (size_t)slots * 8, stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->wf_pool.as<unsigned long long>() + (size_t)kWfSeq * slots, 0, (size_t)slots * 8, stream));
 
-    const bool wide = useWideNodes(ctx);
-    // MCRT_WF_SCHED=1: the slot-scheduled trace kernel (ray state in LDS, steps issued for 64 rays that want the same step)
-    const bool sched = ctxOptOn(ctx, "MCRT_WF_SCHED") && halvesWanted(ctx) < 2;
-    const bool defer = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0;  // deferred leaves: the default since round 3 (C3 / C4 -1.3 %)
-    const bool share = defer && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // ... tested by the whole wave (travSharedLeafStep): round 4
-    // MCRT_WF_LEAN (round 5; default 1): the shared form's inner visit is travInnerStepQLean - with one block per visit when the tree
-    // has no node with more than four children (every quaternary tree); 0: round 4's visit
-    // (MCRT_WF_LEAN=2: the block loop kept on a quaternary tree - A/B runs)
-    const int lean = share && !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
-    void (*trace)(WfTraceArgs, PoolRays) = wide        ? (count_tests ? wfTraceKernel<PoolRays, true, 1> : wfTraceKernel<PoolRays, false, 1>)
-                                           : lean == 3 ? wfTraceKernel<PoolRays, false, 3, 3>
-                                           : lean == 1 ? wfTraceKernel<PoolRays, false, 3, 1>
-                                           : share     ? (count_tests ? wfTraceKernel<PoolRays, true, 3> : wfTraceKernel<PoolRays, false, 3>)
-                                           : defer     ? (count_tests ? wfTraceKernel<PoolRays, true, 2> : wfTraceKernel<PoolRays, false, 2>)
+    // MCRT_WF_LEAN (round 5; default 1): the inner visit is travInnerStepQLean - with one block per visit when the tree has no node with
+    // more than four children (every quaternary tree); 0 (and MCRT_COUNT_TESTS): round 4's visit; 2: the block loop kept on a quaternary tree
+    const int lean = !count_tests && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;
+    void (*trace)(WfTraceArgs, PoolRays) = lean == 3   ? wfTraceKernel<PoolRays, false, 3>
+                                           : lean == 1 ? wfTraceKernel<PoolRays, false, 1>
                                                        : (count_tests ? wfTraceKernel<PoolRays, true> : wfTraceKernel<PoolRays, false>);
-    void (*trace_sched)(WfTraceArgs, PoolRays, double*) = count_tests ? wfTraceKernelSched<PoolRays, true> : wfTraceKernelSched<PoolRays, false>;
     // + the materials and the light tables when they are small (MCRT_WF_LDS_TABLES=0: read them from memory)
     uint32_t shade_tables = wfShadeTableBytes(ctx->scene.num_materials, ctx->scene.num_lights);
     if (shade_tables > kWfShadeTableMax || ctxOptL(ctx, "MCRT_WF_LDS_TABLES", 1) == 0) shade_tables = 0;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u + shade_tables;
     TracePlan tp;
-    if (int rc = sched ? planTrace(ctx, trace_sched, slots * 2, tp, false, true) : planTrace(ctx, trace, slots * 2, tp, wide, false, share)) return rc;
+    if (int rc = planTrace(ctx, trace, slots * 2, tp)) return rc;
 
-    // MCRT_WF_HALVES=2 (experiment, off by default): two halves of the pool on two streams, so that while one half's trace
-    // launch drains (its slowest rays) the other half's launches take over the CUs that are already free. Measured: no
-    // gain (C3 1074 vs 1101 Mray/s, C4 619 vs 681): a trace workgroup owns a CU's whole LDS, so the halves mostly
-    // alternate, and each now pays its tail on half as many rays.
-    const int halves = (!photon && slots >= 4u * kWfBlock && envi("MCRT_WF_HALVES", 1) >= 2) ? 2 : 1;
-    hipStream_t hs[2] = {stream, stream};
-    if (halves == 2) {
-        for (int i = 0; i < 2; i++)
-            if (!ctx->wf_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[i], hipStreamNonBlocking));
-        for (int i = 0; i < 3; i++)
-            if (!ctx->wf_ev[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[i], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[2], stream));  // the setup above precedes both halves
-        for (int i = 0; i < 2; i++) {
-            hs[i] = ctx->wf_stream[i];
-            HIP_TRY(ctx, hipStreamWaitEvent(hs[i], ctx->wf_ev[2], 0));
-        }
-    }
+    // control words: {count[2] (one per iteration parity), pop} of the ray queue; 4..6 = {rcount[2], rpop} of the estimate requests
     unsigned long long* ctrl = ctx->wf_ctrl.as<unsigned long long>();
-    WfTraceArgs ta[2];
-    PoolRays pr[2];
-    WfShadeArgs sa[2];
-    uint32_t shade_grid[2];
-    const uint32_t half_slots = halves == 2 ? (uint32_t)((slots / 2 + kWfBlock - 1) / kWfBlock * kWfBlock) : (uint32_t)slots;
-    for (int h = 0; h < halves; h++) {
-        unsigned long long* c = ctrl + 4 * h;  // {count[2], pop} of this half
-        ta[h] = tp.args;
-        ta[h].pop = c + 2;
-        ta[h].spill = tp.args.spill + (size_t)h * tp.args.total_lanes * ctx->scene.stack_depth;
-        pr[h].pool.w = ctx->wf_pool.as<unsigned long long>();
-        pr[h].pool.n = (uint32_t)slots;
-        {
-            // each half owns the entries [h * 2 * half_slots, ...) of every plane
-            const size_t cap = ((size_t)slots + 2 * kWfBlock) * 2, off = (size_t)h * 2 * half_slots;
-            uint32_t* words = ctx->wf_queue.as<uint32_t>();
-            pr[h].q.item = words + off;
-            pr[h].q.light = words + cap + off;
-            pr[h].q.ray = reinterpret_cast<double*>(words + 2 * cap) + off;  // iteration parity 0; parity 1: + 8 * cap
-            pr[h].q.prev_ray = pr[h].q.ray + 8 * cap;
-            pr[h].q.cap = cap;
-        }
-        memset(&sa[h], 0, sizeof(WfShadeArgs));
-        sa[h].pool = pr[h].pool;
-        sa[h].slot_base = (uint32_t)h * half_slots;
-        sa[h].slot_count = h == 0 ? std::min<uint32_t>(half_slots, (uint32_t)slots) : (uint32_t)slots - half_slots;
-        sa[h].fr = fr;
-        sa[h].queue = pr[h].q;
-        sa[h].pop_reset = c + 2;
-        sa[h].work = ctx->work_counter.as<unsigned long long>();
-        sa[h].stats = ctx->stats.as<unsigned long long>();
-        sa[h].lds_tables = shade_tables;
-        shade_grid[h] = (sa[h].slot_count + kWfBlock - 1) / kWfBlock;
-    }
+    WfTraceArgs ta = tp.args;
+    ta.pop = ctrl + 2;
+    PoolRays pr;
+    pr.pool.w = ctx->wf_pool.as<unsigned long long>();
+    pr.pool.n = (uint32_t)slots;
+    const size_t qcap = ((size_t)slots + 2 * kWfBlock) * 2;
+    double* const ray_set0 = reinterpret_cast<double*>(ctx->wf_queue.as<uint32_t>() + 2 * qcap);  // iteration parity 0; parity 1: + 8 * qcap
+    pr.q.item = ctx->wf_queue.as<uint32_t>();
+    pr.q.light = pr.q.item + qcap;
+    pr.q.ray = ray_set0;
+    pr.q.prev_ray = ray_set0 + 8 * qcap;
+    pr.q.cap = qcap;
+    WfShadeArgs sa;
+    memset(&sa, 0, sizeof(WfShadeArgs));
+    sa.pool = pr.pool;
+    sa.slot_base = 0u;
+    sa.slot_count = (uint32_t)slots;
+    sa.fr = fr;
+    sa.queue = pr.q;
+    sa.pop_reset = ctrl + 2;
+    sa.work = ctx->work_counter.as<unsigned long long>();
+    sa.stats = ctx->stats.as<unsigned long long>();
+    sa.lds_tables = shade_tables;
+    const uint32_t shade_grid = (sa.slot_count + kWfBlock - 1) / kWfBlock;
 
     // photon mapper: estimate requests and the kNN launch that serves them (control words 4..6 = {rcount[2], rpop})
     WfKnnArgs ka;
@@ -606,7 +525,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
             ctx->wf_res_slots = (uint32_t)slots;
             ctx->wf_res_k = k;
         }
-        ka.pool = pr[0].pool;
+        ka.pool = pr.pool;
         ka.requests = ctx->wf_requests.as<uint32_t>();
         ka.pop = ctrl + 6;
         ka.stats = ctx->stats.as<unsigned long long>();
@@ -622,7 +541,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         knn_grid = (uint32_t)ctx->num_cus * 8u;
         HIP_TRY(ctx, ctx->knn_spill.reserve((size_t)knn_grid * 4 * kWaveSpill * 12));
         ka.spill = ctx->knn_spill.as<uint32_t>();
-        WfShadeArgs& s0 = sa[0];
+        WfShadeArgs& s0 = sa;
         s0.requests = ctx->wf_requests.as<uint32_t>();
         s0.rpop_reset = ctrl + 6;
         s0.pm.photons[0] = ctx->maps[0].photons;
@@ -637,63 +556,45 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         s0.stage = knn_eval ? ctx->wf_stage.as<double>() : nullptr;
     }
 
+    // The host looks at the queue length every MCRT_WF_CHECK iterations (a launch with nothing to do costs microseconds)
     const uint64_t check_every = (uint64_t)std::max<long>(2, envi("MCRT_WF_CHECK", 16));
-    bool done[2] = {false, halves == 1};
-    for (uint64_t it = 0; !(done[0] && done[1]); it++) {
-        for (int h = 0; h < halves; h++) {
-            if (done[h]) continue;
-            unsigned long long* c = ctrl + 4 * h;
-            sa[h].count_out = c + (it & 1);
-            sa[h].count_reset = c + ((it + 1) & 1);
-            {
-                double* set0 = reinterpret_cast<double*>(ctx->wf_queue.as<uint32_t>() + 2 * pr[h].q.cap) + (size_t)h * 2 * half_slots;
-                pr[h].q.ray = set0 + (it & 1) * 8 * pr[h].q.cap;
-                pr[h].q.prev_ray = set0 + ((it + 1) & 1) * 8 * pr[h].q.cap;
-                sa[h].queue = pr[h].q;
-            }
-            if (photon) {
-                sa[h].rcount_out = ctrl + 4 + (it & 1);
-                sa[h].rcount_reset = ctrl + 4 + ((it + 1) & 1);
-                hipLaunchKernelGGL(wfShadeKernel<true>, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
-            } else {
-                hipLaunchKernelGGL(wfShadeKernel<false>, dim3(shade_grid[h]), dim3(kWfBlock), shade_lds, hs[h], ctx->scene, sa[h]);
-            }
+    for (uint64_t it = 0;; it++) {
+        sa.count_out = ctrl + (it & 1);
+        sa.count_reset = ctrl + ((it + 1) & 1);
+        pr.q.ray = ray_set0 + (it & 1) * 8 * qcap;
+        pr.q.prev_ray = ray_set0 + ((it + 1) & 1) * 8 * qcap;
+        sa.queue = pr.q;
+        if (photon) {
+            sa.rcount_out = ctrl + 4 + (it & 1);
+            sa.rcount_reset = ctrl + 4 + ((it + 1) & 1);
+            hipLaunchKernelGGL(wfShadeKernel<true>, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
+        } else {
+            hipLaunchKernelGGL(wfShadeKernel<false>, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
+        }
+        ctx->launches++;
+        if (it % check_every == check_every - 1 || it < 2) {
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host, ctrl + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            if (photon)  // requests count as work too
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + 1, ctrl + 4 + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            if (ctxOptOn(ctx, "MCRT_WF_LOG"))  // queue length over the frame
+                fprintf(stderr, "[mcrt wf] iteration %llu queued %llu at %.2f ms\n", (unsigned long long)it, ctx->wf_host[0],
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
+            if (ctx->wf_host[0] == 0ull && (!photon || ctx->wf_host[1] == 0ull)) break;  // nothing queued: every slot is done
+        }
+        ta.count = ctrl + (it & 1);
+        hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, stream, ta, pr);
+        ctx->launches++;
+        if (photon) {
+            ka.count = ctrl + 4 + (it & 1);
+            const bool large_k = ctx->k_nearest > waveMaxK(kWaveRows);  // the wide candidate buffer (mcrt_waveknn.hpp)
+            if (knn_eval) hipLaunchKernelGGL((large_k ? wfKnnKernel<true, kWaveRowsLarge> : wfKnnKernel<true>), dim3(knn_grid), dim3(256), 0, stream, ka);
+            else hipLaunchKernelGGL((large_k ? wfKnnKernel<false, kWaveRowsLarge> : wfKnnKernel<false>), dim3(knn_grid), dim3(256), 0, stream, ka);
             ctx->launches++;
-            // the two halves look at their queue length at different iterations, so that one stream always has work queued
-            if (it % check_every == (h == 0 ? check_every - 1 : check_every / 2 - 1) || it < 2) {
-                HIP_TRY(ctx, hipGetLastError());
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + h, c + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
-                if (photon)  // (one half only) requests count as work too
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host + 1, ctrl + 4 + (it & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, hs[h]));
-                HIP_TRY(ctx, hipStreamSynchronize(hs[h]));
-                const bool wf_log = ctxOptOn(ctx, "MCRT_WF_LOG");  // queue length over the frame
-                if (wf_log)
-                    fprintf(stderr, "[mcrt wf] iteration %llu queued %llu at %.2f ms\n", (unsigned long long)it, ctx->wf_host[h],
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->t_begin).count());
-                if (ctx->wf_host[h] == 0ull && (!photon || ctx->wf_host[1] == 0ull)) {  // nothing queued: every slot of this half is done
-                    done[h] = true;
-                    continue;
-                }
-            }
-            ta[h].count = c + (it & 1);
-            if (sched) hipLaunchKernelGGL(trace_sched, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h], ctx->wf_ray_scratch.as<double>());
-            else hipLaunchKernelGGL(trace, dim3(tp.grid), dim3(tp.block), tp.lds_bytes, hs[h], ta[h], pr[h]);
-            ctx->launches++;
-            if (photon) {
-                ka.count = ctrl + 4 + (it & 1);
-                const bool large_k = ctx->k_nearest > waveMaxK(kWaveRows);  // the wide candidate buffer (mcrt_waveknn.hpp)
-                if (knn_eval) hipLaunchKernelGGL((large_k ? wfKnnKernel<true, kWaveRowsLarge> : wfKnnKernel<true>), dim3(knn_grid), dim3(256), 0, hs[h], ka);
-                else hipLaunchKernelGGL((large_k ? wfKnnKernel<false, kWaveRowsLarge> : wfKnnKernel<false>), dim3(knn_grid), dim3(256), 0, hs[h], ka);
-                ctx->launches++;
-            }
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (halves == 2)
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[i], hs[i]));
-            HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev[i], 0));
-        }
     return MCRT_OK;
     };
     for (uint32_t row = 0; row < owned_rows; row += (uint32_t)pass_rows) {
@@ -743,24 +644,13 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
 int launchRender(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_seed, int integrator, double* d_out, hipStream_t stream,
                  double* film_out = nullptr) {
     if (!ctx) return MCRT_ERR_INVALID;
-    // MCRT_DEVICE_ORDER=0 in the ENVIRONMENT (read once per process) switches the ordering off: for tools/shared_gpu_stress.py, which
-    // looks for the fault the ordering was added against (round 5: 3 processes x 2 contexts, 600 concurrent frames, none wrong)
-    static const bool ordered = !(getenv("MCRT_DEVICE_ORDER") && atoi(getenv("MCRT_DEVICE_ORDER")) == 0);
-    if (!ordered) {
-        const int rc = launchRenderImpl(ctx, cam, global_seed, integrator, d_out, stream, film_out);
-        if (rc == MCRT_OK && ctx->pending) {
-            if (cam != &ctx->last_cam) ctx->last_cam = *cam;
-            ctx->last_seed = global_seed;
-            ctx->last_integrator = integrator;
-            ctx->last_out = d_out;
-            ctx->last_film = film_out;
-            ctx->last_stream = stream;
-        }
-        return rc;
-    }
+    // Option MCRT_DEVICE_ORDER=0 (per context, like every option; TEST ONLY: tools/shared_gpu_stress.py, which looks for the fault the
+    // ordering was added against): this context's frames do not wait on the GPU for the device's previous launcher. The mutex stays
+    // either way - "size this kernel's dynamic LDS, then launch it" must be one step (DeviceOrder's comment).
+    const bool gpu_wait = ctxOptL(ctx, "MCRT_DEVICE_ORDER", 1) != 0;
     DeviceOrder& o = g_device_order[(unsigned)ctx->device & 63u];
     std::lock_guard<std::mutex> guard(o.m);
-    if (o.owner && o.owner != ctx) {
+    if (gpu_wait && o.owner && o.owner != ctx) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamWaitEvent(stream, o.last, 0));
     }
@@ -1239,10 +1129,6 @@ void mcrt_destroy(mcrt_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
-    for (int i = 0; i < 2; i++)
-        if (ctx->wf_stream[i]) (void)hipStreamDestroy(ctx->wf_stream[i]);
-    for (int i = 0; i < 3; i++)
-        if (ctx->wf_ev[i]) (void)hipEventDestroy(ctx->wf_ev[i]);
     delete ctx;
 }
 
@@ -1273,12 +1159,7 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     const size_t ns = s->num_surfaces;
     HostLayout L;
     std::string lerr;
-    #if defined(MCRT_DEVICE_LEAF_CULL)
-    const bool want_leaf_cull = ctxOptOn(ctx, "MCRT_LEAF_CULL");
-#else
-    const bool want_leaf_cull = false;
-#endif
-    if (int rc = buildLayout(s, L, lerr, want_leaf_cull)) return fail(ctx, rc, lerr);
+    if (int rc = buildLayout(s, L, lerr)) return fail(ctx, rc, lerr);
     const bool any_vn = L.any_vn;
     std::vector<double>& prim = L.prim;
     std::vector<double>& normal = L.normal;
@@ -1289,19 +1170,6 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->node_meta, meta.data(), meta.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->nodes64, L.nodes64.data(), L.nodes64.size())) return rc;
     if (int rc = uploadArray(ctx, ctx->qblocks, L.qblocks.data(), L.qblocks.size())) return rc;
-    // leaf cull (mcrt_lanesm.hpp): built and bit-exact, measured SLOWER inside the wave-level steps (C3 466 -> 544 ms, spaceship
-    // 318 -> 385 ms: a wave still runs the exact test whenever one of its lanes has a survivor), and merely compiled into the kernels
-    // it cost the default path 4 %: the device code carries it only in builds made with -DMCRT_DEVICE_LEAF_CULL (+ option MCRT_LEAF_CULL);
-    // the host emulation always has it (tests/test_device_code_host_emulation.py)
-#if defined(MCRT_DEVICE_LEAF_CULL)
-    const bool leaf_cull = !L.leaf_pre.empty();
-#else
-    const bool leaf_cull = false;
-#endif
-    if (!leaf_cull) ctx->leaf_pre.release();
-    else if (int rc = uploadArray(ctx, ctx->leaf_pre, L.leaf_pre.data(), L.leaf_pre.size())) return rc;
-    if (L.wnodes.empty()) ctx->wnodes.release();
-    else if (int rc = uploadArray(ctx, ctx->wnodes, L.wnodes.data(), L.wnodes.size())) return rc;
     // quadric records first: the primitive records and surf_v of quadric surfaces carry their device addresses
     if (L.num_quadric_surfaces) {
         for (uint32_t i = 0; i < s->num_lights; i++)
@@ -1366,13 +1234,6 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
     ctx->q_single = L.q_single;
-    d.wnodes = L.wnodes.empty() ? nullptr : ctx->wnodes.as<WNode>();
-    d.num_wnodes = (uint32_t)L.wnodes.size();
-    d.leaf_pre = leaf_cull ? ctx->leaf_pre.as<float>() : nullptr;
-    d.leaf_cx = L.leaf_centre[0];
-    d.leaf_cy = L.leaf_centre[1];
-    d.leaf_cz = L.leaf_centre[2];
-    d.leaf_bound = L.leaf_bound;
     d.prim = ctx->prim.as<double>();
     d.flat_prim = ctx->flat_prim.as<double>();
     d.flat_index = ctx->flat_index.as<uint32_t>();
@@ -1496,11 +1357,7 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
             fprintf(stderr, "[mcrt phase] %-9s wave-cycles %6.2f%%  lane utilisation %5.1f%%\n", names[i], 100.0 * h[8 + i] / (double)(tw ? tw : 1),
                     h[8 + i] ? 100.0 * h[8 + kNumPhases + i] / (64.0 * h[8 + i]) : 0.0);
     }
-    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS") && ctxOptOn(ctx, "MCRT_WF_SCHED"))
-        fprintf(stderr, "[mcrt trace sched] steps %llu: inner %.1f%% with %.1f slots, leaf %.1f%% with %.1f slots, refill %.1f%%; idle polls per step %.2f\n",
-                h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
-                100.0 * (h[8] - h[10] - h[12]) / h[8], (double)h[14] / h[8]);
-    else if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
+    if (ctx->kernel_id == MCRT_KERNEL_WAVEFRONT && h[8] && ctxOptOn(ctx, "MCRT_COUNT_TESTS"))
         fprintf(stderr, "[mcrt trace] per wave iteration: %.1f lanes hold a ray; inner step in %.1f%% of the iterations with %.1f lanes, leaf step in %.1f%% with %.1f lanes, "
                         "%.1f leaf lanes wait; wave cycles: inner %.1f%%, leaf %.1f%%, rest %.1f%% (of the kernel: refills %.1f%%, pop site %.1f%%); per ray: %.2f inner steps, %.2f leaf steps\n",
                 (double)h[9] / h[8], 100.0 * h[10] / h[8], h[10] ? (double)h[11] / h[10] : 0.0, 100.0 * h[12] / h[8], h[12] ? (double)h[13] / h[12] : 0.0,
@@ -1530,19 +1387,25 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
     if (h[5])
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
-        // The megakernels keep kMaxIors (8) refraction-history entries per lane; the wavefront pipeline's slot pool holds kMaxIorsDeep
-        // (32). A frame that nested deeper than 8 media is rendered AGAIN through the pipeline: slower for the scenes the megakernels
-        // are chosen for, and correct. (The reference's vector is unbounded; no scene of it nests deeper than 4.)
+        // RefractionHistory (ray.cpp:74-98) is an unbounded vector. The megakernels keep kMaxIors (8) entries per lane, the pipeline
+        // ctx->iors_depth per slot (32 to begin with). A frame that nested deeper is rendered AGAIN: a megakernel frame through the
+        // pipeline, a pipeline frame with four times the rows (round 6; until then the frame failed beyond 32) - slower, and correct.
+        // The rows a scene needed stay with the context. (No scene of the reference nests deeper than 4.)
         const bool was_pipeline = ctx->kernel_id == MCRT_KERNEL_WAVEFRONT || ctx->kernel_id == MCRT_KERNEL_WAVEFRONT_PM;
         const bool photon = ctx->last_integrator == MCRT_INTEGRATOR_PHOTON_MAPPER;
-        if (!was_pipeline && !ctx->force_wf && ctx->scene.q_nodes > 0 && (!photon || ctx->k_nearest <= waveMaxK(kWaveRowsLarge))) {
+        const bool can_pipeline = ctx->scene.q_nodes > 0 && (!photon || ctx->k_nearest <= waveMaxK(kWaveRowsLarge));
+        constexpr uint32_t kIorsDepthLimit = 1u << 15;  // (32 768 nested media - a slot keeps the history's size in 16 bits; beyond it something other than a scene is going on)
+        if (can_pipeline && ((!was_pipeline && !ctx->force_wf) || (was_pipeline && ctx->iors_depth < kIorsDepthLimit))) {
+            if (was_pipeline) ctx->iors_depth *= 4u;
+            const bool keep = ctx->force_wf;
             ctx->force_wf = true;
             const int rc = launchRender(ctx, &ctx->last_cam, ctx->last_seed, ctx->last_integrator, ctx->last_out, ctx->last_stream, ctx->last_film);
-            ctx->force_wf = false;
+            ctx->force_wf = keep;
             if (rc != MCRT_OK) return rc;
             return mcrt_render_finish(ctx, stats);
         }
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "a path entered more than 32 nested dielectric media (RefractionHistory, ray.cpp:74-98, is kept to kMaxIorsDeep entries per slot)");
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "a path entered more nested dielectric media than this frame can keep (RefractionHistory, ray.cpp:74-98: 8 per lane in the "
+                                               "megakernels of scenes the pipeline cannot take; 32 768 per slot in the pipeline)");
     }
     return MCRT_OK;
 }
@@ -1853,16 +1716,10 @@ int mcrt_intersect(mcrt_ctx* ctx, uint64_t n, const double* start, const double*
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->scene.stage_all && ctx->scene.num_nodes > 0 && n <= 0xFFF00000ull) {  // (32-bit queue cursors with room for the waves' overshoot)
         // tree in HBM: the trace kernel of the wavefront pipeline, fed from the arrays
-        const bool wide = useWideNodes(ctx);
-        const bool share = !wide && ctxOptL(ctx, "MCRT_WF_DEFER", 1) != 0 && ctxOptL(ctx, "MCRT_WF_SHARE", 1) != 0;  // the pipeline's default form
-        const int lean = share && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;  // as launchWavefront
-        auto trace = wide        ? wfTraceKernel<ArrayRays, false, 1>
-                     : lean == 3 ? wfTraceKernel<ArrayRays, false, 3, 3>
-                     : lean == 1 ? wfTraceKernel<ArrayRays, false, 3, 1>
-                     : share     ? wfTraceKernel<ArrayRays, false, 3>
-                                 : wfTraceKernel<ArrayRays, false>;
+        const int lean = ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 0 ? (ctx->q_single && ctxOptL(ctx, "MCRT_WF_LEAN", 1) != 2 ? 3 : 1) : 0;  // as launchWavefront
+        auto trace = lean == 3 ? wfTraceKernel<ArrayRays, false, 3> : lean == 1 ? wfTraceKernel<ArrayRays, false, 1> : wfTraceKernel<ArrayRays, false>;
         TracePlan tp;
-        if (int rc = planTrace(ctx, trace, n, tp, wide, false, share)) return rc;
+        if (int rc = planTrace(ctx, trace, n, tp)) return rc;
         DevBuf &ds = ctx->op_buf[0], &dd = ctx->op_buf[1], &dt = ctx->op_buf[2], &dsf = ctx->op_buf[3], &duv = ctx->op_buf[4];
         if (int rc = uploadInto(ctx, ds, start, n * 3)) return rc;
         if (int rc = uploadInto(ctx, dd, direction, n * 3)) return rc;

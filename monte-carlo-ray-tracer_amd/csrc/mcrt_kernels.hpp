@@ -27,10 +27,6 @@ struct DeviceScene {
     const Node64* nodes64;
     const QBlock* qblocks;        // quantised child blocks of the trace kernel (mcrt_qbvh.hpp)
     uint32_t num_qblocks, q_root_a, q_root_m;
-    const WNode* wnodes;          // eight-wide quantised nodes (mcrt_wbvh.hpp); null: the tree has none
-    uint32_t num_wnodes;
-    const float* leaf_pre;        // FP32 cull records of the primitives in BVH order (mcrt_lanesm.hpp "leaf cull"); null: none
-    double leaf_cx, leaf_cy, leaf_cz, leaf_bound;
     uint32_t stack_depth;         // traversal-stack entries per lane (LDS + spill slab): max(kMaxStackDepth, the tree's stack bound), mcrt_upload_scene
     uint32_t q_nodes;             // records in nodes64 = num_nodes, or — scene without a BVH — the nodes of the index-range tree the wavefront pipeline walks (mcrt_layout.hpp)
     const double* prim;
@@ -125,15 +121,6 @@ constexpr uint32_t kBlock = 512;  // 8 waves per workgroup, one workgroup per CU
 
 constexpr uint32_t kPmLdsIors = 2;  // refraction-history entries per lane the 1024-lane photon-mapping kernel keeps in LDS
 
-template <class SV>
-__host__ __device__ inline void setLeafCull(SV& sv, const float* pre, double cx, double cy, double cz, double bound) {
-    sv.pre = pre;
-    sv.pre_cx = cx;
-    sv.pre_cy = cy;
-    sv.pre_cz = cz;
-    sv.pre_bound = bound;
-}
-
 struct LdsPlan {
     uint32_t sobol, stack, iors, node_bounds, node_meta, prim, flat_prim, flat_index, flat_pre, surf_v, surf_normal, surf_vn, surf_area, surf_material,
         surf_kind, materials, light_surface, light_cdf, total;
@@ -188,7 +175,9 @@ __device__ inline void stageCopy(MCRT_LDS_AS T* dst, const T* src, uint32_t coun
 // Builds the per-lane views; stages the scene into LDS (ends with __syncthreads()).
 // kAll: whole scene LDS-resident (the views carry address-space-3 pointers, so every scene access in
 // the hot loops is a ds_read); otherwise only the top of the BVH is staged.
-template <bool kAll, bool kFlat = false>
+// kPreK: the flat loop reads its cull records from the kernel's argument block (renderKernelFlatK): the LDS copy is not filled (its
+// 2.8 KB stay carved - planLds is shared with the host's launch geometry - but no workgroup spends a staging loop on them).
+template <bool kAll, bool kFlat = false, bool kPreK = false>
 __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, SceneViewT<kAll>& sv, ShadeViewT<kAll>& sh,
                                   SobolTab& tab, LaneStack& stk, RefractionHistory& rh, StackEntry* spill, uint32_t total_lanes,
                                   uint32_t stack_depth = kLdsStackDepth, double* iors_global = nullptr) {
@@ -245,7 +234,7 @@ __device__ inline void setupViews(const DeviceScene& s, unsigned char* lds, Scen
         sv.pre_cy = s.pre_centre[1];
         sv.pre_cz = s.pre_centre[2];
         sv.pre_bound = s.pre_bound;
-        if (cull) stageCopy(lpre, s.flat_pre, s.pre_tri_pairs * (uint32_t)kTriPairFloats + s.pre_sph_pairs * (uint32_t)kSphPairFloats);
+        if (cull && !kPreK) stageCopy(lpre, s.flat_pre, s.pre_tri_pairs * (uint32_t)kTriPairFloats + s.pre_sph_pairs * (uint32_t)kSphPairFloats);
         if (s.flat) {
             MCRT_LDS_AS double* lfp = ldsAt<double>(lds, p.flat_prim);
             stageCopy(lfp, s.flat_prim, ns * kPrimStride);
@@ -353,7 +342,7 @@ __device__ __forceinline__ void renderKernelBody(const DeviceScene& scene, const
     SobolTab tab;
     LaneStack stk;
     RefractionHistory rh;
-    setupViews<kAll, kFlat != 0>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
+    setupViews<kAll, kFlat != 0, kPreK>(scene, lds, sv, sh, tab, stk, rh, prm.spill, prm.total_lanes);
     sv.flat_pre_k = pre_k;
 
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,7 +575,6 @@ __global__ void __launch_bounds__(kLanes) renderKernelSM(const DeviceScene scene
     } else {
         sv.nodes = scene.nodes64;
         sv.prim = scene.prim;
-        setLeafCull(sv, scene.leaf_pre, scene.leaf_cx, scene.leaf_cy, scene.leaf_cz, scene.leaf_bound);
         sh.surf_v = scene.surf_v;
         sh.surf_normal = scene.surf_normal;
         sh.surf_rec = scene.surf_rec;
@@ -756,11 +744,8 @@ struct WfTraceArgs {
     unsigned long long* stats;
     const Node64* nodes;                // exact records: root test, rays with a zero direction component
     const QBlock* qblocks;
-    const WNode* wnodes;                // kWide instance: eight-wide nodes (mcrt_wbvh.hpp)
     uint32_t num_nodes, lds_blocks, q_root_a, q_root_m;
     const double* prim;
-    const float* leaf_pre;              // leaf cull records (mcrt_lanesm.hpp), or null
-    double leaf_cx, leaf_cy, leaf_cz, leaf_bound;
     SmStackEntry* spill;
     uint32_t total_lanes;
     int refill_lanes, leaf_lanes, min_inner, lds_stack;
@@ -804,20 +789,19 @@ struct ArrayRays {  // mcrt_intersect: closest hits of n rays given as arrays
 // Persistent waves; every lane owns one ray at a time and takes the next one from the queue as soon as its
 // traversal has finished (refills are batched: refill_lanes idle lanes, or nothing left to do). Inner nodes
 // are visited through quantised child blocks, the top of the tree from LDS.
-// kForm: 0 = the first walk (4-wide quantised blocks, a lane waits at its leaf), 1 = eight-wide nodes (mcrt_wbvh.hpp), 2 = deferred
-// leaves (mcrt_lanesm.hpp), 3 = deferred leaves tested by the whole wave (travSharedLeafStep above; the default since round 4). The optional forms are their own instances: compiled into one kernel behind run-time switches they cost the
-// default form a register spill and ~1 % of a frame.
-// kLean (forms 2 / 3; round 5): bit 0 = the inner visit is travInnerStepQLean (mcrt_qbvh.hpp: FP32 ray kept in the Trav, the three
-// pushes as one block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per visit).
-template <class Rays, bool kCount, int kForm = 0, int kLean = 0>
+// Leaves are DEFERRED (mcrt_lanesm.hpp: a lane parks the leaf it reaches and keeps walking) and tested by the WHOLE WAVE
+// (travSharedLeafStep, mcrt_sharedleaf.hpp; the default since round 4). The forms this replaced - a lane waiting at its leaf (round 2),
+// a pending leaf tested by its own lane (round 3), eight-wide nodes, a slot-scheduled workgroup, two half pools on two streams - lost
+// every A/B they were in and were removed in round 6 (measurements: profiles/NOTES_r01_r03.md ... NOTES_r05.md).
+// kLean (round 5): bit 0 = the inner visit is travInnerStepQLean (mcrt_qbvh.hpp: FP32 ray kept in the Trav, the three pushes as one
+// block of unconditional LDS writes), bit 1 = ... and the tree has no node with more than four children (one block per visit).
+// kLean == 0 (round 4's visit) serves MCRT_COUNT_TESTS and MCRT_WF_LEAN=0.
+template <class Rays, bool kCount, int kLean = 0>
 __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArgs a, const Rays rays) {
-    constexpr bool kWide = kForm == 1, kShare = kForm == 3, kDefer = kForm == 2 || kShare;
-    static_assert(kLean == 0 || kShare, "the lean visit pops at the loop's one pop site and refreshes best_up behind the shared leaf step");
     MCRT_DYNAMIC_LDS(lds, 64);
     MCRT_LDS_AS QBlock* lq = ldsAt<QBlock>(lds, 0);
-    if constexpr (!kWide)
-        for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
-            reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
+    for (uint32_t i = threadIdx.x; i < a.lds_blocks * 16u; i += blockDim.x)
+        reinterpret_cast<MCRT_LDS_AS uint32_t*>(lq)[i] = reinterpret_cast<const uint32_t*>(a.qblocks)[i];
     SmStack stk;
     stk.lds = ldsAt<SmStackEntry>(lds, a.lds_blocks * 64u) + threadIdx.x;
     stk.lds_stride = blockDim.x;
@@ -831,7 +815,6 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     sv.prim = a.prim;
     sv.lds_nodes = 1;            // the root (below)
     sv.lds_node_ptr = nullptr;   // set once the root is staged
-    setLeafCull(sv, a.leaf_pre, a.leaf_cx, a.leaf_cy, a.leaf_cz, a.leaf_bound);
     QView<true> qv;
     qv.blocks = a.qblocks;
     qv.lds_blocks = a.lds_blocks;
@@ -870,10 +853,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     T.sp = 0;
     LeanRay LR;  // kLean: the ray in FP32 and floatAbove(best.t), kept per ray (travInnerStepQLean)
     LR.of[0] = LR.of[1] = LR.of[2] = LR.invf[0] = LR.invf[1] = LR.invf[2] = LR.best_up = 0.0f;
-    PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking; kWide: the leaf being tested
-    WLeaves Lv;  // kWide: hit leaf children still to be tested
-    WView wv;
-    wv.nodes = a.wnodes;
+    PendLeaf P;  // deferred leaves (mcrt_lanesm.hpp): a lane parks the leaf it reaches and keeps walking
     TraceCounters cnt = {0u, 0u, 0u, 0u};
     // MCRT_COUNT_TESTS: where the wave's issue slots go (per wave: iterations, lanes holding a ray, inner / leaf steps and the lanes
     // that took part, leaf lanes kept waiting by the gate, wave cycles inside the two steps and in all)
@@ -885,7 +865,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     for (;;) {
         // Finished rays (deferred leaves: none pending, nothing left to pop) hand their hits back in BATCHES - together with the refill
         // that replaces them (a store per iteration for the three rays that finish in it cost the whole wave ~30 instructions each time)
-        const bool done = have && !T.active && (!kDefer || (P.n == 0u && !T.need_pop));
+        const bool done = have && !T.active && P.n == 0u && !T.need_pop;
         const unsigned long long m_done = waveBallot(done);
         unsigned long long m_have = waveBallot(have) & ~m_done;
         const bool want_refill = !exhausted && (64 - __popcll(m_have) >= a.refill_lanes || m_have == 0ull);
@@ -914,8 +894,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
                 bool shadow;
                 ShadowQuery sq;
                 item = rays.load(w, o, d, shadow, sq);
-                if constexpr (kWide) travBeginW<false, kCount>(sv, T, Lv, P, o, d, rcp3(d), shadow, &sq, cnt);
-                else travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
+                travBeginQ<false, true, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
                 if constexpr (kLean != 0) leanRayBegin(LR, T);
                 have = true;
             }
@@ -926,134 +905,63 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
             if (exhausted) break;
             continue;
         }
-        if constexpr (kWide) {
-            // eight-wide nodes (mcrt_wbvh.hpp): a lane with hit leaves works them off first (their hits prune what follows), the
-            // others take one wide step; rays with a zero direction component walk the exact records
-            const bool fast = T.fast;
-            const bool leaf0 = have && T.active && (fast ? (P.n | Lv.bits) != 0u : !(T.node_m & kSmInner));
-            const bool inner = have && T.active && !leaf0;
-            unsigned long long tc = 0ull;
-            if (kCount) {
-                const unsigned long long mi = waveBallot(inner);
-                ph_iter++;
-                ph_have += __popcll(waveBallot(have));
-                ph_in_steps += mi ? 1u : 0u;
-                ph_in_lanes += __popcll(mi);
-                tc = clock64();
-            }
-            if (inner && fast) travWideStep<kCount>(wv, T, Lv, stk, cnt);
-            if (inner && !fast) travInnerStep<false, kCount>(sv, T, stk, cnt);
-            if (kCount) ph_in_cyc += clock64() - tc;
-            const bool leaf = have && T.active && (fast ? (P.n | Lv.bits) != 0u : !(T.node_m & kSmInner));
-            const unsigned long long m_leaf = waveBallot(leaf);
-            const unsigned long long m_inner = waveBallot(have && T.active && !leaf);
-            if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
-                if (kCount) {
-                    ph_lf_steps++;
-                    ph_lf_lanes += __popcll(m_leaf);
-                    tc = clock64();
-                }
-                if (leaf && fast) {
-                    travWideNextLeaf(wv, T, Lv, P);
-                    travPendStep<false, kCount>(sv, T, P, cnt);
-                    travWideAfterLeaf(T, Lv, P);
-                }
-                if (leaf && !fast) travLeafStep<false, kCount>(sv, T, stk, cnt);
-                if (kCount) ph_lf_cyc += clock64() - tc;
-            } else if (kCount) {
-                ph_lf_wait += __popcll(m_leaf);
-            }
-            continue;
+        // A lane standing at a leaf whose pending slot is free parks the leaf; it and every lane whose last visit kept no child take
+        // their next node from the stack HERE - the loop's one pop site (round 4; the walk used to pop in three places per
+        // iteration - after each of two parking sites and at the end of the inner step - each a chain of dependent LDS reads the
+        // whole wave waits for). A lane that pops a leaf while its slot is taken waits; with a free slot it parks it next time round.
+        if (have && T.active && !(T.node_m & kSmInner) && P.n == 0u) {
+            P.a = T.node_a;
+            P.n = T.node_m;
+            T.active = false;
+            T.need_pop = true;
         }
-        if constexpr (kDefer) {
-            // A lane standing at a leaf whose pending slot is free parks the leaf; it and every lane whose last visit kept no child take
-            // their next node from the stack HERE - the loop's one pop site (round 4; the walk used to pop in three places per
-            // iteration - after each of two parking sites and at the end of the inner step - each a chain of dependent LDS reads the
-            // whole wave waits for). A lane that pops a leaf while its slot is taken waits; with a free slot it parks it next time round.
-            if (have && T.active && !(T.node_m & kSmInner) && P.n == 0u) {
-                P.a = T.node_a;
-                P.n = T.node_m;
-                T.active = false;
-                T.need_pop = true;
+        if (waveBallot(have && T.need_pop)) {
+            const unsigned long long t_pop = kCount ? clock64() : 0ull;
+            if (have && T.need_pop) {
+                travPopCached(T, stk);
+                T.need_pop = false;
             }
-            if (waveBallot(have && T.need_pop)) {
-                const unsigned long long t_pop = kCount ? clock64() : 0ull;
-                if (have && T.need_pop) {
-                    travPopCached(T, stk);
-                    T.need_pop = false;
-                }
-                if (kCount) ph_pop_cyc += clock64() - t_pop;
-            }
-            const bool inner = have && T.active && (T.node_m & kSmInner);
-            unsigned long long ti = 0ull;
-            if (kCount) {
-                const unsigned long long mi = waveBallot(inner);
-                ph_iter++;
-                ph_have += __popcll(waveBallot(have));
-                ph_in_steps += mi ? 1u : 0u;
-                ph_in_lanes += __popcll(mi);
-                ti = clock64();
-            }
-            if constexpr ((kLean & 1) != 0) {
-                if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, LR, stk, cnt);
-            } else {
-                if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
-            }
-            if (inner && !T.fast) travInnerStep<false, kCount, true>(sv, T, stk, cnt);  // zero direction component: exact records
-            if (kCount) ph_in_cyc += clock64() - ti;
-            const bool pend = have && P.n != 0u;
-            const unsigned long long m_pend = waveBallot(pend);
-            const unsigned long long m_inner = waveBallot(have && (T.need_pop || (T.active && (T.node_m & kSmInner))));
-            ShareOffer so;
-            bool go = m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner);
-            if constexpr (kShare) {  // the shared step is gated by what it would TEST: enough offered primitives to fill the wave
-                // (counting the offers only for a step that is going to run - the item gate is off by default - was tried in round 5: the
-                // extra branch cost the kernel a spilled register and 20 instructions)
-                so = shareOffer(pend, P);
-                go = go || (int)so.total >= a.leaf_items;
-            }
-            if (go) {
-                unsigned long long tc = 0ull;
-                if (kCount) {
-                    ph_lf_steps++;
-                    ph_lf_lanes += __popcll(m_pend);
-                    tc = clock64();
-                }
-                if constexpr (kShare) travSharedLeafStep<kCount>(sv, T, P, so, share_map, cnt);
-                else if (pend) travPendStep<false, kCount>(sv, T, P, cnt);
-                if constexpr (kLean != 0) LR.best_up = floatAbove(T.best.t);  // (the step may have improved the hit)
-                if (kCount) ph_lf_cyc += clock64() - tc;
-            } else if (kCount) {
-                ph_lf_wait += __popcll(m_pend);
-            }
-            continue;
+            if (kCount) ph_pop_cyc += clock64() - t_pop;
         }
         const bool inner = have && T.active && (T.node_m & kSmInner);
-        unsigned long long tc = 0ull;
+        unsigned long long ti = 0ull;
         if (kCount) {
             const unsigned long long mi = waveBallot(inner);
             ph_iter++;
             ph_have += __popcll(waveBallot(have));
             ph_in_steps += mi ? 1u : 0u;
             ph_in_lanes += __popcll(mi);
-            tc = clock64();
+            ti = clock64();
         }
-        if (inner && T.fast) travInnerStepQ<true, kCount>(qv, T, stk, cnt);
-        if (inner && !T.fast) travInnerStep<false, kCount>(sv, T, stk, cnt);  // zero direction component: exact records
-        if (kCount) ph_in_cyc += clock64() - tc;
-        const bool leaf = have && T.active && !(T.node_m & kSmInner);
-        const unsigned long long m_leaf = waveBallot(leaf);
-        const unsigned long long m_inner = waveBallot(have && T.active && (T.node_m & kSmInner));
-        if (m_leaf && (__popcll(m_leaf) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner)) {
+        if constexpr ((kLean & 1) != 0) {
+            if (inner && T.fast) travInnerStepQLean<true, kCount, (kLean & 2) != 0>(qv, T, LR, stk, cnt);
+        } else {
+            if (inner && T.fast) travInnerStepQ<true, kCount, true>(qv, T, stk, cnt);
+        }
+        if (inner && !T.fast) travInnerStep<false, kCount, true>(sv, T, stk, cnt);  // zero direction component: exact records
+        if (kCount) ph_in_cyc += clock64() - ti;
+        const bool pend = have && P.n != 0u;
+        const unsigned long long m_pend = waveBallot(pend);
+        const unsigned long long m_inner = waveBallot(have && (T.need_pop || (T.active && (T.node_m & kSmInner))));
+        ShareOffer so;
+        bool go = m_pend && (__popcll(m_pend) >= a.leaf_lanes || __popcll(m_inner) < a.min_inner);
+        // the shared step is gated by what it would TEST: enough offered primitives to fill the wave
+        // (counting the offers only for a step that is going to run - the item gate is off by default - was tried in round 5: the
+        // extra branch cost the kernel a spilled register and 20 instructions)
+        so = shareOffer(pend, P);
+        go = go || (int)so.total >= a.leaf_items;
+        if (go) {
+            unsigned long long tc = 0ull;
             if (kCount) {
                 ph_lf_steps++;
-                ph_lf_lanes += __popcll(m_leaf);
+                ph_lf_lanes += __popcll(m_pend);
                 tc = clock64();
             }
-            if (leaf) travLeafStep<false, kCount>(sv, T, stk, cnt);
+            travSharedLeafStep<kCount>(sv, T, P, so, share_map, cnt);
+            if constexpr (kLean != 0) LR.best_up = floatAbove(T.best.t);  // (the step may have improved the hit)
             if (kCount) ph_lf_cyc += clock64() - tc;
         } else if (kCount) {
-            ph_lf_wait += __popcll(m_leaf);
+            ph_lf_wait += __popcll(m_pend);
         }
     }
     if (kCount && laneId() == 0) {
@@ -1074,316 +982,6 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     if (kCount) {
         waveAccumulate(a.stats + 2, cnt.node_tests);
         waveAccumulate(a.stats + 3, cnt.prim_tests);
-    }
-    waveAccumulate(a.stats + 5, cnt.overflow);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Slot-scheduled trace kernel (round 3): ray state in LDS, every step issued for 64 rays that want THAT step
-// ------------------------------------------------------------------------------------------------
-// What the counters of wfTraceKernel say (MCRT_COUNT_TESTS, C3): per loop iteration 50 of a wave's 64 lanes hold a ray, 35 of
-// them take the inner step and - in 57 % of the iterations - 23 the leaf step; the wave pays for both at 64 lanes each: 39 %
-// VALU lane utilisation on a kernel that is bound by VALU issue (75 % busy). The rays' states cannot be aligned inside one wave
-// (a ray alternates inner, inner, leaf, inner ... at its own pace); they can across the 16 waves of a workgroup. Here a ray is
-// not owned by a lane: the workgroup keeps kSchedSlots ray slots in LDS (FP32 origin / inverse direction for the block visits,
-// best t, node link, a stack of 8 entries per slot, [field][slot] planes; the FP64 ray for the exact primitive tests stays in
-// HBM) and three queues of slot numbers - slots whose next step is an INNER visit, a LEAF step, or that are FREE. A wave takes
-// up to 64 slot numbers from ONE queue, loads their state, runs that one step for all of them (the per-lane step functions of
-// mcrt_qbvh.hpp / mcrt_lanesm.hpp, unchanged: same visits, same tests, same hits), writes the state back and files every slot
-// under its next step. Free slots are refilled 64 at a time from the workgroup's share of the ray queue. Queues are rings with
-// lock-free tickets (producers reserve with an atomic add and fill their entries, consumers move the head with compare-and-swap
-// and wait for an entry to be filled); a slot is in at most one queue, so rings of kSchedSlots entries cannot overflow.
-// Rays with a zero direction component (the exact-record walk, rare) are traced to the end by the lane that loaded them.
-//
-// MEASURED (C3, 64 spp, MCRT_WF_SCHED=1): the same 60.9 box and 11.6 primitive tests per ray, bit-identical
-// frames, inner steps issued with 59 of 64 lanes and leaf steps with 52 (lane-owned kernel: 35 and 23) - and the frame is NOT
-// faster: 499 ms against 487. A step's latency chain (ticket, slot records, block fetch, visit, records, ticket) now limits a wave
-// to one step per ~4.7 us, and with 1024 of the 1216 slots checked out by the 16 waves the queues rarely hold a full batch for
-// the wave that looks (0.5-1.1 idle polls per step). What would make it pay is slack - several thousand slots per workgroup, i.e.
-// the stacks out of LDS - not a leaner scheduler (two leaner ones measured the same or worse). Kept as an option, off by default.
-constexpr uint32_t kSchedSlots = 1216;   // 116 B of LDS each + the queues: 153 KB of the CU's 160
-constexpr uint32_t kSchedStack = 8;      // stack entries per slot in LDS (deeper ones: HBM, per slot)
-constexpr uint32_t kSchedRing = 2048;    // ring entries per queue (a power of two >= kSchedSlots)
-struct SchedRay {                        // what a block visit reads of a slot, one 32-byte record
-    float of[3], invf[3];
-    uint32_t node_a, node_m;
-};
-struct SchedHit {                        // 16 bytes
-    double best_t;
-    uint32_t best_s, misc;               // misc: sp | shadow << 8
-};
-struct SchedLds {
-    SchedRay ray[kSchedSlots];
-    SchedHit hit[kSchedSlots];
-    uint32_t item[kSchedSlots];
-    SmStackEntry stack[kSchedStack][kSchedSlots];
-    uint16_t ring[3][kSchedRing];        // slot + 1, 0 = not filled yet
-    uint32_t head[4], tail[4];           // monotonic tickets of the three queues (one 16-byte read each)
-    uint32_t cursor, dead;               // next entry of the workgroup's share of the ray queue; slots that found it drained
-};
-enum : int { kQInner = 0, kQLeaf = 1, kQFree = 2 };
-
-template <class Rays, bool kCount>
-__global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernelSched(const WfTraceArgs a, const Rays rays, double* ray_scratch) {
-    MCRT_DYNAMIC_LDS(lds, 64);
-    MCRT_LDS_AS SchedLds* L = reinterpret_cast<MCRT_LDS_AS SchedLds*>((MCRT_LDS_AS unsigned char*)lds);
-    const uint32_t lane = laneId();
-    // every slot starts free
-    for (uint32_t i = threadIdx.x; i < kSchedRing; i += blockDim.x) {
-        L->ring[kQFree][i] = i < kSchedSlots ? (uint16_t)(i + 1u) : (uint16_t)0;
-        L->ring[kQInner][i] = 0;
-        L->ring[kQLeaf][i] = 0;
-    }
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < 4; i++) L->head[i] = L->tail[i] = 0u;
-        L->tail[kQFree] = kSchedSlots;
-        L->cursor = 0u;
-        L->dead = 0u;
-    }
-    __syncthreads();
-    SmSceneView<false> sv;
-    sv.num_nodes = a.num_nodes;
-    sv.nodes = a.nodes;
-    sv.prim = a.prim;
-    sv.lds_nodes = 0;
-    sv.lds_node_ptr = nullptr;
-    setLeafCull(sv, a.leaf_pre, a.leaf_cx, a.leaf_cy, a.leaf_cz, a.leaf_bound);
-    QView<false> qv;  // blocks from HBM / L2 (the LDS belongs to the ray slots)
-    qv.blocks = a.qblocks;
-    qv.lds_blocks = 0;
-    qv.lds_ptr = nullptr;
-    qv.root_a = a.q_root_a;
-    qv.root_m = a.q_root_m;
-    const unsigned long long n = *a.count;
-    const uint32_t deal_shift = a.deal_shift, deal_mask = (1u << deal_shift) - 1u;
-    auto dealt = [&](uint32_t v) -> unsigned long long {  // the v-th entry of this workgroup's share of the ray queue
-        return ((((unsigned long long)(v >> deal_shift) * gridDim.x + blockIdx.x) << deal_shift) | (v & deal_mask));
-    };
-    double* const scratch = ray_scratch + (size_t)blockIdx.x * kSchedSlots * 16u;  // [slot][16], one 128-byte line: o, d, 1/d, t_near, light bits
-    TraceCounters cnt = {0u, 0u, 0u, 0u};
-    auto stackOf = [&](uint32_t slot) {
-        SmStack stk;
-        stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(&L->stack[0][0]) + slot;
-        stk.lds_stride = kSchedSlots;
-        stk.lds_depth = (int)kSchedStack;
-        stk.spill = a.spill + (size_t)blockIdx.x * kSchedSlots + slot;
-        stk.spill_stride = a.total_lanes;  // (= grid * kSchedSlots: planTrace)
-        stk.max_depth = (int)a.max_stack;
-        return stk;
-    };
-    // file the slots of this wave's lanes under queue q (lanes with `want`): one ticket reservation per wave
-    auto push = [&](int q, bool want, uint32_t slot) {
-        const unsigned long long m = waveBallot(want);
-        if (!m) return;
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0u;
-        if ((int)lane == leader) base = __atomic_fetch_add(&L->tail[q], (uint32_t)__popcll(m), __ATOMIC_RELAXED);
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (want) {
-            const uint32_t pos = (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (kSchedRing - 1u);
-            // (the entry's previous ticket, kSchedRing pushes ago, was consumed - but its consumer may not have picked it up yet)
-            for (uint32_t spin = 0; __atomic_load_n(&L->ring[q][pos], __ATOMIC_RELAXED) != 0; spin++)
-                if (spin > (1u << 24)) { cnt.overflow = 1; break; }  // (watchdog: a scheduling bug must end the launch, not hang the GPU)
-            __atomic_store_n(&L->ring[q][pos], (uint16_t)(slot + 1u), __ATOMIC_RELAXED);
-        }
-    };
-    unsigned long long ph_steps[3] = {0, 0, 0}, ph_lanes[3] = {0, 0, 0}, ph_idle = 0;
-    uint32_t idle_spins = 0;
-
-    for (;;) {
-        // ---- take up to 64 slots from one queue: a full batch of leaf steps first (their hits prune), then inner, then refills;
-        //      with no full batch anywhere, the fullest queue. Every lane reads the six tickets (one address: a broadcast) and
-        //      decides alike; lane 0 moves the head (compare-and-swap: a lost race is simply another round).
-        struct U3 { uint32_t x, y, z; };
-        U3 hd, tl;  // (heads first: a tail read later is never smaller than its head)
-        hd.x = __atomic_load_n(&L->head[0], __ATOMIC_RELAXED); hd.y = __atomic_load_n(&L->head[1], __ATOMIC_RELAXED); hd.z = __atomic_load_n(&L->head[2], __ATOMIC_RELAXED);
-        tl.x = __atomic_load_n(&L->tail[0], __ATOMIC_RELAXED); tl.y = __atomic_load_n(&L->tail[1], __ATOMIC_RELAXED); tl.z = __atomic_load_n(&L->tail[2], __ATOMIC_RELAXED);
-        const uint32_t av_in = tl.x - hd.x, av_lf = tl.y - hd.y, av_fr = tl.z - hd.z;
-        int q;
-        if (av_lf >= 64u) q = kQLeaf;
-        else if (av_in >= 64u) q = kQInner;
-        else if (av_fr >= 64u) q = kQFree;
-        else q = (av_in >= av_lf && av_in >= av_fr) ? kQInner : (av_lf >= av_fr ? kQLeaf : kQFree);
-        const uint32_t av = q == kQInner ? av_in : q == kQLeaf ? av_lf : av_fr;
-        const uint32_t h = q == kQInner ? hd.x : q == kQLeaf ? hd.y : hd.z;
-        // Tickets up to `tail` are RESERVED by their producers but not necessarily written yet: every lane looks at its candidate
-        // entry and the wave takes the filled prefix (no lane ever waits for an entry to appear).
-        uint16_t v = 0;
-        if (lane < av) v = __atomic_load_n(&L->ring[q][(h + lane) & (kSchedRing - 1u)], __ATOMIC_RELAXED);
-        const unsigned long long filled = waveBallot(v != 0);
-        const uint32_t k = filled == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~filled);  // leading filled entries
-        if (k) {
-            int won = 0;
-            if (lane == 0) {
-                uint32_t expect = h;
-                won = __atomic_compare_exchange_n(&L->head[q], &expect, h + k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) ? 1 : 0;
-            }
-            if (!__builtin_amdgcn_readfirstlane(won)) continue;  // another wave took them first
-        } else {
-            if (av == 0u && __atomic_load_n(&L->dead, __ATOMIC_RELAXED) >= kSchedSlots) break;  // every slot has seen the ray queue drained
-            if (++idle_spins > (1u << 22)) {  // (watchdog, ~seconds)
-                cnt.overflow = 1;
-                break;
-            }
-            if (kCount) ph_idle++;
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        idle_spins = 0;
-        const bool on = lane < k;
-        uint32_t slot = 0u;
-        if (on) {
-            __atomic_store_n(&L->ring[q][(h + lane) & (kSchedRing - 1u)], (uint16_t)0, __ATOMIC_RELAXED);  // ours since the head moved past it
-            slot = (uint32_t)v - 1u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the slot's records as its last holder left them
-        if (kCount) { ph_steps[q]++; ph_lanes[q] += k; }
-
-        bool to_inner = false, to_leaf = false, to_free = false;
-        if (q == kQFree) {
-            // ---- refill: the next ray of the workgroup's share, root test, state into the slot
-            unsigned long long w = n;
-            {
-                const unsigned long long need = waveBallot(on);
-                const int leader = __ffsll((long long)need) - 1;
-                uint32_t base = 0u;
-                if ((int)lane == leader) base = __atomic_fetch_add(&L->cursor, (uint32_t)__popcll(need), __ATOMIC_RELAXED);
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                if (on) w = dealt(base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull)));
-            }
-            if (on && w >= n) {
-                __atomic_fetch_add(&L->dead, 1u, __ATOMIC_RELAXED);  // the queue is drained: this slot retires
-            } else if (on) {
-                d3 o, d;
-                bool shadow;
-                ShadowQuery sq;
-                const uint32_t item = rays.load(w, o, d, shadow, sq);
-                Trav T;
-                SmStack stk = stackOf(slot);
-                travBeginQ<false, false, kCount>(sv, qv, T, o, d, rcp3(d), shadow, &sq, cnt);
-                if (T.active && !T.fast) {  // zero direction component: the exact-record walk, to the end, by this lane
-                    while (T.active) {
-                        if (T.node_m & kSmInner) travInnerStep<false, kCount>(sv, T, stk, cnt);
-                        else travLeafStep<false, kCount>(sv, T, stk, cnt);
-                    }
-                }
-                if (!T.active) {
-                    rays.store(item, T.best);
-                    to_free = true;
-                } else {
-                    SchedRay R;
-                    R.of[0] = (float)o.x; R.of[1] = (float)o.y; R.of[2] = (float)o.z;
-                    R.invf[0] = (float)T.inv.x; R.invf[1] = (float)T.inv.y; R.invf[2] = (float)T.inv.z;
-                    R.node_a = T.node_a;
-                    R.node_m = T.node_m;
-                    L->ray[slot] = R;
-                    SchedHit H;
-                    H.best_t = T.best.t;
-                    H.best_s = kNoSurface;
-                    H.misc = (uint32_t)T.sp | (shadow ? 0x100u : 0u);
-                    L->hit[slot] = H;
-                    L->item[slot] = item;
-                    double* r = scratch + (size_t)slot * 16u;
-                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
-                    r[6] = T.inv.x; r[7] = T.inv.y; r[8] = T.inv.z;  // (quadrics test their slicing box with it)
-                    r[9] = T.t_near;
-                    r[10] = __longlong_as_double((long long)(unsigned long long)T.light);
-                    to_inner = (T.node_m & kSmInner) != 0u;
-                    to_leaf = !to_inner;
-                }
-            }
-        } else if (q == kQInner) {
-            // ---- one block visit per slot
-            if (on) {
-                const SchedRay R = L->ray[slot];
-                const SchedHit H = L->hit[slot];
-                Trav T;
-                T.o = d3{(double)R.of[0], (double)R.of[1], (double)R.of[2]};        // (float -> double -> float is the identity:
-                T.inv = d3{(double)R.invf[0], (double)R.invf[1], (double)R.invf[2]};  //  the visit converts them back)
-                T.d = splat(0.0);
-                T.best.t = H.best_t;
-                T.best.u = T.best.v = 0.0;
-                T.best.surface = kNoSurface;
-                T.best.interpolate = false;
-                T.node_a = R.node_a;
-                T.node_m = R.node_m;
-                T.sp = (int)(H.misc & 0xFFu);
-                T.active = true;
-                T.fast = true;
-                T.shadow = false;
-                T.light = kNoSurface;
-                T.t_near = 0.0;
-                SmStack stk = stackOf(slot);
-                travInnerStepQ<false, kCount>(qv, T, stk, cnt);
-                L->hit[slot].misc = (H.misc & ~0xFFu) | (uint32_t)T.sp;
-                if (!T.active) {
-                    if (H.best_s == kNoSurface) rays.store(L->item[slot], T.best);  // never hit: the record of a miss (a hit was stored when it was found)
-                    to_free = true;
-                } else {
-                    *reinterpret_cast<MCRT_LDS_AS uint2*>(&L->ray[slot].node_a) = uint2{T.node_a, T.node_m};
-                    to_inner = (T.node_m & kSmInner) != 0u;
-                    to_leaf = !to_inner;
-                }
-            }
-        } else {
-            // ---- one leaf step per slot: the exact tests on the FP64 ray
-            if (on) {
-                const double* r = scratch + (size_t)slot * 16u;
-                const uint2 nd = *reinterpret_cast<MCRT_LDS_AS const uint2*>(&L->ray[slot].node_a);
-                const SchedHit H = L->hit[slot];
-                Trav T;
-                T.o = d3{r[0], r[1], r[2]};
-                T.d = d3{r[3], r[4], r[5]};
-                T.inv = d3{r[6], r[7], r[8]};
-                T.t_near = r[9];
-                T.light = (uint32_t)(unsigned long long)__double_as_longlong(r[10]);
-                T.best.t = H.best_t;
-                T.best.u = T.best.v = 0.0;
-                T.best.surface = H.best_s;
-                T.best.interpolate = false;
-                T.node_a = nd.x;
-                T.node_m = nd.y;
-                T.sp = (int)(H.misc & 0xFFu);
-                T.shadow = (H.misc & 0x100u) != 0u;
-                T.active = true;
-                T.fast = true;
-                SmStack stk = stackOf(slot);
-                travLeafStep<false, kCount>(sv, T, stk, cnt);
-                const bool closer_hit = T.best.t != H.best_t || T.best.surface != H.best_s;
-                if (closer_hit) rays.store(L->item[slot], T.best);  // its record goes out now (u, v are not kept in the slot)
-                SchedHit H2;
-                H2.best_t = T.best.t;
-                H2.best_s = T.best.surface;
-                H2.misc = (H.misc & ~0xFFu) | (uint32_t)T.sp;
-                L->hit[slot] = H2;
-                if (!T.active) {
-                    if (T.best.surface == kNoSurface) rays.store(L->item[slot], T.best);
-                    to_free = true;
-                } else {
-                    *reinterpret_cast<MCRT_LDS_AS uint2*>(&L->ray[slot].node_a) = uint2{T.node_a, T.node_m};
-                    to_inner = (T.node_m & kSmInner) != 0u;
-                    to_leaf = !to_inner;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the slot's records before its number appears in a queue
-        push(kQLeaf, to_leaf, slot);
-        push(kQInner, to_inner, slot);
-        push(kQFree, to_free, slot);
-    }
-    waveAccumulate(a.stats + 1, cnt.rays);
-    if (kCount) {
-        waveAccumulate(a.stats + 2, cnt.node_tests);
-        waveAccumulate(a.stats + 3, cnt.prim_tests);
-        if (lane == 0) {
-            atomicAdd(a.stats + 8, ph_steps[0] + ph_steps[1] + ph_steps[2]);
-            atomicAdd(a.stats + 10, ph_steps[kQInner]);
-            atomicAdd(a.stats + 11, ph_lanes[kQInner]);
-            atomicAdd(a.stats + 12, ph_steps[kQLeaf]);
-            atomicAdd(a.stats + 13, ph_lanes[kQLeaf]);
-            atomicAdd(a.stats + 14, ph_idle);
-            atomicAdd(a.stats + 9, ph_lanes[0] + ph_lanes[1] + ph_lanes[2]);
-        }
     }
     waveAccumulate(a.stats + 5, cnt.overflow);
 }
@@ -1599,8 +1197,11 @@ struct WfKnnArgs {
 // kEval: the launch evaluates the estimate itself — the k photons' BSDF terms by k lanes at once, a wave reduction
 // (waveEvalPhotons, as in renderKernelPM) — from the Interaction the shade launch staged, instead of handing the k photons
 // back for a per-lane loop in the next shade launch (2 x k x 12 B per slot written and read, k divergent BSDF evaluations).
+// Occupancy of the kNN launch (round 6, C5 through the pipeline at 64 spp, ms per frame; profiles/r06_ab_knn_occupancy.log): the
+// compiler's own choice (165 VGPRs, 3 waves per SIMD, no spill) 882.9; 4 waves (128 VGPRs, 21 spilled) 828.0; 5 waves (96 VGPRs, 61
+// spilled) 816.0 - a search is a chain of dependent reads (octree records, leaf runs), and waves are what hides it.
 #ifndef MCRT_KNN_OCC
-#define MCRT_KNN_OCC  // (build-time A/B: __attribute__((amdgpu_waves_per_eu(4, 4))) = 128 VGPRs, 21 spilled)
+#define MCRT_KNN_OCC __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 template <bool kEval, int R = kWaveRows>
 __global__ void __launch_bounds__(256) MCRT_KNN_OCC wfKnnKernel(const WfKnnArgs a) {
@@ -1708,7 +1309,6 @@ __device__ inline void setupQWalk(const DeviceScene& scene, unsigned char* lds, 
     q.sv.prim = scene.prim;
     q.sv.lds_nodes = 0;
     q.sv.lds_node_ptr = nullptr;
-    setLeafCull(q.sv, scene.leaf_pre, scene.leaf_cx, scene.leaf_cy, scene.leaf_cz, scene.leaf_bound);
     q.stk.lds = reinterpret_cast<MCRT_LDS_AS SmStackEntry*>(lstk.lds);  // same 8-byte entries, same [depth][lanes] region
     q.stk.lds_depth = (int)stack_depth;
     q.stk.lds_stride = lstk.lds_stride;

@@ -34,9 +34,6 @@ struct SmSceneView {
     cptr<double, kAll> prim;
     uint32_t lds_nodes;  // nodes [0, lds_nodes) are also in LDS (used when !kAll)
     MCRT_LDS_AS const Node64* lds_node_ptr;
-    // leaf cull (below): FP32 records of the primitives, one per aligned pair, or null; centre and domain of the records
-    const float* pre = nullptr;
-    double pre_cx = 0.0, pre_cy = 0.0, pre_cz = 0.0, pre_bound = 0.0;
 };
 
 struct SmStackEntry {
@@ -345,42 +342,12 @@ MCRT_HD void travInnerStep(const SmSceneView<kAll>& sv, Trav& T, const SmStack& 
     }
 }
 
-// ---- Leaf cull (round 3) ---------------------------------------------------------------------------------------------------
-// A leaf step used to run the reference's FP64 Moeller-Trumbore on two primitives (~170 instructions and two 80-byte records),
-// and nine tests in ten end in a reject (C3: 13.4 tests per ray for one hit). Now the step first decides in packed FP32 which
-// of an ALIGNED pair of consecutive primitives cannot be hit - the cull of the flat loop (mcrt_scene.hpp "FP32 cull": one
-// 128-byte record per pair, error-bounded thresholds, a certain reject or a survivor) - and runs the exact test on the
-// survivors only. Survivors are a superset of what the exact tests accept, the exact tests and the tie rule are unchanged, so
-// the closest hit is the same. A range that starts at an odd index spends its first step on one primitive.
-//
-// Tests the next primitive(s) of the range [i, i + count) against the ray of T; returns how many were consumed (1 or 2).
+// Tests the next primitive(s) of the range [i, i + count) against the ray of T with the reference's FP64 tests; returns how many
+// were consumed (1 or 2). (Round 3 put an FP32 cull of an aligned primitive pair in front - the flat loop's records per leaf pair;
+// compiled into the gfx950 kernels the branch cost 4-5 % of a frame, it never shipped enabled and was removed in round 6.)
 template <bool kAll, bool kCount>
 MCRT_HD uint32_t leafTestNext(const SmSceneView<kAll>& sv, Trav& T, uint32_t i, uint32_t count, TraceCounters& cnt, bool& decided) {
     const Ray r = travRay(T);
-#if !defined(__HIP_DEVICE_COMPILE__) || defined(MCRT_DEVICE_LEAF_CULL)
-    // (host emulation, and device builds made with -DMCRT_DEVICE_LEAF_CULL for A/B runs: compiled into the gfx950 kernels the
-    // unused branch alone cost 4 % of a C3 frame and 5 % of the spaceship's - registers and code size of every leaf step)
-    if (!kAll && sv.pre != nullptr) {
-        const uint32_t pb = i & ~1u;
-        const uint32_t in_range = ((i & 1u) ? 2u : 3u) & ((pb + 1u < i + count) ? 3u : 1u);
-        const CullRay cr = cullRayAt(sv.pre_cx, sv.pre_cy, sv.pre_cz, sv.pre_bound, T.o, T.d);
-        uint32_t surv = cullTriangles(sv.pre + (size_t)(pb >> 1) * kTriPairFloats, 1u, 2u, cr) & in_range;
-        while (surv) {
-            const uint32_t j = pb + lowestBit(surv);
-            surv &= surv - 1u;
-            const PrimRec rec = loadPrim(sv.prim + (size_t)j * kPrimStride);
-            Hit h;
-            if (kCount) cnt.prim_tests++;
-            if (primTestRec<QuadricsIn<kAll>::value>(rec, r, h) && closer(h.t, j, T.best)) {
-                T.best = h;
-                T.best.surface = j;
-                if (T.shadow && j != T.light && h.t < T.t_near) decided = true;  // occluded for sure
-            }
-        }
-        const uint32_t used = 2u - (i & 1u);
-        return used < count ? used : count;
-    }
-#endif
     const bool two = count > 1u;
     const uint32_t j = two ? i + 1 : i;
     const PrimRec r0 = loadPrim(sv.prim + (size_t)i * kPrimStride);

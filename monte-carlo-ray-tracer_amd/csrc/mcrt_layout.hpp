@@ -12,7 +12,6 @@
 #include "../../include/mcrt.h"
 #include "mcrt_scene.hpp"
 #include "mcrt_qbvh.hpp"
-#include "mcrt_wbvh.hpp"
 #include "mcrt_bvh_shared.hpp"  // surfaceBounds
 
 namespace mcrt {
@@ -40,9 +39,6 @@ struct HostLayout {
     uint32_t q_root_a = 0, q_root_m = 0;
     bool q_single = false;             // every inner node is ONE block (no node with more than four children): travInnerStepQLean<.., kSingle>
     // FP32 cull records of the primitives in BVH order, one 128-byte record per ALIGNED pair (2p, 2p + 1) (mcrt_lanesm.hpp "leaf cull")
-    std::vector<float> leaf_pre;
-    double leaf_centre[3] = {0.0, 0.0, 0.0}, leaf_bound = 0.0;
-    std::vector<WNode> wnodes;         // eight-wide quantised nodes (mcrt_wbvh.hpp), breadth-first, inner children of a node contiguous
     uint32_t num_quadric_surfaces = 0;
     std::vector<double> surf_v_patched;  // surf_v with quadric record addresses (only when the scene has quadrics)
     // Most traversal-stack entries any depth-first walk of nodes64 can hold at once: on the way down a visit continues with one child
@@ -179,133 +175,6 @@ inline int buildQBlocks(HostLayout& L, std::string& err) {
             }
         }
     }
-    return MCRT_OK;
-}
-
-// Eight-wide nodes (mcrt_wbvh.hpp) from the breadth-first Node64 array: every wide node stands for a reference inner node and
-// holds, as its children, that node's children with the largest of them (by box area) opened up for as long as eight slots
-// suffice - two reference levels of a 4-ary tree, three of a binary one, one of the octree hierarchy. Children go to slots
-// by octant around the node's centre (greedy assignment on the signed, extent-normalised centroid offsets).
-// Leaves the array empty when the tree has no inner node or a node has more than eight children (the 4-wide blocks then serve).
-inline int buildWNodes(HostLayout& L, std::string& err) {
-    L.wnodes.clear();
-    const uint32_t n = (uint32_t)L.nodes64.size();
-    if (n == 0 || !(L.nodes64[0].m & kSmInner)) return MCRT_OK;
-    for (uint32_t i = 0; i < n; i++)
-        if ((L.nodes64[i].m & kSmInner) && (L.nodes64[i].m & 0xFFu) > 8u) return MCRT_OK;
-    auto area = [&](const Node64& nd) {
-        const double dx = nd.b[3] - nd.b[0], dy = nd.b[4] - nd.b[1], dz = nd.b[5] - nd.b[2];
-        return dx * dy + dy * dz + dz * dx;
-    };
-    std::vector<uint32_t> ref_of(1, 0u);  // wide node -> reference inner node
-    std::vector<WNode> out;
-    for (size_t wi = 0; wi < ref_of.size(); wi++) {
-        const Node64& R = L.nodes64[ref_of[wi]];
-        std::vector<uint32_t> kids;
-        for (uint32_t c = 0; c < (R.m & 0xFFu); c++) kids.push_back(R.a + c);
-        if (kids.empty()) {
-            err = "BVH inner node without children";
-            return MCRT_ERR_INVALID;
-        }
-        for (;;) {
-            int pick = -1;
-            double best = -1.0;
-            for (size_t k = 0; k < kids.size(); k++) {
-                const Node64& nd = L.nodes64[kids[k]];
-                if (!(nd.m & kSmInner)) continue;
-                const uint32_t cc = nd.m & 0xFFu;
-                if (cc == 0u || kids.size() - 1 + cc > 8) continue;
-                const double a = area(nd);
-                if (a > best || pick < 0) {
-                    best = a;
-                    pick = (int)k;
-                }
-            }
-            if (pick < 0) break;
-            const Node64 nd = L.nodes64[kids[pick]];
-            kids.erase(kids.begin() + pick);
-            for (uint32_t c = 0; c < (nd.m & 0xFFu); c++) kids.push_back(nd.a + c);
-        }
-        const int nk = (int)kids.size();
-        // slots by octant
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int k = 0; k < nk; k++)
-            for (int ax = 0; ax < 3; ax++) {
-                lo[ax] = std::min(lo[ax], L.nodes64[kids[k]].b[ax]);
-                hi[ax] = std::max(hi[ax], L.nodes64[kids[k]].b[3 + ax]);
-            }
-        double score[8][8];
-        for (int k = 0; k < nk; k++) {
-            double off[3];
-            for (int ax = 0; ax < 3; ax++) {
-                const double half = 0.5 * (hi[ax] - lo[ax]), centre = 0.5 * (hi[ax] + lo[ax]);
-                const double cen = 0.5 * (L.nodes64[kids[k]].b[ax] + L.nodes64[kids[k]].b[3 + ax]);
-                off[ax] = (half > 0.0 && std::isfinite(half)) ? (cen - centre) / half : 0.0;
-                if (!std::isfinite(off[ax])) off[ax] = 0.0;
-            }
-            for (int sl = 0; sl < 8; sl++)
-                score[k][sl] = ((sl & 1) ? off[0] : -off[0]) + ((sl & 2) ? off[1] : -off[1]) + ((sl & 4) ? off[2] : -off[2]);
-        }
-        int slot_of[8], kid_in[8];
-        for (int k = 0; k < 8; k++) slot_of[k] = kid_in[k] = -1;
-        for (int round = 0; round < nk; round++) {
-            int bk = -1, bs = -1;
-            for (int k = 0; k < nk; k++) {
-                if (slot_of[k] >= 0) continue;
-                for (int sl = 0; sl < 8; sl++) {
-                    if (kid_in[sl] >= 0) continue;
-                    if (bk < 0 || score[k][sl] > score[bk][bs]) {
-                        bk = k;
-                        bs = sl;
-                    }
-                }
-            }
-            slot_of[bk] = bs;
-            kid_in[bs] = bk;
-        }
-        WNode q{};
-        uint8_t exps[3];
-        for (int ax = 0; ax < 3; ax++) {
-            double clo[8], chi[8];
-            uint8_t qlo[8], qhi[8];
-            for (int k = 0; k < nk; k++) {
-                clo[k] = L.nodes64[kids[k]].b[ax];
-                chi[k] = L.nodes64[kids[k]].b[3 + ax];
-            }
-            float o;
-            if (!quantiseAxis(clo, chi, nk, o, exps[ax], qlo, qhi)) {
-                err = "BVH bounds cannot be quantised (non-finite or beyond float range)";
-                return MCRT_ERR_UNSUPPORTED;
-            }
-            memcpy(&q.w[ax], &o, 4);
-            for (int k = 0; k < nk; k++) {
-                const int sl = slot_of[k];
-                q.w[4 + 4 * ax + (sl >> 2)] |= (uint32_t)qlo[k] << (8 * (sl & 3));
-                q.w[6 + 4 * ax + (sl >> 2)] |= (uint32_t)qhi[k] << (8 * (sl & 3));
-            }
-            for (int sl = 0; sl < 8; sl++)  // empty slots: an inverted box (lower plane 255, upper plane 0)
-                if (kid_in[sl] < 0) q.w[4 + 4 * ax + (sl >> 2)] |= 0xFFu << (8 * (sl & 3));
-        }
-        uint32_t imask = 0, valid = 0;
-        q.w[16] = (uint32_t)ref_of.size();
-        for (int sl = 0; sl < 8; sl++) {
-            if (kid_in[sl] < 0) continue;
-            const uint32_t ref = kids[kid_in[sl]];
-            const Node64& nd = L.nodes64[ref];
-            valid |= 1u << sl;
-            if (nd.m & kSmInner) {
-                imask |= 1u << sl;
-                ref_of.push_back(ref);
-            } else {
-                q.w[20 + sl] = nd.a;
-                q.w[18 + (sl >> 2)] |= (nd.m & 0xFFu) << (8 * (sl & 3));
-            }
-        }
-        q.w[3] = (uint32_t)exps[0] | ((uint32_t)exps[1] << 8) | ((uint32_t)exps[2] << 16) | (imask << 24);
-        q.w[17] = valid;
-        out.push_back(q);
-    }
-    L.wnodes.swap(out);
     return MCRT_OK;
 }
 
@@ -461,80 +330,6 @@ inline void buildFlatCull(HostLayout& L, uint32_t ns) {
     }
 }
 
-// The same records for the primitives of a walked BVH, in BVH order (L.prim): the leaf steps test an ALIGNED pair of consecutive
-// primitives per step, so pair p = primitives 2p and 2p + 1 share one 128-byte record (one L2 line). Error bounds and thresholds
-// are buildFlatCull's (unit direction, ray start within `bound` = four half-extents of the scene box per axis - a ray outside
-// that domain keeps every primitive); spheres, quadrics and degenerate triangles are always survivors.
-inline void buildLeafCull(HostLayout& L, size_t ns) {
-    L.leaf_pre.clear();
-    L.leaf_bound = 0.0;
-    if (ns == 0) return;
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    auto grow = [&](const double* p, double r) {
-        for (int a = 0; a < 3; a++) {
-            lo[a] = std::min(lo[a], p[a] - r);
-            hi[a] = std::max(hi[a], p[a] + r);
-        }
-    };
-    size_t tris = 0;
-    for (size_t i = 0; i < ns; i++) {
-        const double* r = &L.prim[i * kPrimStride];
-        if (r[9] == 0.0 || r[9] == 2.0) {
-            const double v1[3] = {r[0] + r[3], r[1] + r[4], r[2] + r[5]}, v2[3] = {r[0] + r[6], r[1] + r[7], r[2] + r[8]};
-            grow(r, 0.0);
-            grow(v1, 0.0);
-            grow(v2, 0.0);
-            tris++;
-        } else if (r[9] == 1.0) {
-            grow(r, fabs(r[3]));
-        }
-    }
-    if (tris == 0) return;
-    double H = 0.0;
-    for (int a = 0; a < 3; a++) {
-        if (!(fabs(lo[a]) <= 1e7) || !(fabs(hi[a]) <= 1e7)) return;  // keeps every FP32 product far from overflow
-        L.leaf_centre[a] = 0.5 * (lo[a] + hi[a]);
-        H = std::max(H, 0.5 * (hi[a] - lo[a]));
-    }
-    if (!(H > 0.0)) return;
-    L.leaf_bound = 4.0 * H;
-    const double u = ldexp(1.0, -24), bound = L.leaf_bound;
-    auto up = [](double x) {
-        float f = (float)x;
-        if ((double)f < x) f = nextafterf(f, INFINITY);
-        return f;
-    };
-    auto len = [](const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    const size_t pairs = (ns + 1) / 2;
-    L.leaf_pre.assign(pairs * kTriPairFloats, 0.0f);
-    for (size_t i = 0; i < 2 * pairs; i++) {
-        float* q = &L.leaf_pre[(i / 2) * kTriPairFloats + (i & 1)];  // component c at q[2 c]
-        const float inf = INFINITY;
-        if (i >= ns) {  // padding slot of an odd count (never in a leaf's range)
-            q[2 * 9] = -inf;
-            continue;
-        }
-        const double* r = &L.prim[i * kPrimStride];
-        if (!(r[9] == 0.0 || r[9] == 2.0)) {  // sphere / quadric: zeros with infinite thresholds = always a survivor
-            q[2 * 9] = q[2 * 10] = q[2 * 11] = q[2 * 12] = inf;
-            continue;
-        }
-        double a[3];
-        for (int c = 0; c < 3; c++) a[c] = r[c] - L.leaf_centre[c];
-        for (int c = 0; c < 3; c++) q[2 * c] = (float)a[c];
-        for (int c = 0; c < 6; c++) q[2 * (3 + c)] = (float)r[3 + c];
-        const double e1 = len(r + 3), e2 = len(r + 6), tmax = sqrt(3.0) * bound + len(a);
-        const double k = 4.0 * u;
-        double eu = k * 31.0 * e1 * e2 * e2 * tmax, ev = k * 31.0 * e1 * e1 * e2 * tmax, et = k * 31.0 * e1 * e1 * e2 * e2 * tmax;
-        double ew = k * 40.0 * e1 * e2 * ((e1 + e2) * tmax + e1 * e2);
-        const bool degenerate = !(e1 > 1e-12) || !(e2 > 1e-12) || !(eu > 1e-30) || !(ev > 1e-30) || !(et > 1e-30) || !(ew > 1e-30);
-        if (degenerate) eu = ev = et = ew = INFINITY;
-        q[2 * 9] = up(eu);
-        q[2 * 10] = up(ev);
-        q[2 * 11] = up(et);
-        q[2 * 12] = up(ew);
-    }
-}
 
 // A tree over INDEX RANGES for scenes that come without a BVH (Scene::intersect then loops over every surface,
 // scene.cpp:163-174): node = a run of consecutive surfaces in the scene's own order, split into up to four consecutive runs
@@ -583,7 +378,7 @@ inline void synthRangeTree(const mcrt_scene_desc* s, std::vector<double>& bounds
     if (ns) Rec::build(0u, ns, sb, bounds, start, count, next);
 }
 
-inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err, bool leaf_cull = false) {
+inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err) {
     const size_t ns = s->num_surfaces;
     L.prim.assign(ns * kPrimStride, 0.0);
     L.normal.assign(ns * 3, 0.0);
@@ -652,8 +447,6 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             slot++;
             if (!sphere) L.flat_tris++;
         }
-    if (leaf_cull) buildLeafCull(L, ns);  // (option MCRT_LEAF_CULL, see mcrt_upload_scene; 64 bytes per primitive)
-    else L.leaf_pre.clear();
     if (flat_possible) buildFlatCull(L, (uint32_t)ns);
     else {
         L.flat_pre.clear();
@@ -686,8 +479,7 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
             n.pad0 = n.pad1 = 0;
         }
         L.stack_bound = stackBound(L.nodes64);
-        if (int rc = buildQBlocks(L, err)) return rc;
-        return buildWNodes(L, err);
+        return buildQBlocks(L, err);
     };
     if (s->num_nodes) return nodeRecords(s, L.node_bounds, L.node_meta);
     L.node_bounds.clear();
@@ -708,7 +500,6 @@ inline int buildLayout(const mcrt_scene_desc* s, HostLayout& L, std::string& err
     if (nodeRecords(&t, nb, nm) != MCRT_OK) {  // (surfaces without finite bounds: no tree, the pipeline stays closed to this scene)
         L.nodes64.clear();
         L.qblocks.clear();
-        L.wnodes.clear();
         L.q_root_a = L.q_root_m = 0;
         L.stack_bound = 0;
     }

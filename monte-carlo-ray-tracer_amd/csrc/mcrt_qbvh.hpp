@@ -293,13 +293,20 @@ MCRT_HD void travInnerStepQLean(const QView<kLds>& qv, Trav& T, const LeanRay& R
     const float of[3] = {R.of[0], R.of[1], R.of[2]}, invf[3] = {R.invf[0], R.invf[1], R.invf[2]};
     const bool pos[3] = {invf[0] >= 0.0f, invf[1] >= 0.0f, invf[2] >= 0.0f};  // (|inv| >= 1: the float keeps the sign, never zero)
     uint32_t near_key = kQMissKey, near_a = 0;
+    // (the general push, taken only when a lane's stack leaves its LDS rows: it keeps the bound test - the stacks are sized to the tree's
+    // own bound, HostLayout::stack_bound, so it never fires, but a wrong bound must end as "traversal stack overflow", not as a write
+    // into another lane's spill slab; the fast path below, sp + 3 <= lds_depth, cannot leave the lane's rows and needs none)
     auto push = [&](uint32_t key, uint32_t a) {
-        SmStackEntry e;
-        e.key = key;
-        e.a = a;
-        stk.put(T.sp++, e);
-        T.top_key = key;
-        T.top_a = a;
+        if (T.sp < stk.max_depth) {
+            SmStackEntry e;
+            e.key = key;
+            e.a = a;
+            stk.put(T.sp++, e);
+            T.top_key = key;
+            T.top_a = a;
+        } else {
+            cnt.overflow = 1;
+        }
     };
     uint32_t bi = T.node_a;
     bool more = true;

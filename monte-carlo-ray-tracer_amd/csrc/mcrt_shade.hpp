@@ -228,9 +228,10 @@ MCRT_HD d3 surfSampleOf(const SurfRec& r, double u, double v) {
 // The reference keeps a std::vector<double> of medium IORs (reserve(8)). Here it is a per-lane stack of
 // kMaxIors doubles in LDS ([entry][lane]); it is a separate object, not a member of the path state,
 // so that the dynamically indexed array does not force the whole path state out of registers.
-// kMaxIors entries per lane live in LDS; nesting deeper than that (no scene of the reference comes near it) continues in memory up to
-// kMaxIorsDeep — the wavefront pool's own words, a per-lane region for the megakernels — and beyond THAT a frame ends with
-// MCRT_ERR_UNSUPPORTED instead of a wrong medium (the reference's vector is unbounded).
+// kMaxIors entries per lane live in LDS; nesting deeper than that (no scene of the reference comes near it) continues in memory: the
+// wavefront pipeline's deep rows (WfFrame::iors_deep, kMaxIorsDeep entries in all to begin with, four times as many on every retry of
+// a frame that nests deeper: the reference's vector is unbounded, and so - up to the device's memory - is this), a per-lane region
+// for the 1024-lane photon kernel. A megakernel frame that nests deeper than its 8 entries is rendered again through the pipeline.
 constexpr int kMaxIors = 8;
 constexpr int kMaxIorsDeep = 32;
 struct RefractionHistory {

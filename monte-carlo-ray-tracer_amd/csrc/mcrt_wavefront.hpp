@@ -63,8 +63,9 @@ enum : uint32_t {
     kWfHit0S = 39,       // surface | interpolate << 32
     kWfHit1T = 40,       // shadow-ray result
     kWfHit1S = 41,
-    kWfIorsDeep = 42,    // 24  RefractionHistory entries kMaxIors .. kMaxIorsDeep - 1: read and written in place (rh.giors), never copied
-    kWfWords = 66
+    kWfWords = 42
+    // (RefractionHistory entries beyond the kMaxIors a lane keeps in LDS live in their own buffer, WfFrame::iors_deep, [row][slot]:
+    // read and written in place, never copied, and as many rows as the deepest path of the frame needs - round 6)
 };
 enum : uint32_t {
     kWfAlive = 1u,        // the bounce ray in the slot was traced for this iteration
@@ -73,7 +74,7 @@ enum : uint32_t {
     kWfDone = 8u,         // no pixels left for this slot
     kWfDirac = 16u,
     kWfRefraction = 32u,
-    kWfRhShift = 8,       // RefractionHistory::size in bits 8..13
+    kWfRhShift = 16,      // RefractionHistory::size in bits 16..31 (bits 8..13 until round 6, when histories could not pass 32 entries)
     kWfEstWait = 1u << 14,  // photon mapper: the hit in the slot waits for its radiance estimates
     kWfEstNeedG = 1u << 15  // ... the global estimate too (the path ends with it)
 };
@@ -107,6 +108,11 @@ struct WfFrame {
     unsigned long long work_items;  // tiles_x * tile rows of the pass * 64 << chunk_shift
     double* samples;
     FilmView film;                  // type != MCRT_FILM_BOX: samples are splatted into film.blob instead (mcrt_film.hpp)
+    // RefractionHistory entries kMaxIors .. kMaxIors + iors_deep_rows - 1 of every slot, [row][slot] (ray.cpp:74-98 is an unbounded
+    // vector: a frame whose paths nest deeper than the rows it was given reports it, and the host renders it again with four times
+    // the rows - mcrt_render_finish)
+    double* iors_deep;
+    uint32_t iors_deep_rows;
 };
 
 // A unit is the samples [c * chunk, min((c + 1) * chunk, spp)) of a pixel: `sample`, just incremented, is past its unit's end
@@ -235,12 +241,12 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long
     bool alive = (flags & kWfAlive) != 0u, have_pixel = (flags & kWfHavePixel) != 0u;
     const bool nee_was_pending = (flags & kWfNeePending) != 0u;
 
-    // histories deeper than the kMaxIors entries a lane has in LDS go on in the slot's own pool words
-    rh.giors = reinterpret_cast<double*>(P.w + (size_t)kWfIorsDeep * P.n);
+    // histories deeper than the kMaxIors entries a lane has in LDS go on in the frame's deep rows
+    rh.giors = fr.iors_deep;
     rh.glane = slot;
     rh.gstride = P.n;
     rh.lds_depth = kMaxIors;
-    rh.max_depth = kMaxIorsDeep;
+    rh.max_depth = kMaxIors + (int)fr.iors_deep_rows;
 
     PathState st;
     NeePending nee;
@@ -314,7 +320,7 @@ MCRT_HD void wfShadeSlot(Env& env, const WfPool& P, uint32_t slot, unsigned long
         ly = ((uint32_t)uw >> 16) & 0xFFFFu;
         sample = (uint32_t)(uw >> 32);
         st.smp.restore(fr.global_seed, localToGlobalRow(fr.cam, ly) * fr.cam.width + px, sample, (uint32_t)sq_w);
-        rh.size = (int)((flags >> kWfRhShift) & 63u);
+        rh.size = (int)(flags >> kWfRhShift);
         rh.put(0, ior0);
         rh.put(1, ior1);
         if (env.any(rh.size > 2))

@@ -142,7 +142,7 @@ static Ray rayDir(v3 start, v3 direction, double medium_ior) { /* ray.cpp:13-14 
 static Ray rayTo(v3 start, v3 end) { return rayDir(start, vnormalize(vsub(end, start)), 1.0); } /* ray.cpp:10-11 */
 static v3 rayAt(const Ray* r, double t) { return vadd(r->start, vscale(r->direction, t)); }      /* ray.cpp:69-72 */
 
-#define MAX_IORS 64
+#define MAX_IORS 1024 /* (the reference's std::vector is unbounded; the GPU tests nest 150 media) */
 typedef struct { double iors[MAX_IORS]; int size; } RefractionHistory; /* ray.cpp:74-98 */
 static void rhInit(RefractionHistory* h, const Ray* ray) { h->iors[0] = ray->medium_ior; h->size = 1; }
 static void rhUpdate(RefractionHistory* h, const Ray* ray) {

@@ -194,10 +194,6 @@ def load_emu():
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
     L.emu_trace_counts.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, vp]
     L.emu_set_defer.argtypes = [C.c_int]
-    L.emu_set_wide.argtypes = [C.c_int]
-    L.emu_set_leaf_cull.argtypes = [C.c_int]
-    L.emu_wide_nodes.argtypes = [vp]
-    L.emu_wide_nodes.restype = C.c_uint64
     return L
 
 

@@ -50,7 +50,7 @@ struct Emu {
 int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
     const bool stage_lds = stage_mode != 0;
     std::string err;
-    if (int rc = buildLayout(s, E.L, err, getenv("MCRT_LEAF_CULL") && atoi(getenv("MCRT_LEAF_CULL")) != 0)) return rc;  // (test harness: the environment is its option channel)
+    if (int rc = buildLayout(s, E.L, err)) return rc;  // (test harness: the environment is its option channel)
     patchQuadricAddresses(s, E.L, s->quadrics);  // quadric records are read where the descriptor keeps them
     E.tab.resize(kSobolTableWords);
     buildSobolByteTables(E.tab.data());
@@ -206,24 +206,12 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
 // half of the blocks on the "LDS" side, exact records for rays with a zero direction component.
 namespace {
 int g_defer = 0;
-int g_wide = 0;  // 1: fast rays walk the eight-wide nodes (mcrt_wbvh.hpp) instead of the 4-wide blocks
-int g_leaf_cull = 1;  // 0: leaf steps without the FP32 cull (the exact tests on every primitive)
-#define emuLeafCull(sv, L)                                                                  \
-    do {                                                                                    \
-        (sv).pre = (g_leaf_cull && !(L).leaf_pre.empty()) ? (L).leaf_pre.data() : nullptr; \
-        (sv).pre_cx = (L).leaf_centre[0];                                                   \
-        (sv).pre_cy = (L).leaf_centre[1];                                                   \
-        (sv).pre_cz = (L).leaf_centre[2];                                                   \
-        (sv).pre_bound = (L).leaf_bound;                                                    \
-    } while (0)
 struct QTrace {
     SmSceneView<false> sv;
     QView<true> qv;
-    WView wv;
     std::vector<SmStackEntry> s_lds, s_spill;
     SmStack stk;
     void init(Emu& E, const mcrt_scene_desc* scene) {
-        wv.nodes = E.L.wnodes.empty() ? nullptr : E.L.wnodes.data();
         s_lds.resize(kLdsStackDepth);
         const int depth = std::max<int>(kMaxStackDepth, (int)E.L.stack_bound + 1);
         s_spill.resize(depth - kLdsStackDepth);
@@ -237,7 +225,6 @@ struct QTrace {
         sv.prim = E.L.prim.data();
         sv.lds_nodes = 0;
         sv.lds_node_ptr = E.L.nodes64.data();
-        emuLeafCull(sv, E.L);
         qv.blocks = E.L.qblocks.data();
         qv.lds_blocks = (uint32_t)E.L.qblocks.size() / 2;
         qv.lds_ptr = E.L.qblocks.data();
@@ -247,32 +234,7 @@ struct QTrace {
     // g_defer: 0 = a leaf is tested when it is reached (round 2's order); 1 = deferred leaves (mcrt_lanesm.hpp), the pending leaf
     // tested only when the lane has nothing else to do - the longest a wave's gating can postpone it; k >= 2 = also every k-th
     // iteration (a gate that opens now and then)
-    Hit runWide(d3 o, d3 d, bool shadow, const ShadowQuery* sq, TraceCounters& cnt) {
-        // the trace kernel's per-lane sequence: leaves first (their hits prune what follows), else one wide step
-        Trav T;
-        WLeaves Lv;
-        PendLeaf P;
-        travBeginW<false, true>(sv, T, Lv, P, o, d, rcp3(d), shadow, sq, cnt);
-        if (!T.fast) {
-            while (T.active) {
-                if (T.node_m & kSmInner) travInnerStep<false, true>(sv, T, stk, cnt);
-                else travLeafStep<false, true>(sv, T, stk, cnt);
-            }
-            return T.best;
-        }
-        while (T.active) {
-            if (P.n != 0u || Lv.bits != 0u) {
-                travWideNextLeaf(wv, T, Lv, P);
-                travPendStep<false, true>(sv, T, P, cnt);
-                travWideAfterLeaf(T, Lv, P);
-            } else {
-                travWideStep<true>(wv, T, Lv, stk, cnt);
-            }
-        }
-        return T.best;
-    }
     Hit run(d3 o, d3 d, bool shadow, const ShadowQuery* sq, TraceCounters& cnt) {
-        if (g_wide && wv.nodes) return runWide(o, d, shadow, sq, cnt);
         Trav T;
         travBeginQ<false, true, true>(sv, qv, T, o, d, rcp3(d), shadow, sq, cnt);
         if (g_defer) {
@@ -412,7 +374,6 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
         sv.prim = E.L.prim.data();
         sv.lds_nodes = scene->num_nodes / 2;
         sv.lds_node_ptr = E.L.nodes64.data();
-        emuLeafCull(sv, E.L);
     };
     fill(sv_all);
     fill(sv_top);
@@ -581,6 +542,7 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     // as on the device, where only the flags and the kWfSeq planes of a fresh pool are cleared: every other word starts as garbage
     // (all ones = NaN as a double, 4e9 as an index), so a word that is read before it is written shows in the frame
     std::vector<unsigned long long> pool((size_t)kWfWords * slots, ~0ull);
+    std::vector<double> iors_deep((size_t)(kMaxIorsDeep - kMaxIors) * slots, -1.0);  // (garbage: an entry is written before it is read)
     for (uint32_t i = 0; i < slots; i++) pool[(size_t)kWfFlags * slots + i] = pool[(size_t)kWfSeq * slots + i] = 0ull;
     WfPool P;
     P.w = pool.data();
@@ -590,6 +552,8 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
     fr.global_seed = global_seed;
     fr.spp = cam->sqrtspp * cam->sqrtspp;
     fr.tiles_x = (cam->width + 7) / 8;
+    fr.iors_deep = iors_deep.data();
+    fr.iors_deep_rows = (uint32_t)(kMaxIorsDeep - kMaxIors);
     // one pass over the owned rows; units per pixel 1, 2 or 4 depending on the slot count, so that the tests cover whole-pixel
     // units, chunks, and chunk counts that do not divide spp (empty last chunk)
     fr.chunk_shift = slots % 3u;
@@ -984,13 +948,6 @@ void emu_libm_host(int fn, uint64_t n, const double* a, const double* b, double*
     }
 }
 
-void emu_set_wide(int on) { g_wide = on; }
-void emu_set_leaf_cull(int on) { g_leaf_cull = on; }
-uint64_t emu_wide_nodes(const mcrt_scene_desc* scene) {
-    Emu E;
-    if (setup(E, scene, 0)) return 0;
-    return E.L.wnodes.size();
-}
 int emu_trace_counts(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int policy, uint64_t* out /* node tests, primitive tests */) {
     Emu E;
     if (int rc = setup(E, scene, 0)) return rc;
@@ -1000,11 +957,8 @@ int emu_trace_counts(const mcrt_scene_desc* scene, uint64_t n, const double* sta
     TraceCounters cnt = {0, 0, 0, 0};
     const int keep = g_defer;
     g_defer = policy < 0 ? 0 : policy;
-    const int keep_wide = g_wide;
-    if (policy < 0) g_wide = 1;  // policy -1: the eight-wide walk
     for (uint64_t i = 0; i < n; i++) qt.run(ld3(start + 3 * i), ld3(direction + 3 * i), false, nullptr, cnt);
     g_defer = keep;
-    g_wide = keep_wide;
     out[0] = cnt.node_tests;
     out[1] = cnt.prim_tests;
     return cnt.overflow ? -100 : 0;

@@ -8,7 +8,6 @@
 
 #include "mcrt_emu.cpp"
 
-#include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_wbvh.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_groupknn.hpp"
 #include "../../monte-carlo-ray-tracer_amd/csrc/mcrt_widerec.hpp"
 
@@ -52,21 +51,21 @@ struct WaveMap {
     }
 };
 
-template <int kForm, int kLean = 0>
+template <int kLean>
 void launchTrace(const WfTraceArgs& a, const ArrayRays& rays, uint32_t grid, uint32_t waves) {
     for (uint32_t g = 0; g < grid; g++) {
         wemu::launch().block_idx = g;
         wemu::launch().block_dim = waves * 64u;
         wemu::launch().grid_dim = grid;
-        wemu::runGroup((int)waves, [&](int) { wfTraceKernel<ArrayRays, true, kForm, kLean>(a, rays); });
+        wemu::runGroup((int)waves, [&](int) { wfTraceKernel<ArrayRays, true, kLean>(a, rays); });
     }
 }
 }  // namespace
 
 extern "C" {
 
-// Closest hits of n rays through wfTraceKernel<ArrayRays, count, form> (form: 0 first walk, 2 deferred leaves, 3 shared leaf step - the
-// default; 1 = eight-wide nodes when the layout has them). grid workgroups of `waves` wavefronts; lds_blocks / lds_stack / refill /
+// Closest hits of n rays through wfTraceKernel<ArrayRays, count, lean> (form: 3 = round 4's visit, 11 = the lean visit, 27 = the lean visit
+// with one block per visit; the forms 0 / 1 / 2 of rounds 2-3 were removed in round 6: -201). grid workgroups of `waves` wavefronts; lds_blocks / lds_stack / refill /
 // leaf_lanes / deal_shift as planTrace's options (lds_blocks 0xFFFFFFFF = as many as the tree has, up to 512). stats: the kernel's
 // counters [kStatsWords] (rays at [1], node / primitive tests at [2] / [3], overflow at [5]). Returns 0, -100 on stack overflow.
 int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* start, const double* direction, int form, uint32_t grid, uint32_t waves,
@@ -75,7 +74,7 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     Emu E;
     if (int rc = setup(E, scene, 0)) return rc;
     if (scene->num_nodes == 0 || grid == 0 || waves == 0 || waves > 16) return -200;
-    if (form == 1 && E.L.wnodes.empty()) return -201;
+    if (form == 0 || form == 1 || form == 2) return -201;
     const uint32_t block = waves * 64u;
     const uint32_t depth = (uint32_t)std::max<int>(kMaxStackDepth, (int)E.L.stack_bound + 1);
     std::vector<SmStackEntry> spill((size_t)grid * block * depth);
@@ -88,9 +87,8 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     a.stats = stats.data();
     a.nodes = E.L.nodes64.data();
     a.qblocks = E.L.qblocks.data();
-    a.wnodes = E.L.wnodes.empty() ? nullptr : E.L.wnodes.data();
     a.num_nodes = (uint32_t)E.L.nodes64.size();
-    a.lds_blocks = form == 1 ? 0u : std::min<uint32_t>(lds_blocks, std::min<uint32_t>((uint32_t)E.L.qblocks.size(), 512u));
+    a.lds_blocks = std::min<uint32_t>(lds_blocks, std::min<uint32_t>((uint32_t)E.L.qblocks.size(), 512u));
     a.q_root_a = E.L.q_root_a;
     a.q_root_m = E.L.q_root_m;
     a.prim = E.L.prim.data();
@@ -111,14 +109,11 @@ int wemu_trace_kernel(const mcrt_scene_desc* scene, uint64_t n, const double* st
     rays.out_t = out_t;
     rays.out_surface = out_surface;
     rays.out_uv = out_uv;
-    if (form == 0) launchTrace<0>(a, rays, grid, waves);
-    else if (form == 1) launchTrace<1>(a, rays, grid, waves);
-    else if (form == 2) launchTrace<2>(a, rays, grid, waves);
-    else if (form == 11) launchTrace<3, 1>(a, rays, grid, waves);  // the lean visit (MCRT_WF_LEAN), any tree
+    if (form == 11) launchTrace<1>(a, rays, grid, waves);  // the lean visit (MCRT_WF_LEAN), any tree
     else if (form == 27) {                                          // ... one block per visit: trees without a node of more than four children
         if (!E.L.q_single) return -203;
-        launchTrace<3, 3>(a, rays, grid, waves);
-    } else launchTrace<3>(a, rays, grid, waves);
+        launchTrace<3>(a, rays, grid, waves);
+    } else launchTrace<0>(a, rays, grid, waves);
     if (stats_out) memcpy(stats_out, stats.data(), kStatsWords * sizeof(unsigned long long));
     return stats[5] ? -100 : 0;
 }
@@ -149,9 +144,6 @@ void fillDeviceScene(const mcrt_scene_desc* s, Emu& E, DeviceScene& d, uint32_t 
     d.stack_depth = std::max<uint32_t>((uint32_t)kMaxStackDepth, L.stack_bound + 1u);
     d.q_root_a = L.q_root_a;
     d.q_root_m = L.q_root_m;
-    d.wnodes = L.wnodes.empty() ? nullptr : L.wnodes.data();
-    d.num_wnodes = (uint32_t)L.wnodes.size();
-    d.leaf_pre = nullptr;
     d.prim = L.prim.data();
     d.flat_prim = L.flat_prim.data();
     d.flat_index = L.flat_index.data();
@@ -372,6 +364,9 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
     fr.pass_pixels = pixels;
     fr.work_items = ((unsigned long long)fr.tiles_x * ((owned_rows + 7) / 8) * 64ull) << fr.chunk_shift;
     std::vector<unsigned long long> pool((size_t)slots * kWfWords, 0xDEADBEEFCAFEF00Dull);  // garbage, like fresh device memory
+    std::vector<double> iors_deep((size_t)(kMaxIorsDeep - kMaxIors) * slots, -1.0);  // (garbage: an entry is written before it is read)
+    fr.iors_deep = iors_deep.data();
+    fr.iors_deep_rows = (uint32_t)(kMaxIorsDeep - kMaxIors);
     for (uint64_t i = 0; i < slots; i++) pool[(size_t)kWfFlags * slots + i] = pool[(size_t)kWfSeq * slots + i] = 0ull;
     const size_t cap = ((size_t)slots + 2 * kWfBlock) * 2;
     std::vector<uint32_t> qwords(2 * cap + 2 * (2 * 8 * cap), 0xA5A5A5A5u);  // item, light, then two sets of eight planes of doubles
@@ -388,23 +383,22 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
     ta.stats = stats.data();
     ta.nodes = d.nodes64;
     ta.qblocks = d.qblocks;
-    ta.wnodes = d.wnodes;
     ta.num_nodes = d.q_nodes;
-    ta.lds_blocks = trace_form == 1 ? 0u : (uint32_t)std::min<uint64_t>(d.num_qblocks, ((uint64_t)sizeof(lds) - stack_bytes - 128u - trace_waves * kShareMapBytes) / 64u);
+    ta.lds_blocks = (uint32_t)std::min<uint64_t>(d.num_qblocks, ((uint64_t)sizeof(lds) - stack_bytes - 128u - trace_waves * kShareMapBytes) / 64u);
     ta.q_root_a = d.q_root_a;
     ta.q_root_m = d.q_root_m;
     ta.prim = d.prim;
     ta.spill = spill.data();
     ta.total_lanes = trace_grid * tblock;
     ta.refill_lanes = 16;
-    ta.leaf_lanes = (trace_form & 7) == 3 ? 16 : 24;
+    ta.leaf_lanes = 16;
     ta.leaf_items = 1 << 20;
     ta.min_inner = 8;
     ta.lds_stack = (int)lds_stack;
     ta.max_stack = d.stack_depth;
     ta.deal_shift = 6;
     ta.pop = ctrl + 2;
-    if (trace_form == 1 && !d.wnodes) return -201;
+    if (trace_form == 0 || trace_form == 1 || trace_form == 2) return -201;  // (forms removed in round 6)
     if (trace_form == 27 && !E.L.q_single) return -204;
     PoolRays pr;
     pr.pool.w = pool.data();
@@ -484,12 +478,9 @@ int wemu_render_pipeline(const mcrt_scene_desc* scene, const mcrt_photon_map_des
             wemu::launch().block_dim = tblock;
             wemu::launch().grid_dim = trace_grid;
             wemu::runGroup((int)trace_waves, [&](int) {
-                if (trace_form == 11) wfTraceKernel<PoolRays, true, 3, 1>(ta, pr);
-                else if (trace_form == 27) wfTraceKernel<PoolRays, true, 3, 3>(ta, pr);
-                else if (trace_form == 0) wfTraceKernel<PoolRays, true, 0>(ta, pr);
-                else if (trace_form == 1) wfTraceKernel<PoolRays, true, 1>(ta, pr);
-                else if (trace_form == 2) wfTraceKernel<PoolRays, true, 2>(ta, pr);
-                else wfTraceKernel<PoolRays, true, 3>(ta, pr);
+                if (trace_form == 11) wfTraceKernel<PoolRays, true, 1>(ta, pr);
+                else if (trace_form == 27) wfTraceKernel<PoolRays, true, 3>(ta, pr);
+                else wfTraceKernel<PoolRays, true, 0>(ta, pr);
             });
         }
         launches++;

@@ -329,14 +329,14 @@ def test_fp32_block_visit_keeps_what_the_fp64_visit_keeps(pkg, emu, manifest, na
 
 @pytest.mark.parametrize("name", ["hexagon_room", "coffee_maker_qsah", "coffee_maker_bsah", "quadric"])
 def test_optional_traversal_forms_return_the_same_hits(pkg, emu, manifest, name, monkeypatch):
-    """Round 3's optional forms of the tree walk - deferred leaves, the eight-wide nodes (mcrt_wbvh.hpp), the FP32 leaf cull
-    (mcrt_lanesm.hpp) - against the 4-wide block walk: t, surface and uv bit for bit on the reference's KAT rays and on random
-    rays (origins inside the scene box, some with zero direction components = the exact-record path), for the octree, binary
-    and quaternary hierarchies and quadrics."""
+    """Deferred leaves (mcrt_lanesm.hpp: the pending leaf tested as late as a wave's gating can postpone it, or every k-th
+    iteration) against the walk that tests a leaf when it is reached: t, surface and uv bit for bit on the reference's KAT rays
+    and on random rays (origins inside the scene box, some with zero direction components = the exact-record path), for the
+    octree, binary and quaternary hierarchies and quadrics. (Round 3's other optional forms - eight-wide nodes, the FP32 leaf
+    cull - lost every A/B and were removed in round 6.)"""
     case = manifest["cases"].get(name)
     if case is None:
         pytest.skip("no such golden case")
-    monkeypatch.setenv("MCRT_LEAF_CULL", "1")  # the emulation builds the records like mcrt_upload_scene does; emu_set_leaf_cull switches their use
     img = pkg.SceneImage(golden_path(case["image"]))
     sc = img.scene
     rng = np.random.default_rng(5)
@@ -354,28 +354,22 @@ def test_optional_traversal_forms_return_the_same_hits(pkg, emu, manifest, name,
     start, d = np.ascontiguousarray(start), np.ascontiguousarray(d)
     n = start.shape[0]
 
-    def walk(defer, wide, cull):
+    def walk(defer):
         emu.emu_set_defer(defer)
-        emu.emu_set_wide(wide)
-        emu.emu_set_leaf_cull(cull)
         t, surf, uv = np.empty(n), np.empty(n, dtype=np.uint32), np.empty((n, 2))
         try:
             rc = emu.emu_intersect(C.byref(sc), n, start.ctypes.data, d.ctypes.data, 3, t.ctypes.data, surf.ctypes.data, uv.ctypes.data)
         finally:
             emu.emu_set_defer(0)
-            emu.emu_set_wide(0)
-            emu.emu_set_leaf_cull(1)
         assert rc == 0
         return t, surf, uv
 
-    base = walk(0, 0, 0)
+    base = walk(0)
     assert (base[1] != 0xFFFFFFFF).sum() > n // 20
-    for form in ((1, 0, 0), (3, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1), (2, 0, 1)):
-        if form[1] and emu.emu_wide_nodes(C.byref(sc)) == 0:
-            continue
-        got = walk(*form)
+    for defer in (1, 2, 3):
+        got = walk(defer)
         for a, b in zip(base, got):
-            np.testing.assert_array_equal(a, b, err_msg="defer/wide/cull = %r" % (form,))
+            np.testing.assert_array_equal(a, b, err_msg="defer = %r" % (defer,))
 
 
 @pytest.mark.parametrize("name", ["baroque", "lego", "pipes"])

@@ -160,11 +160,10 @@ def test_full_size_rows_match_reference(pkg, name, monkeypatch):
     ctx.close()
 
 
-# (name, environment): the default walk on every scene, and the optional forms of round 3 - the eight-wide nodes (mcrt_wbvh.hpp) on
-# the quaternary SAH tree (C3) and the octree hierarchy (C5), the walk without deferred leaves (the round-2 form) on C3
+# (name, environment): the default walk on every scene; round 4's visit on the quaternary SAH tree (C3); the leaf gate wide open on
+# the octree hierarchy (C5)
 @pytest.mark.parametrize("name,env", [("c3", {}), ("c4", {}), ("c5", {}), ("baroque", {}), ("lego", {}), ("pipes", {}),
-                                      ("c3", {"MCRT_WF_WIDE": "1"}), ("c5", {"MCRT_WF_WIDE": "1"}), ("c3", {"MCRT_WF_DEFER": "0"}),
-                                      ("c3", {"MCRT_WF_SHARE": "0"}), ("c5", {"MCRT_WF_LEAF": "1"})])
+                                      ("c3", {"MCRT_WF_LEAN": "0"}), ("c5", {"MCRT_WF_LEAF": "1"})])
 def test_full_size_traversal_equals_oracle(pkg, oracle, name, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -124,11 +124,11 @@ def test_wavefront_pipeline_matches_reference(pkg, ctx, manifest, kernel_env, na
 
 @pytest.mark.parametrize("name", ["coffee_maker_qsah", "coffee_maker_bsah", "quadric"])
 def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name, monkeypatch):
-    """The wavefront pipeline's optional trace kernels - slot-scheduled (MCRT_WF_SCHED: ray state in LDS, steps issued for 64 rays
-    that want the same step), eight-wide nodes (MCRT_WF_WIDE), lanes waiting at their leaves (MCRT_WF_DEFER=0, the round-2 form), a
-    pending leaf tested by its own lane (MCRT_WF_SHARE=0, round 3's default), and the default's leaf gate at both extremes (a shared
-    leaf step for every single pending lane: four item lanes per leaf; only when 40 lanes wait: one item lane per leaf) - give the
-    default kernel's frame, bit for bit."""
+    """The trace kernel's remaining switches - round 4's visit instead of the lean one (MCRT_WF_LEAN=0), the lean visit with the block
+    loop kept (MCRT_WF_LEAN=2), and the leaf gate at both extremes (a shared leaf step for every single pending lane: four item lanes
+    per leaf; only when 40 lanes wait: one item lane per leaf) - give the default kernel's frame, bit for bit. (The optional kernels of
+    rounds 2-4 - slot-scheduled, eight-wide nodes, lanes waiting at their leaves, a pending leaf tested by its own lane, two half
+    pools - lost every A/B and were removed in round 6.)"""
     case = manifest["cases"][name]
     img = pkg.SceneImage(golden_path(case["image"]))
     r = case["renders"][0]
@@ -137,9 +137,7 @@ def test_optional_trace_kernels_same_frame(pkg, ctx, manifest, kernel_env, name,
     ctx.upload_image(img)
     base, st0 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
     assert st0["kernel_id"] == pkg.KERNEL_WAVEFRONT
-    # (MCRT_WF_SHARE=0: round 3's default - a pending leaf tested by its own lane, two primitives per step; the default since round 4
-    # deals the wave's pending (leaf, primitive) pairs over all 64 lanes, travSharedLeafStep)
-    for key, value in (("MCRT_WF_SCHED", "1"), ("MCRT_WF_WIDE", "1"), ("MCRT_WF_DEFER", "0"), ("MCRT_WF_SHARE", "0"), ("MCRT_WF_LEAF", "1"), ("MCRT_WF_LEAF", "40")):
+    for key, value in (("MCRT_WF_LEAN", "0"), ("MCRT_WF_LEAN", "2"), ("MCRT_WF_LEAF", "1"), ("MCRT_WF_LEAF", "40")):
         monkeypatch.setenv(key, value)
         out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
         monkeypatch.delenv(key)

@@ -32,5 +32,19 @@ def test_default_path_kernels_stay_within_their_spill_budgets():
         assert k["scratch"] <= w["scratch"], "%s uses %d B of scratch per lane (budget %d)" % (name, k["scratch"], w["scratch"])
     # the trace kernel of the pipeline must not spill at all: it runs at 4 waves per SIMD on 128 VGPRs
     for name, k in have.items():
-        if name.startswith("wfTraceKernel<PoolRays, false, 3"):
+        if name.startswith("wfTraceKernel<PoolRays, false"):
             assert k["vgpr_spill"] == 0 and k["scratch"] == 0, name
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not in this image")
+@pytest.mark.parametrize("switch,kernel", [("-DMCRT_EXACT_PHOTON_DIR", "renderKernelPM<false, false, 1024, 4>"),
+                                           ("-DMCRT_PLATFORM_LIBM", "wfShadeKernel<false>")])
+def test_build_switches_compile_for_gfx950(switch, kernel):
+    """The two build-time switches of csrc (monte-carlo-ray-tracer_amd/build.py reads them from the environment) produce device code:
+    one kernel that contains the switched code is compiled for gfx950 with each (tools/one_kernel.sh; the whole tolerance library, which
+    is built with -DMCRT_PLATFORM_LIBM, has its own GPU test: tests/test_gpu_tolerance_build.py)."""
+    import subprocess
+    p = subprocess.run([os.path.join(ROOT, "tools", "one_kernel.sh"), kernel, switch], capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert "error" not in out.lower(), out[-2000:]
+    assert kernel.split("<")[0] in out and "vgpr=" in out, out[-2000:]

@@ -7,5 +7,5 @@ C=monte-carlo-ray-tracer_amd/csrc; B=tools/_build; mkdir -p $B
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC"
 if [[ " $* " == *" -ffp-contract=fast "* ]]; then FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"; fi
 hipcc $FLAGS "$@" -c $C/mcrt_hip.hip -o $B/mcrt_hip_$NAME.o 2> $B/$NAME.err || { tail -20 $B/$NAME.err; exit 1; }
-OTHERS=$(ls $C/_obj/*.o | grep -v mcrt_hip.hip.o)
+OTHERS=$(ls $C/_obj/*.o | grep -v "mcrt_hip\.hip\.")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $B/lib$NAME.so $B/mcrt_hip_$NAME.o $OTHERS && echo "built $B/lib$NAME.so"

@@ -21,8 +21,8 @@ LIB = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc", "libmcrt_hip.so")
 BUDGET = os.path.join(ROOT, "tests", "golden", "kernel_spill_budget.json")
 LLVM = "/opt/rocm/lib/llvm/bin"
 # the kernel instances the default options launch (launchRender / launchWavefront / the photon pass, csrc/mcrt_hip.hip), by demangled-name prefix
-DEFAULT_PATH = ("renderKernelFlatK<768>", "renderKernelSM<false, false, false, 512>", "wfTraceKernel<(anonymous namespace)::PoolRays, false, 3, 3>",
-                "wfTraceKernel<(anonymous namespace)::PoolRays, false, 3, 1>", "wfShadeKernel<false>", "wfShadeKernel<true>", "wfKnnKernel<true, 4>",
+DEFAULT_PATH = ("renderKernelFlatK<768>", "renderKernelSM<false, false, false, 512>", "wfTraceKernel<(anonymous namespace)::PoolRays, false, 3>",
+                "wfTraceKernel<(anonymous namespace)::PoolRays, false, 1>", "wfShadeKernel<false>", "wfShadeKernel<true>", "wfKnnKernel<true, 4>",
                 "renderKernelPM<false, false, 1024, 4>", "renderKernelPM<false, true, 1024, 4>", "emitKernel<false>", "emitKernel<true>", "sampleResolveKernel")
 
 

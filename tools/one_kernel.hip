@@ -6,7 +6,6 @@
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_integrator.hpp"
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_lanesm.hpp"
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_qbvh.hpp"
-#include "../monte-carlo-ray-tracer_amd/csrc/mcrt_wbvh.hpp"
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_wavefront.hpp"
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_waveknn.hpp"
 #include "../monte-carlo-ray-tracer_amd/csrc/mcrt_groupknn.hpp"
