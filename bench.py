@@ -92,8 +92,9 @@ SECONDARY = ("c2_ggx", "spaceship", "pm", "c3", "c4", "c5")
 REFERENCE_SCENE_LEGS = ("c1", "c2", "c2_ggx", "pm")
 # per leg: timed steps (None = --secondary-steps), spp of the untimed warm-up frame (None = the leg's own), spp of the frame the PMC
 # child passes count (None = the leg's own; per-sample work is the same at any spp, the scale is stated in frame_scale)
-LEG_PLAN = {"c3": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=8),
-            "c4": dict(steps=2, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~30 s: two timed frames after a 16 spp warm-up frame
+LEG_PLAN = {"c3": dict(steps=2, warm_sqrtspp=8, pmc_sqrtspp=8),      # 5.2 s a frame: two timed frames after a 64 spp warm-up frame
+            "c4": dict(steps=1, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~29 s: ONE timed frame after a 16 spp warm-up frame (round 6: the
+                                                                  # run has to stay within minutes with the tolerance legs in it; frames repeat within 0.3 %)
             "c5": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=4)}
 # photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths): BASELINE configs[4] says 1e8 emission paths for C5
 EMISSIONS = {"pm": 1e6, "c5": 1e7}

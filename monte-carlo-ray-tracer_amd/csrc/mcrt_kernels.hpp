@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(kTraceMaxBlock) wfTraceKernel(const WfTraceArg
     // address, about what an L2 channel serves — refilling at 16 idle lanes instead of 32 cost 37 % of the frame. One
     // contiguous share per workgroup has no atomics either, but neighbouring entries are rays from the same part of the
     // image and the parts differ in cost: the same rays traced 12 % faster shuffled than in pixel order and 20 % slower
-    // sorted by origin; dealt in blocks of 64 every order gains and pixel order is the fastest, tools/ray_sort_probe.py.
+    // sorted by origin; dealt in blocks of 64 every order gains and pixel order is the fastest (round 2's ray-sort probe, profiles/r02_ray_sort_probe.log).
     // Interleaved blocks keep a refill's reads consecutive and give every workgroup a sample of the whole queue. Numbering a round's
     // blocks XCD by XCD - the workgroups that share an L2 taking 2048+ NEIGHBOURING rays - changes nothing: +-0.1 % on C3 / C4 /
     // spaceship, round 5, profiles/r05_ab_trace_deal_xcd.log.)

@@ -63,7 +63,7 @@ int oracle_emit_photons(const mcrt_scene_desc* scene, double emissions, double c
                         float* caustic_photons, uint64_t* caustic_keys, uint64_t caustic_capacity, uint64_t* caustic_count,
                         uint64_t* emission_paths, uint64_t* rays);
 
-/* Study hooks (tools/knn_hint_study.py): record the kNN searches of a SINGLE-THREADED oracle_render into buf ([cap][6]:
+/* Study hooks (round 2's kNN hint study): record the kNN searches of a SINGLE-THREADED oracle_render into buf ([cap][6]:
  * map, x, y, z, pixel, sample); and run searches with a caller-given initial squared bound, counting octants / photons. */
 void oracle_knn_recorder(double* buf, uint64_t cap);
 uint64_t oracle_knn_recorded(void);

@@ -9,17 +9,18 @@ mkdir -p $O
 export TMPDIR=/tmp
 ( time timeout 1200 python -m pytest tests -m gpu -q -rA ) > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
-( time timeout 1500 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
+( time timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_default.json 2> $O/bench_default.err  # as the driver runs it
 tail -c 400 $O/bench_default.json; tail -4 $O/bench_default.err
 cp -r $R/gpurun_out/bench_profiles $O/ 2>/dev/null
 cd /tmp
-timeout 1200 rocprofv3 --kernel-trace --stats -d $O/kt_default -- python $R/bench.py --no-cpu --no-counters > $O/kt_default.json 2> $O/kt_default.err
+timeout 1500 rocprofv3 --kernel-trace --stats -d $O/kt_default -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-counters --no-tolerance > $O/kt_default.json 2> $O/kt_default.err
 cd $R
 python tools/summarize_rocprof.py $O/kt_default > $O/rocprof_kernel_trace.md 2>&1
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete; find $O -type d -empty -delete
 head -30 $O/rocprof_kernel_trace.md
 # one-GPU strong-scaling rehearsal of the configurations BASELINE names (tools/shard_probe.py), and the trace kernel's per-iteration statistics at full size
-for w in "c2 --sqrtspp 16" "c3" "c4 --sqrtspp 16" "c5"; do set -- $w; timeout 900 python tools/shard_probe.py $@ --reps 2 > $O/shard_$1.json 2> $O/shard_$1.err; python - <<PY
+# (C4 at full size takes minutes per shard: profiles/r05_shard_probe_c4.json stands)
+for w in "c2 --sqrtspp 16" "c3" "c5"; do set -- $w; timeout 900 python tools/shard_probe.py $@ --reps 2 > $O/shard_$1.json 2> $O/shard_$1.err; python - <<PY
 import json
 try:
     r = json.load(open("$O/shard_$1.json"))
