@@ -177,6 +177,11 @@ extern "C" int mcrt_photon_pass_multi(mcrt_ctx* const* ctxs, uint32_t count, dou
             uint64_t og = 0, oc = 0;
             for (uint32_t j = 0; j < count; j++) {
                 const int src = ctxDevice(ctxs[j]);
+                if (src != dev) {  // direct xGMI copies where the devices can reach each other (without it hipMemcpyPeer stages through the host: correct, slower)
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, dev, src) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src, 0);  // (hipErrorPeerAccessAlreadyEnabled is fine)
+                    (void)hipGetLastError();
+                }
                 if (em[j].global_count && hipMemcpyPeer(dg + og * 8, dev, em[j].d_global_photons, src, em[j].global_count * 8 * sizeof(float)) != hipSuccess) {
                     release();
                     return ctxFail(ctxs[i], MCRT_ERR_HIP, "mcrt_photon_pass_multi: copying a global photon list between devices failed");
