@@ -178,8 +178,10 @@ void Camera::sampleImage()
                                               pm->direct_visualization ? 1 : 0, ps.data()) != MCRT_OK) {
                 throw std::runtime_error(firstError(ctxs));
             }
-            unsigned long long paths = 0;
-            for (auto& s : ps) paths += s.emission_paths;
+            unsigned long long paths = 0;  // of the pass: the shards' sum, or - replicated - what every context traced
+            if (envLong("MCRT_DROPIN_REPLICATED_PHOTONS", 0) != 0) paths = ps[0].emission_paths;
+            else
+                for (auto& s : ps) paths += s.emission_paths;
             std::printf("\n[mcrt_hip] PhotonMapper pass on the GPU(s): %llu emission paths over %zu context(s) (%llu by the first), %llu global + %llu caustic photons, "
                         "%.1f ms (emission %.1f ms in the first context)\n",
                         paths, ctxs.size(), (unsigned long long)ps[0].emission_paths, (unsigned long long)ps[0].global_count,

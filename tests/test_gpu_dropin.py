@@ -40,15 +40,19 @@ def _scene_dir(tmp_path, scene, render, emissions=None):
 
 # extra: the drop-in's switches (integration/camera_sample_image_gpu.cpp). Default = one context per device the process sees and the
 # photon pass on the GPU (the reference's PhotonMapper constructor replaced); MCRT_DROPIN_CONTEXTS=2/3: the fan-out over several
-# contexts (mcrt_render_multi) exercised on the one GPU of the test box; MCRT_DROPIN_CPU_PHOTONS=1: the reference's own CPU photon pass.
+# contexts (mcrt_render_multi, and since round 6 the SHARDED photon pass mcrt_photon_pass_multi) exercised on the one GPU of the test box;
+# MCRT_DROPIN_REPLICATED_PHOTONS=1: round 5's photon pass (every context traces all paths); MCRT_DROPIN_CPU_PHOTONS=1: the reference's own CPU photon pass.
 @pytest.mark.parametrize("name,scene,answers,emissions,extra", [
     ("hexagon_room", "hexagon_room.json", "0\nn\n", None, {}),
     ("hexagon_room", "hexagon_room.json", "0\nn\n", None, {"MCRT_DROPIN_CONTEXTS": "2"}),
     ("metals", "metals.json", "0\n", None, {"MCRT_DROPIN_CONTEXTS": "3"}),
     ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {}),
     ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CONTEXTS": "2"}),
+    ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CONTEXTS": "3"}),
+    ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CONTEXTS": "2", "MCRT_DROPIN_REPLICATED_PHOTONS": "1"}),
     ("hexagon_room_pm", "hexagon_room.json", "0\ny\n", 4000, {"MCRT_DROPIN_CPU_PHOTONS": "1"})],
-    ids=["hexagon_room", "hexagon_room-2ctx", "metals-3ctx", "hexagon_room_pm-gpu_photons", "hexagon_room_pm-gpu_photons-2ctx", "hexagon_room_pm-cpu_photons"])
+    ids=["hexagon_room", "hexagon_room-2ctx", "metals-3ctx", "hexagon_room_pm-gpu_photons", "hexagon_room_pm-gpu_photons-2ctx", "hexagon_room_pm-sharded_photons-3ctx",
+         "hexagon_room_pm-replicated_photons-2ctx", "hexagon_room_pm-cpu_photons"])
 def test_reference_main_renders_through_the_gpu(manifest, tmp_path, name, scene, answers, emissions, extra):
     if not os.path.exists(BIN) or not os.path.exists(os.path.join(SCENES, scene)):
         pytest.skip("oracle/_ref/mcrt_ref_gpu not built (python __graft_entry__.py build in the build container)")
