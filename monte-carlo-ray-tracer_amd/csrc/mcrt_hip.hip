@@ -105,6 +105,11 @@ struct mcrt_ctx {
     DevBuf work_counter, stats, spill, knn_res_d2, knn_res_idx, knn_visit_d2, knn_visit_oct, out_tmp;
     size_t spill_bytes = 0;
     uint32_t knn_lanes = 0, knn_k = 0;
+    // per-lane photon search (the kernel of k > 768 and of MCRT_KERNEL=legacy): frontier entries per lane, grown - frame rendered again,
+    // operator call repeated - when a search ran out (KnnScratch::max_visit); force_pm_lane: a photon-mapped frame whose wave-cooperative
+    // searches overflowed THEIR frontier (128 register entries + a 1 024-entry list per wave) is rendered again by the per-lane kernel
+    uint32_t knn_visit_cap = kMaxVisit, knn_visit_alloc = 0;
+    bool force_pm_lane = false;
 
     // scratch of the operator-level entry points (mcrt_intersect / mcrt_knn / mcrt_sampler / mcrt_bsdf): kept between calls, grown
     // on demand, so that a host that only wants traversal or k-NN does not pay five hipMalloc / hipFree pairs per call
@@ -223,14 +228,16 @@ int ensureScratch(mcrt_ctx* ctx, uint32_t total_lanes, bool photon) {
     if (!ctx->work_counter.p) HIP_TRY(ctx, ctx->work_counter.alloc(sizeof(unsigned long long)));
     if (!ctx->stats.p) HIP_TRY(ctx, ctx->stats.alloc(kStatsWords * sizeof(unsigned long long)));
     if (int rc = ensureSpill(ctx, (size_t)total_lanes * (ctx->scene.stack_depth - kLdsStackDepth) * sizeof(StackEntry))) return rc;
-    if (photon && (ctx->knn_lanes < total_lanes || ctx->knn_k < ctx->k_nearest)) {
+    if (photon && (ctx->knn_lanes < total_lanes || ctx->knn_k < ctx->k_nearest || ctx->knn_visit_alloc < ctx->knn_visit_cap)) {
         const uint32_t k = std::max<uint32_t>(ctx->k_nearest, 1);
+        ctx->knn_lanes = ctx->knn_k = ctx->knn_visit_alloc = 0;
         HIP_TRY(ctx, ctx->knn_res_d2.alloc((size_t)total_lanes * k * sizeof(double)));
         HIP_TRY(ctx, ctx->knn_res_idx.alloc((size_t)total_lanes * k * sizeof(uint32_t)));
-        HIP_TRY(ctx, ctx->knn_visit_d2.alloc((size_t)total_lanes * kMaxVisit * sizeof(double)));
-        HIP_TRY(ctx, ctx->knn_visit_oct.alloc((size_t)total_lanes * kMaxVisit * sizeof(uint32_t)));
+        HIP_TRY(ctx, ctx->knn_visit_d2.alloc((size_t)total_lanes * ctx->knn_visit_cap * sizeof(double)));
+        HIP_TRY(ctx, ctx->knn_visit_oct.alloc((size_t)total_lanes * ctx->knn_visit_cap * sizeof(uint32_t)));
         ctx->knn_lanes = total_lanes;
         ctx->knn_k = k;
+        ctx->knn_visit_alloc = ctx->knn_visit_cap;
     }
     return MCRT_OK;
 }
@@ -746,7 +753,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
     // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
     // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
-    if (photon && has_tree && ctx->k_nearest <= kWaveKMax && want_wf)
+    if (photon && has_tree && ctx->k_nearest <= kWaveKMax && want_wf && !ctx->force_pm_lane)
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true, film_out);
     // workgroup size of the state-machine kernel for trees that stay in HBM (MCRT_SM_BLOCK: 512 / 768 / 1024 lanes) and the
     // stack entries per lane it keeps in LDS (MCRT_SM_STACK; the rest of a lane's stack is in the HBM spill area)
@@ -767,7 +774,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
 
     // photon mapping: wave-cooperative estimates unless k is too large for the widest per-wave buffer (k <= 128: 256 candidates per
     // wave; k <= 768: 1024 candidates per wave, 512 lanes per workgroup)
-    bool use_pm_wave = photon && ctx->k_nearest <= kWaveKMax && !(kenv && strcmp(kenv, "legacy") == 0);
+    bool use_pm_wave = photon && ctx->k_nearest <= kWaveKMax && !(kenv && strcmp(kenv, "legacy") == 0) && !ctx->force_pm_lane;
     const bool pm_large_k = use_pm_wave && ctx->k_nearest > waveMaxK(kWaveRows);
     if (pm_large_k) {
         // the wide buffers take 100 KB of a 512-lane workgroup's LDS: a BVH staged whole with its 16 stack entries per lane may not
@@ -893,6 +900,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         prm.knn_res_idx = ctx->knn_res_idx.as<uint32_t>();
         prm.knn_visit_d2 = ctx->knn_visit_d2.as<double>();
         prm.knn_visit_oct = ctx->knn_visit_oct.as<uint32_t>();
+        prm.knn_max_visit = ctx->knn_visit_alloc;
     }
     ctx->kernel_id = prm.owned_rows == 0 ? MCRT_KERNEL_NONE
                      : use_pm_wave   ? MCRT_KERNEL_PM_WAVE
@@ -1381,9 +1389,36 @@ int mcrt_render_finish(mcrt_ctx* ctx, mcrt_stats* stats) {
         stats->kernel_launches = ctx->launches;
         stats->kernel_id = ctx->kernel_id;
     }
-    if (h[5] >= kKnnOverflowFlag)
-        return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more than 128 + 1024 octants pending at once (the wave's registers + its list in memory); a "
-                                               "photon octree whose leaves hold far fewer photons than k_nearest_photons can do that");
+    // (test hook: MCRT_TEST_KNN_OVERFLOW=1 treats the first frame of a wave-cooperative photon-mapping kernel as if a search had overflowed;
+    // no tree the tests can build in reasonable time fills 128 + 1 024 frontier entries through the render path, whose record lists
+    // are made for the k it searches with)
+    const bool pm_wave_frame = ctx->kernel_id == MCRT_KERNEL_PM_WAVE || ctx->kernel_id == MCRT_KERNEL_WAVEFRONT_PM;
+    if (pm_wave_frame && !ctx->force_pm_lane && ctxOptOn(ctx, "MCRT_TEST_KNN_OVERFLOW")) h[5] |= kKnnOverflowFlag;
+    if (h[5] >= kKnnOverflowFlag) {
+        // The reference's frontier is an unbounded priority queue (linear-octree.cpp:33). A wave-cooperative search keeps 128 entries
+        // in registers and 1 024 in a list in memory; a frame in which one of them ran out is rendered AGAIN by the per-lane kernel (the
+        // reference's two queues per lane, in memory), whose own frontier - 160 entries per lane to begin with - grows eightfold per
+        // attempt, up to kMaxVisitLimit. Slower, and correct (round 6; until then: MCRT_ERR_UNSUPPORTED, and the per-lane search DROPPED
+        // the entry without a word).
+        const bool lane_frame = ctx->kernel_id == MCRT_KERNEL_PM_LANE;
+        const bool splats = filmSplats(ctx->last_cam.film_filter, ctx->last_cam.film_radius);  // (only the pipeline splats: no second kernel for such a frame)
+        if (!splats && ((pm_wave_frame && !ctx->force_pm_lane) || (lane_frame && ctx->knn_visit_cap < kMaxVisitLimit))) {
+            if (lane_frame) ctx->knn_visit_cap = std::min<uint32_t>(ctx->knn_visit_cap * 8u, kMaxVisitLimit);
+            else ctx->knn_visit_cap = std::max<uint32_t>(ctx->knn_visit_cap, 2048u);
+            const bool keep = ctx->force_pm_lane;
+            ctx->force_pm_lane = true;
+            const int rc = launchRender(ctx, &ctx->last_cam, ctx->last_seed, ctx->last_integrator, ctx->last_out, ctx->last_stream, ctx->last_film);
+            if (rc != MCRT_OK) {
+                ctx->force_pm_lane = keep;
+                return rc;
+            }
+            const int rc2 = mcrt_render_finish(ctx, stats);
+            ctx->force_pm_lane = keep;
+            return rc2;
+        }
+        return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more than " + std::to_string(kMaxVisitLimit) + " octants pending at once in the per-lane "
+                                               "kernel's frontier (the reference's queue is unbounded, linear-octree.cpp:33)");
+    }
     if (h[5])
         return fail(ctx, MCRT_ERR_UNSUPPORTED, "traversal stack overflow (internal error: the stacks are sized to the tree's own bound, HostLayout::stack_bound)");
     if (h[7]) {
@@ -1895,30 +1930,46 @@ int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k, 
         }
         unsigned long long f = 0;
         HIP_TRY(ctx, hipMemcpy(&f, flags.p, 8, hipMemcpyDeviceToHost));
-        if (f) return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more octants pending at once than the wave's frontier holds (128 in registers + a "
-                                                      "1024-entry list in memory for the wave-per-query kernel; 128 for the four-queries-per-wave kernel of small k)");
-        HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));
-        return MCRT_OK;
+        if (ctxOptOn(ctx, "MCRT_TEST_KNN_OVERFLOW")) f = 1;  // (test hook: take the branch below whatever the searches did)
+        if (!f) {
+            HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));
+            return MCRT_OK;
+        }
+        // a search had more octants pending at once than the wave's frontier holds (128 in registers + a 1 024-entry list in memory for the
+        // wave-per-query kernel; 128 for the four-queries-per-wave kernel of small k): the call is served by the per-lane kernel below,
+        // whose frontier grows (the reference's queue is unbounded, linear-octree.cpp:33; until round 6: MCRT_ERR_UNSUPPORTED)
+        ctx->knn_visit_cap = std::max<uint32_t>(ctx->knn_visit_cap, 2048u);
     }
     const uint32_t block = 64;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cus * 8, (n + block - 1) / block);
     const uint32_t lanes = grid * block;
-    DevBuf dp, dc, di, dd, r_d2, r_idx, v_d2, v_oct;
+    DevBuf dp, dc, di, dd, r_d2, r_idx, v_d2, v_oct, lane_flag;
     if (int rc = uploadArray(ctx, dp, p, n * 3)) return rc;
     HIP_TRY(ctx, dc.alloc(n * 4));
     HIP_TRY(ctx, di.alloc(n * k * 4));
     HIP_TRY(ctx, dd.alloc(n * k * 8));
     HIP_TRY(ctx, r_d2.alloc((size_t)lanes * k * 8));
     HIP_TRY(ctx, r_idx.alloc((size_t)lanes * k * 4));
-    HIP_TRY(ctx, v_d2.alloc((size_t)lanes * kMaxVisit * 8));
-    HIP_TRY(ctx, v_oct.alloc((size_t)lanes * kMaxVisit * 4));
-    hipLaunchKernelGGL(knnKernel, dim3(grid), dim3(block), 0, ctx->stream, ctx->maps[which], n, dp.as<double>(), k, dc.as<uint32_t>(),
-                       di.as<uint32_t>(), dd.as<double>(), r_d2.as<double>(), r_idx.as<uint32_t>(), v_d2.as<double>(),
-                       v_oct.as<uint32_t>(), lanes);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, lane_flag.alloc(8));
+    for (;;) {  // (the per-lane frontier: 160 entries per lane to begin with, eight times as many whenever a search ran out)
+        const uint32_t cap = ctx->knn_visit_cap;
+        HIP_TRY(ctx, v_d2.alloc((size_t)lanes * cap * 8));
+        HIP_TRY(ctx, v_oct.alloc((size_t)lanes * cap * 4));
+        HIP_TRY(ctx, hipMemsetAsync(lane_flag.p, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(knnKernel, dim3(grid), dim3(block), 0, ctx->stream, ctx->maps[which], n, dp.as<double>(), k, dc.as<uint32_t>(),
+                           di.as<uint32_t>(), dd.as<double>(), r_d2.as<double>(), r_idx.as<uint32_t>(), v_d2.as<double>(),
+                           v_oct.as<uint32_t>(), lanes, cap, lane_flag.as<unsigned long long>());
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long f = 0;
+        HIP_TRY(ctx, hipMemcpy(&f, lane_flag.p, 8, hipMemcpyDeviceToHost));
+        if (!f) break;
+        if (cap >= kMaxVisitLimit)
+            return fail(ctx, MCRT_ERR_UNSUPPORTED, "kNN frontier overflow: a search had more than " + std::to_string(kMaxVisitLimit) + " octants pending at once (per-lane kernel)");
+        ctx->knn_visit_cap = std::min<uint32_t>(cap * 8u, kMaxVisitLimit);
+    }
     HIP_TRY(ctx, hipMemcpy(out_count, dc.p, n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(out_index, di.p, n * k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(out_distance2, dd.p, n * k * 8, hipMemcpyDeviceToHost));

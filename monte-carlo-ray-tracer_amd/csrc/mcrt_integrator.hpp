@@ -229,12 +229,20 @@ struct KnnScratch {
     double* visit_d2;    // &visit_d2[lane], stride lanes, kMaxVisit slots
     uint32_t* visit_oct;
     uint32_t stride;
+    // The frontier's capacity per lane (the reference's is an unbounded priority queue, linear-octree.cpp:33): the host sizes the two
+    // visit arrays to it and renders a frame / repeats an operator call with a larger one when a search ran out (round 6; until then a
+    // full frontier dropped the entry WITHOUT a word - 160 entries, which a best-first descent of a 21-level octree cannot exceed
+    // before its first scan but a crowd of inner octants inside the bound can).
+    uint32_t max_visit;
+    mutable uint32_t overflowed;  // kLaneKnnOverflow once a push found the frontier full (the result is then not to be trusted)
     MCRT_HD KnnEntry res(uint32_t i) const { return KnnEntry{res_d2[(size_t)i * stride], res_idx[(size_t)i * stride]}; }
     MCRT_HD void setRes(uint32_t i, KnnEntry e) const { res_d2[(size_t)i * stride] = e.distance2; res_idx[(size_t)i * stride] = e.index; }
     MCRT_HD OctantEntry visit(uint32_t i) const { return OctantEntry{visit_d2[(size_t)i * stride], visit_oct[(size_t)i * stride]}; }
     MCRT_HD void setVisit(uint32_t i, OctantEntry e) const { visit_d2[(size_t)i * stride] = e.distance2; visit_oct[(size_t)i * stride] = e.octant; }
 };
-constexpr uint32_t kMaxVisit = 160;  // best-first frontier: <= 7 new entries per level of an octree (22 levels)
+constexpr uint32_t kMaxVisit = 160;  // default frontier capacity: <= 7 new entries per level of an octree's first descent (22 levels)
+constexpr uint32_t kMaxVisitLimit = 1u << 15;  // what the host grows it to at most (x 12 bytes x the launch's lanes)
+constexpr uint32_t kLaneKnnOverflow = 0x10000u;  // = kKnnOverflowFlag (mcrt_waveknn.hpp): the host tells it from the traversal stacks' overflow counts by the bits above 15
 
 MCRT_HD double boxDistance2(const double* b, d3 p) {  // BoundingBox::distance2, bounding-box.cpp:43-47
     d3 a = ld3(b) - p, c = p - ld3(b + 3);
@@ -294,7 +302,10 @@ MCRT_HD void knnMakeHeap(const KnnScratch& s, uint32_t size) {
 }
 // Min-heap on distance2 of octants still to visit (linear-octree.cpp:37-44; priority-queue.hpp:19-45).
 MCRT_HD void visitPush(const KnnScratch& s, uint32_t& size, OctantEntry value) {
-    if (size >= kMaxVisit) return;  // cannot happen for octrees of depth <= 13; guarded anyway
+    if (size >= s.max_visit) {  // reported, never silent: the host repeats the work with a larger frontier
+        s.overflowed = kLaneKnnOverflow;
+        return;
+    }
     uint32_t index = size++;
     while (index > 0) {
         uint32_t parent = (index - 1) / 2;

@@ -68,6 +68,7 @@ struct RenderParams {
     unsigned long long* stats;  // paths, rays, node_tests, prim_tests, knn_searches, overflow, knn_octants
     StackEntry* spill;
     uint32_t total_lanes;
+    uint32_t knn_max_visit;  // per-lane photon search: frontier entries per lane (KnnScratch::max_visit; in the padding before the maps)
     // photon mapping
     PhotonMapView global_map, caustic_map;
     uint32_t k_nearest, direct_visualization;
@@ -347,6 +348,8 @@ __device__ __forceinline__ void renderKernelBody(const DeviceScene& scene, const
 
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
     KnnScratch ks;
+    ks.overflowed = 0u;
+    ks.max_visit = 0u;
     PhotonViews pv;
     if (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER) {
         ks.res_d2 = prm.knn_res_d2 + gl;
@@ -354,6 +357,7 @@ __device__ __forceinline__ void renderKernelBody(const DeviceScene& scene, const
         ks.visit_d2 = prm.knn_visit_d2 + gl;
         ks.visit_oct = prm.knn_visit_oct + gl;
         ks.stride = prm.total_lanes;
+        ks.max_visit = prm.knn_max_visit;
         pv.global_map = prm.global_map;
         pv.caustic_map = prm.caustic_map;
         pv.k_nearest = prm.k_nearest;
@@ -424,7 +428,8 @@ __device__ __forceinline__ void renderKernelBody(const DeviceScene& scene, const
         waveAccumulate(prm.stats + 3, cnt.prim_tests);
     }
     waveAccumulate(prm.stats + 4, searches);
-    waveAccumulate(prm.stats + 5, cnt.overflow);
+    if constexpr (kIntegrator == MCRT_INTEGRATOR_PHOTON_MAPPER) waveAccumulate(prm.stats + 5, cnt.overflow | ks.overflowed);  // (a search that ran out of frontier)
+    else waveAccumulate(prm.stats + 5, cnt.overflow);
     waveAccumulate(prm.stats + 7, rh.overflow ? 1u : 0u);
     waveAccumulate(prm.stats + 6, octant_visits);
     if constexpr (kProf) {
@@ -1798,7 +1803,7 @@ __global__ void __launch_bounds__(256) bsdfKernel(uint64_t n, const double* in, 
 
 __global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count,
                           uint32_t* out_index, double* out_d2, double* res_d2, uint32_t* res_idx, double* visit_d2,
-                          uint32_t* visit_oct, uint32_t total_lanes) {
+                          uint32_t* visit_oct, uint32_t total_lanes, uint32_t max_visit, unsigned long long* overflow_flag) {
     const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
     KnnScratch ks;
     ks.res_d2 = res_d2 + gl;
@@ -1806,6 +1811,8 @@ __global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, 
     ks.visit_d2 = visit_d2 + gl;
     ks.visit_oct = visit_oct + gl;
     ks.stride = total_lanes;
+    ks.max_visit = max_visit;
+    ks.overflowed = 0u;
     for (uint64_t i = gl; i < n; i += total_lanes) {
         uint32_t visits = 0;
         uint32_t c = knnSearch(map, ld3(p + 3 * i), k, ks, visits);
@@ -1836,4 +1843,5 @@ __global__ void knnKernel(const PhotonMapView map, uint64_t n, const double* p, 
             }
         }
     }
+    if (ks.overflowed) *overflow_flag = 1ull;  // (any lane; the host repeats the call with a larger frontier)
 }

@@ -58,6 +58,7 @@ constexpr uint32_t kWaveHist = 128;   // bins of the per-wave distance histogram
 // what a search sets its overflow word to: the photon-mapping megakernel adds the word into the SAME statistics word as the lanes'
 // traversal-stack overflows (one per lane), and the host tells the two apart by the bits above 15 (mcrt_render_finish)
 constexpr uint32_t kKnnOverflowFlag = 0x10000u;
+static_assert(kKnnOverflowFlag == kLaneKnnOverflow, "one flag for the wave-cooperative and the per-lane searches");
 constexpr uint32_t kWaveStateBytes = 16u;  // per wave, for the searches that keep their spill list's state in LDS ("Frontier overflow" below)
 __host__ __device__ constexpr uint32_t waveKnnBytes(int R) { return waveCand(R) * 12u + kWaveHist * 4u; }  // LDS per wave: candidates + histogram
 constexpr uint32_t kWaveKnnBytes = waveKnnBytes(kWaveRows);

@@ -192,6 +192,8 @@ def load_emu():
     L.emu_flat_cull.argtypes = [vp, C.c_uint64, vp, vp, vp]
     L.emu_qstep_check.argtypes = [vp, C.c_uint64, vp, vp, vp]
     L.emu_knn.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp]
+    L.emu_knn_cap.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.emu_knn_cap.restype = C.c_int
     L.emu_trace_counts.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, vp]
     L.emu_set_defer.argtypes = [C.c_int]
     return L

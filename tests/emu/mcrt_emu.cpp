@@ -44,7 +44,7 @@ struct Emu {
     PhotonViews pv;
     std::vector<double> res_d2, visit_d2;
     std::vector<uint32_t> res_idx, visit_oct;
-    KnnScratch ks;
+    KnnScratch ks{};  // (zeroed: path-traced frames never set it up, and report its overflow word with the stacks')
 };
 
 int setup(Emu& E, const mcrt_scene_desc* s, int stage_mode) {
@@ -139,11 +139,13 @@ void setupMap(Emu& E, int which, const mcrt_photon_map_desc* m, PhotonMapView& v
     v.photons = m->photons;
 }
 
-void setupKnn(Emu& E, uint32_t k) {
+void setupKnn(Emu& E, uint32_t k, uint32_t visit_cap = kMaxVisit) {
     E.res_d2.resize(k ? k : 1);
     E.res_idx.resize(k ? k : 1);
-    E.visit_d2.resize(kMaxVisit);
-    E.visit_oct.resize(kMaxVisit);
+    E.visit_d2.resize(visit_cap);
+    E.visit_oct.resize(visit_cap);
+    E.ks.max_visit = visit_cap;
+    E.ks.overflowed = 0u;
     E.ks.res_d2 = E.res_d2.data();
     E.ks.res_idx = E.res_idx.data();
     E.ks.visit_d2 = E.visit_d2.data();
@@ -192,7 +194,7 @@ int emu_render(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gmap, c
                 acc[0] += st.radiance.x * 1.0;
                 acc[1] += st.radiance.y * 1.0;
                 acc[2] += st.radiance.z * 1.0;
-                totals[0] += cnt.rays; totals[1] += cnt.node_tests; totals[2] += cnt.prim_tests; totals[3] += cnt.overflow;
+                totals[0] += cnt.rays; totals[1] += cnt.node_tests; totals[2] += cnt.prim_tests; totals[3] += cnt.overflow | E.ks.overflowed;
                 cnt = TraceCounters{0, 0, 0, 0};
             }
             double* o = out_rgb + ((size_t)(y - row0) * cam->width + x) * 3;
@@ -438,7 +440,7 @@ int emu_render_sm(const mcrt_scene_desc* scene, const mcrt_camera_desc* cam, uin
             for (int c = 0; c < 3; c++) o[c] = gmax(acc[c] / (double)spp, 0.0);
         }
     if (counters) {
-        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
+        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow | E.ks.overflowed; counters[4] = paths;
     }
     return 0;
 }
@@ -642,7 +644,7 @@ static int renderWf(const mcrt_scene_desc* scene, const mcrt_photon_map_desc* gm
             for (int c = 0; c < 3; c++) out_rgb[i * 3 + c] = gmax(acc[c] / (double)fr.spp, 0.0);
         }
     if (counters) {
-        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow; counters[4] = paths;
+        counters[0] = cnt.rays; counters[1] = cnt.node_tests; counters[2] = cnt.prim_tests; counters[3] = cnt.overflow | E.ks.overflowed; counters[4] = paths;
         counters[5] = iterations;
         if (photon) counters[6] = searches;
     }
@@ -1112,15 +1114,27 @@ int emu_shade_rec(const mcrt_scene_desc* scene, double* out) {
     return 0;
 }
 
+// visit_cap: the per-lane frontier's capacity (0: the library's default, 160). Returns 0, or 1 when a search ran out of frontier (the
+// host of the library then repeats the work with eight times the capacity; here the caller does).
+int emu_knn_cap(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, uint32_t visit_cap, uint32_t* out_count, uint32_t* out_index,
+                double* out_d2);
 int emu_knn(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, uint32_t* out_count, uint32_t* out_index,
             double* out_d2) {
+    for (uint32_t cap = kMaxVisit;; cap *= 8u) {  // (as mcrt_knn's per-lane branch does)
+        const int rc = emu_knn_cap(map, n, p, k, cap, out_count, out_index, out_d2);
+        if (rc != 1 || cap >= kMaxVisitLimit) return rc == 1 ? -300 : rc;
+    }
+}
+int emu_knn_cap(const mcrt_photon_map_desc* map, uint64_t n, const double* p, uint32_t k, uint32_t visit_cap, uint32_t* out_count, uint32_t* out_index,
+                double* out_d2) {
     Emu E;
     PhotonMapView v;
     setupMap(E, 0, map, v);
-    setupKnn(E, k);
+    setupKnn(E, k, visit_cap ? visit_cap : kMaxVisit);
     for (uint64_t i = 0; i < n; i++) {
         uint32_t visits = 0;
         uint32_t c = knnSearch(v, ld3(p + 3 * i), k, E.ks, visits);
+        if (E.ks.overflowed) return 1;
         out_count[i] = c;
         std::vector<std::pair<double, uint32_t>> r;
         for (uint32_t q = 0; q < c; q++) r.push_back({E.ks.res(q).distance2, E.ks.res(q).index});

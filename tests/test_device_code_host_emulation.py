@@ -251,6 +251,36 @@ def test_knn_device_code_kat(pkg, emu, manifest):
         np.testing.assert_array_equal(idx, np.fromfile(os.path.join(d, "knn_%s_index.u32" % tag), dtype=np.uint32).reshape(-1, k))
 
 
+def test_per_lane_search_reports_a_full_frontier_and_a_larger_one_recovers(pkg, emu):
+    """knnSearch per lane (csrc/mcrt_integrator.hpp: the kernel of k > 768 and of MCRT_KERNEL=legacy) keeps its frontier in a fixed number of
+    entries per lane; the reference's is an unbounded priority queue (linear-octree.cpp:33). Until round 6 a push into a full frontier
+    DROPPED the entry without a word. Now the search says so (KnnScratch::overflowed) and the host repeats the work with eight times
+    the entries: with a frontier of 6 entries the searches on a tree of one-photon leaves report the overflow, with the library's
+    default they return the brute-force answer."""
+    rng = np.random.default_rng(5)
+    count, k = 4000, 40
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    m = pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), 1)
+    pts = lo + rng.random((32, 3)) * (hi - lo)
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)
+    dd = pts[:, None, :] - pos[None, :, :]
+    d2_all = (dd[:, :, 0] * dd[:, :, 0] + dd[:, :, 1] * dd[:, :, 1]) + dd[:, :, 2] * dd[:, :, 2]
+    want = np.sort(d2_all, axis=1)[:, :k]
+    n = len(pts)
+    cnt, idx, d2 = np.empty(n, dtype=np.uint32), np.empty((n, k), dtype=np.uint32), np.empty((n, k))
+    args = (C.byref(m.desc), n, pts.ctypes.data, k)
+    outs = (cnt.ctypes.data, idx.ctypes.data, d2.ctypes.data)
+    assert emu.emu_knn_cap(*args, 6, *outs) == 1  # a full frontier is reported ...
+    assert emu.emu_knn_cap(*args, 0, *outs) == 0  # ... the default (160 entries) holds this tree's
+    np.testing.assert_array_equal(d2, want)
+    np.testing.assert_array_equal(d2_all[np.arange(n)[:, None], idx], want)
+    assert emu.emu_knn(*args, *outs) == 0  # (the growing loop of mcrt_knn's per-lane branch)
+    np.testing.assert_array_equal(d2, want)
+    m.close()
+
+
 def _cull_rays(img, rng, n):
     """Rays that stress the cull's error bounds: from points ON the primitives (where t, u, v sit at the edge of their
     ranges) towards vertices, edge points and sphere tangent points, plus random rays in and around the scene."""

@@ -115,3 +115,70 @@ def test_gpu_knn_octree_with_tiny_leaves(pkg, ctx, manifest, leaf, k):
     rows = np.arange(len(pts))[:, None]
     np.testing.assert_array_equal(d2_all[rows, idx], want)
     m.close()
+
+
+def _uniform_map(pkg, count, leaf, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array([-3.0, -2.0, -1.0]), np.array([5.0, 2.0, 4.0])
+    ph = np.zeros((count, 8), dtype=np.float32)
+    ph[:, 3:6] = (lo + rng.random((count, 3)) * (hi - lo)).astype(np.float32)
+    ph[:, 0:3] = 1.0
+    return pkg.PhotonMap(ph, lo.tolist(), hi.tolist(), leaf), lo, hi, rng
+
+
+def _brute(m, count, pts, k):
+    pos = np.ctypeslib.as_array(m.desc.photons, (count, 8))[:, 3:6].astype(np.float64)  # in the map's order
+    d = pts[:, None, :] - pos[None, :, :]
+    d2_all = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    return d2_all, np.sort(d2_all, axis=1)[:, :k]
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_gpu_knn_frontier_beyond_the_waves_list_is_served_by_the_per_lane_kernel(pkg, ctx, manifest, forced):
+    """The reference's frontier is an unbounded priority queue (linear-octree.cpp:33). A wave-cooperative search keeps 128 entries in
+    registers and 1 024 in a list in memory; until round 6 a search that needed more ended the call with MCRT_ERR_UNSUPPORTED. Now the
+    call is served by the per-lane kernel, whose own frontier grows on demand. The case: record lists made for k = 1 (only single
+    photons are scanned whole) searched with k = 700 on leaves of one photon - thousands of octants inside the bound at once; and
+    the same branch taken through the test hook, whatever the searches did. Against a brute-force selection."""
+    img = pkg.SceneImage(golden_path(manifest["cases"]["hexagon_room_pm"]["image"]))
+    ctx.upload_image(img)
+    count, k = 60000, 700
+    m, lo, hi, rng = _uniform_map(pkg, count, 1, 77)
+    ctx.upload_photons(m.desc, m.desc, 1, False)
+    pts = lo + rng.random((48, 3)) * (hi - lo)
+    d2_all, want = _brute(m, count, pts, k)
+    if forced:
+        ctx.set_option("MCRT_TEST_KNN_OVERFLOW", 1)
+    cnt, idx, d2 = ctx.knn(0, pts, k)
+    if forced:
+        ctx.set_option("MCRT_TEST_KNN_OVERFLOW", None)
+    assert np.all(cnt == k)
+    np.testing.assert_array_equal(d2, want)
+    np.testing.assert_array_equal(d2_all[np.arange(len(pts))[:, None], idx], want)
+    m.close()
+
+
+def test_gpu_frame_whose_searches_overflow_is_rendered_again_by_the_per_lane_kernel(pkg, ctx, manifest, kernel_env):
+    """mcrt_render_finish on a photon-mapped frame in which a wave-cooperative search ran out of frontier: the frame is rendered again by
+    the per-lane kernel (until round 6: MCRT_ERR_UNSUPPORTED). No tree the tests can build fills 128 + 1 024 entries through the render
+    path (its record lists are made for the k it searches with), so the overflow is raised by the test hook: the frame that comes back
+    must be the per-lane kernel's, bit for bit, and say so."""
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    ctx.upload_image(img)
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 96, 54, 1
+    kernel_env("legacy")
+    want, st0 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    assert st0["kernel_id"] == pkg.KERNEL_PM_LANE
+    os.environ.pop("MCRT_KERNEL")
+    os.environ["MCRT_TEST_KNN_OVERFLOW"] = "1"
+    try:
+        out, st = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    finally:
+        os.environ.pop("MCRT_TEST_KNN_OVERFLOW")
+    assert st["kernel_id"] == pkg.KERNEL_PM_LANE, pkg.KERNEL_NAMES.get(st["kernel_id"])
+    np.testing.assert_array_equal(out, want)
+    out2, st2 = ctx.sample_image(cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)  # and the next frame is the fast kernel's again
+    assert st2["kernel_id"] == pkg.KERNEL_PM_WAVE
+    assert rel_error(out2, want).max() <= 1e-10

@@ -7,6 +7,6 @@ LIB=monte-carlo-ray-tracer_amd/csrc/libmcrt_hip.so
 cp $LIB /tmp/lib_orig.so
 for x in "$@"; do
   cp tools/_build/lib$x.so $LIB
-  echo "build $x: $(timeout 300 python tools/ab_probe.py ${WORKLOAD:-c3} --sqrtspp ${SQRTSPP:-8} --steps ${STEPS:-2} ${EMISSIONS:+--emissions $EMISSIONS} "base:" 2>&1 | tail -1 | cut -c1-120)"
+  echo "build $x: $(timeout 300 python tools/ab_probe.py ${WORKLOAD:-c3} --sqrtspp ${SQRTSPP:-8} --steps ${STEPS:-2} ${EMISSIONS:+--emissions $EMISSIONS} "base:" 2>&1 | tail -1 | cut -c1-200)"
 done
 cp /tmp/lib_orig.so $LIB
