@@ -388,7 +388,10 @@ int mcrt_libm(mcrt_ctx* ctx, int fn, uint64_t n, const double* a, const double* 
 /* LinearOctree<Photon>::knnSearch (octree/linear-octree.cpp:25-117) on the uploaded map
  * (which = 0 global, 1 caustic) for n query points p[n][3]. Outputs per query: count found
  * (≤ k), photon indices and squared distances sorted by ascending distance (ties by index),
- * each [n][k]; unused slots get 0xFFFFFFFF / +inf. */
+ * each [n][k]; unused slots get 0xFFFFFFFF / +inf. Any k: k <= 768 is served by the wave-cooperative search,
+ * larger k by the per-lane search. The search's frontier is unbounded like the reference's priority queue
+ * (linear-octree.cpp:33): a wave-cooperative search that fills its 128 + 1 024 entries is repeated by the per-lane
+ * search, whose frontier grows on demand (the same holds for photon-mapped frames: mcrt_render_finish). */
 int mcrt_knn(mcrt_ctx* ctx, int which, uint64_t n, const double* p, uint32_t k,
              uint32_t* out_count, uint32_t* out_index, double* out_distance2);
 
