@@ -52,7 +52,9 @@ def sources():
     return src
 
 
-TUS = ["mcrt_hip.hip", "mcrt_octree_gpu.hip", "mcrt_sah_gpu.hip", "mcrt_output.hip", "mcrt_multi.hip", "mcrt_image.cpp", "mcrt_octree.cpp", "mcrt_bvh.cpp"]
+# the translation units that hold kernels of the render path: the tolerance library has its own objects of these
+KERNEL_TUS = ("mcrt_hip.hip", "mcrt_hip_lean.hip")
+TUS = ["mcrt_hip.hip", "mcrt_hip_lean.hip", "mcrt_octree_gpu.hip", "mcrt_sah_gpu.hip", "mcrt_output.hip", "mcrt_multi.hip", "mcrt_image.cpp", "mcrt_octree.cpp", "mcrt_bvh.cpp"]
 OBJ = os.path.join(CSRC, "_obj")
 
 
@@ -81,7 +83,7 @@ def _compile_jobs(force, variants):
     flags = [f for f in HIPCC_FLAGS if f != "-shared"]
     jobs = []
     for tu in TUS:
-        for tol in sorted(set(bool(v) and tu == "mcrt_hip.hip" for v in variants)):
+        for tol in sorted(set(bool(v) and tu in KERNEL_TUS for v in variants)):
             stem = os.path.join(OBJ, tu + (".tol" if tol else ""))
             obj, dep = stem + ".o", stem + ".d"
             if force or _stale(obj, dep):
@@ -91,7 +93,7 @@ def _compile_jobs(force, variants):
 
 
 def _objects(tolerance):
-    return [os.path.join(OBJ, tu + (".tol" if tolerance and tu == "mcrt_hip.hip" else "") + ".o") for tu in TUS]
+    return [os.path.join(OBJ, tu + (".tol" if tolerance and tu in KERNEL_TUS else "") + ".o") for tu in TUS]
 
 
 def build_lib(force=False, verbose=True, tolerance=False, both=False):

@@ -24,6 +24,7 @@
 #include "mcrt_internal.hpp"
 #include "mcrt_plan.hpp"
 #include "mcrt_octree_shared.hpp"
+#include "mcrt_lean.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -124,6 +125,8 @@ struct mcrt_ctx {
     double* last_film = nullptr;
     hipStream_t last_stream = nullptr;
     bool force_wf = false;
+    mutable bool lean_used = false;  // the last launch (frame, photon pass) ran a lean instance: mcrt_get_option("MCRT_LEAN_USED")
+    uint32_t material_flags_or = 0xFFFFFFFFu;  // OR of the uploaded scene's material flags: which compiled-out features a lean kernel instance may lack (leanOf)
     uint32_t iors_depth = kMaxIorsDeep;  // RefractionHistory entries per pipeline slot (8 in LDS + deep rows); grows when a frame nests deeper
     DevBuf wf_iors_deep;
     DevPool pass_pool;  // work buffers of the device photon pass (mcrt_photon_device.hpp)
@@ -307,6 +310,41 @@ using mcrt::ctxOpt;
 using mcrt::ctxOptL;
 using mcrt::ctxOptOn;
 
+// Lean kernel instances (csrc/mcrt_hip_lean.hip: the default path's kernels compiled without Oren-Nayar, GGX and conductor Fresnel). A
+// scene whose materials carry none of those flags renders through them - same bits, fewer registers (mcrt_shade.hpp) - unless
+// MCRT_LEAN_KERNELS=0. `full` is the instance the selection code above chose; the table says which of them has a lean twin.
+bool leanScene(const mcrt_ctx* ctx) { return (ctx->material_flags_or & MCRT_LEAN_FEATURES_OFF) == 0u && ctxOptL(ctx, "MCRT_LEAN_KERNELS", 1) != 0; }
+template <class K>
+K leanOf(mcrt_ctx* ctx, K full) {
+    if (!full || !leanScene(ctx)) return full;
+    constexpr int PT = MCRT_INTEGRATOR_PATH_TRACER;
+    static const struct { const void* full; int id; } twins[] = {
+        {reinterpret_cast<const void*>(renderKernelFlatK<>), MCRT_LEAN_FLATK_512},
+        {reinterpret_cast<const void*>(renderKernelFlatK<768>), MCRT_LEAN_FLATK_768},
+        {reinterpret_cast<const void*>(renderKernel<PT, false, true, false, 1>), MCRT_LEAN_FLAT_512},
+        {reinterpret_cast<const void*>(renderKernel<PT, false, true, false, 2>), MCRT_LEAN_FLAT_768},
+        // (the photon-mapping kernel of trees in MEMORY keeps its full instance: lean it spills 883 registers instead of 769 and a C5 frame
+        // takes 845 ms instead of 815 - that kernel's frame time follows its spill placement, not its instruction count, DESIGN 4.4 -
+        // while the LDS-resident scenes' instance gains 7 %: profiles/r06_ab_lean_kernels.log)
+        {reinterpret_cast<const void*>(renderKernelPM<false, true, 1024>), MCRT_LEAN_PM_1024_ALL},
+        {reinterpret_cast<const void*>(renderKernelPM<false, true>), MCRT_LEAN_PM_512_ALL},
+        {reinterpret_cast<const void*>(renderKernelSM<false, false>), MCRT_LEAN_SM},
+        {reinterpret_cast<const void*>(renderKernelSM<false, true>), MCRT_LEAN_SM_ALL},
+        {reinterpret_cast<const void*>(wfShadeKernel<false>), MCRT_LEAN_SHADE},
+        {reinterpret_cast<const void*>(wfShadeKernel<true>), MCRT_LEAN_SHADE_PM},
+        {reinterpret_cast<const void*>(emitKernel<false>), MCRT_LEAN_EMIT},
+        {reinterpret_cast<const void*>(emitKernel<true>), MCRT_LEAN_EMIT_ALL},
+    };
+    const void* f = reinterpret_cast<const void*>(full);
+    for (const auto& t : twins)
+        if (t.full == f)
+            if (const void* l = mcrt_lean_kernel(t.id)) {
+                ctx->lean_used = true;
+                return reinterpret_cast<K>(const_cast<void*>(l));
+            }
+    return full;
+}
+
 template <class K>
 int planTrace(mcrt_ctx* ctx, K kernel, uint64_t max_items, TracePlan& tp) {
     auto envi = [ctx](const char* k, long d) { return ctxOptL(ctx, k, d); };
@@ -478,6 +516,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     uint32_t shade_tables = wfShadeTableBytes(ctx->scene.num_materials, ctx->scene.num_lights);
     if (shade_tables > kWfShadeTableMax || ctxOptL(ctx, "MCRT_WF_LDS_TABLES", 1) == 0) shade_tables = 0;
     const uint32_t shade_lds = kSobolTableWords * 4u + kMaxIors * kWfBlock * 8u + shade_tables;
+    // (the instances without the material features this scene does not use, when it uses none of them: leanOf)
+    const auto shade_pt = leanOf(ctx, wfShadeKernel<false>);
+    const auto shade_pm = leanOf(ctx, wfShadeKernel<true>);
     TracePlan tp;
     if (int rc = planTrace(ctx, trace, slots * 2, tp)) return rc;
 
@@ -574,9 +615,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         if (photon) {
             sa.rcount_out = ctrl + 4 + (it & 1);
             sa.rcount_reset = ctrl + 4 + ((it + 1) & 1);
-            hipLaunchKernelGGL(wfShadeKernel<true>, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
+            hipLaunchKernelGGL(shade_pm, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
         } else {
-            hipLaunchKernelGGL(wfShadeKernel<false>, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
+            hipLaunchKernelGGL(shade_pt, dim3(shade_grid), dim3(kWfBlock), shade_lds, stream, ctx->scene, sa);
         }
         ctx->launches++;
         if (it % check_every == check_every - 1 || it < 2) {
@@ -685,6 +726,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     if (photon && !ctx->has_photons) return fail(ctx, MCRT_ERR_NO_PHOTONS, "photon mapping render before mcrt_upload_photons");
     if (ctx->pending) return fail(ctx, MCRT_ERR_INVALID, "a render is already in flight: call mcrt_render_finish");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->lean_used = false;
 
     const bool count_tests = ctxOptOn(ctx, "MCRT_COUNT_TESTS");
     using KernelT = void (*)(const DeviceScene, const RenderParams);
@@ -711,13 +753,15 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // (profiles/r05_ab_c2_flat_karg.log) - so that is the default where the argument-block form applies, 512 lanes elsewhere.
     const bool flat_karg = flat_only && ctxOptL(ctx, "MCRT_FLAT_KARG", 1) != 0 && !ctx->flat_pre_host.empty() && ctx->flat_pre_host.size() <= kFlatPreArgFloats &&
                            ctx->flat_pre_host.size() == (size_t)ctx->scene.pre_tri_pairs * kTriPairFloats + (size_t)ctx->scene.pre_sph_pairs * kSphPairFloats;
-    int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", flat_karg ? 768 : 512);
+    // (... of the full instance. The lean one - a scene without rough / conductor materials, leanOf - spills NOTHING at 512 lanes and is
+    // fastest there: C2 108.2 ms per 64-spp frame against 111.0 at 768 lanes and the full instance's 112.0, profiles/r06_ab_feature_strip_probe.log)
+    int flat_block = (int)ctxOptL(ctx, "MCRT_FLAT_BLOCK", flat_karg && !leanScene(ctx) ? 768 : 512);
     if (flat_block != 512 && flat_block != 768 && flat_block != 1024) flat_block = 512;
     // (Round 4 built a form that dealt a wave's (ray, cull survivor) pairs over all 64 lanes for the FP64 tests; measured in round 5 it
     // LOST 8 % on C2 and on C2-GGX - 482 ms against 446, 663 against 614, profiles/r05_ab_c2_flat_share.log - and was removed.)
     if (flat_only)
-        kernel = flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
-                                    : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>;
+        kernel = leanOf(ctx, flat_block == 1024 ? renderKernel<PT, false, true, false, 3>
+                                                : flat_block == 768 ? renderKernel<PT, false, true, false, 2> : renderKernel<PT, false, true, false, 1>);
     // path tracing of scenes whose BVH is walked: lane-state-machine kernel (MCRT_KERNEL=legacy keeps the
     // wave-synchronous one for A/B runs)
     const char* kenv = ctxOpt(ctx, "MCRT_KERNEL");
@@ -761,7 +805,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     if (use_sm) {
         static const KernelT sm_table[2][2] = {{renderKernelSM<false, false>, renderKernelSM<false, true>},
                                                {renderKernelSM<true, false>, renderKernelSM<true, true>}};
-        kernel = sm_table[count_tests ? 1 : 0][all ? 1 : 0];
+        kernel = leanOf(ctx, sm_table[count_tests ? 1 : 0][all ? 1 : 0]);
         if (profile_phases) kernel = all ? renderKernelSM<false, true, true> : renderKernelSM<false, false, true>;
         const int want = (int)ctxOptL(ctx, "MCRT_SM_BLOCK", (long)kBlock);
         if (!all && !count_tests && !profile_phases && (want == 768 || want == 1024)) {
@@ -787,6 +831,8 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     }
     using PmKernelT = void (*)(const DeviceScene, const RenderParams, const PmExtra);
     PmKernelT pm_kernel = nullptr;
+    using FlatKT = void (*)(const DeviceScene, const RenderParams, const FlatPreArg);
+    FlatKT flatk_kernel = nullptr;
     DeviceScene launch_scene = ctx->scene;
     if (ctxOpt(ctx, "MCRT_FLAT_CULL") && !ctxOptOn(ctx, "MCRT_FLAT_CULL")) launch_scene.flat_pre = nullptr;  // A/B: every primitive in FP64
     LaunchGeom g;
@@ -833,6 +879,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
             }
         }
         pm_kernel = pm_large_k ? pm_table_large[count_tests ? 1 : 0][all ? 1 : 0] : pm_table[g.block == 1024 ? 1 : 0][count_tests ? 1 : 0][all ? 1 : 0];
+        pm_kernel = leanOf(ctx, pm_kernel);
         g.lds_bytes = ldsBytes(g.block, pm_stack_depth);
         if (g.lds_bytes > ctx->max_lds) return fail(ctx, MCRT_ERR_INVALID, "LDS plan exceeds the device limit");
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
@@ -856,10 +903,8 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
         g.grid = (uint32_t)(per_cu * ctx->num_cus);
         g.total_lanes = g.grid * g.block;
     } else if (flat_karg && launch_scene.flat_pre) {
-        if (int rc = flat_block == 1024  ? launchGeometry(ctx, renderKernelFlatK<1024>, launch_scene, g, 4)
-                     : flat_block == 768 ? launchGeometry(ctx, renderKernelFlatK<768>, launch_scene, g, 3)
-                                         : launchGeometry(ctx, renderKernelFlatK<>, launch_scene, g, 2))
-            return rc;
+        flatk_kernel = leanOf(ctx, flat_block == 1024 ? renderKernelFlatK<1024> : flat_block == 768 ? renderKernelFlatK<768> : renderKernelFlatK<>);
+        if (int rc = launchGeometry(ctx, flatk_kernel, launch_scene, g, flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2)) return rc;
     } else if (int rc = launchGeometry(ctx, kernel, launch_scene, g, flat_only ? (flat_block == 1024 ? 4 : flat_block == 768 ? 3 : 2) : 0)) {
         return rc;
     }
@@ -968,9 +1013,7 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
                 FlatPreArg pre;
                 memset(&pre, 0, sizeof(pre));
                 memcpy(pre.v, ctx->flat_pre_host.data(), ctx->flat_pre_host.size() * sizeof(float));
-                if (g.block == 1024u) hipLaunchKernelGGL(renderKernelFlatK<1024>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
-                else if (g.block == 768u) hipLaunchKernelGGL(renderKernelFlatK<768>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
-                else hipLaunchKernelGGL(renderKernelFlatK<>, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
+                hipLaunchKernelGGL(flatk_kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm, pre);
             } else {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(g.block), g.lds_bytes, stream, launch_scene, prm);
             }
@@ -1149,7 +1192,11 @@ int mcrt_set_option(mcrt_ctx* ctx, const char* key, const char* value) {
     return MCRT_OK;
 }
 
-const char* mcrt_get_option(const mcrt_ctx* ctx, const char* key) { return (ctx && key) ? mcrt::ctxOpt(ctx, key) : nullptr; }
+const char* mcrt_get_option(const mcrt_ctx* ctx, const char* key) {
+    if (!ctx || !key) return nullptr;
+    if (strcmp(key, "MCRT_LEAN_USED") == 0) return ctx->lean_used ? "1" : "0";  // (read-only: did the last frame / photon pass run a lean kernel instance)
+    return mcrt::ctxOpt(ctx, key);
+}
 
 int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (!ctx) return MCRT_ERR_INVALID;
@@ -1206,6 +1253,8 @@ int mcrt_upload_scene(mcrt_ctx* ctx, const mcrt_scene_desc* s) {
     if (int rc = uploadArray(ctx, ctx->surf_material, s->surf_material, ns)) return rc;
     if (int rc = uploadArray(ctx, ctx->surf_kind, s->surf_kind, ns)) return rc;
     if (int rc = uploadArray(ctx, ctx->materials, s->materials, (size_t)s->num_materials)) return rc;
+    ctx->material_flags_or = 0u;
+    for (uint32_t i = 0; i < s->num_materials; i++) ctx->material_flags_or |= s->materials[i].flags;
     if (int rc = uploadArray(ctx, ctx->light_surface, s->light_surface, (size_t)s->num_lights)) return rc;
     if (int rc = uploadArray(ctx, ctx->light_cdf, s->light_cdf, (size_t)s->num_lights)) return rc;
 
@@ -1515,7 +1564,8 @@ int emitOnDevice(mcrt_ctx* ctx, double emissions, double caustic_factor, uint32_
     if (int rc = uploadArray(ctx, ctx->emit_flux, pflux.data(), pflux.size())) return rc;
     if (!ctx->emit_counters.p) HIP_TRY(ctx, ctx->emit_counters.alloc(8 * sizeof(unsigned long long)));
 
-    auto kernel = ctx->scene.stage_all ? emitKernel<true> : emitKernel<false>;
+    ctx->lean_used = false;
+    auto kernel = leanOf(ctx, ctx->scene.stage_all ? emitKernel<true> : emitKernel<false>);
     DeviceScene scene = ctx->scene;
     scene.flat = 0;  // the emission kernel walks the BVH
     LaunchGeom g;

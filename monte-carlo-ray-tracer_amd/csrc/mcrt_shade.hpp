@@ -11,6 +11,19 @@
 
 namespace mcrt {
 
+// Material FEATURES a translation unit compiles out (round 6). The rough-diffuse (Oren-Nayar), rough-specular (GGX) and conductor-Fresnel
+// branches are the register peak of every shading kernel whether or not a scene has such a material: compiled for "none of the three" the
+// flat megakernel's 512-lane form spills nothing (13 registers with them), the photon-mapping kernels 100+ fewer, and a frame of
+// hexagon_room / water_caustics renders 2-7 % faster with the same bits (profiles/r06_ab_feature_strip*.log). csrc/mcrt_hip_lean.hip
+// compiles the default path's kernels once more with MCRT_MAT_FEATURES_OFF = those three bits; launchRender picks them for scenes whose
+// materials carry none of the bits (HostLayout / mcrt_upload_scene: the OR of all material flags). Default: nothing compiled out.
+#ifndef MCRT_MAT_FEATURES_OFF
+#define MCRT_MAT_FEATURES_OFF 0u
+#endif
+constexpr uint32_t kMatFeaturesOff = (uint32_t)(MCRT_MAT_FEATURES_OFF);
+// a material's flag bits as this translation unit sees them
+MCRT_HD constexpr uint32_t matFlags(uint32_t flags) { return flags & ~kMatFeaturesOff; }
+
 // Per-surface data needed after the closest hit is known, plus materials and lights.
 // L: the arrays are the workgroup's LDS copies (small scenes) instead of global memory.
 template <bool L>
@@ -120,7 +133,7 @@ MCRT_HD d3 matDiffuseReflection(const M& m, d3 wi, d3 wo, double& pdf) {  // :17
         return splat(0.0);
     }
     pdf = wi.z * kInvPi;
-    return (m.flags & MCRT_MAT_ROUGH) ? matOrenNayar(m, wi, wo) : matLambertian(m);
+    return (matFlags(m.flags) & MCRT_MAT_ROUGH) ? matOrenNayar(m, wi, wo) : matLambertian(m);
 }
 template <class M>
 MCRT_HD d3 matSpecularReflection(const M& m, d3 wi, d3 wo, double& pdf) {  // :29-45
@@ -128,7 +141,7 @@ MCRT_HD d3 matSpecularReflection(const M& m, d3 wi, d3 wo, double& pdf) {  // :2
         pdf = 0.0;
         return splat(0.0);
     }
-    if (m.flags & MCRT_MAT_ROUGH_SPECULAR) return ld3(m.specular_reflectance) * ggxReflection(wi, wo, m.a[0], m.a[1], pdf);
+    if (matFlags(m.flags) & MCRT_MAT_ROUGH_SPECULAR) return ld3(m.specular_reflectance) * ggxReflection(wi, wo, m.a[0], m.a[1], pdf);
     pdf = 1.0;
     return ld3(m.specular_reflectance) / fabs(wi.z);
 }
@@ -140,7 +153,7 @@ MCRT_HD d3 matSpecularTransmission(const M& m, d3 wi, d3 wo, double n1, double n
         return splat(0.0);
     }
     d3 btdf = !inside ? ld3(m.transmittance) : splat(1.0);
-    if (m.flags & MCRT_MAT_ROUGH_SPECULAR) {
+    if (matFlags(m.flags) & MCRT_MAT_ROUGH_SPECULAR) {
         btdf = btdf * ggxTransmission(wi, wo, n1, n2, m.a[0], m.a[1], pdf);
         if (flux) btdf = btdf * sq(n2 / n1);
     } else {
@@ -336,7 +349,7 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
             ia.normal = surfNormalOf<L>(rec, ia.position);
         }
     }
-    const uint32_t flags = ia.material->flags;
+    const uint32_t flags = matFlags(ia.material->flags);
 
     double cos_theta = dot(ray.direction, ia.normal);
     ia.inside = cos_theta > 0.0;
@@ -376,7 +389,7 @@ MCRT_HD void interactionInit(InteractionT<L>& ia, const ShadeViewT<L>& sh, const
 template <bool L>
 MCRT_HD d3 interactionBSDFLocal(const InteractionT<L>& ia, d3 wo, d3 wi, double& pdf, bool flux, bool wi_dirac_delta) {
     const auto& m = *ia.material;
-    const uint32_t f = m.flags;
+    const uint32_t f = matFlags(m.flags);
     const double n1 = ia.n1, n2 = ia.n2;
     double cos_theta = wo.z;
     if (f & MCRT_MAT_ROUGH_SPECULAR) {
@@ -439,7 +452,7 @@ MCRT_HD d3 cosWeightedHemi(double u, double v) {  // sampling/sampling.hpp:35-44
 
 template <bool L>
 MCRT_HD d3 interactionSpecularNormal(const InteractionT<L>& ia, const Sampler& smp, SobolTab tab) {  // interaction.cpp:185-193
-    if (ia.material->flags & MCRT_MAT_ROUGH_SPECULAR) {
+    if (matFlags(ia.material->flags) & MCRT_MAT_ROUGH_SPECULAR) {
         double u0 = smp.get(kDimBsdf, tab), u1 = smp.get(kDimBsdf + 1, tab);
         return csFrom(ia.shading_cs, ggxVisibleMicrofacet<!L>(u0, u1, csTo(ia.shading_cs, ia.out), ia.material->a[0], ia.material->a[1]));
     }

@@ -123,19 +123,16 @@ def wave_walk_emu():
     return L
 
 
-@pytest.fixture(scope="session")
-def wave_kernel_emu():
-    """Host build of the product's KERNELS (tests/emu/wave_kernel_emu.cpp: csrc/mcrt_kernels.hpp unchanged, workgroups of emulated
-    wavefronts with __syncthreads, LDS and the launch geometry) — test harness only."""
+def _wave_kernel_emu(lib_name, extra_flags=()):
     src = os.path.join(TESTS, "emu", "wave_kernel_emu.cpp")
-    out = os.path.join(TESTS, "emu", "_build", "libwave_kernel_emu.so")
+    out = os.path.join(TESTS, "emu", "_build", lib_name)
     csrc = os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc")
     deps = [src, os.path.join(TESTS, "emu", "wave_emu.hpp"), os.path.join(TESTS, "emu", "mcrt_emu.cpp")] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         tmp = "%s.%d.tmp" % (out, os.getpid())
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fno-inline", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fno-inline", "-ffp-contract=off", "-fPIC", "-shared"] + list(extra_flags) + ["-o", tmp, src])
         os.replace(tmp, out)
     L = C.CDLL(out)
     vp = C.c_void_p
@@ -150,6 +147,20 @@ def wave_kernel_emu():
     L.wemu_set_shuffle.argtypes = [C.c_uint64]
     L.wemu_set_shuffle.restype = None
     return L
+
+
+@pytest.fixture(scope="session")
+def wave_kernel_emu():
+    """Host build of the product's KERNELS (tests/emu/wave_kernel_emu.cpp: csrc/mcrt_kernels.hpp unchanged, workgroups of emulated
+    wavefronts with __syncthreads, LDS and the launch geometry) — test harness only."""
+    return _wave_kernel_emu("libwave_kernel_emu.so")
+
+
+@pytest.fixture(scope="session")
+def wave_kernel_emu_lean():
+    """The same kernels compiled as csrc/mcrt_hip_lean.hip compiles them: without Oren-Nayar, GGX and conductor Fresnel
+    (MCRT_MAT_FEATURES_OFF = MCRT_MAT_ROUGH | MCRT_MAT_ROUGH_SPECULAR | MCRT_MAT_COMPLEX_IOR, csrc/mcrt_shade.hpp) — test harness only."""
+    return _wave_kernel_emu("libwave_kernel_emu_lean.so", ["-DMCRT_MAT_FEATURES_OFF=67u"])
 
 
 def load_emu():

@@ -433,3 +433,43 @@ def test_large_scene_kernels_on_the_host(pkg, wave_kernel_emu, oracle, name):
     else:
         np.testing.assert_array_equal(out, want)
         np.testing.assert_array_equal(pipe, want)
+
+
+@pytest.mark.parametrize("name", ["hexagon_room", "hexagon_room_dof", "ior_test", "coffee_maker_qsah", "coffee_maker_bsah"])
+def test_lean_kernel_instances_on_the_host_give_the_oracle_frame(pkg, wave_kernel_emu_lean, oracle, manifest, name):
+    """csrc/mcrt_hip_lean.hip compiles the default path's kernels WITHOUT the rough-diffuse, rough-specular and conductor branches
+    (MCRT_MAT_FEATURES_OFF, csrc/mcrt_shade.hpp), for scenes none of whose materials carries one of those flags. The same kernels built
+    that way for the host: the megakernel launchRender picks, the flat megakernel with its records as a kernel argument, and the wavefront
+    pipeline render such scenes to the oracle's frame, bit for bit. (On the GPU: tests/test_gpu_lean_kernels.py.)"""
+    case = manifest["cases"].get(name)
+    if case is None:
+        pytest.skip("no such golden case")
+    from conftest import camera_for
+    img = pkg.SceneImage(golden_path(case["image"]))
+    s = img.scene
+    assert not any(s.materials[i].flags & 67 for i in range(s.num_materials)), "the lean instances are not for this scene"
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 24, 14, 2
+    want, info = oracle.render(img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER)
+    for force, grid in ((0, 1), (6, 2)):
+        rc, out, stats, kid = _emulated_frame(pkg, wave_kernel_emu_lean, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, force, grid)
+        if force == 6 and (rc == -206 or kid != 16):
+            continue
+        assert rc == 0 and int(stats[1]) == info["rays"]
+        np.testing.assert_array_equal(out, want, err_msg="%s: lean %s is not the oracle's frame" % (name, KERNEL_NAMES.get(kid)))
+    rc, out, stats, launches = _emulated_pipeline_frame(wave_kernel_emu_lean, img, cam, manifest["seed"], pkg.INTEGRATOR_PATH_TRACER, 512, 2, 2, 11)
+    assert rc == 0
+    np.testing.assert_array_equal(out, want, err_msg="%s: lean pipeline" % name)
+
+
+def test_lean_photon_mapping_kernel_on_the_host(pkg, wave_kernel_emu, wave_kernel_emu_lean, manifest):
+    """... and renderKernelPM: the lean instance's hexagon_room_pm frame is the full instance's, bit for bit."""
+    from conftest import camera_for
+    case = manifest["cases"]["hexagon_room_pm"]
+    img = pkg.SceneImage(golden_path(case["image"]))
+    cam = camera_for(img, case["renders"][0])
+    cam.width, cam.height, cam.sqrtspp = 20, 10, 2
+    rc0, full, st0, kid0 = _emulated_frame(pkg, wave_kernel_emu, img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    rc1, lean, st1, kid1 = _emulated_frame(pkg, wave_kernel_emu_lean, img, cam, manifest["seed"], pkg.INTEGRATOR_PHOTON_MAPPER)
+    assert rc0 == 0 and rc1 == 0 and kid0 == kid1 == 5 and int(st0[4]) == int(st1[4]) > 0
+    np.testing.assert_array_equal(lean, full)

@@ -23,7 +23,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # the kernel instances the default options launch (launchRender / launchWavefront / the photon pass, csrc/mcrt_hip.hip), by demangled-name prefix
 DEFAULT_PATH = ("renderKernelFlatK<768>", "renderKernelSM<false, false, false, 512>", "wfTraceKernel<(anonymous namespace)::PoolRays, false, 3>",
                 "wfTraceKernel<(anonymous namespace)::PoolRays, false, 1>", "wfShadeKernel<false>", "wfShadeKernel<true>", "wfKnnKernel<true, 4>",
-                "renderKernelPM<false, false, 1024, 4>", "renderKernelPM<false, true, 1024, 4>", "emitKernel<false>", "emitKernel<true>", "sampleResolveKernel")
+                "renderKernelPM<false, false, 1024, 4>", "renderKernelPM<false, true, 1024, 4>", "emitKernel<false>", "emitKernel<true>", "sampleResolveKernel",
+                # the lean instances (csrc/mcrt_hip_lean.hip: scenes without rough / conductor materials - hexagon_room, water_caustics - run these)
+                "lean::renderKernelFlatK<512>", "lean::renderKernelPM<false, true, 1024, 4>", "lean::renderKernelSM<false, false, false, 512>",
+                "lean::wfShadeKernel<false>", "lean::wfShadeKernel<true>", "lean::emitKernel<false>", "lean::emitKernel<true>")
 
 
 def short(name):
