@@ -929,7 +929,9 @@ def measure(name, args, m, tiling, rank, world, local_rank, dist, steps, warmup,
                        "seed": SEED, "sharding": "rows in groups of %d, round-robin over %d GPU(s)" % (SHARD_ROWS, world),
                        "rays_per_step": total_rays / steps, "paths_per_step": total_paths / steps,
                        "frame_mean_radiance": float(frame.mean().item()), "frame_finite": bool(torch.isfinite(frame).all().item()),
-                       "kernel": m.KERNEL_NAMES.get(kernel_id, "?"), "kernel_id": kernel_id, "kernel_launches_per_step": stats[-1]["kernel_launches"],
+                       "kernel": m.KERNEL_NAMES.get(kernel_id, "?") + (" [lean instance: compiled without the material branches this scene does not use]"
+                                                                          if wl.ctx.get_option("MCRT_LEAN_USED") == "1" else ""),
+                       "kernel_id": kernel_id, "kernel_launches_per_step": stats[-1]["kernel_launches"],
                        "knn_searches_per_s": total_knn / elapsed if total_knn else None,
                        "photon_pass": wl.emit_info if wl.photon else None},
         }
