@@ -48,3 +48,21 @@ def test_build_switches_compile_for_gfx950(switch, kernel):
     out = p.stdout + p.stderr
     assert "error" not in out.lower(), out[-2000:]
     assert kernel.split("<")[0] in out and "vgpr=" in out, out[-2000:]
+
+
+def test_every_lean_kernel_id_has_an_instance(pkg):
+    """csrc/mcrt_lean.hpp lists the lean instances by id; csrc/mcrt_hip_lean.hip must hold one for each (mcrt_lean_kernel returns the
+    address hipLaunchKernel takes - a host stub, valid without a GPU), and none beyond the list."""
+    import ctypes as C
+    import re
+    hdr = open(os.path.join(ROOT, "monte-carlo-ray-tracer_amd", "csrc", "mcrt_lean.hpp")).read()
+    body = hdr[hdr.index("enum McrtLeanKernelId {"):hdr.index("MCRT_LEAN_COUNT")]
+    ids = re.findall(r"^\s*(MCRT_LEAN_[A-Z0-9_]+)", body, re.M)
+    assert len(ids) >= 10
+    L = pkg.lib()
+    L.mcrt_lean_kernel.argtypes = [C.c_int]
+    L.mcrt_lean_kernel.restype = C.c_void_p
+    got = [L.mcrt_lean_kernel(i) for i in range(len(ids))]
+    assert all(got), "no instance for %s" % [n for n, g in zip(ids, got) if not g]
+    assert len(set(got)) == len(got)
+    assert L.mcrt_lean_kernel(len(ids)) is None and L.mcrt_lean_kernel(-1) is None
