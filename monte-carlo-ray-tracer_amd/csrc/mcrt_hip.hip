@@ -334,6 +334,7 @@ K leanOf(mcrt_ctx* ctx, K full) {
         {reinterpret_cast<const void*>(wfShadeKernel<true>), MCRT_LEAN_SHADE_PM},
         {reinterpret_cast<const void*>(emitKernel<false>), MCRT_LEAN_EMIT},
         {reinterpret_cast<const void*>(emitKernel<true>), MCRT_LEAN_EMIT_ALL},
+        {reinterpret_cast<const void*>(wfKnnKernel<true>), MCRT_LEAN_KNN_EVAL},
     };
     const void* f = reinterpret_cast<const void*>(full);
     for (const auto& t : twins)
@@ -637,7 +638,7 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
         if (photon) {
             ka.count = ctrl + 4 + (it & 1);
             const bool large_k = ctx->k_nearest > waveMaxK(kWaveRows);  // the wide candidate buffer (mcrt_waveknn.hpp)
-            if (knn_eval) hipLaunchKernelGGL((large_k ? wfKnnKernel<true, kWaveRowsLarge> : wfKnnKernel<true>), dim3(knn_grid), dim3(256), 0, stream, ka);
+            if (knn_eval) hipLaunchKernelGGL((large_k ? wfKnnKernel<true, kWaveRowsLarge> : leanOf(ctx, wfKnnKernel<true>)), dim3(knn_grid), dim3(256), 0, stream, ka);
             else hipLaunchKernelGGL((large_k ? wfKnnKernel<false, kWaveRowsLarge> : wfKnnKernel<false>), dim3(knn_grid), dim3(256), 0, stream, ka);
             ctx->launches++;
         }
@@ -797,7 +798,17 @@ int launchRenderImpl(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global
     // renderKernelPM (C5 9.3 vs 7.4 s per frame, hexagon_room map 308 vs 242 ms) — the kNN search is bound by the number of
     // wave instructions per query (one query per wave leaves most lanes idle), which more waves per SIMD do not fix, and
     // the pipeline adds its shade launches on top. k must fit the per-wave candidate buffer.
-    if (photon && has_tree && ctx->k_nearest <= kWaveKMax && want_wf && !ctx->force_pm_lane)
+    // Round 6: ... and by itself for a scene whose tree stays in memory, whose materials allow the lean instances (leanOf) and whose k
+    // fits the narrow buffers, once the frame is large enough (MCRT_WF_PM_MIN_PATHS path samples in this call's rows, default 32 M). With
+    // the lean kNN launch (17 instead of 61 spilled registers, 6 waves per SIMD) and the lean shade launch (8 instead of 192) C5 renders
+    // in 739 ms per 64-spp frame against the megakernel's 817 (profiles/r06_ab_lean_knn_occupancy.log): the pipeline's kernels each run at
+    // their own register budget, the megakernel's estimates at the budget of its bounce code. LDS-resident scenes stay with the
+    // megakernel (hexagon_room_pm 93.7 ms against 136).
+    const char* pmp = ctxOpt(ctx, "MCRT_WF_PM_MIN_PATHS");
+    const uint64_t wf_pm_min_paths = pmp ? strtoull(pmp, nullptr, 0) : 32000000ull;
+    const bool pm_pipeline = photon && has_tree && !all && !kenv && !count_tests && leanScene(ctx) && ctx->k_nearest <= waveMaxK(kWaveRows) &&
+                             frame_paths >= wf_pm_min_paths;
+    if (photon && has_tree && ctx->k_nearest <= kWaveKMax && (want_wf || pm_pipeline) && !ctx->force_pm_lane)
         return launchWavefront(ctx, cam, global_seed, d_out, stream, count_tests, true, film_out);
     // workgroup size of the state-machine kernel for trees that stay in HBM (MCRT_SM_BLOCK: 512 / 768 / 1024 lanes) and the
     // stack entries per lane it keeps in LDS (MCRT_SM_STACK; the rest of a lane's stack is in the HBM spill area)

@@ -15,6 +15,9 @@
 
 #include "mcrt_lean.hpp"
 #define MCRT_MAT_FEATURES_OFF MCRT_LEAN_FEATURES_OFF
+// the lean kNN launch's occupancy: with 17 spilled registers at 96 VGPRs it has room for a sixth wave per SIMD (80 VGPRs, 24 spilled) - C5
+// through the pipeline 777 -> 739 ms, a seventh changes nothing (profiles/r06_ab_lean_knn_occupancy.log); the full instance stays at 5
+#define MCRT_KNN_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
 // Every inline function of the headers below exists in mcrt_hip.hip's objects too, compiled with all features: this unit's copies live
 // in a namespace of their own so that the linker never folds the two (the C ABI's identifiers, mcrt_*, are not touched by the macro).
 #define mcrt mcrt_lean
@@ -55,6 +58,7 @@ extern "C" const void* mcrt_lean_kernel(int id) {
         case MCRT_LEAN_SHADE_PM: return reinterpret_cast<const void*>(wfShadeKernel<true>);
         case MCRT_LEAN_EMIT: return reinterpret_cast<const void*>(emitKernel<false>);
         case MCRT_LEAN_EMIT_ALL: return reinterpret_cast<const void*>(emitKernel<true>);
+        case MCRT_LEAN_KNN_EVAL: return reinterpret_cast<const void*>(wfKnnKernel<true>);
         default: return nullptr;
     }
 }

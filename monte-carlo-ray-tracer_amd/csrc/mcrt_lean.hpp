@@ -17,6 +17,7 @@ enum McrtLeanKernelId {
     MCRT_LEAN_SHADE_PM,        // wfShadeKernel<true>
     MCRT_LEAN_EMIT,            // emitKernel<false>
     MCRT_LEAN_EMIT_ALL,        // emitKernel<true>
+    MCRT_LEAN_KNN_EVAL,        // wfKnnKernel<true>  (the pipeline's kNN launch that evaluates the estimates: Interaction::BSDF per photon)
     MCRT_LEAN_COUNT
 };
 // the material flag bits those instances are compiled without (include/mcrt.h: MCRT_MAT_ROUGH | MCRT_MAT_ROUGH_SPECULAR | MCRT_MAT_COMPLEX_IOR)

@@ -23,7 +23,7 @@ def _uses_rough(img):
 
 @pytest.fixture
 def env():
-    keys = ("MCRT_KERNEL", "MCRT_LEAN_KERNELS")
+    keys = ("MCRT_KERNEL", "MCRT_LEAN_KERNELS", "MCRT_WF_PM_MIN_PATHS")
     old = {k: os.environ.get(k) for k in keys}
     yield os.environ
     for k, v in old.items():
@@ -104,3 +104,32 @@ def test_photon_mapped_frame_and_photon_pass_through_lean_instances(pkg, manifes
     np.testing.assert_array_equal(frames[1], frames[0])
     np.testing.assert_array_equal(lists[1][0], lists[0][0])
     np.testing.assert_array_equal(lists[1][1], lists[0][1])
+
+
+def test_large_photon_mapped_frame_of_a_tree_in_memory_goes_through_the_pipeline(pkg, env):
+    """launchRender's rule (round 6): a photon-mapped frame of a scene whose tree stays in memory and whose materials allow the lean
+    instances goes through the pipeline - lean shade launch, trace launch, lean kNN launch at 6 waves per SIMD - once it has
+    MCRT_WF_PM_MIN_PATHS path samples (default 32 M); below that, and with the option out of reach, the megakernel renders it. The two
+    are the same bits (every estimate is the same wave-cooperative search and sum)."""
+    from test_gpu_large_scene import _config
+    img, c, _ = _config(pkg, "c5")
+    assert not _uses_rough(img)
+    ctx = pkg.Context(0)
+    ctx.upload_image(img)
+    ctx.upload_photons(img.photons(0), img.photons(1), img.param("k_nearest_photons"), bool(img.param("direct_visualization")))
+    cam = img.camera
+    cam.sqrtspp = 2
+    r0, r1 = 496, 504
+    cam.shard_rows, cam.shard_count = r1 - r0, (cam.height + r1 - r0 - 1) // (r1 - r0)
+    cam.shard_index = r0 // (r1 - r0)
+    mega, st0 = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PHOTON_MAPPER)
+    assert st0["kernel_id"] == pkg.KERNEL_PM_WAVE  # 32 000 path samples: far below the rule
+    env["MCRT_WF_PM_MIN_PATHS"] = "1000"
+    try:
+        pipe, st1 = ctx.sample_image(cam, 0x12345678, pkg.INTEGRATOR_PHOTON_MAPPER)
+    finally:
+        env.pop("MCRT_WF_PM_MIN_PATHS")
+    assert st1["kernel_id"] == pkg.KERNEL_WAVEFRONT_PM and ctx.get_option("MCRT_LEAN_USED") == "1"
+    assert st1["knn_searches"] == st0["knn_searches"] > 0
+    np.testing.assert_array_equal(pipe, mega)
+    ctx.close()

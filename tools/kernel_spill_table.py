@@ -26,7 +26,7 @@ DEFAULT_PATH = ("renderKernelFlatK<768>", "renderKernelSM<false, false, false, 5
                 "renderKernelPM<false, false, 1024, 4>", "renderKernelPM<false, true, 1024, 4>", "emitKernel<false>", "emitKernel<true>", "sampleResolveKernel",
                 # the lean instances (csrc/mcrt_hip_lean.hip: scenes without rough / conductor materials - hexagon_room, water_caustics - run these)
                 "lean::renderKernelFlatK<512>", "lean::renderKernelPM<false, true, 1024, 4>", "lean::renderKernelSM<false, false, false, 512>",
-                "lean::wfShadeKernel<false>", "lean::wfShadeKernel<true>", "lean::emitKernel<false>", "lean::emitKernel<true>")
+                "lean::wfShadeKernel<false>", "lean::wfShadeKernel<true>", "lean::emitKernel<false>", "lean::emitKernel<true>", "lean::wfKnnKernel<true, 4>")
 
 
 def short(name):
