@@ -97,7 +97,8 @@ LEG_PLAN = {"c3": dict(steps=2, warm_sqrtspp=None, pmc_sqrtspp=8),   # 5.2 s a f
                                                                   # frame: measured +0.55 s per frame over two frames, round 6)
             "c4": dict(steps=2, warm_sqrtspp=4, pmc_sqrtspp=4),   # a 4K @ 1024 spp frame is ~29 s: two timed frames after a 16 spp warm-up frame (the first one
                                                                   # pays the allocations: ~1 % of the pair)
-            "c5": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=4)}
+            "c5": dict(steps=None, warm_sqrtspp=None, pmc_sqrtspp=6)}  # (36 spp = 36 M path samples: the counted frame must take the path the timed
+                                                                        # one takes - photon-mapped frames go through the pipeline from 32 M, csrc/mcrt_hip.hip)
 # photon_map.emissions of the photon-mapped workloads (x caustic_factor 10 paths): BASELINE configs[4] says 1e8 emission paths for C5
 EMISSIONS = {"pm": 1e6, "c5": 1e7}
 # emissions of the REFERENCE's own photon pass in the cpu_baseline leg of C5 (its CPU emission pass at 1e8 paths takes minutes; the
