@@ -477,7 +477,9 @@ int launchWavefront(mcrt_ctx* ctx, const mcrt_camera_desc* cam, uint32_t global_
     }
     // ... and no more than the pass has work for: paths / 48, at least 2.5 M, never fewer than 4 samples per slot (planPoolSlots,
     // mcrt_plan.hpp: the measurements; options MCRT_WF_SLOT_PATHS, MCRT_WF_SLOT_FLOOR)
-    slots = planPoolSlots(pixels * fr.spp, slots, kWfBlock, (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_PATHS", 48)),
+    // (photon-mapped frames: 16 path samples per slot - their iterations carry a kNN launch whose tails a larger pool amortises: C5 at
+    // full size 2 757 ms with 48, 2 725 with 24, 2 713 with 12, 2 874 with 96: profiles/r06_ab_c5_pipeline_pool.log)
+    slots = planPoolSlots(pixels * fr.spp, slots, kWfBlock, (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_PATHS", photon ? 16 : 48)),
                           (uint64_t)std::max(1l, (long)envi("MCRT_WF_SLOT_FLOOR", 2500000)), ctxOpt(ctx, "MCRT_WF_SLOT_PATHS") != nullptr);
     {
         const ChunkPlan cp = planChunks(fr.spp, unitsWanted(slots, 16, pixels, ctxOpt(ctx, "MCRT_CHUNKS")));
